@@ -1,0 +1,178 @@
+/*
+ * metaenc.h -- C ABI of libmetaenc.so: the MI355X (gfx950 / CDNA4) implementation of the
+ * Meta-Transformer modality-shared encoder hot path and the Data2Seq tokenizers that feed it.
+ *
+ * This is the drop-in boundary.  The reference has no native code on this path
+ * -- its Block runs as ~15 stock ATen launches per layer -- so each entry point cites the
+ * reference *Python* interface it replaces (paths relative to the reference checkout).  The
+ * calling convention follows the reference's own native-op precedent
+ * (PointCloud/openpoints/cpp/pointnet2_batch/src/sampling.cpp:16-48): plain device pointers +
+ * explicit integer dims, caller pre-allocates every output, default-or-given stream -- except
+ * that errors are returned (never exit(-1) as sampling_gpu.cu:253-257 does).
+ *
+ * Conventions
+ *   - extern "C", no C++ / torch types.  All pointers are DEVICE pointers owned by the caller
+ *     (torch tensors on the Python side); the library never allocates or frees persistent memory.
+ *   - Tensors are row-major, last dim contiguous: tokens are [B*N, C] ("rows" = tokens).
+ *   - dtype codes: ME_F32 / ME_BF16.  Statistics, biases, LayerNorm affine and accumulators are fp32.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  Launches are asynchronous
+ *     on that stream; no implicit device synchronisation.
+ *   - Return value: 0 = OK, negative = error; message via me_last_error() (thread-local).
+ *   - Thread-safe for distinct streams; no hidden global state.
+ */
+#ifndef METAENC_H
+#define METAENC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ME_ABI_VERSION 1
+
+enum { ME_F32 = 0, ME_BF16 = 1 };
+
+enum { ME_OK = 0, ME_ERR_ARG = -1, ME_ERR_UNSUPPORTED = -2, ME_ERR_HIP = -3, ME_ERR_WORKSPACE = -4 };
+
+int me_abi_version(void);
+const char* me_last_error(void);
+/* name of the gfx arch the kernels were compiled for ("gfx950") */
+const char* me_build_arch(void);
+/* device facts used by bench.py: number of CUs, LDS bytes per CU, clock MHz of device `dev` */
+int me_device_info(int dev, int* num_cus, int* lds_bytes, int* clock_mhz, char* name, int name_len);
+
+/* ------------------------------------------------------------------ LayerNorm
+ * Replaces nn.LayerNorm(C, eps) on [rows, C] tokens: Block.norm1 / Block.norm2
+ * (PointCloud/openpoints/models/layers/attention.py:46,50 via norm.py:65).
+ * mean/rstd ([rows], fp32) may be NULL in inference; they are what backward needs. */
+int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
+                     void* y, int y_dtype, float* mean, float* rstd,
+                     int64_t rows, int cols, float eps, void* stream);
+
+/* dx = LN-backward(dy) [+ dres]   ;  dgamma/dbeta ([C], fp32) are OVERWRITTEN (or accumulated when
+ * accumulate_affine != 0); pass NULL for both to skip them (frozen encoder).  `dres` (optional) is the
+ * gradient arriving through the residual connection, added into dx (Block.forward, attention.py:56-57).
+ * workspace: me_layernorm_bwd_workspace(cols) bytes. */
+size_t me_layernorm_bwd_workspace(int cols);
+int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
+                     const float* mean, const float* rstd, const float* gamma,
+                     const void* dres, int dres_dtype, void* dx, int dx_dtype,
+                     float* dgamma, float* dbeta, int accumulate_affine,
+                     int64_t rows, int cols, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ Linear / GEMM with fused epilogue
+ * Replaces nn.Linear forward (Attention.qkv / Attention.proj attention.py:21-23,28,36; Mlp.fc1/fc2
+ * mlp.py:23-27,30-34), the GELU between fc1 and fc2 (mlp.py:31), the residual adds of Block.forward
+ * (attention.py:56-57), and -- for backward -- the dgrad / wgrad contractions autograd derives from them.
+ *
+ *   ME_GEMM_NT : C[M,N] = A[M,K] * B[N,K]^T          (A, B both K-contiguous; forward, dgrad with W^T)
+ *   ME_GEMM_TN : C[M,N] = A[K,M]^T * B[K,N]          (A, B both K-major rows; wgrad: dW = dY^T X)
+ *
+ * Epilogue, applied in this order on the fp32 accumulator v:
+ *   v = alpha * v ; v += bias[n] ; (store preact) ; v = act(v) ; v *= gelu'(aux[m,n]) ;
+ *   v *= colscale[n] ; v += residual[res_row(m), n] ; v += beta * C_old[m,n] ; C[out_row(m), n] = v
+ * with res_row(m) = res_row_mod ? m % res_row_mod : m   (pos-embed broadcast over the batch) and
+ * out_row(m) = out_group_rows ? (m / out_group_rows) * out_group_stride + m % out_group_rows + out_row_offset : m
+ * (patch tokens written behind a cls token).  Requirements: K % (16/sizeof(A elt)) == 0, N % 4 == 0,
+ * 16-byte aligned rows. */
+enum { ME_GEMM_NT = 0, ME_GEMM_TN = 1 };
+enum { ME_ACT_NONE = 0, ME_ACT_GELU = 1 };
+
+typedef struct me_gemm_desc {
+    int32_t op;            /* ME_GEMM_NT / ME_GEMM_TN */
+    int32_t ab_dtype;      /* dtype of A and B (ME_F32 -> exact fp32 MFMA, ME_BF16 -> bf16 MFMA, fp32 accumulate) */
+    int64_t M, N, K;
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb;
+    void* C; int64_t ldc; int32_t c_dtype;
+    int32_t act;           /* ME_ACT_* */
+    float alpha, beta;
+    const float* bias;     /* [N] or NULL */
+    const float* colscale; /* [N] or NULL (layer-scale gamma, Image/.../base/vit.py:313-316) */
+    void* preact; int64_t ldpre; int32_t preact_dtype;      /* optional: pre-activation saved for backward */
+    int32_t aux_dtype;
+    const void* aux; int64_t ldaux;                          /* optional: multiply by gelu'(aux) (GELU backward) */
+    const void* residual; int64_t ldres; int32_t res_dtype;  /* optional */
+    int32_t reserved0;
+    int64_t res_row_mod;
+    int64_t out_group_rows, out_group_stride, out_row_offset;
+} me_gemm_desc;
+
+int me_gemm(const me_gemm_desc* d, void* stream);
+
+/* column sums of a [rows, cols] matrix -> out[cols] fp32 (bias gradients).  accumulate != 0 adds into out.
+ * workspace: me_colsum_workspace(cols) bytes. */
+size_t me_colsum_workspace(int64_t cols);
+int me_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, int64_t cols,
+              float* out, int accumulate, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ Multi-head self-attention core
+ * Replaces attention.py:28-35: the reshape/permute of qkv into heads, (q @ k^T) * scale, softmax(-1),
+ * attn @ v and the transpose back to [B,N,C] -- as one fused kernel that never materialises [B,H,N,N].
+ * qkv is the Linear output as the reference lays it out: row = token, columns [0,C)=Q, [C,2C)=K,
+ * [2C,3C)=V, head h = columns [h*hd,(h+1)*hd) inside each third (ld_qkv = row stride in elements,
+ * normally 3C).  out is [B*N, C] head-major.  lse ([B,H,N] fp32, may be NULL) = log-sum-exp of the scaled
+ * scores, needed by backward.  scale is applied to the scores in fp32 AFTER QK^T (attention.py:31). */
+int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse,
+                     int B, int N, int H, int head_dim, float scale, int dtype, void* stream);
+
+/* Backward of the above.  dqkv has the layout of qkv.  delta ([B,H,N] fp32) is scratch the caller provides. */
+int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out, int64_t ld_out,
+                     const void* dout, int64_t ld_dout, const float* lse, float* delta,
+                     void* dqkv, int64_t ld_dqkv,
+                     int B, int N, int H, int head_dim, float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ element-wise helpers */
+/* dst = (dst_dtype) src, n elements */
+int me_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* dst[c, r] = (dst_dtype) src[r, c]  (weight repack for dgrad: W[out,in] -> W^T[in,out]) */
+int me_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
+                      int64_t rows, int64_t cols, void* stream);
+/* y = x + pos (pos broadcast over batch: row m uses pos row m % pos_rows); PointCloud re-injects pos before
+ * every block (PointCloud/openpoints/models/backbone/metatransformer.py:161-163). */
+int me_add_rows(const void* x, int x_dtype, const void* pos, int pos_dtype, void* y, int y_dtype,
+                int64_t rows, int64_t pos_rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------ Data2Seq tokenizers
+ * Patch gather ("im2col") for the convolutional patch-embeds; the projection itself is me_gemm (NT) on
+ * the gathered matrix with the conv weight viewed as [Cout, Cin*kt*kh*kw].
+ *   Image    Data2Seq/Image.py:16,26          Conv2d(3,C,k16,s16)            -> kt=1,kh=kw=16,st=1,sh=sw=16
+ *   Acoustic Data2Seq/Acoustic.py:16,22       Conv2d(1,C,k16,stride(10,10))  -> overlapping patches
+ *   Video    Video/models/modeling_finetune.py:283-297  Conv3d(3,C,k=s=(2,16,16))
+ * x: [B,Cin,T,H,W] (T=1 for 2-D), cols out: [B*gt*gh*gw, Cin*kt*kh*kw] with feature order (c,dt,dy,dx),
+ * token order (t,h,w) row-major == conv_out.flatten(2).transpose(1,2).  The index arithmetic is integer
+ * and bit-exact. */
+int me_patchify(const void* x, int x_dtype, void* cols, int cols_dtype,
+                int B, int Cin, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw,
+                void* stream);
+/* backward of me_patchify when patches do not overlap is the same gather reversed (scatter); for
+ * overlapping patches gradients are accumulated.  dx must be zero-initialised by the caller. */
+int me_unpatchify_add(const void* dcols, int dcols_dtype, float* dx,
+                      int B, int Cin, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw,
+                      void* stream);
+
+/* Time-series DataEmbedding (Data2Seq/Time_Series.py:109-126), eval-mode:
+ *   out[b,l,:] = sum_{j<3} Wc[:, :, j] x[b,(l-1+j) mod L,:]  (Conv1d k3 circular, no bias, :29-42)
+ *              + sum_f table_f[mark[b,l,f]]                     (TemporalEmbedding gathers, :82-93)
+ *              + pe[l]                                          (PositionalEmbedding, :25-26)
+ * x [B,L,cin] fp32, conv_w [C,cin,3] fp32, marks [B,L,n_mark] int32 or NULL, tables: n_mark device
+ * pointers to [size_f, C] fp32 tables given in the order of the mark columns, table_rows[f] their sizes
+ * (indices are bounds-checked: an out-of-range index returns ME_ERR_ARG through *err_flag, device int). */
+int me_timeseries_embed(const float* x, const float* conv_w, const int32_t* marks, int n_mark,
+                        const float* const* tables, const int32_t* table_rows, const float* pe,
+                        void* out, int out_dtype, int B, int L, int cin, int C, int32_t* err_flag,
+                        void* stream);
+
+/* ------------------------------------------------------------------ optimizer (fine-tune paths)
+ * Fused AdamW step on a flat fp32 parameter / gradient bucket (torch.optim.AdamW semantics, decoupled
+ * weight decay), grad_scale multiplies the gradient first (1/world_size after an all-reduce sum). */
+int me_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METAENC_H */

@@ -1,0 +1,13 @@
+"""metatransformer_amd -- MI355X-native Meta-Transformer encoder hot path.
+
+Drop-in for the reference's `timm.models.vision_transformer.Block` stack and the Data2Seq tokenizers that
+feed it (see encoder.py / data2seq.py); all compute runs in libmetaenc.so (hand-written HIP for gfx950)
+behind the C ABI of include/metaenc.h.
+"""
+from ._capi import MetaEncError, load as load_library  # noqa: F401
+from .encoder import Attention, Block, Mlp, build_encoder, encoder_flops_per_sample  # noqa: F401
+from .data2seq import (AcousticPatchEmbed, Data2Seq, DataEmbedding, PatchEmbed, VideoPatchEmbed,  # noqa: F401
+                       sinusoid_table, video_sinusoid_table)
+
+__all__ = ["Block", "Attention", "Mlp", "build_encoder", "encoder_flops_per_sample", "Data2Seq", "PatchEmbed",
+           "AcousticPatchEmbed", "VideoPatchEmbed", "DataEmbedding", "MetaEncError", "load_library"]

@@ -1,0 +1,128 @@
+"""ctypes binding of libmetaenc.so (the C ABI declared in include/metaenc.h).
+
+The north star asks for a "thin C-ABI cffi layer"; ``cffi`` is not installed in this image, so the same
+C ABI is bound with the standard library's ``ctypes`` (no compile-time dependency, identical symbols).
+
+The shared library is built in-tree (``python -m metatransformer_amd.build`` or ``__graft_entry__.build()``)
+and MUST be present: there is no CPU or PyTorch fallback for any op -- loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch  # noqa: F401  (imported first so libamdhip64.so.7 resolves to the copy torch already loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmetaenc.so")
+
+ME_F32, ME_BF16 = 0, 1
+ME_GEMM_NT, ME_GEMM_TN = 0, 1
+ME_ACT_NONE, ME_ACT_GELU = 0, 1
+
+
+class MetaEncError(RuntimeError):
+    pass
+
+
+class GemmDesc(ctypes.Structure):
+    """Mirror of ``struct me_gemm_desc`` (include/metaenc.h)."""
+    _fields_ = [
+        ("op", c_int32), ("ab_dtype", c_int32),
+        ("M", c_int64), ("N", c_int64), ("K", c_int64),
+        ("A", c_void_p), ("lda", c_int64),
+        ("B", c_void_p), ("ldb", c_int64),
+        ("C", c_void_p), ("ldc", c_int64), ("c_dtype", c_int32),
+        ("act", c_int32),
+        ("alpha", c_float), ("beta", c_float),
+        ("bias", c_void_p),
+        ("colscale", c_void_p),
+        ("preact", c_void_p), ("ldpre", c_int64), ("preact_dtype", c_int32),
+        ("aux_dtype", c_int32),
+        ("aux", c_void_p), ("ldaux", c_int64),
+        ("residual", c_void_p), ("ldres", c_int64), ("res_dtype", c_int32),
+        ("reserved0", c_int32),
+        ("res_row_mod", c_int64),
+        ("out_group_rows", c_int64), ("out_group_stride", c_int64), ("out_row_offset", c_int64),
+    ]
+
+
+# name -> (restype, argtypes).  Every symbol include/metaenc.h declares must be listed here
+# (tests/test_boundary.py cross-checks the header against this table and against the built .so).
+SIGNATURES = {
+    "me_abi_version": (c_int, []),
+    "me_last_error": (c_char_p, []),
+    "me_build_arch": (c_char_p, []),
+    "me_device_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "me_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                 c_int64, c_int, c_float, c_void_p]),
+    "me_layernorm_bwd_workspace": (c_size_t, [c_int]),
+    "me_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                 c_int64, c_int, c_void_p, c_void_p]),
+    "me_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "me_colsum_workspace": (c_size_t, [c_int64]),
+    "me_colsum": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    "me_attention_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int,
+                                 c_float, c_int, c_void_p]),
+    "me_attention_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                 c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "me_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "me_transpose_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p]),
+    "me_add_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "me_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 11 + [c_void_p]),
+    "me_unpatchify_add": (c_int, [c_void_p, c_int, c_void_p] + [c_int] * 11 + [c_void_p]),
+    "me_timeseries_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_void_p), POINTER(c_int32),
+                                    c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "me_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                              c_float, c_int, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libmetaenc.so and bind every declared symbol.  Raises MetaEncError if the library or a symbol is
+    missing -- the product path never silently degrades to PyTorch ops."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise MetaEncError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m metatransformer_amd.build` "
+            "(needs hipcc; cross-compiles gfx950 without a GPU). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MetaEncError(f"libmetaenc.so does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.me_abi_version() != 1:
+        raise MetaEncError(f"libmetaenc.so ABI version {lib.me_abi_version()} != 1; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().me_last_error()
+        raise MetaEncError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return ME_F32
+    if dt == torch.bfloat16:
+        return ME_BF16
+    raise MetaEncError(f"unsupported dtype {dt}: libmetaenc computes in float32 or bfloat16")
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream

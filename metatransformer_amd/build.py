@@ -1,0 +1,75 @@
+"""Build libmetaenc.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m metatransformer_amd.build [--force]
+
+Sources: metatransformer_amd/csrc/*.hip  ->  metatransformer_amd/libmetaenc.so
+(the .so is git-ignored but travels to the GPU box with the snapshot).
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libmetaenc.so")
+OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value", "-ffp-contract=fast"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.isfile(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def _deps() -> list:
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))
+                  + [os.path.join(os.path.dirname(HERE), "include", "metaenc.h")])
+
+
+def needs_build() -> bool:
+    if not os.path.isfile(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(f) > t for f in _deps())
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return OUT
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    headers = [f for f in _deps() if f.endswith(".h")]
+    hdr_t = max(os.path.getmtime(h) for h in headers)
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        if (not force and os.path.isfile(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and os.path.getmtime(obj) > hdr_t):
+            return obj
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print("[metaenc build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT + ".tmp"] + objs
+    if verbose:
+        print("[metaenc build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(OUT + ".tmp", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

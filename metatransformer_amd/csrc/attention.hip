@@ -1,0 +1,625 @@
+// attention.hip -- fused multi-head self-attention core (forward + backward), flash-style.
+//
+// Replaces PointCloud/openpoints/models/layers/attention.py:28-35: the qkv reshape/permute, (q @ k^T) * scale,
+// softmax(-1), attn @ v and the transpose back to [B,N,C].  The [B,H,N,N] score matrix is never written: K/V
+// tiles of 64 keys are staged in LDS, the softmax runs online in registers, heads are addressed in place in
+// the [tokens, 3C] Linear output (no permute copy) and O is written head-major straight into [tokens, C].
+//
+// MFMA formulation (32x32 shapes, see common.h): every product is issued "transposed" so that the softmax
+// row (one query) lives in ONE lane (plus its partner lane^32):
+//   S^T[kv][q] = K Q^T           A = K rows (from LDS), B = Q rows (registers)      -> lane q, regs kv
+//   O^T[d][q] += V^T P^T         A = V^T rows d (LDS, transposed while staging), B = P (registers, in place)
+// The row max / row sum are 16-register reductions plus one xor-32 shuffle; the running rescale of O^T is a
+// per-lane scalar.  The reduction-index permutation the accumulator layout imposes on P is absorbed by reading
+// V^T with the same permutation (common.h: any assignment works if A and B agree).
+// fp32 runs the same code on the exact-fp32 MFMA (parity mode); bf16 is the performance mode.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int AT_THREADS = 256;
+constexpr int KVT = 64;      // keys per LDS tile
+constexpr int QPB = 128;     // queries per block (32 per wave)
+
+template <typename T, int HD> struct Cfg {
+    static constexpr int E = 16 / sizeof(T);
+    static constexpr int CPR = HD / E;                       // 16-byte chunks per row along d
+    static constexpr int NKK = HD / (2 * E);                 // chunk pairs along d
+    static constexpr int NDB = HD / 32;                      // 32-wide d blocks
+    static constexpr int RROW = HD * sizeof(T) + 16;         // row-major tile row stride (bytes), conflict-free pad
+    static constexpr int TROW = KVT * sizeof(T) + (sizeof(T) == 2 ? 8 : 16);   // transposed tile row stride
+    static constexpr int R_BYTES = KVT * RROW;               // [64][HD] row-major tile
+    static constexpr int T_BYTES = HD * TROW;                // [HD][64] transposed tile
+    static constexpr int NPC = KVT / (2 * E);                // P chunks per 64-key tile (4 bf16 / 8 fp32)
+    static constexpr int R_ITEMS = (KVT * CPR + AT_THREADS - 1) / AT_THREADS;
+    static constexpr int T_ITEMS = sizeof(T) == 2 ? ((KVT / 2) * CPR + AT_THREADS - 1) / AT_THREADS
+                                                  : (KVT * CPR + AT_THREADS - 1) / AT_THREADS;
+    static constexpr int T_REGS = sizeof(T) == 2 ? 2 * T_ITEMS : T_ITEMS;
+};
+
+__device__ __forceinline__ u32x4 zero4() { return u32x4{0u, 0u, 0u, 0u}; }
+
+// ---- row-major [64][HD] tile: global -> regs -> LDS
+template <typename T, int HD> struct RowStage {
+    typedef Cfg<T, HD> C;
+    u32x4 v[C::R_ITEMS];
+    __device__ __forceinline__ void load(const T* __restrict__ base, int64_t ld, int r0, int nrows, int hd, int tid) {
+#pragma unroll
+        for (int i = 0; i < C::R_ITEMS; ++i) {
+            const int it = tid + AT_THREADS * i;
+            const int chunk = it % C::CPR, row = it / C::CPR;
+            const bool ok = (row < KVT) && (r0 + row < nrows) && (chunk * C::E < hd);
+            v[i] = ok ? *reinterpret_cast<const u32x4*>(base + (int64_t)(r0 + row) * ld + chunk * C::E) : zero4();
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < C::R_ITEMS; ++i) {
+            const int it = tid + AT_THREADS * i;
+            const int chunk = it % C::CPR, row = it / C::CPR;
+            if (row < KVT) *reinterpret_cast<u32x4*>(lds + row * C::RROW + chunk * 16) = v[i];
+        }
+    }
+};
+
+// ---- transposed [HD][64] tile (rows = d, 64 keys/queries contiguous): global -> regs -> LDS
+template <typename T, int HD> struct TransStage;
+template <int HD> struct TransStage<bf16_t, HD> {
+    typedef Cfg<bf16_t, HD> C;
+    u32x4 v[C::T_REGS];
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int64_t ld, int r0, int nrows, int hd, int tid) {
+#pragma unroll
+        for (int i = 0; i < C::T_ITEMS; ++i) {
+            const int it = tid + AT_THREADS * i;
+            const int chunk = it % C::CPR, p = it / C::CPR;
+            const int row = r0 + 2 * p;
+            const bool okc = (p < KVT / 2) && (chunk * 8 < hd);
+            v[2 * i] = (okc && row < nrows) ? *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + chunk * 8) : zero4();
+            v[2 * i + 1] = (okc && row + 1 < nrows) ? *reinterpret_cast<const u32x4*>(base + (int64_t)(row + 1) * ld + chunk * 8) : zero4();
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < C::T_ITEMS; ++i) {
+            const int it = tid + AT_THREADS * i;
+            const int chunk = it % C::CPR, p = it / C::CPR;
+            if (p < KVT / 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t w0 = v[2 * i][e >> 1], w1 = v[2 * i + 1][e >> 1];
+                    const uint32_t lo = (e & 1) ? (w0 >> 16) : (w0 & 0xffffu);
+                    const uint32_t hi = (e & 1) ? (w1 & 0xffff0000u) : (w1 << 16);
+                    *reinterpret_cast<uint32_t*>(lds + (chunk * 8 + e) * C::TROW + p * 4) = lo | hi;
+                }
+            }
+        }
+    }
+};
+template <int HD> struct TransStage<float, HD> {
+    typedef Cfg<float, HD> C;
+    u32x4 v[C::T_REGS];
+    __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int r0, int nrows, int hd, int tid) {
+#pragma unroll
+        for (int i = 0; i < C::T_ITEMS; ++i) {
+            const int it = tid + AT_THREADS * i;
+            const int chunk = it % C::CPR, row = it / C::CPR;
+            const bool ok = (row < KVT) && (r0 + row < nrows) && (chunk * 4 < hd);
+            v[i] = ok ? *reinterpret_cast<const u32x4*>(base + (int64_t)(r0 + row) * ld + chunk * 4) : zero4();
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < C::T_ITEMS; ++i) {
+            const int it = tid + AT_THREADS * i;
+            const int chunk = it % C::CPR, row = it / C::CPR;
+            if (row < KVT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    *reinterpret_cast<uint32_t*>(lds + (chunk * 4 + e) * C::TROW + row * 4) = v[i][e];
+            }
+        }
+    }
+};
+
+// A-operand chunk from a row-major tile: row, d-chunk index (2*kk + h)
+template <typename T, int HD>
+__device__ __forceinline__ typename Chunk<T>::type rtile_chunk(const char* lds, int row, int chunk) {
+    return *reinterpret_cast<const typename Chunk<T>::type*>(lds + row * Cfg<T, HD>::RROW + chunk * 16);
+}
+// A-operand chunk from a transposed tile: row d, P-chunk c (0..NPC-1) of the 64-wide tile, half h.
+// Element e of the chunk is reduction index (within the 64-tile):
+//   bf16: 16c + 4h + (e&3) + 8(e>>2)        fp32: 8c + 4h + e
+// which is exactly the index that accumulator register (E*(c % (NPC/2)) + e) of 32-subtile u = c / (NPC/2)
+// holds in half h (acc_row), so S/P registers feed the next MFMA without any cross-lane movement.
+template <int HD>
+__device__ __forceinline__ bf16x8 ttile_chunk(const bf16_t*, const char* lds, int d, int c, int h) {
+    const char* base = lds + d * Cfg<bf16_t, HD>::TROW;
+    union { u32x2 w[2]; bf16x8 b; } u;
+    u.w[0] = *reinterpret_cast<const u32x2*>(base + (16 * c + 4 * h) * 2);
+    u.w[1] = *reinterpret_cast<const u32x2*>(base + (16 * c + 8 + 4 * h) * 2);
+    return u.b;
+}
+template <int HD>
+__device__ __forceinline__ f32x4 ttile_chunk(const float*, const char* lds, int d, int c, int h) {
+    return *reinterpret_cast<const f32x4*>(lds + d * Cfg<float, HD>::TROW + (8 * c + 4 * h) * 4);
+}
+// B-operand chunk c from the two 32x32 accumulators of a 64-wide tile
+__device__ __forceinline__ bf16x8 pack_chunk(const bf16_t*, const f32x16 (&s)[2], int c) {
+    const int u = c >> 1, o = (c & 1) * 8;
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16_t)s[u][o + e];
+    return r;
+}
+__device__ __forceinline__ f32x4 pack_chunk(const float*, const f32x16 (&s)[2], int c) {
+    const int u = c >> 2, o = (c & 3) * 4;
+    return f32x4{s[u][o], s[u][o + 1], s[u][o + 2], s[u][o + 3]};
+}
+
+template <typename T> __device__ __forceinline__ void store_quad(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store_quad<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store_quad<bf16_t>(bf16_t* p, f32x4 v) {
+    bf16x4 o;
+    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// =====================================================================================================
+// forward
+// =====================================================================================================
+template <typename T, int HD>
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restrict__ qkv, int64_t ld,
+                                                              T* __restrict__ out, int64_t ldo,
+                                                              float* __restrict__ lse, int N, int H, int hd,
+                                                              float scale) {
+    typedef Cfg<T, HD> C;
+    typedef typename Chunk<T>::type chunk_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + C::R_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int qbase = blockIdx.x * QPB + wave * 32;
+    const int Cdim = H * hd;
+    const T* qptr = qkv + (int64_t)b * N * ld + head * hd;
+    const T* kptr = qptr + Cdim;
+    const T* vptr = qptr + 2 * Cdim;
+
+    chunk_t qf[C::NKK];
+    {
+        const int qrow = (qbase + l31 < N) ? qbase + l31 : N - 1;
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            const int d = (2 * kk + h) * C::E;
+            u32x4 raw = (d < hd) ? *reinterpret_cast<const u32x4*>(qptr + (int64_t)qrow * ld + d) : zero4();
+            qf[kk] = *reinterpret_cast<chunk_t*>(&raw);
+        }
+    }
+    f32x16 o[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const bool active = qbase < N;      // wave-uniform
+    const int ntiles = (N + KVT - 1) / KVT;
+
+    RowStage<T, HD> ks;
+    TransStage<T, HD> vs;
+    ks.load(kptr, ld, 0, N, hd, tid);
+    vs.load(vptr, ld, 0, N, hd, tid);
+    for (int j = 0; j < ntiles; ++j) {
+        __syncthreads();
+        ks.store(Ks, tid);
+        vs.store(Vs, tid);
+        __syncthreads();
+        if (j + 1 < ntiles) {
+            ks.load(kptr, ld, (j + 1) * KVT, N, hd, tid);
+            vs.load(vptr, ld, (j + 1) * KVT, N, hd, tid);
+        }
+        if (!active) continue;
+        f32x16 s[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < C::NKK; ++kk)
+                s[u] = mma_chunk(rtile_chunk<T, HD>(Ks, 32 * u + l31, 2 * kk + h), qf[kk], s[u]);
+        }
+        const int kv0 = j * KVT;
+        float mt = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv0 + 32 * u + acc_row(r, h);
+                const float v = (kv < N) ? s[u][r] * scale : -INFINITY;
+                s[u][r] = v;
+                mt = fmaxf(mt, v);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);      // finite: every tile holds at least one valid key
+        const float alpha = __expf(m_run - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(s[u][r] - m_new);
+                s[u][r] = p;
+                ps += p;
+            }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) o[db] *= alpha;
+#pragma unroll
+        for (int c = 0; c < C::NPC; ++c) {
+            const chunk_t pb = pack_chunk((const T*)nullptr, s, c);
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db)
+                o[db] = mma_chunk(ttile_chunk<HD>((const T*)nullptr, Vs, 32 * db + l31, c, h), pb, o[db]);
+        }
+    }
+    if (!active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = qbase + l31;
+    if (q < N) {
+        T* orow = out + ((int64_t)b * N + q) * ldo + head * hd;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * db + 8 * g + 4 * h;
+                if (d < hd)
+                    store_quad<T>(orow + d, f32x4{o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv,
+                                                  o[db][4 * g + 3] * inv});
+            }
+        if (lse && h == 0) lse[((int64_t)b * H + head) * N + q] = m_run + __logf(l_tot);
+    }
+}
+
+// =====================================================================================================
+// backward
+//   delta[q]   = sum_d dO[q,d] O[q,d]
+//   P          = exp(S*scale - lse[q]) ; dP = dO V^T ; dS = P * (dP - delta[q]) * scale
+//   dV = P^T dO ; dK = dS^T Q ; dQ = dS K
+// Two kernels, no atomics: (1) dK/dV: a wave owns 32 keys, walks query tiles; (2) dQ: a wave owns 32 queries,
+// walks key tiles (recomputing S and dP).
+// =====================================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const void* __restrict__ o, int64_t ldo,
+                                                         const void* __restrict__ dout, int64_t lddo, int dt,
+                                                         float* __restrict__ delta, int N, int H, int hd, int64_t rows) {
+    // one wave per (token row, head)
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= rows * H) return;
+    const int64_t row = gw / H;
+    const int head = (int)(gw % H);
+    float s = 0.f;
+    for (int d = lane; d < hd; d += 64)
+        s += load1_as_f32(o, dt, row * ldo + head * hd + d) * load1_as_f32(dout, dt, row * lddo + head * hd + d);
+    s = wave_sum(s);
+    if (lane == 0) {
+        const int64_t b = row / N, n = row % N;
+        delta[(b * H + head) * N + n] = s;
+    }
+}
+
+// ---- dK / dV
+template <typename T, int HD>
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkdv_kernel(const T* __restrict__ qkv, int64_t ld,
+                                                                   const T* __restrict__ dout, int64_t lddo,
+                                                                   const float* __restrict__ lse,
+                                                                   const float* __restrict__ delta,
+                                                                   T* __restrict__ dqkv, int64_t lddq, int N, int H,
+                                                                   int hd, float scale) {
+    typedef Cfg<T, HD> C;
+    typedef typename Chunk<T>::type chunk_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;                           // [64 q][HD]
+    char* dOs = Qs + C::R_BYTES;               // [64 q][HD]
+    char* QTs = dOs + C::R_BYTES;              // [HD][64 q]
+    char* dOTs = QTs + C::T_BYTES;             // [HD][64 q]
+    float* lse_s = reinterpret_cast<float*>(dOTs + C::T_BYTES);   // [64]
+    float* del_s = lse_s + KVT;                                   // [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int kvbase = blockIdx.x * QPB + wave * 32;
+    const int Cdim = H * hd;
+    const T* qptr = qkv + (int64_t)b * N * ld + head * hd;
+    const T* kptr = qptr + Cdim;
+    const T* vptr = qptr + 2 * Cdim;
+    const T* doptr = dout + (int64_t)b * N * lddo + head * hd;
+    const float* lse_bh = lse + ((int64_t)b * H + head) * N;
+    const float* del_bh = delta + ((int64_t)b * H + head) * N;
+
+    chunk_t kf[C::NKK], vf[C::NKK];
+    {
+        const int kvrow = (kvbase + l31 < N) ? kvbase + l31 : N - 1;
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            const int d = (2 * kk + h) * C::E;
+            u32x4 rk = (d < hd) ? *reinterpret_cast<const u32x4*>(kptr + (int64_t)kvrow * ld + d) : zero4();
+            u32x4 rv = (d < hd) ? *reinterpret_cast<const u32x4*>(vptr + (int64_t)kvrow * ld + d) : zero4();
+            kf[kk] = *reinterpret_cast<chunk_t*>(&rk);
+            vf[kk] = *reinterpret_cast<chunk_t*>(&rv);
+        }
+    }
+    f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    const bool active = kvbase < N;
+    const bool kv_ok = kvbase + l31 < N;
+    const int ntiles = (N + KVT - 1) / KVT;
+
+    RowStage<T, HD> qs, dos;
+    TransStage<T, HD> qts, dots;
+    for (int j = 0; j < ntiles; ++j) {
+        const int q0 = j * KVT;
+        qs.load(qptr, ld, q0, N, hd, tid);
+        dos.load(doptr, lddo, q0, N, hd, tid);
+        qts.load(qptr, ld, q0, N, hd, tid);
+        dots.load(doptr, lddo, q0, N, hd, tid);
+        __syncthreads();
+        qs.store(Qs, tid);
+        dos.store(dOs, tid);
+        qts.store(QTs, tid);
+        dots.store(dOTs, tid);
+        if (tid < KVT) {
+            const int q = q0 + tid;
+            lse_s[tid] = (q < N) ? lse_bh[q] : INFINITY;     // exp(s - inf) = 0 masks padded queries
+            del_s[tid] = (q < N) ? del_bh[q] : 0.f;
+        }
+        __syncthreads();
+        if (!active) continue;
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[u][r] = 0.f; dp[u][r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < C::NKK; ++kk) {
+                s[u] = mma_chunk(rtile_chunk<T, HD>(Qs, 32 * u + l31, 2 * kk + h), kf[kk], s[u]);      // S[q][kv]
+                dp[u] = mma_chunk(rtile_chunk<T, HD>(dOs, 32 * u + l31, 2 * kk + h), vf[kk], dp[u]);   // dP[q][kv]
+            }
+        }
+        // lane: kv = l31 (fixed), regs: q = 32u + acc_row(r,h)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 L = *reinterpret_cast<const f32x4*>(lse_s + 32 * u + 8 * g + 4 * h);
+                const f32x4 D = *reinterpret_cast<const f32x4*>(del_s + 32 * u + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float p = kv_ok ? __expf(s[u][r] * scale - L[e]) : 0.f;
+                    s[u][r] = p;                                   // P
+                    dp[u][r] = p * (dp[u][r] - D[e]) * scale;      // dS
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < C::NPC; ++c) {
+            const chunk_t pb = pack_chunk((const T*)nullptr, s, c);
+            const chunk_t dsb = pack_chunk((const T*)nullptr, dp, c);
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) {
+                dv[db] = mma_chunk(ttile_chunk<HD>((const T*)nullptr, dOTs, 32 * db + l31, c, h), pb, dv[db]);   // dV^T[d][kv]
+                dk[db] = mma_chunk(ttile_chunk<HD>((const T*)nullptr, QTs, 32 * db + l31, c, h), dsb, dk[db]);  // dK^T[d][kv]
+            }
+        }
+    }
+    if (!active || !kv_ok) return;
+    T* dkrow = dqkv + ((int64_t)b * N + kvbase + l31) * lddq + Cdim + head * hd;
+    T* dvrow = dkrow + Cdim;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 32 * db + 8 * g + 4 * h;
+            if (d < hd) {
+                store_quad<T>(dkrow + d, f32x4{dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]});
+                store_quad<T>(dvrow + d, f32x4{dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]});
+            }
+        }
+}
+
+// ---- dQ
+template <typename T, int HD>
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __restrict__ qkv, int64_t ld,
+                                                                 const T* __restrict__ dout, int64_t lddo,
+                                                                 const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta,
+                                                                 T* __restrict__ dqkv, int64_t lddq, int N, int H,
+                                                                 int hd, float scale) {
+    typedef Cfg<T, HD> C;
+    typedef typename Chunk<T>::type chunk_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                    // [64 kv][HD]
+    char* Vs = Ks + C::R_BYTES;         // [64 kv][HD]
+    char* KTs = Vs + C::R_BYTES;        // [HD][64 kv]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int qbase = blockIdx.x * QPB + wave * 32;
+    const int Cdim = H * hd;
+    const T* qptr = qkv + (int64_t)b * N * ld + head * hd;
+    const T* kptr = qptr + Cdim;
+    const T* vptr = qptr + 2 * Cdim;
+    const T* doptr = dout + (int64_t)b * N * lddo + head * hd;
+
+    const bool q_ok = qbase + l31 < N;
+    const int qrow = q_ok ? qbase + l31 : N - 1;
+    chunk_t qf[C::NKK], dof[C::NKK];
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk) {
+        const int d = (2 * kk + h) * C::E;
+        u32x4 rq = (d < hd) ? *reinterpret_cast<const u32x4*>(qptr + (int64_t)qrow * ld + d) : zero4();
+        u32x4 rd = (d < hd) ? *reinterpret_cast<const u32x4*>(doptr + (int64_t)qrow * lddo + d) : zero4();
+        qf[kk] = *reinterpret_cast<chunk_t*>(&rq);
+        dof[kk] = *reinterpret_cast<chunk_t*>(&rd);
+    }
+    const float lse_q = lse[((int64_t)b * H + head) * N + qrow];
+    const float del_q = delta[((int64_t)b * H + head) * N + qrow];
+    f32x16 dq[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+    const bool active = qbase < N;
+    const int ntiles = (N + KVT - 1) / KVT;
+
+    RowStage<T, HD> ks, vs;
+    TransStage<T, HD> kts;
+    for (int j = 0; j < ntiles; ++j) {
+        const int kv0 = j * KVT;
+        ks.load(kptr, ld, kv0, N, hd, tid);
+        vs.load(vptr, ld, kv0, N, hd, tid);
+        kts.load(kptr, ld, kv0, N, hd, tid);
+        __syncthreads();
+        ks.store(Ks, tid);
+        vs.store(Vs, tid);
+        kts.store(KTs, tid);
+        __syncthreads();
+        if (!active) continue;
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[u][r] = 0.f; dp[u][r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < C::NKK; ++kk) {
+                s[u] = mma_chunk(rtile_chunk<T, HD>(Ks, 32 * u + l31, 2 * kk + h), qf[kk], s[u]);      // S^T[kv][q]
+                dp[u] = mma_chunk(rtile_chunk<T, HD>(Vs, 32 * u + l31, 2 * kk + h), dof[kk], dp[u]);   // dP^T[kv][q]
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv0 + 32 * u + acc_row(r, h);
+                const float p = (kv < N) ? __expf(s[u][r] * scale - lse_q) : 0.f;
+                dp[u][r] = p * (dp[u][r] - del_q) * scale;     // dS^T
+            }
+#pragma unroll
+        for (int c = 0; c < C::NPC; ++c) {
+            const chunk_t dsb = pack_chunk((const T*)nullptr, dp, c);
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db)
+                dq[db] = mma_chunk(ttile_chunk<HD>((const T*)nullptr, KTs, 32 * db + l31, c, h), dsb, dq[db]);   // dQ^T[d][q]
+        }
+    }
+    if (!active || !q_ok) return;
+    T* dqrow = dqkv + ((int64_t)b * N + qbase + l31) * lddq + head * hd;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 32 * db + 8 * g + 4 * h;
+            if (d < hd)
+                store_quad<T>(dqrow + d, f32x4{dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]});
+        }
+}
+
+template <typename K> void set_smem(K kernel, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename T, int HD>
+int launch_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
+               hipStream_t stream) {
+    typedef Cfg<T, HD> C;
+    const size_t smem = C::R_BYTES + C::T_BYTES;
+    static bool once = false;
+    if (!once) { set_smem(attn_fwd_kernel<T, HD>, smem); once = true; }
+    dim3 grid((N + QPB - 1) / QPB, H, B);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), grid, dim3(AT_THREADS), smem, stream, reinterpret_cast<const T*>(qkv), ld,
+                       reinterpret_cast<T*>(out), ldo, lse, N, H, hd, scale);
+    ME_CHECK_LAUNCH("me_attention_fwd");
+    return ME_OK;
+}
+
+template <typename T, int HD>
+int launch_bwd(const void* qkv, int64_t ld, const void* dout, int64_t lddo, const float* lse, const float* delta, void* dqkv,
+               int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
+    typedef Cfg<T, HD> C;
+    const size_t smem1 = 2 * C::R_BYTES + 2 * C::T_BYTES + 2 * KVT * sizeof(float);
+    const size_t smem2 = 2 * C::R_BYTES + C::T_BYTES;
+    static bool once = false;
+    if (!once) {
+        set_smem(attn_bwd_dkdv_kernel<T, HD>, smem1);
+        set_smem(attn_bwd_dq_kernel<T, HD>, smem2);
+        once = true;
+    }
+    dim3 grid((N + QPB - 1) / QPB, H, B);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, HD>), grid, dim3(AT_THREADS), smem1, stream,
+                       reinterpret_cast<const T*>(qkv), ld, reinterpret_cast<const T*>(dout), lddo, lse, delta,
+                       reinterpret_cast<T*>(dqkv), lddq, N, H, hd, scale);
+    ME_CHECK_LAUNCH("me_attention_bwd(dkdv)");
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), grid, dim3(AT_THREADS), smem2, stream,
+                       reinterpret_cast<const T*>(qkv), ld, reinterpret_cast<const T*>(dout), lddo, lse, delta,
+                       reinterpret_cast<T*>(dqkv), lddq, N, H, hd, scale);
+    ME_CHECK_LAUNCH("me_attention_bwd(dq)");
+    return ME_OK;
+}
+
+int check_attn_args(const char* fn, int64_t ld, int B, int N, int H, int hd, int dtype) {
+    ME_CHECK_ARG(me_dtype_ok(dtype), "%s: bad dtype", fn);
+    ME_CHECK_ARG(B > 0 && N > 0 && H > 0 && hd > 0, "%s: bad shape B=%d N=%d H=%d hd=%d", fn, B, N, H, hd);
+    const int E = dtype == ME_BF16 ? 8 : 4;
+    ME_CHECK_ARG(hd % E == 0, "%s: head_dim=%d must be a multiple of %d", fn, hd, E);
+    ME_CHECK_ARG(hd <= 128, "%s: head_dim=%d > 128 unsupported", fn, hd);
+    ME_CHECK_ARG(ld % E == 0, "%s: row stride must be a multiple of %d elements", fn, E);
+    ME_CHECK_ARG(B <= 65535 && H <= 65535, "%s: B and H must be <= 65535", fn);
+    return ME_OK;
+}
+
+}  // namespace
+
+#define ATTN_DISPATCH(FN, ...)                                                                   \
+    do {                                                                                         \
+        if (dtype == ME_BF16) {                                                                  \
+            if (head_dim <= 32) return FN<bf16_t, 32>(__VA_ARGS__);                              \
+            if (head_dim <= 64) return FN<bf16_t, 64>(__VA_ARGS__);                              \
+            return FN<bf16_t, 128>(__VA_ARGS__);                                                 \
+        } else {                                                                                 \
+            if (head_dim <= 32) return FN<float, 32>(__VA_ARGS__);                               \
+            if (head_dim <= 64) return FN<float, 64>(__VA_ARGS__);                               \
+            return FN<float, 128>(__VA_ARGS__);                                                  \
+        }                                                                                        \
+    } while (0)
+
+extern "C" int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int B, int N,
+                                int H, int head_dim, float scale, int dtype, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(qkv && out, "me_attention_fwd: null pointer");
+    int rc = check_attn_args("me_attention_fwd", ld_qkv, B, N, H, head_dim, dtype);
+    if (rc) return rc;
+    ME_CHECK_ARG(ld_out % 4 == 0, "me_attention_fwd: ld_out must be a multiple of 4");
+    ATTN_DISPATCH(launch_fwd, qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+}
+
+extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out, int64_t ld_out, const void* dout,
+                                int64_t ld_dout, const float* lse, float* delta, void* dqkv, int64_t ld_dqkv, int B,
+                                int N, int H, int head_dim, float scale, int dtype, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(qkv && out && dout && lse && delta && dqkv, "me_attention_bwd: null pointer");
+    int rc = check_attn_args("me_attention_bwd", ld_qkv, B, N, H, head_dim, dtype);
+    if (rc) return rc;
+    const int E = dtype == ME_BF16 ? 8 : 4;
+    ME_CHECK_ARG(ld_dout % E == 0 && ld_dqkv % 4 == 0, "me_attention_bwd: bad strides");
+    const int64_t rows = (int64_t)B * N;
+    const int64_t nw = rows * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, stream, out, ld_out, dout, ld_dout,
+                       dtype, delta, N, H, head_dim, rows);
+    ME_CHECK_LAUNCH("me_attention_bwd(delta)");
+    ATTN_DISPATCH(launch_bwd, qkv, ld_qkv, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale, stream);
+}

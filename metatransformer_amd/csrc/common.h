@@ -1,0 +1,123 @@
+// common.h -- shared device/host helpers for libmetaenc (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/metaenc.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define ME_WAVE 64
+
+// ---- host-side error plumbing (api.cpp owns the storage)
+void me_set_error(const char* fmt, ...);
+#define ME_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            me_set_error(__VA_ARGS__);          \
+            return ME_ERR_ARG;                  \
+        }                                       \
+    } while (0)
+#define ME_CHECK_LAUNCH(name)                                                        \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            me_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return ME_ERR_HIP;                                                       \
+        }                                                                            \
+    } while (0)
+
+static inline size_t me_dtype_size(int dt) { return dt == ME_BF16 ? 2 : 4; }
+static inline bool me_dtype_ok(int dt) { return dt == ME_F32 || dt == ME_BF16; }
+
+// ---- device helpers
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// 4 consecutive elements at element index idx (idx % 4 == 0) of a [.., ld] matrix of dtype dt -> fp32
+__device__ __forceinline__ f32x4 load4_as_f32(const void* base, int dt, int64_t idx) {
+    if (dt == ME_BF16) {
+        u32x2 raw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+        f32x4 r;
+        r[0] = __uint_as_float(raw[0] << 16);
+        r[1] = __uint_as_float(raw[0] & 0xffff0000u);
+        r[2] = __uint_as_float(raw[1] << 16);
+        r[3] = __uint_as_float(raw[1] & 0xffff0000u);
+        return r;
+    }
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+}
+__device__ __forceinline__ void store4_from_f32(void* base, int dt, int64_t idx, f32x4 v) {
+    if (dt == ME_BF16) {
+        bf16x4 o;
+        o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(base) + idx) = o;
+    } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
+    }
+}
+__device__ __forceinline__ float load1_as_f32(const void* base, int dt, int64_t idx) {
+    if (dt == ME_BF16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(base)[idx]);
+    return reinterpret_cast<const float*>(base)[idx];
+}
+__device__ __forceinline__ void store1_from_f32(void* base, int dt, int64_t idx, float v) {
+    if (dt == ME_BF16) reinterpret_cast<bf16_t*>(base)[idx] = (bf16_t)v;
+    else reinterpret_cast<float*>(base)[idx] = v;
+}
+
+// exact-erf GELU and its derivative (nn.GELU(approximate='none'))
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- MFMA "16-byte chunk" abstraction.
+// A chunk is 16 bytes of an operand row along the reduction dimension: 8 bf16 or 4 fp32.
+// For the 32x32 MFMA shapes lane l supplies, for output row/col (l & 31), the reduction slice owned by
+// half h = l >> 5.  mma_chunk() contracts one chunk-pair (both halves) into a 32x32 fp32 accumulator:
+//   bf16: one v_mfma_f32_32x32x16_bf16   (16 reduction elements: 8 per half)
+//   fp32: four v_mfma_f32_32x32x2_f32    ( 8 reduction elements: 4 per half; exact fp32 fma chain)
+// Any assignment of reduction indices to (half, element) is valid as long as A and B use the same one.
+// Accumulator layout (both dtypes): acc[r] = D[i = (r&3) + 8*(r>>2) + 4*h][j = l & 31].
+template <typename T> struct Chunk;
+template <> struct Chunk<bf16_t> {
+    typedef bf16x8 type;
+    static constexpr int E = 8;   // elements per chunk
+};
+template <> struct Chunk<float> {
+    typedef f32x4 type;
+    static constexpr int E = 4;
+};
+
+__device__ __forceinline__ f32x16 mma_chunk(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma_chunk(f32x4 a, f32x4 b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+}
+// row index inside a 32x32 accumulator tile for register r of half h
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

@@ -1,0 +1,324 @@
+// elementwise.hip -- HBM-bound helpers around the encoder: casts / weight repacks, bias-gradient column sums,
+// pos-embed row adds, the Data2Seq patch gathers and the time-series embedding, fused AdamW.
+// All of these are bandwidth-bound integer/index or element-wise work: coalesced 16-byte accesses, grid-stride
+// loops, no LDS unless a transpose needs it.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+inline unsigned ew_blocks(int64_t work_items) {
+    int64_t b = (work_items + EW_THREADS - 1) / EW_THREADS;
+    const int64_t cap = 256 * 8;   // 256 CUs x 8 blocks, grid-stride the rest
+    return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+__global__ __launch_bounds__(EW_THREADS) void cast_kernel(const void* __restrict__ src, int sdt, void* __restrict__ dst,
+                                                          int ddt, int64_t n) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS)
+        store4_from_f32(dst, ddt, i * 4, load4_as_f32(src, sdt, i * 4));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        store1_from_f32(dst, ddt, i, load1_as_f32(src, sdt, i));
+    }
+}
+
+// dst[c, r] = src[r, c]; 64x64 tiles through LDS (padded), coalesced on both sides
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const void* __restrict__ src, int sdt, void* __restrict__ dst,
+                                                             int ddt, int64_t rows, int64_t cols) {
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? load1_as_f32(src, sdt, r * cols + c) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) store1_from_f32(dst, ddt, c * rows + r, tile[tx][i]);
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void add_rows_kernel(const void* __restrict__ x, int xdt,
+                                                              const void* __restrict__ pos, int pdt, void* __restrict__ y,
+                                                              int ydt, int64_t rows, int64_t pos_rows, int cols) {
+    const int c4 = cols / 4;
+    const int64_t total = rows * c4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t r = i / c4;
+        const int c = (int)(i % c4) * 4;
+        f32x4 v = load4_as_f32(x, xdt, r * cols + c);
+        v += load4_as_f32(pos, pdt, (r % pos_rows) * cols + c);
+        store4_from_f32(y, ydt, r * cols + c, v);
+    }
+}
+
+// ---- column sums (bias gradients): stage 1: grid (col blocks of 256, row splits); each thread owns 4 columns? no:
+// lanes own single columns (coalesced 2/4-byte reads across the wave are fine for this size); 4 waves x splits rows.
+constexpr int CS_SPLITS = 128;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ x, int xdt, int64_t ldx, int64_t rows,
+                                                             int64_t cols, float* __restrict__ partial) {
+    // block: 64 columns x 4 row-lanes; blockIdx.y = row split
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t rows_per = (rows + CS_SPLITS - 1) / CS_SPLITS;
+    const int64_t rb = (int64_t)blockIdx.y * rows_per;
+    const int64_t re = rb + rows_per < rows ? rb + rows_per : rows;
+    float a = 0.f;
+    if (c < cols)
+        for (int64_t r = rb + w; r < re; r += 4) a += load1_as_f32(x, xdt, r * ldx + c);
+    sh[w][lane] = a;
+    __syncthreads();
+    if (w == 0 && c < cols)
+        partial[(int64_t)blockIdx.y * cols + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int64_t cols,
+                                                           float* __restrict__ out, int accumulate) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float a = 0.f;
+    for (int s = 0; s < CS_SPLITS; ++s) a += partial[(int64_t)s * cols + c];
+    out[c] = accumulate ? out[c] + a : a;
+}
+
+// ---- patch gather: cols[(b, pt, py, px), (c, dt, dy, dx)] = x[b, c, pt*st+dt, py*sh+dy, px*sw+dx]
+struct PatchGeom {
+    int B, Cin, T, H, W, kt, kh, kw, st, sh, sw, gt, gh, gw;
+};
+__global__ __launch_bounds__(EW_THREADS) void patchify_kernel(const void* __restrict__ x, int xdt, void* __restrict__ out,
+                                                              int odt, PatchGeom g) {
+    const int64_t feat = (int64_t)g.Cin * g.kt * g.kh * g.kw;
+    const int64_t ntok = (int64_t)g.B * g.gt * g.gh * g.gw;
+    const int64_t total = ntok * feat;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t tok = i / feat;
+        int64_t f = i % feat;
+        const int dx = (int)(f % g.kw); f /= g.kw;
+        const int dy = (int)(f % g.kh); f /= g.kh;
+        const int dt = (int)(f % g.kt); f /= g.kt;
+        const int c = (int)f;
+        int64_t t = tok;
+        const int px = (int)(t % g.gw); t /= g.gw;
+        const int py = (int)(t % g.gh); t /= g.gh;
+        const int pt = (int)(t % g.gt); t /= g.gt;
+        const int b = (int)t;
+        const int64_t src = ((((int64_t)b * g.Cin + c) * g.T + (pt * g.st + dt)) * g.H + (py * g.sh + dy)) * g.W + (px * g.sw + dx);
+        store1_from_f32(out, odt, i, load1_as_f32(x, xdt, src));
+    }
+}
+__global__ __launch_bounds__(EW_THREADS) void unpatchify_add_kernel(const void* __restrict__ dcols, int ddt,
+                                                                    float* __restrict__ dx_out, PatchGeom g) {
+    const int64_t feat = (int64_t)g.Cin * g.kt * g.kh * g.kw;
+    const int64_t ntok = (int64_t)g.B * g.gt * g.gh * g.gw;
+    const int64_t total = ntok * feat;
+    const bool overlap = g.st < g.kt || g.sh < g.kh || g.sw < g.kw;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t tok = i / feat;
+        int64_t f = i % feat;
+        const int dx = (int)(f % g.kw); f /= g.kw;
+        const int dy = (int)(f % g.kh); f /= g.kh;
+        const int dt = (int)(f % g.kt); f /= g.kt;
+        const int c = (int)f;
+        int64_t t = tok;
+        const int px = (int)(t % g.gw); t /= g.gw;
+        const int py = (int)(t % g.gh); t /= g.gh;
+        const int pt = (int)(t % g.gt); t /= g.gt;
+        const int b = (int)t;
+        const int64_t dst = ((((int64_t)b * g.Cin + c) * g.T + (pt * g.st + dt)) * g.H + (py * g.sh + dy)) * g.W + (px * g.sw + dx);
+        const float v = load1_as_f32(dcols, ddt, i);
+        if (overlap) atomicAdd(dx_out + dst, v);
+        else dx_out[dst] += v;
+    }
+}
+
+// ---- time-series DataEmbedding
+constexpr int TS_MAX_MARK = 8;
+struct TsTables {
+    const float* tab[TS_MAX_MARK];
+    int rows[TS_MAX_MARK];
+};
+__global__ __launch_bounds__(EW_THREADS) void ts_embed_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const int32_t* __restrict__ marks, int n_mark, TsTables tt,
+                                                              const float* __restrict__ pe, void* __restrict__ out, int odt,
+                                                              int B, int L, int cin, int C, int32_t* __restrict__ err) {
+    // one block per (b, l) token; threads over channels.  Reference summation order (Data2Seq/Time_Series.py:93,123):
+    // value + (hour + weekday + day + month [+ minute]) + pos, i.e. mark columns 3,2,1,0[,4].
+    const int64_t tok = blockIdx.x;
+    const int b = (int)(tok / L), l = (int)(tok % L);
+    const int lm = (l - 1 + L) % L, lp = (l + 1) % L;
+    const float* x0 = x + ((int64_t)b * L + lm) * cin;
+    const float* x1 = x + ((int64_t)b * L + l) * cin;
+    const float* x2 = x + ((int64_t)b * L + lp) * cin;
+    for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+        const float* wc = w + (int64_t)c * cin * 3;
+        float v = 0.f;
+        for (int i = 0; i < cin; ++i) v += wc[i * 3 + 0] * x0[i];
+        float v1 = 0.f;
+        for (int i = 0; i < cin; ++i) v1 += wc[i * 3 + 1] * x1[i];
+        float v2 = 0.f;
+        for (int i = 0; i < cin; ++i) v2 += wc[i * 3 + 2] * x2[i];
+        v = (v + v1) + v2;
+        if (marks) {
+            float t = 0.f;
+            const int order[5] = {3, 2, 1, 0, 4};
+            bool first = true;
+            for (int k = 0; k < 5; ++k) {
+                const int f = order[k];
+                if (f >= n_mark) continue;
+                int idx = marks[tok * n_mark + f];
+                if (idx < 0 || idx >= tt.rows[f]) {
+                    if (err) atomicExch(err, 1);
+                    idx = 0;
+                }
+                const float e = tt.tab[f][(int64_t)idx * C + c];
+                t = first ? e : t + e;
+                first = false;
+            }
+            v += t;
+        }
+        if (pe) v += pe[(int64_t)l * C + c];
+        store1_from_f32(out, odt, tok * C + c, v);
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                           float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                           float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        const float gi = g[i] * gscale;
+        float pi = p[i];
+        pi *= (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int me_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(src && dst && n >= 0, "me_cast: bad args");
+    ME_CHECK_ARG(me_dtype_ok(src_dtype) && me_dtype_ok(dst_dtype), "me_cast: bad dtype");
+    if (n == 0) return ME_OK;
+    hipLaunchKernelGGL(cast_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(EW_THREADS), 0, stream, src, src_dtype, dst, dst_dtype, n);
+    ME_CHECK_LAUNCH("me_cast");
+    return ME_OK;
+}
+
+extern "C" int me_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t rows, int64_t cols,
+                                 void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(src && dst && rows > 0 && cols > 0, "me_transpose_cast: bad args");
+    ME_CHECK_ARG(me_dtype_ok(src_dtype) && me_dtype_ok(dst_dtype), "me_transpose_cast: bad dtype");
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+    hipLaunchKernelGGL(transpose_cast_kernel, grid, dim3(256), 0, stream, src, src_dtype, dst, dst_dtype, rows, cols);
+    ME_CHECK_LAUNCH("me_transpose_cast");
+    return ME_OK;
+}
+
+extern "C" int me_add_rows(const void* x, int x_dtype, const void* pos, int pos_dtype, void* y, int y_dtype, int64_t rows,
+                           int64_t pos_rows, int cols, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(x && pos && y && rows > 0 && pos_rows > 0 && cols > 0 && cols % 4 == 0, "me_add_rows: bad args");
+    ME_CHECK_ARG(me_dtype_ok(x_dtype) && me_dtype_ok(pos_dtype) && me_dtype_ok(y_dtype), "me_add_rows: bad dtype");
+    hipLaunchKernelGGL(add_rows_kernel, dim3(ew_blocks(rows * (cols / 4))), dim3(EW_THREADS), 0, stream, x, x_dtype, pos,
+                       pos_dtype, y, y_dtype, rows, pos_rows, cols);
+    ME_CHECK_LAUNCH("me_add_rows");
+    return ME_OK;
+}
+
+extern "C" size_t me_colsum_workspace(int64_t cols) { return (size_t)CS_SPLITS * (size_t)cols * sizeof(float); }
+
+extern "C" int me_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, int64_t cols, float* out, int accumulate,
+                         void* workspace, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(x && out && workspace && rows > 0 && cols > 0, "me_colsum: bad args");
+    ME_CHECK_ARG(me_dtype_ok(x_dtype), "me_colsum: bad dtype");
+    float* partial = reinterpret_cast<float*>(workspace);
+    dim3 grid((unsigned)((cols + 63) / 64), CS_SPLITS);
+    hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, stream, x, x_dtype, ldx, rows, cols, partial);
+    ME_CHECK_LAUNCH("me_colsum(partial)");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, partial, cols, out,
+                       accumulate);
+    ME_CHECK_LAUNCH("me_colsum(final)");
+    return ME_OK;
+}
+
+static int make_geom(PatchGeom& g, int B, int Cin, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw) {
+    ME_CHECK_ARG(B > 0 && Cin > 0 && T > 0 && H > 0 && W > 0 && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
+                 "patchify: bad geometry");
+    ME_CHECK_ARG(T >= kt && H >= kh && W >= kw, "patchify: kernel larger than input");
+    g = PatchGeom{B, Cin, T, H, W, kt, kh, kw, st, sh, sw, (T - kt) / st + 1, (H - kh) / sh + 1, (W - kw) / sw + 1};
+    return ME_OK;
+}
+
+extern "C" int me_patchify(const void* x, int x_dtype, void* cols, int cols_dtype, int B, int Cin, int T, int H, int W,
+                           int kt, int kh, int kw, int st, int sh, int sw, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(x && cols, "me_patchify: null pointer");
+    ME_CHECK_ARG(me_dtype_ok(x_dtype) && me_dtype_ok(cols_dtype), "me_patchify: bad dtype");
+    PatchGeom g;
+    int rc = make_geom(g, B, Cin, T, H, W, kt, kh, kw, st, sh, sw);
+    if (rc) return rc;
+    const int64_t total = (int64_t)B * g.gt * g.gh * g.gw * Cin * kt * kh * kw;
+    hipLaunchKernelGGL(patchify_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, stream, x, x_dtype, cols, cols_dtype, g);
+    ME_CHECK_LAUNCH("me_patchify");
+    return ME_OK;
+}
+
+extern "C" int me_unpatchify_add(const void* dcols, int dcols_dtype, float* dx, int B, int Cin, int T, int H, int W, int kt,
+                                 int kh, int kw, int st, int sh, int sw, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(dcols && dx, "me_unpatchify_add: null pointer");
+    ME_CHECK_ARG(me_dtype_ok(dcols_dtype), "me_unpatchify_add: bad dtype");
+    PatchGeom g;
+    int rc = make_geom(g, B, Cin, T, H, W, kt, kh, kw, st, sh, sw);
+    if (rc) return rc;
+    const int64_t total = (int64_t)B * g.gt * g.gh * g.gw * Cin * kt * kh * kw;
+    hipLaunchKernelGGL(unpatchify_add_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, stream, dcols, dcols_dtype, dx, g);
+    ME_CHECK_LAUNCH("me_unpatchify_add");
+    return ME_OK;
+}
+
+extern "C" int me_timeseries_embed(const float* x, const float* conv_w, const int32_t* marks, int n_mark,
+                                   const float* const* tables, const int32_t* table_rows, const float* pe, void* out,
+                                   int out_dtype, int B, int L, int cin, int C, int32_t* err_flag, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(x && conv_w && out && B > 0 && L > 0 && cin > 0 && C > 0, "me_timeseries_embed: bad args");
+    ME_CHECK_ARG(me_dtype_ok(out_dtype), "me_timeseries_embed: bad dtype");
+    ME_CHECK_ARG(n_mark >= 0 && n_mark <= 5, "me_timeseries_embed: n_mark must be 0..5");
+    ME_CHECK_ARG(n_mark == 0 || (marks && tables && table_rows), "me_timeseries_embed: marks given without tables");
+    TsTables tt;
+    for (int f = 0; f < TS_MAX_MARK; ++f) { tt.tab[f] = nullptr; tt.rows[f] = 0; }
+    for (int f = 0; f < n_mark; ++f) {   // `tables` / `table_rows` are HOST arrays of device pointers / sizes
+        tt.tab[f] = tables[f];
+        tt.rows[f] = table_rows[f];
+        ME_CHECK_ARG(tt.tab[f] && tt.rows[f] > 0, "me_timeseries_embed: bad table %d", f);
+    }
+    hipLaunchKernelGGL(ts_embed_kernel, dim3((unsigned)((int64_t)B * L)), dim3(EW_THREADS), 0, stream, x, conv_w,
+                       n_mark ? marks : nullptr, n_mark, tt, pe, out, out_dtype, B, L, cin, C, err_flag);
+    ME_CHECK_LAUNCH("me_timeseries_embed");
+    return ME_OK;
+}
+
+extern "C" int me_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                             void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "me_adamw_step: bad args");
+    if (n == 0) return ME_OK;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+    ME_CHECK_LAUNCH("me_adamw_step");
+    return ME_OK;
+}

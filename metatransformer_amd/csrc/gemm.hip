@@ -1,0 +1,313 @@
+// gemm.hip -- MFMA GEMM with fused epilogue for the encoder's Linear layers (forward, dgrad, wgrad).
+//
+// Replaces nn.Linear / GELU / residual-add of the reference Block
+// (PointCloud/openpoints/models/layers/attention.py:28,36,56-57; mlp.py:30-34) -- see include/metaenc.h.
+//
+// Kernel family "g128": 128x128 output tile, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile made
+// of 2x2 MFMA 32x32 accumulators.  Operand rows are staged through LDS as 128-byte rows of reduction data
+// (64 bf16 or 32 fp32 per K-step), XOR-swizzled so that the 16-byte fragment reads (row = lane) are
+// bank-conflict free, double-buffered with one barrier per K-step, global loads for step t+1 in flight
+// while step t computes.  The MFMA is issued with the *weight* tile as the A operand and the *activation*
+// tile as the B operand, so every lane owns one output row and 4 consecutive output columns per
+// accumulator quad -> 8/16-byte epilogue loads and stores.
+//
+//   NT: C[M,N] = A[M,K] B[N,K]^T   rows of both operands are K-contiguous: 16-byte chunk copies.
+//   TN: C[M,N] = A[K,M]^T B[K,N]   (wgrad) the loader transposes while staging: pairs of reduction rows are
+//                                  interleaved into dwords so that LDS rows are again reduction-contiguous.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BN = 128;
+constexpr int ROWB = 128;                 // bytes of reduction data per LDS row per K-step
+constexpr int TILE_BYTES = BM * ROWB;     // 16 KiB per operand tile
+constexpr int NT = 256;
+
+struct GemmParams {
+    const void* A; const void* B; void* C;
+    int64_t M, N, K, lda, ldb, ldc;
+    int c_dtype, act;
+    float alpha, beta;
+    const float* bias; const float* colscale;
+    void* preact; int64_t ldpre; int preact_dtype;
+    const void* aux; int64_t ldaux; int aux_dtype;
+    const void* residual; int64_t ldres; int res_dtype;
+    int64_t res_row_mod, out_group_rows, out_group_stride, out_row_offset;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int lds_off(int row, int byteoff) {
+    const int chunk = byteoff >> 4;
+    return row * ROWB + (((chunk ^ ((row >> 1) & 7)) << 4) | (byteoff & 15));
+}
+
+struct Stage { u32x4 v[4]; };
+
+// ---- NT loader: operand S[nrows, K] (K contiguous); tile rows r0.., reduction k0..
+template <typename T>
+__device__ __forceinline__ void load_nt(Stage& s, const T* __restrict__ S, int64_t ld, int64_t nrows, int64_t K,
+                                        int64_t r0, int64_t k0, int tid) {
+    constexpr int E = 16 / sizeof(T);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int item = tid + NT * i;
+        const int chunk = item & 7, row = item >> 3;
+        int64_t gr = r0 + row;
+        gr = gr < nrows ? gr : nrows - 1;
+        const int64_t gk = k0 + chunk * E;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        s.v[i] = (gk < K) ? *reinterpret_cast<const u32x4*>(S + gr * ld + gk) : z;
+    }
+}
+__device__ __forceinline__ void store_nt(const Stage& s, char* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int item = tid + NT * i;
+        const int chunk = item & 7, row = item >> 3;
+        *reinterpret_cast<u32x4*>(lds + lds_off(row, chunk * 16)) = s.v[i];
+    }
+}
+
+// ---- TN loader: operand S[Tred, ncols] (reduction index is the ROW); tile cols c0.., reduction t0..
+template <typename T> struct TnLoader;
+template <> struct TnLoader<bf16_t> {
+    static __device__ __forceinline__ void load(Stage& s, const bf16_t* __restrict__ S, int64_t ld, int64_t ncols,
+                                                int64_t Tred, int64_t c0, int64_t t0, int tid) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int item = tid + NT * i;
+            const int cc = item & 15, tp = item >> 4;
+            int64_t col = c0 + cc * 8;
+            col = col <= ncols - 8 ? col : ncols - 8;
+            const int64_t t = t0 + 2 * tp;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            s.v[2 * i] = (t < Tred) ? *reinterpret_cast<const u32x4*>(S + t * ld + col) : z;
+            s.v[2 * i + 1] = (t + 1 < Tred) ? *reinterpret_cast<const u32x4*>(S + (t + 1) * ld + col) : z;
+        }
+    }
+    static __device__ __forceinline__ void store(const Stage& s, char* lds, int tid) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int item = tid + NT * i;
+            const int cc = item & 15, tp = item >> 4;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t w0 = s.v[2 * i][e >> 1], w1 = s.v[2 * i + 1][e >> 1];
+                const uint32_t lo = (e & 1) ? (w0 >> 16) : (w0 & 0xffffu);
+                const uint32_t hi = (e & 1) ? (w1 & 0xffff0000u) : (w1 << 16);
+                *reinterpret_cast<uint32_t*>(lds + lds_off(cc * 8 + e, tp * 4)) = lo | hi;
+            }
+        }
+    }
+};
+template <> struct TnLoader<float> {
+    static __device__ __forceinline__ void load(Stage& s, const float* __restrict__ S, int64_t ld, int64_t ncols,
+                                                int64_t Tred, int64_t c0, int64_t t0, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int item = tid + NT * i;
+            const int cc = item & 31, t = item >> 5;
+            int64_t col = c0 + cc * 4;
+            col = col <= ncols - 4 ? col : ncols - 4;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            s.v[i] = (t0 + t < Tred) ? *reinterpret_cast<const u32x4*>(S + (t0 + t) * ld + col) : z;
+        }
+    }
+    static __device__ __forceinline__ void store(const Stage& s, char* lds, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int item = tid + NT * i;
+            const int cc = item & 31, t = item >> 5;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                *reinterpret_cast<uint32_t*>(lds + lds_off(cc * 4 + e, t * 4)) = s.v[i][e];
+        }
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void compute_tile(const char* ldsA, const char* ldsB, f32x16 (&acc)[2][2],
+                                             int wm, int wn, int lane) {
+    typedef typename Chunk<T>::type chunk_t;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        chunk_t a[2], b[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+            a[mi] = *reinterpret_cast<const chunk_t*>(ldsA + lds_off(wm * 64 + mi * 32 + l31, (2 * kk + h) * 16));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+            b[ni] = *reinterpret_cast<const chunk_t*>(ldsB + lds_off(wn * 64 + ni * 32 + l31, (2 * kk + h) * 16));
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = mma_chunk(b[ni], a[mi], acc[mi][ni]);   // D[i = n][j = m]
+    }
+}
+
+__device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, int64_t n, f32x4 v) {
+    v *= p.alpha;
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.preact) store4_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v);
+    if (p.act == ME_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (p.aux) {
+        const f32x4 a = load4_as_f32(p.aux, p.aux_dtype, m * p.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a[e]);
+    }
+    if (p.colscale) v *= *reinterpret_cast<const f32x4*>(p.colscale + n);
+    if (p.residual) {
+        const int64_t rr = p.res_row_mod ? (m % p.res_row_mod) : m;
+        v += load4_as_f32(p.residual, p.res_dtype, rr * p.ldres + n);
+    }
+    const int64_t orow = p.out_group_rows
+                             ? (m / p.out_group_rows) * p.out_group_stride + (m % p.out_group_rows) + p.out_row_offset
+                             : m;
+    if (p.beta != 0.0f) v += p.beta * load4_as_f32(p.C, p.c_dtype, orow * p.ldc + n);
+    store4_from_f32(p.C, p.c_dtype, orow * p.ldc + n, v);
+}
+
+template <typename T, bool TN>
+__global__ __launch_bounds__(NT) void gemm_g128_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap: block b runs on XCD b % 8; give every XCD a contiguous range of tiles so
+    // that the blocks sharing an activation row-panel hit the same L2.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tm = wgid / p.tiles_n, tn = wgid % p.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+    constexpr int KSTEP = ROWB / sizeof(T);
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+    const int nk = (int)((p.K + KSTEP - 1) / KSTEP);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    Stage sa, sb;
+    auto gload = [&](int t) {
+        const int64_t k0 = (int64_t)t * KSTEP;
+        if (TN) {
+            TnLoader<T>::load(sa, A, p.lda, p.M, p.K, m0, k0, tid);
+            TnLoader<T>::load(sb, B, p.ldb, p.N, p.K, n0, k0, tid);
+        } else {
+            load_nt<T>(sa, A, p.lda, p.M, p.K, m0, k0, tid);
+            load_nt<T>(sb, B, p.ldb, p.N, p.K, n0, k0, tid);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* la = smem + buf * 2 * TILE_BYTES;
+        char* lb = la + TILE_BYTES;
+        if (TN) {
+            TnLoader<T>::store(sa, la, tid);
+            TnLoader<T>::store(sb, lb, tid);
+        } else {
+            store_nt(sa, la, tid);
+            store_nt(sb, lb, tid);
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) gload(t + 1);
+        compute_tile<T>(smem + buf * 2 * TILE_BYTES, smem + buf * 2 * TILE_BYTES + TILE_BYTES, acc, wm, wn, lane);
+        if (t + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int64_t m = m0 + wm * 64 + mi * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * h;
+                if (n >= p.N) continue;
+                f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+                epilogue_quad(p, m, n, v);
+            }
+        }
+    }
+}
+
+template <typename T, bool TN>
+int launch_g128(const GemmParams& p, hipStream_t stream) {
+    const size_t lds = 4 * TILE_BYTES;   // 64 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g128_kernel<T, TN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int64_t nblk = (int64_t)p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((gemm_g128_kernel<T, TN>), dim3((unsigned)nblk), dim3(NT), lds, stream, p);
+    ME_CHECK_LAUNCH("me_gemm(g128)");
+    return ME_OK;
+}
+
+}  // namespace
+
+extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(d != nullptr, "me_gemm: null descriptor");
+    ME_CHECK_ARG(d->op == ME_GEMM_NT || d->op == ME_GEMM_TN, "me_gemm: bad op %d", d->op);
+    ME_CHECK_ARG(me_dtype_ok(d->ab_dtype) && me_dtype_ok(d->c_dtype), "me_gemm: bad dtype");
+    ME_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "me_gemm: empty problem M=%lld N=%lld K=%lld",
+                 (long long)d->M, (long long)d->N, (long long)d->K);
+    ME_CHECK_ARG(d->A && d->B && d->C, "me_gemm: null operand");
+    const int E = d->ab_dtype == ME_BF16 ? 8 : 4;
+    ME_CHECK_ARG(d->N % 4 == 0, "me_gemm: N=%lld must be a multiple of 4", (long long)d->N);
+    ME_CHECK_ARG(d->ldc % 4 == 0, "me_gemm: ldc must be a multiple of 4");
+    if (d->op == ME_GEMM_NT) {
+        ME_CHECK_ARG(d->K % E == 0 && d->lda % E == 0 && d->ldb % E == 0,
+                     "me_gemm(NT): K, lda, ldb must be multiples of %d elements (16 bytes)", E);
+    } else {
+        ME_CHECK_ARG(d->M % E == 0 && d->N % E == 0 && d->lda % E == 0 && d->ldb % E == 0,
+                     "me_gemm(TN): M, N, lda, ldb must be multiples of %d elements (16 bytes)", E);
+    }
+    ME_CHECK_ARG(((uintptr_t)d->A | (uintptr_t)d->B | (uintptr_t)d->C) % 16 == 0, "me_gemm: operands must be 16-byte aligned");
+    ME_CHECK_ARG(d->act == ME_ACT_NONE || d->act == ME_ACT_GELU, "me_gemm: bad act");
+    if (d->preact) ME_CHECK_ARG(me_dtype_ok(d->preact_dtype) && d->ldpre % 4 == 0, "me_gemm: bad preact");
+    if (d->aux) ME_CHECK_ARG(me_dtype_ok(d->aux_dtype) && d->ldaux % 4 == 0, "me_gemm: bad aux");
+    if (d->residual) ME_CHECK_ARG(me_dtype_ok(d->res_dtype) && d->ldres % 4 == 0, "me_gemm: bad residual");
+
+    GemmParams p;
+    p.A = d->A; p.B = d->B; p.C = d->C;
+    p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+    p.c_dtype = d->c_dtype; p.act = d->act; p.alpha = d->alpha; p.beta = d->beta;
+    p.bias = d->bias; p.colscale = d->colscale;
+    p.preact = d->preact; p.ldpre = d->ldpre; p.preact_dtype = d->preact_dtype;
+    p.aux = d->aux; p.ldaux = d->ldaux; p.aux_dtype = d->aux_dtype;
+    p.residual = d->residual; p.ldres = d->ldres; p.res_dtype = d->res_dtype;
+    p.res_row_mod = d->res_row_mod; p.out_group_rows = d->out_group_rows;
+    p.out_group_stride = d->out_group_stride; p.out_row_offset = d->out_row_offset;
+    p.tiles_m = (int)((d->M + BM - 1) / BM);
+    p.tiles_n = (int)((d->N + BN - 1) / BN);
+    ME_CHECK_ARG((int64_t)p.tiles_m * p.tiles_n < (1ll << 31), "me_gemm: too many tiles");
+
+    if (d->ab_dtype == ME_BF16)
+        return d->op == ME_GEMM_NT ? launch_g128<bf16_t, false>(p, stream) : launch_g128<bf16_t, true>(p, stream);
+    return d->op == ME_GEMM_NT ? launch_g128<float, false>(p, stream) : launch_g128<float, true>(p, stream);
+}

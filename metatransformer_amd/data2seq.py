@@ -1,0 +1,298 @@
+"""Data2Seq tokenizers on the HIP path: ``Data2Seq(modality, dim)(data) -> [B, N, dim]``.
+
+Mirrors the reference's tokenizer plugin point (Data2Seq/Data2Seq.py:19-55, README.md:113-122) for the
+modalities whose tokenizers are on the north-star path:
+
+  image        Data2Seq/Image.py:8-28        Conv2d(3, C, k16, s16)           -> patch gather + MFMA GEMM
+  audio        Data2Seq/Acoustic.py:5-23     Conv2d(1, C, k16, stride 10x10)  -> overlapping gather + GEMM
+               (as written the reference class cannot be constructed -- it double-tuples patch_size; the working
+               construction is Audio/src/models/ast_models.py:86, which this follows)
+  video        Video/models/modeling_finetune.py:263-297  Conv3d(3, C, k=s=(2,16,16)) tubelets
+               (Data2Seq/Video.py is broken in the reference)
+  time-series  Data2Seq/Time_Series.py:109-126  Conv1d k3 circular + sinusoid PE + temporal-embedding gathers
+
+Parameter names follow the reference modules (``proj.weight`` / ``proj.bias``;
+``value_embedding.tokenConv.weight`` ...), so their state_dicts interchange.  The text / graph / hyper-spectral
+tokenizers of the reference are CLIP / eigen-decomposition / broken glue and are out of scope.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _capi, ops
+from ._capi import ME_GEMM_TN, MetaEncError, check, dtype_code, ptr, stream_ptr
+
+
+def _compute_dtype(weight: torch.Tensor) -> torch.dtype:
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_gpu_dtype()
+        if dt != torch.bfloat16:
+            raise MetaEncError(f"autocast dtype {dt} unsupported")
+        return dt
+    return weight.dtype
+
+
+class _PatchEmbedFn(torch.autograd.Function):
+    """conv-as-GEMM: gather patches (integer index math, bit-exact), project with the MFMA GEMM, fuse bias,
+    optional pos-embed add and cls-token row offset into the GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pos, geom, cdt, prefix_rows):
+        kt, kh, kw, st, sh, sw = geom
+        B = x.shape[0]
+        Cout = weight.shape[0]
+        x = x.contiguous()
+        cols, tps = ops.patchify(x, kt, kh, kw, st, sh, sw, cdt)
+        w2 = ops.cast(weight.detach().reshape(Cout, -1).contiguous(), cdt)
+        out_tps = tps + prefix_rows
+        if prefix_rows:
+            y = torch.zeros((B * out_tps, Cout), dtype=cdt, device=x.device)
+        else:
+            y = torch.empty((B * out_tps, Cout), dtype=cdt, device=x.device)
+        pos2 = None
+        if pos is not None:
+            pos2 = pos.detach().reshape(-1, Cout)
+            if pos2.shape[0] != tps:
+                raise MetaEncError(f"pos-embed has {pos2.shape[0]} rows, tokenizer produces {tps} tokens")
+            pos2 = pos2.contiguous()
+        ops.gemm(cols, w2, out=y, bias=bias, residual=pos2, res_row_mod=tps if pos2 is not None else 0,
+                 out_group=(tps, out_tps, prefix_rows) if prefix_rows else (0, 0, 0))
+        ctx.save_for_backward(cols, weight)
+        ctx.meta = (tuple(x.shape), geom, cdt, tps, out_tps, prefix_rows, bias is not None, pos is not None)
+        return y.reshape(B, out_tps, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, weight = ctx.saved_tensors
+        x_shape, geom, cdt, tps, out_tps, prefix_rows, has_bias, has_pos = ctx.meta
+        kt, kh, kw, st, sh, sw = geom
+        B = x_shape[0]
+        Cout = weight.shape[0]
+        dy = dy.contiguous()
+        if prefix_rows:
+            dy = dy[:, prefix_rows:, :].contiguous()
+        dy2 = ops.cast(dy.reshape(B * tps, Cout), cdt)
+        ng = ctx.needs_input_grad
+        dW = db = dx = dpos = None
+        if ng[1]:
+            dW = ops.gemm(dy2, cols, op=ME_GEMM_TN, out_dtype=weight.dtype).reshape(weight.shape)
+        if ng[2] and has_bias:
+            db = ops.colsum(dy2).to(weight.dtype)
+        if ng[0]:
+            wT = ops.transpose_cast(weight.detach().reshape(Cout, -1).contiguous(), cdt)     # [K, Cout]
+            dcols = ops.gemm(dy2, wT)                                                        # [B*tps, K]
+            dx = ops.unpatchify_add(dcols, x_shape, kt, kh, kw, st, sh, sw)
+        if has_pos and ng[3]:
+            raise MetaEncError("gradient w.r.t. a fused pos-embed is not implemented; add it outside the tokenizer")
+        return dx, dW, db, dpos, None, None, None
+
+
+class _ConvPatchEmbed(nn.Module):
+    geom = (1, 16, 16, 1, 16, 16)
+
+    def forward(self, x: torch.Tensor, pos_embed: Optional[torch.Tensor] = None, prefix_rows: int = 0) -> torch.Tensor:
+        if not x.is_cuda:
+            raise MetaEncError(f"{type(self).__name__} runs on MI355X only (CPU tensor given; no CPU fallback)")
+        self._check_input(x)
+        cdt = _compute_dtype(self.proj.weight)
+        return _PatchEmbedFn.apply(x, self.proj.weight, self.proj.bias, pos_embed, self.geom, cdt, prefix_rows)
+
+    def _check_input(self, x):
+        pass
+
+
+class PatchEmbed(_ConvPatchEmbed):
+    """2D Image to Patch Embedding -- Data2Seq/Image.py:4-28 (same constructor, same parameter names)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_c=3, embed_dim=768, norm_layer=None):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_c, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        if norm_layer is not None:
+            raise MetaEncError("norm_layer is unused by the reference forward (Data2Seq/Image.py:27) and unsupported")
+        self.norm = nn.Identity()
+        self.geom = (1, patch_size, patch_size, 1, patch_size, patch_size)
+
+    def _check_input(self, x):
+        B, C, H, W = x.shape
+        assert H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+
+
+class AcousticPatchEmbed(_ConvPatchEmbed):
+    """Spectrogram patch embed, Conv2d(in_chans, C, k=(16,16), stride=(fstride,tstride)) -- Data2Seq/Acoustic.py:5-23,
+    Audio/src/models/ast_models.py:86."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=1, embed_dim=768, fstride=10, tstride=10):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=(fstride, tstride))
+        self.geom = (1, patch_size, patch_size, 1, fstride, tstride)
+
+    @staticmethod
+    def num_tokens(F: int, T: int, patch: int = 16, fstride: int = 10, tstride: int = 10) -> int:
+        return ((F - patch) // fstride + 1) * ((T - patch) // tstride + 1)
+
+
+class VideoPatchEmbed(_ConvPatchEmbed):
+    """Tubelet embed, Conv3d(3, C, k=s=(tubelet,16,16)) -- Video/models/modeling_finetune.py:263-297."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, num_frames=16, tubelet_size=2):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.tubelet_size = tubelet_size
+        self.patch_size = (patch_size, patch_size)
+        self.num_patches = (img_size // patch_size) ** 2 * (num_frames // tubelet_size)
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=(tubelet_size, patch_size, patch_size),
+                              stride=(tubelet_size, patch_size, patch_size))
+        self.geom = (tubelet_size, patch_size, patch_size, tubelet_size, patch_size, patch_size)
+
+    def _check_input(self, x):
+        B, C, T, H, W = x.shape
+        assert H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+
+
+def sinusoid_table(n: int, d_model: int) -> torch.Tensor:
+    """PositionalEmbedding / FixedEmbedding table -- Data2Seq/Time_Series.py:12-23,49-57 (host-side constant)."""
+    pe = torch.zeros(n, d_model).float()
+    position = torch.arange(0, n).float().unsqueeze(1)
+    div_term = (torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model)).exp()
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def video_sinusoid_table(n_position: int, d_hid: int) -> torch.Tensor:
+    """get_sinusoid_encoding_table -- Video/models/modeling_finetune.py:302-318 (float64 math, float32 result)."""
+    pos = torch.arange(n_position, dtype=torch.float64).unsqueeze(1)
+    j = torch.arange(d_hid, dtype=torch.float64)
+    angle = pos / torch.pow(torch.tensor(10000.0, dtype=torch.float64), 2 * torch.div(j, 2, rounding_mode="floor") / d_hid)
+    tab = angle.clone()
+    tab[:, 0::2] = torch.sin(angle[:, 0::2])
+    tab[:, 1::2] = torch.cos(angle[:, 1::2])
+    return tab.float().unsqueeze(0)
+
+
+class _TokenConv(nn.Module):
+    def __init__(self, c_in, d_model):
+        super().__init__()
+        self.tokenConv = nn.Conv1d(c_in, d_model, kernel_size=3, padding=1, padding_mode="circular", bias=False)
+        nn.init.kaiming_normal_(self.tokenConv.weight, mode="fan_in", nonlinearity="leaky_relu")
+
+
+class _FixedEmb(nn.Module):
+    def __init__(self, c_in, d_model):
+        super().__init__()
+        self.emb = nn.Embedding(c_in, d_model)
+        self.emb.weight = nn.Parameter(sinusoid_table(c_in, d_model), requires_grad=False)
+
+
+class _Temporal(nn.Module):
+    SIZES = (("month", 13), ("day", 32), ("weekday", 7), ("hour", 24), ("minute", 4))   # mark column order 0..4
+
+    def __init__(self, d_model, freq="h"):
+        super().__init__()
+        if freq == "t":
+            self.minute_embed = _FixedEmb(4, d_model)
+        self.hour_embed = _FixedEmb(24, d_model)
+        self.weekday_embed = _FixedEmb(7, d_model)
+        self.day_embed = _FixedEmb(32, d_model)
+        self.month_embed = _FixedEmb(13, d_model)
+
+    def tables(self):
+        names = ["month", "day", "weekday", "hour"] + (["minute"] if hasattr(self, "minute_embed") else [])
+        return [getattr(self, f"{n}_embed").emb.weight for n in names]
+
+
+class _PosEmb(nn.Module):
+    def __init__(self, d_model, max_len=5000):
+        super().__init__()
+        self.register_buffer("pe", sinusoid_table(max_len, d_model).unsqueeze(0))
+
+
+class DataEmbedding(nn.Module):
+    """Time-series DataEmbedding -- Data2Seq/Time_Series.py:109-126 (``embed_type='fixed'``).
+    forward(x [B,L,c_in], x_mark [B,L,4|5] or None) -> [B,L,C].  The three terms (circular Conv1d k3, temporal
+    table gathers indexed by ``x_mark.long()``, positional slice ``pe[:, :L]``) are one fused kernel; the gathers
+    are integer-indexed and bit-exact.  Dropout(p=0.1) is identity in eval; training-mode dropout is applied by
+    the caller's nn.Dropout if wanted."""
+
+    def __init__(self, c_in, d_model, embed_type="fixed", freq="h", dropout=0.1):
+        super().__init__()
+        if embed_type != "fixed":
+            raise MetaEncError("only embed_type='fixed' (the reference default) is implemented")
+        self.value_embedding = _TokenConv(c_in, d_model)
+        self.position_embedding = _PosEmb(d_model)
+        self.temporal_embedding = _Temporal(d_model, freq)
+        self.dropout = nn.Dropout(p=dropout)
+        self.d_model = d_model
+
+    def forward(self, x: torch.Tensor, x_mark: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if not x.is_cuda:
+            raise MetaEncError("DataEmbedding runs on MI355X only (CPU tensor given; no CPU fallback)")
+        if self.training and self.dropout.p > 0:
+            raise MetaEncError("training-mode dropout inside DataEmbedding is not implemented; call .eval() or p=0")
+        if torch.is_grad_enabled() and self.value_embedding.tokenConv.weight.requires_grad:
+            raise MetaEncError("backward through the time-series tokenizer is not implemented yet: "
+                               "freeze value_embedding or run under torch.no_grad()")
+        lib = _capi.load()
+        B, L, cin = x.shape
+        C = self.d_model
+        w = self.value_embedding.tokenConv.weight.detach().float().contiguous()
+        xf = x.detach().float().contiguous()
+        out_dtype = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) else torch.float32
+        out = torch.empty((B, L, C), dtype=out_dtype, device=x.device)
+        pe = self.position_embedding.pe[0].contiguous()
+        if L > pe.shape[0]:
+            raise MetaEncError(f"sequence length {L} exceeds positional table {pe.shape[0]}")
+        err = torch.zeros(1, dtype=torch.int32, device=x.device)
+        n_mark = 0
+        marks = None
+        tab_arr = None
+        rows_arr = None
+        if x_mark is not None:
+            tabs = [t.detach().float().contiguous() for t in self.temporal_embedding.tables()]
+            n_mark = len(tabs)
+            if x_mark.shape[-1] < n_mark:
+                raise MetaEncError(f"x_mark has {x_mark.shape[-1]} columns, need {n_mark}")
+            marks = x_mark[..., :n_mark].long().to(torch.int32).contiguous()      # == x.long() (Time_Series.py:83)
+            tab_arr = (ctypes.c_void_p * n_mark)(*[t.data_ptr() for t in tabs])
+            rows_arr = (ctypes.c_int32 * n_mark)(*[t.shape[0] for t in tabs])
+        check(lib.me_timeseries_embed(ptr(xf), ptr(w), ptr(marks), n_mark, tab_arr, rows_arr, ptr(pe), ptr(out),
+                                      dtype_code(out_dtype), B, L, cin, C, ptr(err), stream_ptr()),
+              "me_timeseries_embed")
+        if x_mark is not None and int(err.item()) != 0:
+            raise IndexError("x_mark holds an index outside its embedding table (nn.Embedding would raise too)")
+        return out
+
+
+class Data2Seq(nn.Module):
+    """``Data2Seq(modality, dim)`` dispatcher -- API shape of Data2Seq/Data2Seq.py:19-55 (which itself does not run
+    as written: SURVEY.md appendix A).  Multi-modal use concatenates along tokens exactly as README.md:118-122:
+    ``features = torch.concat([image_tokenizer(img), ts_tokenizer(ts), audio_tokenizer(spec)], dim=1)``."""
+
+    def __init__(self, modality: str, dim: int, **kw):
+        super().__init__()
+        self.modality = modality
+        if modality == "image":
+            self.embed = PatchEmbed(embed_dim=dim, **kw)
+        elif modality == "audio":
+            self.embed = AcousticPatchEmbed(embed_dim=dim, **kw)
+        elif modality == "video":
+            self.embed = VideoPatchEmbed(embed_dim=dim, **kw)
+        elif modality == "time-series":
+            self.embed = DataEmbedding(c_in=kw.pop("c_in", 1), d_model=dim, **kw)
+        else:
+            raise MetaEncError(f"modality '{modality}' has no HIP tokenizer (in scope: image, audio, video, time-series)")
+
+    def forward(self, data, *args, **kw):
+        return self.embed(data, *args, **kw)

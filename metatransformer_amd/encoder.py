@@ -1,0 +1,258 @@
+"""Drop-in replacement for the reference's encoder plugin point.
+
+Reference usage being replaced (README.md:113-150; every call site in SURVEY.md 2.2):
+
+    from timm.models.vision_transformer import Block
+    encoder = nn.Sequential(*[Block(dim=768, num_heads=12, mlp_ratio=4., qkv_bias=True,
+                                    norm_layer=nn.LayerNorm, act_layer=nn.GELU) for _ in range(12)])
+    encoder.load_state_dict(torch.load("Meta-Transformer_base_patch16_encoder.pth"), strict=True)
+    y = encoder(x)                                # [B, N, C] -> [B, N, C]
+
+With this package only the import changes:
+
+    from metatransformer_amd import Block
+
+``Block`` keeps timm's constructor signature, owns ordinary ``nn.Parameter`` tensors under the reference
+names (``norm1.weight``, ``attn.qkv.weight``, ``mlp.fc1.bias`` ...; in-tree twin of the timm class:
+PointCloud/openpoints/models/layers/attention.py:12-58, mlp.py:11-35) so ``state_dict()`` round-trips with
+the reference checkpoint, works inside ``nn.Sequential`` / slicing / DataParallel / DDP / checkpointing,
+and dispatches forward AND backward to the hand-written HIP kernels of libmetaenc.so through one
+``torch.autograd.Function`` per block.  There is no PyTorch-op fallback: CPU tensors raise.
+
+Compute dtype: bf16 when the parameters are bf16 or when called under ``torch.autocast(dtype=bfloat16)``
+(fp32 master weights, bf16 MFMA, fp32 accumulation / statistics / residual stream), otherwise exact fp32 MFMA.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _capi, ops
+from ._capi import ME_ACT_GELU, ME_GEMM_NT, ME_GEMM_TN, MetaEncError
+
+
+def _resolve_eps(norm_layer) -> float:
+    """timm passes a class or a functools.partial(nn.LayerNorm, eps=1e-6) (1e-5 vs 1e-6 sites)."""
+    probe = norm_layer(8)
+    if not isinstance(probe, nn.LayerNorm):
+        raise MetaEncError(f"norm_layer must build an nn.LayerNorm (got {type(probe).__name__})")
+    return float(probe.eps)
+
+
+class Mlp(nn.Module):
+    """Parameter container with the reference names (mlp.py:15-27): fc1 -> GELU -> fc2."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if act_layer is not nn.GELU:
+            raise MetaEncError("only act_layer=nn.GELU (exact erf) is implemented, as every reference call site uses")
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+
+class Attention(nn.Module):
+    """Parameter container with the reference names (attention.py:13-24)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        if dim % num_heads:
+            raise MetaEncError(f"dim {dim} not divisible by num_heads {num_heads}")
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+
+class _WeightCache:
+    """Compute-dtype copies of the four weight matrices of a block ([out,in] for forward, transposed
+    [in,out] for dgrad), rebuilt when the parameter changes (optimizer step / load_state_dict / .to())."""
+
+    def __init__(self):
+        self._fwd = {}
+        self._tr = {}
+
+    @staticmethod
+    def _key(p: torch.Tensor, dtype):
+        return (p.data_ptr(), p._version, ops.WEIGHT_EPOCH, p.dtype, dtype, p.device)
+
+    def fwd(self, name: str, p: torch.Tensor, dtype) -> torch.Tensor:
+        if p.dtype == dtype:
+            return p.detach()
+        k = self._key(p, dtype)
+        hit = self._fwd.get(name)
+        if hit is None or hit[0] != k:
+            hit = (k, ops.cast(p.detach().contiguous(), dtype))
+            self._fwd[name] = hit
+        return hit[1]
+
+    def transposed(self, name: str, p: torch.Tensor, dtype) -> torch.Tensor:
+        k = self._key(p, dtype)
+        hit = self._tr.get(name)
+        if hit is None or hit[0] != k:
+            hit = (k, ops.transpose_cast(p.detach().contiguous(), dtype))
+            self._tr[name] = hit
+        return hit[1]
+
+
+class _BlockFn(torch.autograd.Function):
+    """forward + backward of one Block on the HIP kernels.  Restates Block.forward (attention.py:55-58)."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g1, g2, blk, cdt):
+        B, N, C = x.shape
+        H = blk.attn.num_heads
+        hd = C // H
+        M = B * N
+        rdt = x.dtype                      # residual-stream dtype
+        cache: _WeightCache = blk._wcache
+        need_grad = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g1, g2))
+        x2 = x.reshape(M, C)
+
+        xn1, mean1, rstd1 = ops.layernorm_fwd(x2, n1w, n1b, blk.eps, cdt, save_stats=need_grad)
+        qkv = ops.gemm(xn1, cache.fwd("qkv", qkvw, cdt), bias=qkvb)
+        o, lse = ops.attention_fwd(qkv, B, N, H, hd, blk.attn.scale, need_lse=need_grad)
+        x1 = ops.gemm(o, cache.fwd("proj", projw, cdt), bias=projb, residual=x2, out_dtype=rdt, colscale=g1)
+        xn2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, blk.eps, cdt, save_stats=need_grad)
+        hpre = torch.empty((M, fc1w.shape[0]), dtype=cdt, device=x.device) if need_grad else None
+        a = ops.gemm(xn2, cache.fwd("fc1", fc1w, cdt), bias=fc1b, act=ME_ACT_GELU, preact=hpre)
+        y = ops.gemm(a, cache.fwd("fc2", fc2w, cdt), bias=fc2b, residual=x1, out_dtype=rdt, colscale=g2)
+
+        if need_grad:
+            ctx.save_for_backward(x2, mean1, rstd1, xn1, qkv, lse, o, x1, mean2, rstd2, xn2, hpre, a,
+                                  n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2)
+            ctx.blk, ctx.cdt, ctx.dims = blk, cdt, (B, N, C, H, hd)
+            ctx.has_bias = (qkvb is not None, projb is not None, fc1b is not None, fc2b is not None)
+        return y.reshape(B, N, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, mean1, rstd1, xn1, qkv, lse, o, x1, mean2, rstd2, xn2, hpre, a,
+         n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2) = ctx.saved_tensors
+        blk, cdt = ctx.blk, ctx.cdt
+        B, N, C, H, hd = ctx.dims
+        M = B * N
+        cache: _WeightCache = blk._wcache
+        rdt = x2.dtype
+        ng = ctx.needs_input_grad      # x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g1, g2
+        dy2 = dy.contiguous().reshape(M, C)
+        if dy2.dtype != rdt:
+            dy2 = ops.cast(dy2, rdt)
+        if g1 is not None or g2 is not None:
+            raise MetaEncError("backward through layer-scale (gamma1/gamma2) is not implemented yet")
+
+        def wgrad(dout, inp, w):      # dW[out,in] = dout^T inp, in the parameter's dtype
+            return ops.gemm(dout, inp, op=ME_GEMM_TN, out_dtype=w.dtype)
+
+        # ---- MLP branch: y = x1 + fc2(gelu(fc1(LN2(x1))))
+        dy_c = ops.cast(dy2, cdt)
+        dh = ops.gemm(dy_c, cache.transposed("fc2", fc2w, cdt), aux=hpre)            # dA * gelu'(h)
+        d_fc2w = wgrad(dy_c, a, fc2w) if ng[11] else None
+        d_fc2b = ops.colsum(dy_c).to(fc2w.dtype) if (ng[12] and ctx.has_bias[3]) else None
+        dxn2 = ops.gemm(dh, cache.transposed("fc1", fc1w, cdt))
+        d_fc1w = wgrad(dh, xn2, fc1w) if ng[9] else None
+        d_fc1b = ops.colsum(dh).to(fc1w.dtype) if (ng[10] and ctx.has_bias[2]) else None
+        need_aff2 = ng[7] or ng[8]
+        dx1, d_n2w, d_n2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w, dy2, rdt, need_aff2)
+
+        # ---- attention branch: x1 = x + proj(attn(qkv(LN1(x))))
+        dx1_c = ops.cast(dx1, cdt)
+        do = ops.gemm(dx1_c, cache.transposed("proj", projw, cdt))
+        d_projw = wgrad(dx1_c, o, projw) if ng[5] else None
+        d_projb = ops.colsum(dx1_c).to(projw.dtype) if (ng[6] and ctx.has_bias[1]) else None
+        dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, hd, blk.attn.scale)
+        dxn1 = ops.gemm(dqkv, cache.transposed("qkv", qkvw, cdt))
+        d_qkvw = wgrad(dqkv, xn1, qkvw) if ng[3] else None
+        d_qkvb = ops.colsum(dqkv).to(qkvw.dtype) if (ng[4] and ctx.has_bias[0]) else None
+        need_aff1 = ng[1] or ng[2]
+        dx, d_n1w, d_n1b = ops.layernorm_bwd(dxn1, x2, mean1, rstd1, n1w, dx1, rdt, need_aff1)
+
+        def aff(g, p):
+            return None if g is None else g.to(p.dtype)
+
+        return (dx.reshape(B, N, C) if ng[0] else None,
+                aff(d_n1w, n1w) if ng[1] else None, aff(d_n1b, n1w) if ng[2] else None,
+                d_qkvw, d_qkvb, d_projw, d_projb,
+                aff(d_n2w, n2w) if ng[7] else None, aff(d_n2b, n2w) if ng[8] else None,
+                d_fc1w, d_fc1b, d_fc2w, d_fc2b, None, None, None, None)
+
+
+class Block(nn.Module):
+    """timm.models.vision_transformer.Block, served by HIP kernels.
+
+    Signature follows timm 0.4.12 (the version the reference pins); ``layer_scale`` adds the per-channel
+    gamma1/gamma2 of the Image pipelines (Image/detection/mmdet_custom/models/backbones/base/vit.py:298-320).
+    """
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, layer_scale=False):
+        super().__init__()
+        self.eps = _resolve_eps(norm_layer)
+        self.norm1 = nn.LayerNorm(dim, eps=self.eps)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                              attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path_prob = float(drop_path)
+        self.drop_path = nn.Identity()          # name kept for state_dict / repr parity (no parameters)
+        self.norm2 = nn.LayerNorm(dim, eps=self.eps)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.layer_scale = bool(layer_scale)
+        if layer_scale:
+            self.gamma1 = nn.Parameter(torch.ones(dim))
+            self.gamma2 = nn.Parameter(torch.ones(dim))
+        self.compute_dtype: Optional[torch.dtype] = None     # override; None = infer (autocast / param dtype)
+        self._wcache = _WeightCache()
+
+    def _compute_dtype(self, x: torch.Tensor) -> torch.dtype:
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_gpu_dtype()
+            if dt != torch.bfloat16:
+                raise MetaEncError(f"autocast dtype {dt} unsupported: libmetaenc computes in bfloat16 or float32")
+            return dt
+        return self.attn.qkv.weight.dtype
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 3:
+            raise MetaEncError(f"Block expects [B, N, C] tokens, got shape {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise MetaEncError("metatransformer_amd.Block runs on MI355X only: input is a CPU tensor and there is "
+                               "no CPU fallback (use oracle/ for CPU reference numbers)")
+        if self.training and (self.attn.attn_drop.p > 0 or self.attn.proj_drop.p > 0 or self.mlp.drop.p > 0
+                              or self.drop_path_prob > 0):
+            raise MetaEncError("stochastic ops (dropout / drop_path with p > 0 in training mode) are not implemented "
+                               "in the HIP path yet; call .eval() or set p = 0")
+        cdt = self._compute_dtype(x)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise MetaEncError(f"unsupported token dtype {x.dtype}")
+        x = x.contiguous()
+        a, m = self.attn, self.mlp
+        g1 = self.gamma1 if self.layer_scale else None
+        g2 = self.gamma2 if self.layer_scale else None
+        return _BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
+                              a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
+                              m.fc2.weight, m.fc2.bias, g1, g2, self, cdt)
+
+
+def build_encoder(depth: int = 12, dim: int = 768, num_heads: int = 12, mlp_ratio: float = 4., qkv_bias: bool = True,
+                  norm_layer=nn.LayerNorm, **kw) -> nn.Sequential:
+    """The reference's canonical construction (README.md:124-135):
+    Base = (12, 768, 12), Large = (24, 1024, 16).  Returns a plain nn.Sequential so that
+    ``load_state_dict(ckpt, strict=True)``, slicing and iteration behave exactly as at the reference call sites."""
+    return nn.Sequential(*[Block(dim=dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                 norm_layer=norm_layer, act_layer=nn.GELU, **kw) for _ in range(depth)])
+
+
+def encoder_flops_per_sample(N: int, C: int, L: int) -> float:
+    """F(N,C,L) = L * (24 N C^2 + 4 N^2 C)  -- the work model of BASELINE.md section 3 (forward)."""
+    return float(L) * (24.0 * N * C * C + 4.0 * N * N * C)

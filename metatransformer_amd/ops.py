@@ -1,0 +1,252 @@
+"""Thin Python wrappers over the C ABI: torch tensors in, device pointers out.
+
+torch is plumbing here (device memory, streams); every computation happens in libmetaenc.so.
+All wrappers require CUDA(ROCm) tensors and raise if handed CPU tensors -- no fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _capi
+from ._capi import GemmDesc, MetaEncError, check, dtype_code, ptr, stream_ptr
+
+# bumped by every libmetaenc op that mutates parameters in place behind autograd's back (the fused optimizer):
+# the per-block weight caches key on it, because raw-pointer writes do not bump tensor._version.
+WEIGHT_EPOCH = 0
+
+# bench.py sets this to a list to bracket every me_gemm launch with events on the launch stream:
+# entries are (op, ab_dtype_code, M, N, K, start_event, end_event).
+GEMM_PROFILE = None
+
+
+def _req(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise MetaEncError(f"{name}: expected a CUDA/ROCm tensor (libmetaenc has no CPU path)")
+    if not t.is_contiguous():
+        raise MetaEncError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Small per-channel vectors (LayerNorm affine, biases) are consumed as fp32."""
+    if t is None:
+        return None
+    return t if t.dtype == torch.float32 else t.float()
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                  out_dtype: torch.dtype, save_stats: bool = True):
+    lib = _capi.load()
+    _req(x, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    g, b = _f32(gamma).contiguous(), _f32(beta).contiguous()
+    check(lib.me_layernorm_fwd(ptr(x), dtype_code(x.dtype), ptr(g), ptr(b), ptr(y), dtype_code(out_dtype),
+                               ptr(mean), ptr(rstd), rows, C, float(eps), stream_ptr()), "me_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor,
+                  dres: Optional[torch.Tensor], dx_dtype: torch.dtype, need_affine: bool):
+    lib = _capi.load()
+    _req(dy, "dy"); _req(x, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)
+    g = _f32(gamma).contiguous()
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if need_affine else None
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if need_affine else None
+    ws = None
+    if need_affine:
+        ws = torch.empty(lib.me_layernorm_bwd_workspace(C), dtype=torch.uint8, device=x.device)
+    check(lib.me_layernorm_bwd(ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype), ptr(mean), ptr(rstd), ptr(g),
+                               ptr(dres), dtype_code(dres.dtype) if dres is not None else 0,
+                               ptr(dx), dtype_code(dx_dtype), ptr(dgamma), ptr(dbeta), 0, rows, C, ptr(ws),
+                               stream_ptr()), "me_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------- GEMM
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: Optional[torch.Tensor] = None,
+         out_dtype: Optional[torch.dtype] = None, bias: Optional[torch.Tensor] = None, act: int = _capi.ME_ACT_NONE,
+         residual: Optional[torch.Tensor] = None, res_row_mod: int = 0, preact: Optional[torch.Tensor] = None,
+         aux: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, alpha: float = 1.0,
+         beta: float = 0.0, out_rows: Optional[int] = None, out_group: Tuple[int, int, int] = (0, 0, 0)) -> torch.Tensor:
+    """NT: out[M,N] = a[M,K] @ b[N,K]^T ;  TN: out[M,N] = a[K,M]^T @ b[K,N]; fused epilogue per include/metaenc.h."""
+    lib = _capi.load()
+    _req(a, "a"); _req(b, "b")
+    if a.dtype != b.dtype:
+        raise MetaEncError(f"gemm: operand dtypes differ ({a.dtype} vs {b.dtype})")
+    a2 = a.reshape(-1, a.shape[-1])
+    b2 = b.reshape(-1, b.shape[-1])
+    if op == _capi.ME_GEMM_NT:
+        M, K = a2.shape
+        N, Kb = b2.shape
+    else:
+        K, M = a2.shape
+        Kb, N = b2.shape
+    if K != Kb:
+        raise MetaEncError(f"gemm: reduction dims differ ({K} vs {Kb})")
+    if out is None:
+        out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype or a.dtype, device=a.device)
+    _req(out, "out")
+    d = GemmDesc()
+    d.op, d.ab_dtype = op, dtype_code(a.dtype)
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda = ptr(a2), a2.stride(0)
+    d.B, d.ldb = ptr(b2), b2.stride(0)
+    d.C, d.ldc, d.c_dtype = ptr(out), out.stride(-2), dtype_code(out.dtype)
+    d.act, d.alpha, d.beta = act, alpha, beta
+    keep = []
+    if bias is not None:
+        bias = _f32(bias).contiguous(); keep.append(bias)
+        d.bias = ptr(bias)
+    if colscale is not None:
+        colscale = _f32(colscale).contiguous(); keep.append(colscale)
+        d.colscale = ptr(colscale)
+    if preact is not None:
+        _req(preact, "preact")
+        d.preact, d.ldpre, d.preact_dtype = ptr(preact), preact.stride(-2), dtype_code(preact.dtype)
+    if aux is not None:
+        _req(aux, "aux")
+        d.aux, d.ldaux, d.aux_dtype = ptr(aux), aux.stride(-2), dtype_code(aux.dtype)
+    if residual is not None:
+        _req(residual, "residual")
+        d.residual, d.ldres, d.res_dtype = ptr(residual), residual.stride(-2), dtype_code(residual.dtype)
+        d.res_row_mod = res_row_mod
+    d.out_group_rows, d.out_group_stride, d.out_row_offset = out_group
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.me_gemm(ctypes.byref(d), stream_ptr()), "me_gemm")
+        e1.record()
+        GEMM_PROFILE.append((op, d.ab_dtype, M, N, K, e0, e1))
+        return out
+    check(lib.me_gemm(ctypes.byref(d), stream_ptr()), "me_gemm")
+    return out
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    lib = _capi.load()
+    _req(x, "x")
+    x2 = x.reshape(-1, x.shape[-1])
+    rows, cols = x2.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.me_colsum_workspace(cols), dtype=torch.uint8, device=x.device)
+    check(lib.me_colsum(ptr(x2), dtype_code(x.dtype), x2.stride(0), rows, cols, ptr(out), 0, ptr(ws), stream_ptr()),
+          "me_colsum")
+    return out
+
+
+# ----------------------------------------------------------------------------- attention
+
+def attention_fwd(qkv: torch.Tensor, B: int, N: int, H: int, hd: int, scale: float, need_lse: bool):
+    lib = _capi.load()
+    _req(qkv, "qkv")
+    C = H * hd
+    out = torch.empty((B * N, C), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if need_lse else None
+    check(lib.me_attention_fwd(ptr(qkv), 3 * C, ptr(out), C, ptr(lse), B, N, H, hd, float(scale),
+                               dtype_code(qkv.dtype), stream_ptr()), "me_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor,
+                  B: int, N: int, H: int, hd: int, scale: float) -> torch.Tensor:
+    lib = _capi.load()
+    _req(qkv, "qkv"); _req(out, "out"); _req(dout, "dout")
+    C = H * hd
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    check(lib.me_attention_bwd(ptr(qkv), 3 * C, ptr(out), C, ptr(dout), C, ptr(lse), ptr(delta), ptr(dqkv), 3 * C,
+                               B, N, H, hd, float(scale), dtype_code(qkv.dtype), stream_ptr()), "me_attention_bwd")
+    return dqkv
+
+
+# ----------------------------------------------------------------------------- element-wise
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if x.dtype == dtype:
+        return x
+    lib = _capi.load()
+    _req(x, "x")
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib.me_cast(ptr(x), dtype_code(x.dtype), ptr(y), dtype_code(dtype), x.numel(), stream_ptr()), "me_cast")
+    return y
+
+
+def transpose_cast(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[rows, cols] -> [cols, rows] in `dtype` (weight repack for dgrad)."""
+    lib = _capi.load()
+    _req(w, "w")
+    rows, cols = w.shape
+    y = torch.empty((cols, rows), dtype=dtype, device=w.device)
+    check(lib.me_transpose_cast(ptr(w), dtype_code(w.dtype), ptr(y), dtype_code(dtype), rows, cols, stream_ptr()),
+          "me_transpose_cast")
+    return y
+
+
+def add_rows(x: torch.Tensor, pos: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """x[B*N, C] + pos[(row % pos_rows), C]"""
+    lib = _capi.load()
+    _req(x, "x"); _req(pos, "pos")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    pos_rows = pos.numel() // C
+    y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    check(lib.me_add_rows(ptr(x), dtype_code(x.dtype), ptr(pos), dtype_code(pos.dtype), ptr(y), dtype_code(y.dtype),
+                          rows, pos_rows, C, stream_ptr()), "me_add_rows")
+    return y
+
+
+def patchify(x: torch.Tensor, kt: int, kh: int, kw: int, st: int, sh: int, sw: int, out_dtype: torch.dtype):
+    """x [B,Cin,(T,)H,W] -> ([B*tokens, Cin*kt*kh*kw], tokens_per_sample)"""
+    lib = _capi.load()
+    _req(x, "x")
+    if x.dim() == 4:
+        B, Cin, H, W = x.shape
+        T = 1
+    else:
+        B, Cin, T, H, W = x.shape
+    gt, gh, gw = (T - kt) // st + 1, (H - kh) // sh + 1, (W - kw) // sw + 1
+    cols = torch.empty((B * gt * gh * gw, Cin * kt * kh * kw), dtype=out_dtype, device=x.device)
+    check(lib.me_patchify(ptr(x), dtype_code(x.dtype), ptr(cols), dtype_code(out_dtype), B, Cin, T, H, W,
+                          kt, kh, kw, st, sh, sw, stream_ptr()), "me_patchify")
+    return cols, gt * gh * gw
+
+
+def unpatchify_add(dcols: torch.Tensor, x_shape, kt, kh, kw, st, sh, sw) -> torch.Tensor:
+    lib = _capi.load()
+    _req(dcols, "dcols")
+    if len(x_shape) == 4:
+        B, Cin, H, W = x_shape
+        T = 1
+    else:
+        B, Cin, T, H, W = x_shape
+    dx = torch.zeros(x_shape, dtype=torch.float32, device=dcols.device)
+    check(lib.me_unpatchify_add(ptr(dcols), dtype_code(dcols.dtype), ptr(dx), B, Cin, T, H, W, kt, kh, kw, st, sh, sw,
+                                stream_ptr()), "me_unpatchify_add")
+    return dx
+
+
+def adamw_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
+               betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01, step: int = 1,
+               grad_scale: float = 1.0) -> None:
+    lib = _capi.load()
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, n)
+        if t.dtype != torch.float32:
+            raise MetaEncError(f"adamw_step: {n} must be float32")
+    check(lib.me_adamw_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, betas[0], betas[1],
+                            eps, weight_decay, step, grad_scale, stream_ptr()), "me_adamw_step")
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1

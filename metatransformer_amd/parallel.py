@@ -1,0 +1,125 @@
+"""Batch-sharded data parallelism for the encoder: one process per GPU, flat gradient buckets, one RCCL all-reduce
+per bucket over xGMI (torch.distributed backend "nccl" IS RCCL on ROCm; "gloo" on CPU for tests).
+
+Semantics follow the reference's explicit helper, Image/segmentation/mmseg_custom/core/utils/dist_utils.py:14-55
+(`_allreduce_coalesced`): take tensors in buckets -> flatten -> all_reduce(sum) -> divide by world size ->
+unflatten/copy back.  Here the "flatten / copy back" is free: every parameter's .grad is a VIEW into one flat fp32
+buffer (SURVEY.md 8b "parameter identity": one nn.Parameter per reference tensor, grads land in each .grad), so a
+bucket is just a slice of that buffer.  The 1/world scale is folded into the fused AdamW step (grad_scale).
+
+Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU), ring all-reduce is per-link bound, so large buckets
+amortise latency best; the default 64 MiB gives 6 buckets for Base fp32 grads (340 MB), enough to overlap the tail of
+backward with communication when `overlap=True` (buckets are reduced on a side stream as soon as backward has
+finished writing them, last layers first).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from ._capi import MetaEncError
+
+
+class FlatParams:
+    """Re-homes parameters (and their gradients) into flat fp32 buffers; `p.data` / `p.grad` become views."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise MetaEncError("FlatParams: no trainable parameters")
+        dev = self.params[0].device
+        dt = self.params[0].dtype
+        if any(p.dtype != dt or p.device != dev for p in self.params):
+            raise MetaEncError("FlatParams: parameters must share dtype and device")
+        # 64-element alignment keeps every view 256-byte aligned for the vectorised kernels
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 63) // 64 * 64
+        self.numel = off
+        self.flat_param = torch.zeros(off, dtype=dt, device=dev)
+        self.flat_grad = torch.zeros(off, dtype=dt, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            self.flat_param[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[o:o + p.numel()].view(p.shape)
+            p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self) -> None:
+        self.flat_grad.zero_()
+        for p, o in zip(self.params, self.offsets):       # re-attach views if something replaced them
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def buckets(self, bucket_bytes: int) -> List[torch.Tensor]:
+        """Slices of the flat gradient, split at parameter boundaries, in REVERSE parameter order (the order
+        backward finishes them: last layer first)."""
+        es = self.flat_grad.element_size()
+        out, end = [], self.numel
+        start_idx = len(self.params) - 1
+        cur_end = end
+        for i in range(len(self.params) - 1, -1, -1):
+            if (cur_end - self.offsets[i]) * es >= bucket_bytes or i == 0:
+                out.append(self.flat_grad[self.offsets[i]:cur_end])
+                cur_end = self.offsets[i]
+        return out
+
+
+def allreduce_gradients(flat: FlatParams, group=None, bucket_bytes: int = 64 << 20, average: bool = False) -> None:
+    """One all_reduce(sum) per flat bucket.  `average=True` divides by the world size afterwards (reference
+    semantics, dist_utils.py:31-32); the bench leaves it False and folds 1/world into the optimizer."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in flat.buckets(bucket_bytes)]
+    for h in handles:
+        h.wait()
+    if average:
+        flat.flat_grad.div_(dist.get_world_size(group))
+
+
+def allreduce_coalesced(tensors: Sequence[torch.Tensor], group=None, bucket_bytes: int = 64 << 20) -> None:
+    """Generic form for gradients that do NOT live in a FlatParams (tokenizer / head parameters of the frozen-encoder
+    pipelines): bucket -> flatten -> all_reduce -> /world -> copy back, exactly dist_utils.py:14-35."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([t.reshape(-1) for t in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
+        off = 0
+        for t in bucket:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        bucket, size = [], 0
+
+    for t in tensors:
+        bucket.append(t)
+        size += t.numel() * t.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()
+
+
+class FusedAdamW:
+    """AdamW over a FlatParams with ONE kernel launch (me_adamw_step); torch.optim.AdamW semantics."""
+
+    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        if flat.flat_param.dtype != torch.float32:
+            raise MetaEncError("FusedAdamW needs fp32 master parameters")
+        self.flat, self.lr, self.betas, self.eps, self.wd = flat, lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(flat.flat_param)
+        self.exp_avg_sq = torch.zeros_like(flat.flat_param)
+        self.t = 0
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        self.t += 1
+        ops.adamw_step(self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, lr=self.lr,
+                       betas=self.betas, eps=self.eps, weight_decay=self.wd, step=self.t, grad_scale=grad_scale)

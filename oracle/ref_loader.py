@@ -1,0 +1,147 @@
+"""Import the reference's OWN hot-path code, unmodified, from /root/reference
+(TEST INFRASTRUCTURE -- see oracle/__init__.py).
+
+Only usable where /root/reference exists (the build container).  Nothing under
+tests -m gpu / smoke() / bench.py may call this; it exists to (a) validate
+oracle/block_oracle.py and (b) generate tests/golden/ via oracle/make_golden.py.
+
+Recipe: the in-tree timm-borrowed Block lives in
+PointCloud/openpoints/models/layers/{attention,mlp,norm,activation,drop,helpers,weight_init}.py.
+The package's __init__ pulls in CUDA extensions, so the seven files are loaded
+one by one under a synthetic parent package that exposes exactly the names
+attention.py:8-9 and mlp.py:7-8 import (`Mlp, DropPath, trunc_normal_, lecun_normal_,
+create_norm, create_act`), plus a stub `easydict.EasyDict` (needed by norm.py:9).
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+REF_ROOT = os.environ.get("METAENC_REFERENCE_ROOT", "/root/reference")
+_LAYERS = os.path.join(REF_ROOT, "PointCloud", "openpoints", "models", "layers")
+_PKG = "_ref_openpoints_layers"
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(_LAYERS, "attention.py"))
+
+
+def _stub_easydict():
+    if "easydict" in sys.modules:
+        return
+    m = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError as e:
+                raise AttributeError(k) from e
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    m.EasyDict = EasyDict
+    sys.modules["easydict"] = m
+
+
+def _load(name: str):
+    full = f"{_PKG}.{name}"
+    if full in sys.modules:
+        return sys.modules[full]
+    spec = importlib.util.spec_from_file_location(full, os.path.join(_LAYERS, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[full] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference_layers():
+    """Returns the module object of the reference's attention.py (has .Block, .Attention)."""
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found under {REF_ROOT}")
+    _stub_easydict()
+    if _PKG not in sys.modules:
+        pkg = types.ModuleType(_PKG)
+        pkg.__path__ = [_LAYERS]
+        sys.modules[_PKG] = pkg
+    pkg = sys.modules[_PKG]
+    wi = _load("weight_init")
+    pkg.trunc_normal_, pkg.lecun_normal_ = wi.trunc_normal_, wi.lecun_normal_
+    _load("helpers")
+    pkg.DropPath = _load("drop").DropPath
+    pkg.create_norm = _load("norm").create_norm
+    pkg.create_act = _load("activation").create_act
+    pkg.Mlp = _load("mlp").Mlp
+    return _load("attention")
+
+
+def reference_encoder(depth: int, dim: int, num_heads: int, eps: float = 1e-5, mlp_ratio: float = 4.0):
+    """nn.Sequential of the reference's in-tree Block, built as README.md:125-148 builds the
+    timm one.  norm eps: README-style sites use nn.LayerNorm's default 1e-5; timm-factory
+    sites use 1e-6 -- passed through norm_args."""
+    import torch.nn as nn
+    att = load_reference_layers()
+    blocks = [att.Block(dim=dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=True,
+                        norm_args={"norm": "ln", "eps": eps}, act_args={"act": "gelu"})
+              for _ in range(depth)]
+    return nn.Sequential(*blocks).eval()
+
+
+def _load_file(modname: str, relpath: str, stubs: dict | None = None):
+    """Load one reference file by path, with optional stub modules for un-installed imports."""
+    for k, v in (stubs or {}).items():
+        sys.modules.setdefault(k, v)
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF_ROOT, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _timm_stub():
+    """Minimal stand-in for the handful of timm helpers the reference tokenizer files import
+    (to_2tuple / trunc_normal_ / drop_path / register_model) -- none of them is arithmetic
+    on the tokenizer path."""
+    import collections.abc
+    from itertools import repeat
+
+    def to_2tuple(x):
+        if isinstance(x, collections.abc.Iterable) and not isinstance(x, str):
+            return tuple(x)
+        return tuple(repeat(x, 2))
+
+    timm = types.ModuleType("timm")
+    models = types.ModuleType("timm.models")
+    layers = types.ModuleType("timm.models.layers")
+    registry = types.ModuleType("timm.models.registry")
+    layers.to_2tuple = to_2tuple
+    layers.trunc_normal_ = lambda t, std=.02, **kw: t.normal_(0, std)
+    layers.drop_path = lambda x, p=0., training=False: x
+    registry.register_model = lambda f: f
+    timm.models, models.layers, models.registry = models, layers, registry
+    return {"timm": timm, "timm.models": models, "timm.models.layers": layers,
+            "timm.models.registry": registry}
+
+
+def reference_image_patch_embed():
+    return _load_file("_ref_d2s_image", "Data2Seq/Image.py").PatchEmbed
+
+
+def reference_time_series_embedding():
+    return _load_file("_ref_d2s_ts", "Data2Seq/Time_Series.py").DataEmbedding
+
+
+def reference_acoustic_patch_embed():
+    return _load_file("_ref_d2s_acoustic", "Data2Seq/Acoustic.py", _timm_stub()).PatchEmbed
+
+
+def reference_video_module():
+    return _load_file("_ref_video_ft", "Video/models/modeling_finetune.py", _timm_stub())

@@ -1,0 +1,140 @@
+"""CPU: the drop-in boundary -- the C-ABI library loads and exports every symbol include/metaenc.h declares, the
+ctypes mirror of the descriptor struct matches the C layout, the product package never touches oracle/, and the
+host-side module mirrors the reference's plugin interface (names, shapes, error behaviour)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import ROOT
+
+import metatransformer_amd as M
+from metatransformer_amd import _capi, build as me_build
+from oracle import block_oracle as bo
+
+HEADER = os.path.join(ROOT, "include", "metaenc.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    me_build.build(verbose=False)
+    return _capi.load()
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(me_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_bound_and_exported(lib):
+    names = header_functions()
+    assert len(names) >= 18
+    assert set(names) == set(_capi.SIGNATURES), "include/metaenc.h and _capi.SIGNATURES disagree"
+    for n in names:
+        assert hasattr(lib, n), f"libmetaenc.so does not export {n}"
+    assert lib.me_abi_version() == 1
+    assert lib.me_build_arch() == b"gfx950"
+
+
+def test_gemm_desc_layout_matches_c():
+    code = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "metaenc.h"
+#define P(f) printf(#f " %zu\n", offsetof(me_gemm_desc, f))
+int main(void){ printf("size %zu\n", sizeof(me_gemm_desc));
+P(op);P(ab_dtype);P(M);P(N);P(K);P(A);P(lda);P(B);P(ldb);P(C);P(ldc);P(c_dtype);P(act);P(alpha);P(beta);P(bias);
+P(colscale);P(preact);P(ldpre);P(preact_dtype);P(aux_dtype);P(aux);P(ldaux);P(residual);P(ldres);P(res_dtype);
+P(reserved0);P(res_row_mod);P(out_group_rows);P(out_group_stride);P(out_row_offset); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(code)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = dict(l.split() for l in out if l)
+    assert int(got.pop("size")) == ctypes.sizeof(_capi.GemmDesc)
+    for name, _ in _capi.GemmDesc._fields_:
+        assert int(got[name]) == getattr(_capi.GemmDesc, name).offset, name
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "metatransformer_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "oracle/_ref" not in txt and "/root/reference" not in txt, f
+
+
+def test_no_cpu_fallback():
+    enc = M.build_encoder(1, 64, 2)
+    with pytest.raises(M.MetaEncError, match="no CPU fallback"):
+        enc(torch.randn(1, 3, 64))
+    with pytest.raises(M.MetaEncError):
+        M.PatchEmbed(img_size=32, embed_dim=64)(torch.randn(1, 3, 32, 32))
+    with pytest.raises(M.MetaEncError):
+        M.DataEmbedding(c_in=3, d_model=64).eval()(torch.randn(1, 8, 3))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libmetaenc.so")
+    with pytest.raises(M.MetaEncError, match="not built"):
+        _capi.load()
+
+
+def test_block_mirrors_reference_interface():
+    # README.md:125-135 construction, verbatim keyword set
+    enc = nn.Sequential(*[M.Block(dim=64, num_heads=4, mlp_ratio=4., qkv_bias=True, norm_layer=nn.LayerNorm,
+                                  act_layer=nn.GELU) for _ in range(3)])
+    sd = bo.make_encoder_state_dict(3, 64, seed=0)
+    assert list(enc.state_dict().keys()) == list(sd.keys())
+    assert all(enc.state_dict()[k].shape == v.shape for k, v in sd.items())
+    enc.load_state_dict(sd, strict=True)
+    # strict=True must reject a foreign key set, like the reference call sites rely on
+    bad = dict(sd); bad["0.attn.q_bias"] = torch.zeros(64)
+    with pytest.raises(RuntimeError):
+        enc.load_state_dict(bad, strict=True)
+    # indexable / sliceable / iterable (vit_adapter.py:107, X-Ray/train.py:80)
+    assert isinstance(enc[1], M.Block) and len(enc[0:2]) == 2 and len(list(enc)) == 3
+    # freezing + optimizer grouping by name (Video/optim_factory.py:30-41,67-73)
+    for p in enc.parameters():
+        p.requires_grad = False
+    assert not any(p.requires_grad for p in enc.parameters())
+    names = [n for n, _ in enc.named_parameters()]
+    assert "1.mlp.fc1.bias" in names and all(len(p.shape) == 1 or n.endswith(".weight") for n, p in enc.named_parameters())
+    # eps routes: default 1e-5, timm-factory sites 1e-6 via partial
+    from functools import partial
+    assert M.Block(64, 4).eps == 1e-5
+    assert M.Block(64, 4, norm_layer=partial(nn.LayerNorm, eps=1e-6)).eps == 1e-6
+    assert M.Block(768, 32).attn.scale == 24 ** -0.5          # Graph call site: 32 heads, head_dim 24
+    with pytest.raises(M.MetaEncError):
+        M.Block(64, 5)
+
+
+def test_tokenizer_parameter_names_match_reference():
+    assert list(M.PatchEmbed().state_dict()) == ["proj.weight", "proj.bias"]
+    assert M.PatchEmbed().proj.weight.shape == (768, 3, 16, 16)
+    assert M.VideoPatchEmbed().proj.weight.shape == (768, 3, 2, 16, 16) and M.VideoPatchEmbed().num_patches == 1568
+    assert M.AcousticPatchEmbed.num_tokens(128, 1024) == 1212       # Audio/src/models/ast_models.py:122
+    ts = M.DataEmbedding(c_in=7, d_model=64)
+    keys = list(ts.state_dict())
+    assert "value_embedding.tokenConv.weight" in keys and "position_embedding.pe" in keys
+    assert "temporal_embedding.hour_embed.emb.weight" in keys
+    assert ts.value_embedding.tokenConv.weight.shape == (64, 7, 3)
+
+
+def test_flop_model():
+    # BASELINE.md section 3
+    assert abs(M.encoder_flops_per_sample(197, 768, 12) / 1e9 - 34.895) < 0.01
+    assert abs(M.encoder_flops_per_sample(512, 1024, 24) / 1e9 - 335.0) < 0.1

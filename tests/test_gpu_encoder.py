@@ -1,0 +1,286 @@
+"""GPU: the drop-in modules (Block stack, tokenizers) against the golden vectors produced by the reference's own code,
+against the CPU oracle on seeded inputs, and -- at BASELINE sizes -- through size-independent properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import GOLDEN, TOL_BF16, TOL_F32, rel_err
+import metatransformer_amd as M
+from oracle import block_oracle as bo
+from oracle import tokenizer_oracle as to
+from oracle.make_golden import ENCODER_CASES, _inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def golden(name):
+    z = np.load(os.path.join(GOLDEN, f"encoder_{name}.npz"), allow_pickle=False)
+    return z, json.loads(str(z["config"]))
+
+
+def make_encoder(c, dev, dtype=torch.float32):
+    from functools import partial
+    enc = M.build_encoder(c["depth"], c["dim"], c["heads"], norm_layer=partial(nn.LayerNorm, eps=c["eps"]))
+    enc.load_state_dict(bo.make_encoder_state_dict(c["depth"], c["dim"], seed=c["seed"]), strict=True)
+    return enc.to(dev).to(dtype).eval()
+
+
+@pytest.mark.parametrize("name", list(ENCODER_CASES))
+def test_forward_fp32_matches_reference_golden(dev, name):
+    z, c = golden(name)
+    enc = make_encoder(c, dev)
+    x, _ = _inputs(c)
+    with torch.no_grad():
+        y = enc(x.to(dev))
+    assert y.shape == x.shape and y.dtype == torch.float32
+    assert rel_err(y[:, ::c["tok_stride"]], torch.from_numpy(z["y"])) < TOL_F32
+
+
+@pytest.mark.parametrize("name", ["small_hd64", "base_1blk", "base_12blk", "large_2blk", "graph_hd24"])
+@pytest.mark.parametrize("mode", ["autocast", "bf16_params"])
+def test_forward_bf16_matches_reference_golden(dev, name, mode):
+    """bf16 MFMA path vs the fp32 reference output: tolerance 3e-2 of max-abs (operands carry 8 mantissa bits)."""
+    z, c = golden(name)
+    x, _ = _inputs(c)
+    with torch.no_grad():
+        if mode == "autocast":
+            enc = make_encoder(c, dev)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = enc(x.to(dev))
+            assert y.dtype == torch.float32            # fp32 residual stream under autocast
+        else:
+            enc = make_encoder(c, dev, torch.bfloat16)
+            y = enc(x.to(dev).bfloat16())
+            assert y.dtype == torch.bfloat16
+    assert rel_err(y[:, ::c["tok_stride"]].float(), torch.from_numpy(z["y"])) < TOL_BF16
+
+
+@pytest.mark.parametrize("name", [n for n, c in ENCODER_CASES.items() if c["backward"]])
+def test_backward_fp32_matches_reference_golden(dev, name):
+    z, c = golden(name)
+    enc = make_encoder(c, dev).train()
+    x, go = _inputs(c)
+    xr = x.to(dev).requires_grad_(True)
+    y = enc(xr)
+    (y * go.to(dev)).sum().backward()
+    s = c["tok_stride"]
+    assert rel_err(xr.grad[:, ::s], torch.from_numpy(z["dx"])) < TOL_F32
+    for k, p in enc.named_parameters():
+        stats = z["dparam_stats/" + k]
+        assert p.grad is not None and p.grad.shape == p.shape, k
+        assert abs(p.grad.double().abs().sum().item() - stats[1]) < 1e-3 * max(stats[1], 1e-6), k
+        head = p.grad.flatten()[:16].cpu().numpy()
+        assert np.allclose(head, z["dparam_head/" + k], rtol=5e-3, atol=1e-3 * stats[1] / p.numel() + 1e-6), k
+
+
+def test_backward_full_parity_vs_oracle(dev):
+    """every gradient element, fp32 and bf16, on a Base-width block with ragged token count"""
+    c = dict(depth=2, dim=256, heads=4, eps=1e-5, seed=5)
+    sd = bo.make_encoder_state_dict(c["depth"], c["dim"], seed=c["seed"])
+    g = torch.Generator().manual_seed(42)
+    x, go = torch.randn(3, 70, 256, generator=g), torch.randn(3, 70, 256, generator=g)
+    y_ref, dx_ref, dp_ref = bo.encoder_forward_backward(x, sd, c["heads"], go)
+    for dt, t in ((torch.float32, TOL_F32), (torch.bfloat16, 5e-2)):
+        enc = make_encoder(c, dev).train()
+        xr = x.to(dev).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+            y = enc(xr)
+        (y * go.to(dev)).sum().backward()
+        assert rel_err(y, y_ref) < t and rel_err(xr.grad, dx_ref) < t
+        for k, p in enc.named_parameters():
+            assert rel_err(p.grad, dp_ref[k]) < t, (k, dt)
+
+
+def test_frozen_encoder_passes_input_grad_only(dev):
+    """most reference pipelines freeze the encoder but train the tokenizer in front of it."""
+    c = dict(depth=1, dim=128, heads=2, eps=1e-5, seed=6)
+    enc = make_encoder(c, dev)
+    for p in enc.parameters():
+        p.requires_grad = False
+    x = torch.randn(2, 33, 128, generator=torch.Generator().manual_seed(1))
+    xr = x.to(dev).requires_grad_(True)
+    enc(xr).square().sum().backward()
+    sd = bo.make_encoder_state_dict(1, 128, seed=6)
+    xo = x.clone().requires_grad_(True)
+    bo.encoder_forward(xo, sd, 2).square().sum().backward()
+    assert rel_err(xr.grad, xo.grad) < TOL_F32
+    assert all(p.grad is None for p in enc.parameters())
+
+
+def test_block_api_behaviours(dev):
+    enc = make_encoder(dict(depth=3, dim=64, heads=4, eps=1e-5, seed=2), dev)
+    x = torch.randn(2, 10, 64, device=dev)
+    with torch.no_grad():
+        y = enc(x)
+        z = x
+        for blk in enc:                      # iteration form (Audio/src/models/ast_models.py:161-162)
+            z = blk(z)
+        assert torch.equal(y, z)
+        assert torch.equal(enc[1:](enc[0:1](x)), y)           # slicing form (vit_adapter.py:107)
+        pos = torch.randn(1, 10, 64, device=dev)
+        w = x
+        for blk in enc:                      # per-block pos re-injection (PointCloud metatransformer.py:161-163)
+            w = blk(w + pos)
+        sd = {k: v.cpu() for k, v in enc.state_dict().items()}
+        ref = bo.encoder_forward(x.cpu(), sd, 4, pos_embed=pos.cpu())
+        assert rel_err(w, ref) < TOL_F32
+        # [T,B,C] fed as batch-first, as the Graph pipeline does (tokengt_graph_encoder.py:321,331-334)
+        assert rel_err(enc(x.transpose(0, 1)), bo.encoder_forward(x.cpu().transpose(0, 1), sd, 4)) < TOL_F32
+    # activation checkpointing (Video/models/modeling_finetune.py:440-441)
+    import torch.utils.checkpoint as cp
+    xr = x.clone().requires_grad_(True)
+    out = xr
+    for blk in enc.train():
+        out = cp.checkpoint(blk, out, use_reentrant=False)
+    out.sum().backward()
+    xr2 = x.clone().requires_grad_(True)
+    enc(xr2).sum().backward()
+    assert rel_err(xr.grad, xr2.grad) < 1e-6
+
+
+def test_layer_scale_variant(dev):
+    blk = M.Block(128, 2, qkv_bias=True, layer_scale=True).to(dev).eval()
+    with torch.no_grad():
+        blk.gamma1.uniform_(0.1, 1.0); blk.gamma2.uniform_(0.1, 1.0)
+        x = torch.randn(2, 20, 128, device=dev)
+        sd = {k: v.cpu() for k, v in blk.state_dict().items()}
+        ref = bo.block_forward(x.cpu(), sd, 2, gamma1=sd["gamma1"], gamma2=sd["gamma2"])
+        assert rel_err(blk(x), ref) < TOL_F32
+
+
+# ----------------------------------------------------------------------------- BASELINE-size properties
+
+def test_base_config2_shape_properties(dev):
+    """[256,197,768] bf16 (BASELINE config 2): too big for the CPU oracle in seconds, so check properties that do not
+    depend on size: batch independence (sample b of the big batch == the same sample run alone, bit-exact, because no
+    kernel reduces across samples) and agreement of the first samples with the CPU oracle."""
+    c = dict(depth=12, dim=768, heads=12, eps=1e-5, seed=14)
+    enc = make_encoder(c, dev, torch.bfloat16)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(256, 197, 768, generator=g).bfloat16()
+    with torch.no_grad():
+        y = enc(x.to(dev))
+        y_sub = enc(x[37:39].to(dev))
+    assert torch.isfinite(y.float()).all()
+    assert torch.equal(y[37:39], y_sub), "batch independence must be bit-exact"
+    sd = bo.make_encoder_state_dict(12, 768, seed=14)
+    ref = bo.encoder_forward(x[:2].float(), sd, 12)
+    assert rel_err(y[:2].float(), ref) < TOL_BF16
+
+
+def test_large_config3_slice_vs_oracle(dev):
+    """Large (24L/1024d/16h), N=512 (BASELINE config 3 shape, batch cut to 2 for the CPU oracle)."""
+    c = dict(depth=24, dim=1024, heads=16, eps=1e-5, seed=21)
+    enc = make_encoder(c, dev)
+    x = torch.randn(2, 512, 1024, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        y32 = enc(x.to(dev))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y16 = enc(x.to(dev))
+    ref = bo.encoder_forward(x, bo.make_encoder_state_dict(24, 1024, seed=21), 16)
+    assert rel_err(y32, ref) < TOL_F32
+    assert rel_err(y16, ref) < 5e-2       # 24 bf16 layers
+
+
+# ----------------------------------------------------------------------------- tokenizers
+
+def _tok():
+    return np.load(os.path.join(GOLDEN, "tokenizers.npz"), allow_pickle=False)
+
+
+def test_image_tokenizer_matches_reference_golden(dev):
+    z = _tok()
+    g = torch.Generator().manual_seed(2001)
+    pe = M.PatchEmbed(img_size=224, patch_size=16, in_c=3, embed_dim=768)
+    pe.proj.weight.data.copy_(0.02 * torch.randn(768, 3, 16, 16, generator=g))
+    pe.proj.bias.data.copy_(0.05 * torch.randn(768, generator=g))
+    x = torch.randn(2, 3, 224, 224, generator=g)
+    pe = pe.to(dev)
+    with torch.no_grad():
+        y = pe(x.to(dev))
+    assert y.shape == (2, 196, 768)
+    assert rel_err(y[:, ::7, ::3], torch.from_numpy(z["image/y"])) < TOL_F32
+    # BASELINE config 1 plumbing: Data2Seq.Image 224x224 patch16 -> 12-layer/768-d encoder, batch 8, + cls/pos fused
+    with torch.no_grad():
+        pos = torch.randn(196, 768, device=dev)
+        y2 = pe(x.to(dev), pos_embed=pos, prefix_rows=1)
+        assert y2.shape == (2, 197, 768) and torch.all(y2[:, 0] == 0)
+        assert rel_err(y2[:, 1:], y + pos) < 1e-5
+    # gradients of the projection
+    pe.train()
+    xg = x.to(dev).requires_grad_(True)
+    out = pe(xg)
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(5))
+    (out * go.to(dev)).sum().backward()
+    conv = nn.Conv2d(3, 768, 16, 16)
+    conv.load_state_dict({k.replace("proj.", ""): v.cpu() for k, v in pe.state_dict().items()})
+    xc = x.clone().requires_grad_(True)
+    (conv(xc).flatten(2).transpose(1, 2) * go).sum().backward()
+    assert rel_err(pe.proj.weight.grad, conv.weight.grad) < TOL_F32
+    assert rel_err(pe.proj.bias.grad, conv.bias.grad) < TOL_F32
+    assert rel_err(xg.grad, xc.grad) < TOL_F32
+
+
+def test_acoustic_and_video_tokenizers_match_reference_golden(dev):
+    z = _tok()
+    g = torch.Generator().manual_seed(2002)
+    ac = M.AcousticPatchEmbed(embed_dim=768)
+    ac.proj.weight.data.copy_(0.02 * torch.randn(768, 1, 16, 16, generator=g))
+    ac.proj.bias.data.copy_(0.05 * torch.randn(768, generator=g))
+    x = torch.randn(2, 1, 128, 100, generator=g)
+    with torch.no_grad():
+        y = ac.to(dev)(x.to(dev))
+    assert y.shape[1] == int(z["acoustic/tokens"])
+    assert rel_err(y[:, ::3, ::3], torch.from_numpy(z["acoustic/y"])) < TOL_F32
+    g = torch.Generator().manual_seed(2003)
+    vp = M.VideoPatchEmbed(img_size=64, patch_size=16, in_chans=3, embed_dim=768, num_frames=4, tubelet_size=2)
+    vp.proj.weight.data.copy_(0.02 * torch.randn(768, 3, 2, 16, 16, generator=g))
+    vp.proj.bias.data.copy_(0.05 * torch.randn(768, generator=g))
+    x = torch.randn(2, 3, 4, 64, 64, generator=g)
+    with torch.no_grad():
+        y = vp.to(dev)(x.to(dev))
+    assert rel_err(y[:, :, ::3], torch.from_numpy(z["video/y"])) < TOL_F32
+    assert np.allclose(M.video_sinusoid_table(32, 768)[0, :, :16].numpy(), z["video/sinusoid_head"], atol=1e-6)
+
+
+def test_time_series_tokenizer_matches_reference_golden(dev):
+    z = _tok()
+    ts = M.DataEmbedding(c_in=7, d_model=768).eval()
+    ts.value_embedding.tokenConv.weight.data.copy_(torch.from_numpy(z["ts/conv_weight"]))
+    ts.value_embedding.tokenConv.weight.requires_grad = False
+    ts = ts.to(dev)
+    x, mark = torch.from_numpy(z["ts/x"]), torch.from_numpy(z["ts/mark"])
+    y = ts(x.to(dev), mark.to(dev))
+    assert rel_err(y[:, ::4, ::3], torch.from_numpy(z["ts/y"])) < 1e-5
+    assert rel_err(ts(x.to(dev))[:, ::4, ::3], torch.from_numpy(z["ts/y_nomark"])) < 1e-5
+    # the temporal gather alone is integer-indexed: with a zero conv weight and no PE term it must be bit-exact
+    tabs = [to.sinusoid_table_ts(n, 768) for n in (13, 32, 7, 24)]
+    ts.value_embedding.tokenConv.weight.data.zero_()
+    ts.position_embedding.pe.zero_()
+    m = mark.long()
+    exact = ((tabs[3][m[..., 3]] + tabs[2][m[..., 2]]) + tabs[1][m[..., 1]]) + tabs[0][m[..., 0]]
+    assert torch.equal(ts(x.to(dev), mark.to(dev)).cpu(), exact)
+    bad = mark.clone(); bad[0, 0, 3] = 24
+    with pytest.raises(IndexError):
+        ts(x.to(dev), bad.to(dev))
+
+
+def test_multimodal_concat_through_encoder(dev):
+    """README.md:118-149 demo: tokens of several modalities concatenated along N, one shared encoder."""
+    torch.manual_seed(0)
+    img_tok = M.Data2Seq("image", 768).to(dev).eval()
+    ts_tok = M.Data2Seq("time-series", 768, c_in=7).to(dev).eval()
+    au_tok = M.Data2Seq("audio", 768).to(dev).eval()
+    ts_tok.embed.value_embedding.tokenConv.weight.requires_grad = False
+    enc = make_encoder(dict(depth=2, dim=768, heads=12, eps=1e-5, seed=4), dev)
+    img, ts, spec = torch.randn(2, 3, 224, 224), torch.randn(2, 96, 7), torch.randn(2, 1, 128, 100)
+    with torch.no_grad():
+        feats = torch.concat([img_tok(img.to(dev)), ts_tok(ts.to(dev)), au_tok(spec.to(dev))], dim=1)
+        assert feats.shape == (2, 196 + 96 + 108, 768)
+        y = enc(feats)
+        ref = bo.encoder_forward(feats.cpu(), bo.make_encoder_state_dict(2, 768, seed=4), 12)
+    assert rel_err(y, ref) < TOL_F32

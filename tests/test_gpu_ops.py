@@ -1,0 +1,228 @@
+"""GPU: per-kernel parity of the HIP path (called through the C ABI wrappers in metatransformer_amd.ops) against the
+CPU oracle restatements, on seeded inputs.  fp32 tolerance 1e-3 relative (north star), bf16 stated per test."""
+import math
+
+import pytest
+import torch
+
+from conftest import TOL_BF16, TOL_F32, rel_err
+from metatransformer_amd import _capi, ops
+from oracle import block_oracle as bo
+from oracle import tokenizer_oracle as to
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return TOL_F32 if dt == torch.float32 else TOL_BF16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return scale * torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+
+@pytest.mark.parametrize("C", [768, 1024, 256, 32, 100])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_layernorm_fwd(dev, C, dt):
+    rows = 77
+    x = (rnd(rows, C, seed=1) * 2 + 0.5).to(dt)
+    g, b = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    ref = bo.layer_norm(x.float(), g, b, 1e-5)
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev), 1e-5, dt)
+    assert rel_err(y.float(), ref) < (1e-5 if dt == torch.float32 else 8e-3)
+    assert rel_err(mean, x.float().mean(-1)) < 1e-5
+    assert rel_err(rstd, 1 / torch.sqrt(x.float().var(-1, unbiased=False) + 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("C", [768, 1024, 32, 100])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_layernorm_bwd(dev, C, dt):
+    rows = 1500 if C >= 256 else 50
+    x = (rnd(rows, C, seed=1) * 2 + 0.5).to(dt)
+    dy = rnd(rows, C, seed=4).to(dt)
+    dres = rnd(rows, C, seed=5).to(dt)
+    g, b = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    xr = x.float().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    bo.layer_norm(xr, gr, br, 1e-5).backward(dy.float())
+    _, mean, rstd = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev), 1e-5, dt)
+    dx, dg, db = ops.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, g.to(dev), dres.to(dev), dt, True)
+    t = 1e-4 if dt == torch.float32 else 1e-2
+    assert rel_err(dx.float(), xr.grad + dres.float()) < t
+    assert rel_err(dg, gr.grad) < t and rel_err(db, br.grad) < t
+    dx2, dg2, _ = ops.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, g.to(dev), None, dt, False)
+    assert dg2 is None and rel_err(dx2.float(), xr.grad) < t
+
+
+# ----------------------------------------------------------------------------- GEMM
+
+@pytest.mark.parametrize("M,N,K", [(197 * 2, 768, 768), (256, 2304, 768), (130, 132, 72), (1, 4, 8), (513, 3072, 768),
+                                   (300, 768, 3072)])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_nt_plain(dev, M, N, K, dt):
+    a, b = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2).to(dt)
+    ref = a.double() @ b.double().t()
+    c = ops.gemm(a.to(dev), b.to(dev), out_dtype=torch.float32)
+    assert rel_err(c, ref) < (2e-6 if dt == torch.float32 else 1e-5), "fp32-accumulated product of exactly representable inputs"
+
+
+def test_gemm_layout_is_transpose_detecting(dev):
+    """A = I with an asymmetric B catches a row<->col swap of the accumulator layout (CDNA guide G9)."""
+    K = 128
+    a = torch.eye(K, dtype=torch.bfloat16)
+    b = (torch.arange(K * K, dtype=torch.float32).reshape(K, K) % 251 - 125).to(torch.bfloat16)   # b[n,k], asymmetric
+    c = ops.gemm(a.to(dev), b.to(dev), out_dtype=torch.float32)          # c[m,n] = sum_k I[m,k] b[n,k] = b[n,m]
+    assert torch.equal(c.cpu(), b.float().t().contiguous())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_nt_epilogues(dev, dt):
+    M, N, K = 394, 1536, 256
+    a, w = rnd(M, K, seed=1).to(dt), (0.05 * rnd(N, K, seed=2)).to(dt)
+    bias, res, cs = 0.1 * rnd(N, seed=3), rnd(M, N, seed=4).to(dt), 1 + 0.2 * rnd(N, seed=5)
+    lin = a.double() @ w.double().t() + bias.double()
+    t = 1e-5 if dt == torch.float32 else 8e-3          # bf16: output rounding only (inputs exact)
+    # bias + GELU with saved pre-activation
+    pre = torch.empty(M, N, dtype=dt, device=dev)
+    y = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), act=_capi.ME_ACT_GELU, preact=pre)
+    assert rel_err(pre.float(), lin) < t and rel_err(y.float(), bo.gelu_erf(lin)) < t
+    # bias + colscale + residual, fp32 output
+    y = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), colscale=cs.to(dev), residual=res.to(dev), out_dtype=torch.float32)
+    assert rel_err(y, lin * cs.double() + res.double()) < 1e-5
+    # GELU backward: multiply by gelu'(aux)
+    aux = rnd(M, N, seed=6).to(dt)
+    xa = aux.double().requires_grad_(True)
+    bo.gelu_erf(xa).sum().backward()
+    y = ops.gemm(a.to(dev), w.to(dev), aux=aux.to(dev), out_dtype=torch.float32)
+    assert rel_err(y, (a.double() @ w.double().t()) * xa.grad) < 1e-5
+    # alpha / beta accumulate
+    c0 = rnd(M, N, seed=7)
+    y = ops.gemm(a.to(dev), w.to(dev), out=c0.clone().to(dev), alpha=0.5, beta=2.0)
+    assert rel_err(y, 0.5 * (a.double() @ w.double().t()) + 2.0 * c0.double()) < 1e-5
+    # pos-embed broadcast (row modulo) + grouped output rows behind a cls slot
+    tps, Bn = 197 - 1, 2
+    a2 = rnd(Bn * tps, K, seed=8).to(dt)
+    pos = rnd(tps, N, seed=9)
+    out = torch.zeros(Bn * 197, N, dtype=torch.float32, device=dev)
+    ops.gemm(a2.to(dev), w.to(dev), out=out, residual=pos.to(dev), res_row_mod=tps, out_group=(tps, 197, 1))
+    ref = (a2.double() @ w.double().t()).reshape(Bn, tps, N) + pos.double()
+    out = out.reshape(Bn, 197, N).cpu()
+    assert torch.all(out[:, 0] == 0) and rel_err(out[:, 1:], ref) < 1e-5
+
+
+@pytest.mark.parametrize("T,M,N", [(394, 768, 768), (1000, 3072, 768), (130, 136, 72), (65, 8, 8)])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_tn_wgrad(dev, T, M, N, dt):
+    a, b = rnd(T, M, seed=1).to(dt), rnd(T, N, seed=2).to(dt)
+    ref = a.double().t() @ b.double()
+    c = ops.gemm(a.to(dev), b.to(dev), op=_capi.ME_GEMM_TN, out_dtype=torch.float32)
+    assert rel_err(c, ref) < 1e-5
+
+
+def test_gemm_rejects_bad_args(dev):
+    a = torch.zeros(4, 12, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(_capi.MetaEncError, match="multiples"):
+        ops.gemm(a, a)                       # K=12 not a multiple of 8 bf16
+    with pytest.raises(_capi.MetaEncError):
+        ops.gemm(a, a.float())               # dtype mismatch
+    with pytest.raises(_capi.MetaEncError, match="CUDA"):
+        ops.gemm(a.cpu(), a.cpu())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_colsum_cast_transpose(dev, dt):
+    x = rnd(1234, 776, seed=1).to(dt)
+    assert rel_err(ops.colsum(x.to(dev)), x.double().sum(0)) < 1e-5
+    w = rnd(300, 520, seed=2)
+    wt = ops.transpose_cast(w.to(dev), dt)
+    assert torch.equal(wt.cpu(), w.t().contiguous().to(dt))
+    assert torch.equal(ops.cast(w.to(dev), dt).cpu(), w.to(dt))
+    pos = rnd(7, 64, seed=3)
+    xx = rnd(21, 64, seed=4)
+    y = ops.add_rows(xx.to(dev), pos.to(dev))
+    assert torch.equal(y.cpu(), xx + pos.repeat(3, 1))
+
+
+# ----------------------------------------------------------------------------- attention
+
+def attn_ref(qkv, B, N, H, hd, scale):
+    q, k, v = qkv.double().reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * scale
+    p = torch.softmax(s, dim=-1)
+    return (p @ v).transpose(1, 2).reshape(B * N, H * hd), torch.logsumexp(s, dim=-1)
+
+
+ATTN_SHAPES = [(2, 197, 12, 64), (1, 64, 2, 64), (3, 37, 2, 64), (2, 5, 2, 16), (2, 40, 32, 24), (1, 300, 4, 32),
+               (1, 130, 2, 128), (1, 1, 1, 64)]
+
+
+@pytest.mark.parametrize("B,N,H,hd", ATTN_SHAPES)
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_fwd(dev, B, N, H, hd, dt):
+    qkv = rnd(B * N, 3 * H * hd, seed=B * 1000 + N).to(dt)
+    scale = hd ** -0.5
+    ref, lse_ref = attn_ref(qkv, B, N, H, hd, scale)
+    out, lse = ops.attention_fwd(qkv.to(dev), B, N, H, hd, scale, True)
+    assert rel_err(out.float(), ref) < (2e-5 if dt == torch.float32 else 1.5e-2)
+    assert rel_err(lse, lse_ref) < (1e-5 if dt == torch.float32 else 5e-3)
+
+
+def test_attention_online_softmax_rescale_path(dev):
+    """Force the running-max rescale: one key far above the rest, placed in the LAST 64-key tile."""
+    B, N, H, hd = 1, 200, 1, 64
+    qkv = 0.3 * rnd(B * N, 3 * hd, seed=9)
+    qkv[190, hd:2 * hd] = 6.0 * qkv[3, 0:hd] / qkv[3, 0:hd].norm() * 8          # key 190 aligned with query 3
+    ref, _ = attn_ref(qkv, B, N, H, hd, hd ** -0.5)
+    for dt in DTYPES:
+        out, _ = ops.attention_fwd(qkv.to(dt).to(dev), B, N, H, hd, hd ** -0.5, False)
+        r2, _ = attn_ref(qkv.to(dt), B, N, H, hd, hd ** -0.5)
+        assert rel_err(out.float(), r2) < (2e-5 if dt == torch.float32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("B,N,H,hd", ATTN_SHAPES)
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_bwd(dev, B, N, H, hd, dt):
+    qkv = rnd(B * N, 3 * H * hd, seed=B * 1000 + N + 1).to(dt)
+    do = rnd(B * N, H * hd, seed=77).to(dt)
+    scale = hd ** -0.5
+    qr = qkv.double().requires_grad_(True)
+    ref, _ = attn_ref(qr, B, N, H, hd, scale)
+    ref.backward(do.double())
+    out, lse = ops.attention_fwd(qkv.to(dev), B, N, H, hd, scale, True)
+    dqkv = ops.attention_bwd(qkv.to(dev), out, do.to(dev), lse, B, N, H, hd, scale)
+    assert rel_err(dqkv.float(), qr.grad) < (5e-5 if dt == torch.float32 else 3e-2)
+
+
+# ----------------------------------------------------------------------------- tokenizer kernels
+
+@pytest.mark.parametrize("geom", [((2, 3, 64, 48), (1, 16, 16, 1, 16, 16)), ((2, 1, 40, 57), (1, 16, 16, 1, 10, 10)),
+                                  ((1, 3, 4, 32, 32), (2, 16, 16, 2, 16, 16))])
+def test_patchify_bit_exact(dev, geom):
+    shape, (kt, kh, kw, st, sh, sw) = geom
+    x = rnd(*shape, seed=3)
+    cols, tps = ops.patchify(x.to(dev), kt, kh, kw, st, sh, sw, torch.float32)
+    ref = to.patchify_2d(x, kh, kw, sh, sw) if len(shape) == 4 else to.patchify_3d(x, kt, kh, kw)
+    assert tps == ref.shape[1]
+    assert torch.equal(cols.cpu().reshape(ref.shape), ref), "patch gather must be bit-exact"
+    # scatter-add back: adjoint of the gather
+    d = rnd(*cols.shape, seed=4)
+    dx = ops.unpatchify_add(d.to(dev), shape, kt, kh, kw, st, sh, sw)
+    xr = x.clone().requires_grad_(True)
+    r = to.patchify_2d(xr, kh, kw, sh, sw) if len(shape) == 4 else to.patchify_3d(xr, kt, kh, kw)
+    r.backward(d.reshape(r.shape))
+    assert rel_err(dx, xr.grad) < 1e-6
+
+
+def test_adamw_matches_torch(dev):
+    p = rnd(5000, seed=1); g = rnd(5000, seed=2)
+    ref = torch.nn.Parameter(p.clone()); ref.grad = g.clone() * 0.5
+    opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    pd, m, v = p.clone().to(dev), torch.zeros(5000, device=dev), torch.zeros(5000, device=dev)
+    for step in (1, 2, 3):
+        opt.step()
+        ops.adamw_step(pd, g.to(dev), m, v, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05, step=step, grad_scale=0.5)
+    assert rel_err(pd, ref.data) < 1e-5
