@@ -30,7 +30,7 @@ from ._capi import ME_GEMM_TN, MetaEncError, check, dtype_code, ptr, stream_ptr
 
 def _compute_dtype(weight: torch.Tensor) -> torch.dtype:
     if torch.is_autocast_enabled():
-        dt = torch.get_autocast_gpu_dtype()
+        dt = torch.get_autocast_dtype("cuda")
         if dt != torch.bfloat16:
             raise MetaEncError(f"autocast dtype {dt} unsupported")
         return dt
@@ -249,7 +249,7 @@ class DataEmbedding(nn.Module):
         C = self.d_model
         w = self.value_embedding.tokenConv.weight.detach().float().contiguous()
         xf = x.detach().float().contiguous()
-        out_dtype = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) else torch.float32
+        out_dtype = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16) else torch.float32
         out = torch.empty((B, L, C), dtype=out_dtype, device=x.device)
         pe = self.position_embedding.pe[0].contiguous()
         if L > pe.shape[0]:

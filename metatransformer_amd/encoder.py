@@ -115,8 +115,8 @@ class _BlockFn(torch.autograd.Function):
         M = B * N
         rdt = x.dtype                      # residual-stream dtype
         cache: _WeightCache = blk._wcache
-        need_grad = torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g1, g2))
+        # grad mode is always off inside Function.forward; needs_input_grad says whether a backward can follow
+        need_grad = any(ctx.needs_input_grad)
         x2 = x.reshape(M, C)
 
         xn1, mean1, rstd1 = ops.layernorm_fwd(x2, n1w, n1b, blk.eps, cdt, save_stats=need_grad)
@@ -216,7 +216,7 @@ class Block(nn.Module):
         if self.compute_dtype is not None:
             return self.compute_dtype
         if torch.is_autocast_enabled():
-            dt = torch.get_autocast_gpu_dtype()
+            dt = torch.get_autocast_dtype("cuda")
             if dt != torch.bfloat16:
                 raise MetaEncError(f"autocast dtype {dt} unsupported: libmetaenc computes in bfloat16 or float32")
             return dt

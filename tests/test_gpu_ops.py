@@ -67,7 +67,7 @@ def test_gemm_nt_plain(dev, M, N, K, dt):
     a, b = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2).to(dt)
     ref = a.double() @ b.double().t()
     c = ops.gemm(a.to(dev), b.to(dev), out_dtype=torch.float32)
-    assert rel_err(c, ref) < (2e-6 if dt == torch.float32 else 1e-5), "fp32-accumulated product of exactly representable inputs"
+    assert rel_err(c, ref) < 1e-5, "fp32-accumulated product of exactly representable inputs"
 
 
 def test_gemm_layout_is_transpose_detecting(dev):

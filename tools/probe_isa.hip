@@ -29,7 +29,8 @@ __global__ void glds_probe(const uint32_t* src, uint32_t* out) {
     __syncthreads();
     // lane l reads 16 B from src + 4*perm(l) with perm(l) = (l * 5) % 64 (a non-identity permutation)
     const uint32_t* g = src + 4 * ((threadIdx.x * 5) % 64);
-    __builtin_amdgcn_global_load_lds(g, lds, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int i = threadIdx.x; i < 512; i += 64) out[i] = lds[i];
