@@ -162,9 +162,18 @@ def main():
         "roofline": roof,
     }
     if not args.no_cpu_baseline and world == 1:
-        from oracle import cpu_baseline
-        out["cpu_baseline"] = cpu_baseline.time_encoder(L, C, H, N, batch=8, backward=train, budget_s=args.cpu_budget_s)
-        out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)
+        # the CPU oracle runs in its own process (fresh OpenMP pool, hard timeout) so it can never stall the bench
+        import subprocess
+        cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--depth", str(L), "--dim", str(C), "--heads", str(H),
+               "--tokens", str(N), "--batch", "8", "--budget-s", str(args.cpu_budget_s)] + ([] if train else ["--forward-only"])
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=args.cpu_budget_s * 6 + 120)
+            cb = json.loads(r.stdout.strip().splitlines()[-1])
+            cb["value"] = round(cb["value"], 3)
+            out["cpu_baseline"] = cb
+        except Exception as e:          # noqa: BLE001 -- a baseline failure must not lose the GPU measurement
+            out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": None, "kind": "port",
+                                   "sample": f"failed: {type(e).__name__}: {e}"[:300]}
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

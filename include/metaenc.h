@@ -98,8 +98,13 @@ typedef struct me_gemm_desc {
     int32_t reserved0;
     int64_t res_row_mod;
     int64_t out_group_rows, out_group_stride, out_row_offset;
+    void* workspace; int64_t workspace_bytes;               /* optional scratch (split-K slabs), see below */
 } me_gemm_desc;
 
+/* Scratch the kernel selected for this problem can use (0 = none).  wgrad-shaped problems (tiny output, very long
+ * reduction) split the reduction over workgroups and fold fp32 slabs deterministically; without a workspace of this
+ * size they still run, unsplit and slower. */
+size_t me_gemm_workspace_bytes(const me_gemm_desc* d);
 int me_gemm(const me_gemm_desc* d, void* stream);
 
 /* column sums of a [rows, cols] matrix -> out[cols] fp32 (bias gradients).  accumulate != 0 adds into out.

@@ -45,6 +45,7 @@ class GemmDesc(ctypes.Structure):
         ("reserved0", c_int32),
         ("res_row_mod", c_int64),
         ("out_group_rows", c_int64), ("out_group_stride", c_int64), ("out_row_offset", c_int64),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 
@@ -61,6 +62,7 @@ SIGNATURES = {
     "me_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                  c_int64, c_int, c_void_p, c_void_p]),
+    "me_gemm_workspace_bytes": (c_size_t, [POINTER(GemmDesc)]),
     "me_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
     "me_colsum_workspace": (c_size_t, [c_int64]),
     "me_colsum": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p]),

@@ -14,7 +14,9 @@
 //   NT: C[M,N] = A[M,K] B[N,K]^T   rows of both operands are K-contiguous: 16-byte chunk copies.
 //   TN: C[M,N] = A[K,M]^T B[K,N]   (wgrad) the loader transposes while staging: pairs of reduction rows are
 //                                  interleaved into dwords so that LDS rows are again reduction-contiguous.
-#include "common.h"
+#include "gemm_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -23,19 +25,6 @@ constexpr int BN = 128;
 constexpr int ROWB = 128;                 // bytes of reduction data per LDS row per K-step
 constexpr int TILE_BYTES = BM * ROWB;     // 16 KiB per operand tile
 constexpr int NT = 256;
-
-struct GemmParams {
-    const void* A; const void* B; void* C;
-    int64_t M, N, K, lda, ldb, ldc;
-    int c_dtype, act;
-    float alpha, beta;
-    const float* bias; const float* colscale;
-    void* preact; int64_t ldpre; int preact_dtype;
-    const void* aux; int64_t ldaux; int aux_dtype;
-    const void* residual; int64_t ldres; int res_dtype;
-    int64_t res_row_mod, out_group_rows, out_group_stride, out_row_offset;
-    int tiles_m, tiles_n;
-};
 
 __device__ __forceinline__ int lds_off(int row, int byteoff) {
     const int chunk = byteoff >> 4;
@@ -148,31 +137,6 @@ __device__ __forceinline__ void compute_tile(const char* ldsA, const char* ldsB,
     }
 }
 
-__device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, int64_t n, f32x4 v) {
-    v *= p.alpha;
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-    if (p.preact) store4_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v);
-    if (p.act == ME_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-    }
-    if (p.aux) {
-        const f32x4 a = load4_as_f32(p.aux, p.aux_dtype, m * p.ldaux + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a[e]);
-    }
-    if (p.colscale) v *= *reinterpret_cast<const f32x4*>(p.colscale + n);
-    if (p.residual) {
-        const int64_t rr = p.res_row_mod ? (m % p.res_row_mod) : m;
-        v += load4_as_f32(p.residual, p.res_dtype, rr * p.ldres + n);
-    }
-    const int64_t orow = p.out_group_rows
-                             ? (m / p.out_group_rows) * p.out_group_stride + (m % p.out_group_rows) + p.out_row_offset
-                             : m;
-    if (p.beta != 0.0f) v += p.beta * load4_as_f32(p.C, p.c_dtype, orow * p.ldc + n);
-    store4_from_f32(p.C, p.c_dtype, orow * p.ldc + n, v);
-}
-
 template <typename T, bool TN>
 __global__ __launch_bounds__(NT) void gemm_g128_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -267,10 +231,72 @@ int launch_g128(const GemmParams& p, hipStream_t stream) {
     return ME_OK;
 }
 
-}  // namespace
+// ---- split-K fold: sum the fp32 slabs [S][M][N] and apply the real epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ slabs, int S) {
+    const int64_t nq = p.N / 4;
+    const int64_t total = p.M * nq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / nq, n = (i % nq) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slabs + m * p.N + n);
+        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(slabs + ((int64_t)s * p.M + m) * p.N + n);
+        epilogue_quad(p, m, n, v);
+    }
+}
 
-extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+struct GemmPlan {
+    int family;      // 0 = g128, 1 = g256
+    int bn;          // g256: 256 / 128
+    int split_k;     // >= 1
+    int ksteps_per_split;
+    size_t ws_bytes;
+};
+
+int forced_family() {   // ME_GEMM_KERNEL = g128 | g256_256 | g256_128   (A/B benchmarking)
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("ME_GEMM_KERNEL");
+        v = -1;
+        if (e) {
+            if (!strcmp(e, "g128")) v = 0;
+            else if (!strcmp(e, "g256_256")) v = 256;
+            else if (!strcmp(e, "g256_128")) v = 128;
+        }
+    }
+    return v;
+}
+
+GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
+    GemmPlan pl{0, 0, 1, 0, 0};
+    const int force = forced_family();
+    if (d->ab_dtype != ME_BF16 || force == 0 || !g256_supported(p, d->op)) return pl;
+    // tiny problems: one 128x128 tile family is enough
+    if (force < 0 && (d->M < 256 || d->N < 128)) return pl;
+    pl.family = 1;
+    const int64_t tm = (d->M + 255) / 256;
+    const int64_t t256 = tm * ((d->N + 255) / 256), t128 = tm * ((d->N + 127) / 128);
+    const int nk = (int)(d->K / 64);
+    const int CUS = 256;
+    if (d->op == ME_GEMM_TN) {
+        pl.bn = (force > 0) ? force : ((d->N % 256 == 0 || d->N > 512) ? 256 : 128);
+        const int64_t tiles = pl.bn == 256 ? t256 : t128;
+        int s = (int)(CUS / tiles);
+        if (s < 1) s = 1;
+        while (s > 1 && nk / s < 8) --s;
+        pl.ksteps_per_split = (nk + s - 1) / s;
+        pl.split_k = (nk + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
+        if (pl.split_k > 1) pl.ws_bytes = (size_t)pl.split_k * (size_t)d->M * (size_t)d->N * sizeof(float);
+    } else {
+        if (force > 0) pl.bn = force;
+        else {
+            const double c256 = (double)((t256 + CUS - 1) / CUS), c128 = 0.55 * (double)((t128 + CUS - 1) / CUS);
+            pl.bn = c256 <= c128 ? 256 : 128;
+        }
+        pl.ksteps_per_split = nk;
+    }
+    return pl;
+}
+
+int fill_params(const me_gemm_desc* d, GemmParams& p) {
     ME_CHECK_ARG(d != nullptr, "me_gemm: null descriptor");
     ME_CHECK_ARG(d->op == ME_GEMM_NT || d->op == ME_GEMM_TN, "me_gemm: bad op %d", d->op);
     ME_CHECK_ARG(me_dtype_ok(d->ab_dtype) && me_dtype_ok(d->c_dtype), "me_gemm: bad dtype");
@@ -292,8 +318,6 @@ extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
     if (d->preact) ME_CHECK_ARG(me_dtype_ok(d->preact_dtype) && d->ldpre % 4 == 0, "me_gemm: bad preact");
     if (d->aux) ME_CHECK_ARG(me_dtype_ok(d->aux_dtype) && d->ldaux % 4 == 0, "me_gemm: bad aux");
     if (d->residual) ME_CHECK_ARG(me_dtype_ok(d->res_dtype) && d->ldres % 4 == 0, "me_gemm: bad residual");
-
-    GemmParams p;
     p.A = d->A; p.B = d->B; p.C = d->C;
     p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
     p.c_dtype = d->c_dtype; p.act = d->act; p.alpha = d->alpha; p.beta = d->beta;
@@ -303,10 +327,49 @@ extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
     p.residual = d->residual; p.ldres = d->ldres; p.res_dtype = d->res_dtype;
     p.res_row_mod = d->res_row_mod; p.out_group_rows = d->out_group_rows;
     p.out_group_stride = d->out_group_stride; p.out_row_offset = d->out_row_offset;
+    p.split_k = 1; p.ksteps_per_split = 0;
     p.tiles_m = (int)((d->M + BM - 1) / BM);
     p.tiles_n = (int)((d->N + BN - 1) / BN);
     ME_CHECK_ARG((int64_t)p.tiles_m * p.tiles_n < (1ll << 31), "me_gemm: too many tiles");
+    return ME_OK;
+}
 
+}  // namespace
+
+extern "C" size_t me_gemm_workspace_bytes(const me_gemm_desc* d) {
+    GemmParams p;
+    if (fill_params(d, p) != ME_OK) return 0;
+    return plan_gemm(d, p).ws_bytes;
+}
+
+extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    GemmParams p;
+    int rc = fill_params(d, p);
+    if (rc) return rc;
+    GemmPlan pl = plan_gemm(d, p);
+    if (pl.family == 1) {
+        p.tiles_m = (int)((d->M + 255) / 256);
+        p.tiles_n = (int)((d->N + pl.bn - 1) / pl.bn);
+        p.ksteps_per_split = pl.ksteps_per_split;
+        if (pl.split_k > 1 && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes) {
+            GemmParams ps = p;
+            ps.C = d->workspace;
+            ps.split_k = pl.split_k;
+            rc = launch_g256(ps, d->op, pl.bn, stream);
+            if (rc) return rc;
+            const int64_t quads = d->M * (d->N / 4);
+            int64_t nb = (quads + 255) / 256;
+            if (nb > 2048) nb = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p,
+                               reinterpret_cast<const float*>(d->workspace), pl.split_k);
+            ME_CHECK_LAUNCH("me_gemm(splitk reduce)");
+            return ME_OK;
+        }
+        p.split_k = 1;
+        p.ksteps_per_split = (int)(d->K / 64);
+        return launch_g256(p, d->op, pl.bn, stream);
+    }
     if (d->ab_dtype == ME_BF16)
         return d->op == ME_GEMM_NT ? launch_g128<bf16_t, false>(p, stream) : launch_g128<bf16_t, true>(p, stream);
     return d->op == ME_GEMM_NT ? launch_g128<float, false>(p, stream) : launch_g128<float, true>(p, stream);

@@ -124,6 +124,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
         d.residual, d.ldres, d.res_dtype = ptr(residual), residual.stride(-2), dtype_code(residual.dtype)
         d.res_row_mod = res_row_mod
     d.out_group_rows, d.out_group_stride, d.out_row_offset = out_group
+    ws_bytes = lib.me_gemm_workspace_bytes(ctypes.byref(d))
+    if ws_bytes:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device); keep.append(ws)
+        d.workspace, d.workspace_bytes = ptr(ws), ws_bytes
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -1,0 +1,87 @@
+"""GEMM kernel-family A/B on the encoder's shapes (dev tool; run on the GPU box).
+    python tools/gemm_bench.py [--quick]
+Sets ME_GEMM_KERNEL per subprocess-free loop by re-importing is not possible (env is read once), so each family runs
+in its own process: the parent spawns `python tools/gemm_bench.py --family X`."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+M = 256 * 197
+SHAPES = [  # (name, op, M, N, K)
+    ("qkv_fwd", "nt", M, 2304, 768), ("proj_fwd", "nt", M, 768, 768), ("fc1_fwd", "nt", M, 3072, 768),
+    ("fc2_fwd", "nt", M, 768, 3072), ("fc1_dgrad", "nt", M, 768, 3072), ("fc2_dgrad", "nt", M, 3072, 768),
+    ("qkv_dgrad", "nt", M, 768, 2304),
+    ("qkv_wgrad", "tn", 2304, 768, M), ("proj_wgrad", "tn", 768, 768, M), ("fc1_wgrad", "tn", 3072, 768, M),
+    ("fc2_wgrad", "tn", 768, 3072, M),
+]
+
+
+def run_family(family, iters):
+    import torch
+    from metatransformer_amd import ops, _capi
+    dev = torch.device("cuda:0")
+    res = {}
+    for name, op, m, n, k in SHAPES:
+        g = torch.Generator().manual_seed(1)
+        if op == "nt":
+            a = torch.randn(m, k, generator=g).bfloat16().to(dev)
+            b = (0.05 * torch.randn(n, k, generator=g)).bfloat16().to(dev)
+            code = _capi.ME_GEMM_NT
+            ref = lambda: a[:512].float() @ b.float().t()
+            sl = lambda c: c[:512]
+        else:
+            a = torch.randn(k, m, generator=g).bfloat16().to(dev)
+            b = torch.randn(k, n, generator=g).bfloat16().to(dev)
+            code = _capi.ME_GEMM_TN
+            ref = lambda: a.float().t() @ b.float()
+            sl = lambda c: c
+        bias = torch.randn(n, device=dev)
+        out_dtype = torch.bfloat16 if op == "nt" else torch.float32
+        c = ops.gemm(a, b, op=code, out_dtype=out_dtype, bias=bias if op == "nt" else None)
+        r = ref() + (bias if op == "nt" else 0)
+        err = float((sl(c).float() - r).abs().max() / r.abs().max())
+        for _ in range(3):
+            ops.gemm(a, b, op=code, out_dtype=out_dtype, bias=bias if op == "nt" else None)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.gemm(a, b, op=code, out_dtype=out_dtype, bias=bias if op == "nt" else None)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / iters
+        res[name] = {"us": round(us, 1), "tflops": round(2.0 * m * n * k / us / 1e6, 1), "relerr": float(f"{err:.2e}")}
+    print(json.dumps({"family": family, "results": res}))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--family", default=None)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--families", default="g128,g256_256,g256_128,auto")
+    a = ap.parse_args()
+    if a.family is not None:
+        run_family(a.family, a.iters)
+        sys.exit(0)
+    rows = []
+    for fam in a.families.split(","):
+        env = dict(os.environ)
+        if fam != "auto":
+            env["ME_GEMM_KERNEL"] = fam
+        else:
+            env.pop("ME_GEMM_KERNEL", None)
+        r = subprocess.run([sys.executable, __file__, "--family", fam, "--iters", str(a.iters)], env=env, capture_output=True, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            print(fam, "FAILED", r.stderr[-2000:])
+            continue
+        rows.append(json.loads(line[-1]))
+    names = [s[0] for s in SHAPES]
+    print(f"{'shape':12s} " + " ".join(f"{r['family']:>22s}" for r in rows))
+    for n in names:
+        print(f"{n:12s} " + " ".join(f"{r['results'][n]['tflops']:8.1f}TF {r['results'][n]['us']:7.1f}us {r['results'][n]['relerr']:.0e}" for r in rows))
