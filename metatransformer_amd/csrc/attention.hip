@@ -310,6 +310,31 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const void* __restrict_
     }
 }
 
+// vector path for bf16 with head_dim a power-of-two multiple of 8 (<= 512): one wave per token row, a lane owns 8
+// consecutive channels (16-byte loads of O and dO), the head_dim/8 lanes of a head fold with xor-shuffles.
+__global__ __launch_bounds__(256) void attn_delta_vec_kernel(const bf16_t* __restrict__ o, int64_t ldo,
+                                                             const bf16_t* __restrict__ dout, int64_t lddo,
+                                                             float* __restrict__ delta, int N, int H, int hd, int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int C8 = (H * hd) / 8, lph = hd / 8;      // chunks per row, lanes per head
+    const int64_t b = row / N, n = row % N;
+    for (int c = lane; c < ((C8 + 63) / 64) * 64; c += 64) {
+        float s = 0.f;
+        if (c < C8) {
+            const u32x4 ro = *reinterpret_cast<const u32x4*>(o + row * ldo + c * 8);
+            const u32x4 rd = *reinterpret_cast<const u32x4*>(dout + row * lddo + c * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                s += __uint_as_float(ro[e] << 16) * __uint_as_float(rd[e] << 16) +
+                     __uint_as_float(ro[e] & 0xffff0000u) * __uint_as_float(rd[e] & 0xffff0000u);
+        }
+        for (int off = 1; off < lph; off <<= 1) s += __shfl_xor(s, off, 64);
+        if (c < C8 && (c % lph) == 0) delta[(b * H + c / lph) * N + n] = s;
+    }
+}
+
 // ---- dK / dV
 template <typename T, int HD>
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkdv_kernel(const T* __restrict__ qkv, int64_t ld,
@@ -618,8 +643,14 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
     ME_CHECK_ARG(ld_dout % E == 0 && ld_dqkv % 4 == 0, "me_attention_bwd: bad strides");
     const int64_t rows = (int64_t)B * N;
     const int64_t nw = rows * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, stream, out, ld_out, dout, ld_dout,
-                       dtype, delta, N, H, head_dim, rows);
+    const int lph = head_dim / 8;
+    if (dtype == ME_BF16 && head_dim % 8 == 0 && (lph & (lph - 1)) == 0 && lph <= 64 && ld_out % 8 == 0 && ld_dout % 8 == 0)
+        hipLaunchKernelGGL(attn_delta_vec_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream,
+                           reinterpret_cast<const bf16_t*>(out), ld_out, reinterpret_cast<const bf16_t*>(dout), ld_dout, delta, N,
+                           H, head_dim, rows);
+    else
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, stream, out, ld_out, dout, ld_dout,
+                           dtype, delta, N, H, head_dim, rows);
     ME_CHECK_LAUNCH("me_attention_bwd(delta)");
     ATTN_DISPATCH(launch_bwd, qkv, ld_qkv, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale, stream);
 }

@@ -58,9 +58,35 @@ __global__ __launch_bounds__(EW_THREADS) void add_rows_kernel(const void* __rest
 // ---- column sums (bias gradients): stage 1: grid (col blocks of 256, row splits); each thread owns 4 columns? no:
 // lanes own single columns (coalesced 2/4-byte reads across the wave are fine for this size); 4 waves x splits rows.
 constexpr int CS_SPLITS = 128;
+// vector path (cols % 4 == 0): a lane owns 4 consecutive columns (8/16-byte loads), a wave covers 256 columns of a
+// row, the 4 waves of a block and blockIdx.y split the rows; 4 rows in flight per wave.
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const void* __restrict__ x, int xdt, int64_t ldx,
+                                                                 int64_t rows, int64_t cols, float* __restrict__ partial) {
+    __shared__ f32x4 sh[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    const int64_t rows_per = (rows + CS_SPLITS - 1) / CS_SPLITS;
+    const int64_t rb = (int64_t)blockIdx.y * rows_per;
+    const int64_t re = rb + rows_per < rows ? rb + rows_per : rows;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (c < cols) {
+        int64_t r = rb + w;
+        for (; r + 12 < re; r += 16) {
+            a0 += load4_as_f32(x, xdt, r * ldx + c);
+            a1 += load4_as_f32(x, xdt, (r + 4) * ldx + c);
+            a2 += load4_as_f32(x, xdt, (r + 8) * ldx + c);
+            a3 += load4_as_f32(x, xdt, (r + 12) * ldx + c);
+        }
+        for (; r < re; r += 4) a0 += load4_as_f32(x, xdt, r * ldx + c);
+    }
+    sh[w][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (w == 0 && c < cols)
+        *reinterpret_cast<f32x4*>(partial + (int64_t)blockIdx.y * cols + c) = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ x, int xdt, int64_t ldx, int64_t rows,
                                                              int64_t cols, float* __restrict__ partial) {
-    // block: 64 columns x 4 row-lanes; blockIdx.y = row split
+    // scalar fallback.  block: 64 columns x 4 row-lanes; blockIdx.y = row split
     __shared__ float sh[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t c = (int64_t)blockIdx.x * 64 + lane;
@@ -243,8 +269,13 @@ extern "C" int me_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, 
     ME_CHECK_ARG(x && out && workspace && rows > 0 && cols > 0, "me_colsum: bad args");
     ME_CHECK_ARG(me_dtype_ok(x_dtype), "me_colsum: bad dtype");
     float* partial = reinterpret_cast<float*>(workspace);
-    dim3 grid((unsigned)((cols + 63) / 64), CS_SPLITS);
-    hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, stream, x, x_dtype, ldx, rows, cols, partial);
+    if (cols % 4 == 0 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0) {
+        dim3 grid((unsigned)((cols + 255) / 256), CS_SPLITS);
+        hipLaunchKernelGGL(colsum_partial_vec_kernel, grid, dim3(256), 0, stream, x, x_dtype, ldx, rows, cols, partial);
+    } else {
+        dim3 grid((unsigned)((cols + 63) / 64), CS_SPLITS);
+        hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, stream, x, x_dtype, ldx, rows, cols, partial);
+    }
     ME_CHECK_LAUNCH("me_colsum(partial)");
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, partial, cols, out,
                        accumulate);

@@ -328,6 +328,11 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     p.res_row_mod = d->res_row_mod; p.out_group_rows = d->out_group_rows;
     p.out_group_stride = d->out_group_stride; p.out_row_offset = d->out_row_offset;
     p.split_k = 1; p.ksteps_per_split = 0;
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("ME_G256_DEBUG"); dbg = e ? atoi(e) : 0; }
+        p.debug = dbg;
+    }
     p.tiles_m = (int)((d->M + BM - 1) / BM);
     p.tiles_n = (int)((d->N + BN - 1) / BN);
     ME_CHECK_ARG((int64_t)p.tiles_m * p.tiles_n < (1ll << 31), "me_gemm: too many tiles");

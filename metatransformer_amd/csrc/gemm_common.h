@@ -13,6 +13,7 @@ struct GemmParams {
     const void* residual; int64_t ldres; int res_dtype;
     int64_t res_row_mod, out_group_rows, out_group_stride, out_row_offset;
     int tiles_m, tiles_n;
+    int debug;                              // dev switches (ME_G256_DEBUG): 1 = skip the epilogue
     int split_k, ksteps_per_split;          // split-K (wgrad): grid.y = split_k, slab z written to C + z*M*ldc
 };
 
@@ -43,6 +44,69 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, in
     store4_from_f32(p.C, p.c_dtype, orow * p.ldc + n, v);
 }
 
+
+
+// Eight consecutive output columns n..n+7 of output row m (two quads), with 16-byte accesses on the bf16 side.
+__device__ __forceinline__ void load8_as_f32(const void* base, int dt, int64_t idx, f32x4& a, f32x4& b) {
+    if (dt == ME_BF16) {
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(base) + idx);
+        a[0] = __uint_as_float(raw[0] << 16); a[1] = __uint_as_float(raw[0] & 0xffff0000u);
+        a[2] = __uint_as_float(raw[1] << 16); a[3] = __uint_as_float(raw[1] & 0xffff0000u);
+        b[0] = __uint_as_float(raw[2] << 16); b[1] = __uint_as_float(raw[2] & 0xffff0000u);
+        b[2] = __uint_as_float(raw[3] << 16); b[3] = __uint_as_float(raw[3] & 0xffff0000u);
+    } else {
+        a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+        b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx + 4);
+    }
+}
+__device__ __forceinline__ void store8_from_f32(void* base, int dt, int64_t idx, f32x4 a, f32x4 b) {
+    if (dt == ME_BF16) {
+        bf16x8 o;
+        o[0] = (bf16_t)a[0]; o[1] = (bf16_t)a[1]; o[2] = (bf16_t)a[2]; o[3] = (bf16_t)a[3];
+        o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<uint16_t*>(base) + idx) = o;
+    } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = a;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx + 4) = b;
+    }
+}
+__device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int64_t n, f32x4 v0, f32x4 v1) {
+    v0 *= p.alpha; v1 *= p.alpha;
+    if (p.bias) {
+        v0 += *reinterpret_cast<const f32x4*>(p.bias + n);
+        v1 += *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+    }
+    if (p.preact) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
+    if (p.act == ME_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[e] = gelu_erf(v0[e]); v1[e] = gelu_erf(v1[e]); }
+    }
+    if (p.aux) {
+        f32x4 a0, a1;
+        load8_as_f32(p.aux, p.aux_dtype, m * p.ldaux + n, a0, a1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[e] *= gelu_erf_grad(a0[e]); v1[e] *= gelu_erf_grad(a1[e]); }
+    }
+    if (p.colscale) {
+        v0 *= *reinterpret_cast<const f32x4*>(p.colscale + n);
+        v1 *= *reinterpret_cast<const f32x4*>(p.colscale + n + 4);
+    }
+    if (p.residual) {
+        const int64_t rr = p.res_row_mod ? (m % p.res_row_mod) : m;
+        f32x4 r0, r1;
+        load8_as_f32(p.residual, p.res_dtype, rr * p.ldres + n, r0, r1);
+        v0 += r0; v1 += r1;
+    }
+    const int64_t orow = p.out_group_rows
+                             ? (m / p.out_group_rows) * p.out_group_stride + (m % p.out_group_rows) + p.out_row_offset
+                             : m;
+    if (p.beta != 0.0f) {
+        f32x4 c0, c1;
+        load8_as_f32(p.C, p.c_dtype, orow * p.ldc + n, c0, c1);
+        v0 += p.beta * c0; v1 += p.beta * c1;
+    }
+    store8_from_f32(p.C, p.c_dtype, orow * p.ldc + n, v0, v1);
+}
 
 // kernel families (each in its own translation unit)
 int launch_g256(const GemmParams& p, int op, int bn, hipStream_t stream);

@@ -90,8 +90,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_generic_kernel(const void* 
 // Each wave walks rows with a grid stride; a lane always owns the same columns, so the affine partial sums
 // live in registers and are written once per wave to the workspace [n_waves, 2, C]; a second kernel folds
 // them (deterministic, no atomics).
-constexpr int LNB_BLOCKS = 512;
+constexpr int LNB_BLOCKS = 1024;
 constexpr int LNB_WAVES = LNB_BLOCKS * (LN_THREADS / 64);
+constexpr int LNB_FOLD = 16;              // second-stage row groups
 
 template <int VPL>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restrict__ dy, int dy_dt,
@@ -103,8 +104,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
                                                             void* __restrict__ dx, int dx_dt,
                                                             float* __restrict__ partial, int want_affine,
                                                             int64_t rows, int C) {
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) float lds_red[];     // [4 waves][2][C] when want_affine
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gw = blockIdx.x * (LN_THREADS / 64) + w;
     f32x4 g[VPL], dg[VPL], db[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -112,56 +114,90 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
         dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int64_t row = gw; row < rows; row += LNB_WAVES) {
-        const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[VPL], d[VPL];
-        float s1 = 0.f, s2 = 0.f;
+    // two rows in flight per wave: the loads of the second row overlap the reductions of the first
+    for (int64_t row0 = gw; row0 < rows; row0 += 2 * LNB_WAVES) {
+        const int64_t row1 = row0 + LNB_WAVES;
+        const bool has1 = row1 < rows;
+        const int64_t r1 = has1 ? row1 : row0;
+        const float mu0 = mean[row0], rs0 = rstd[row0], mu1 = mean[r1], rs1 = rstd[r1];
+        f32x4 xh0[VPL], d0[VPL], xh1[VPL], d1[VPL];
+        float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            const int64_t idx = row * C + (int64_t)(lane + 64 * i) * 4;
-            const f32x4 xv = load4_as_f32(x, x_dt, idx);
-            d[i] = load4_as_f32(dy, dy_dt, idx);
+            const int64_t c = (int64_t)(lane + 64 * i) * 4;
+            const f32x4 xv0 = load4_as_f32(x, x_dt, row0 * C + c);
+            d0[i] = load4_as_f32(dy, dy_dt, row0 * C + c);
+            const f32x4 xv1 = load4_as_f32(x, x_dt, r1 * C + c);
+            d1[i] = load4_as_f32(dy, dy_dt, r1 * C + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                xh[i][e] = (xv[e] - mu) * rs;
-                const float ge = d[i][e] * g[i][e];
-                s1 += ge;
-                s2 += ge * xh[i][e];
-                dg[i][e] += d[i][e] * xh[i][e];
-                db[i][e] += d[i][e];
+                xh0[i][e] = (xv0[e] - mu0) * rs0;
+                xh1[i][e] = (xv1[e] - mu1) * rs1;
+                const float ge0 = d0[i][e] * g[i][e], ge1 = d1[i][e] * g[i][e];
+                a0 += ge0; b0 += ge0 * xh0[i][e];
+                a1 += ge1; b1 += ge1 * xh1[i][e];
+                dg[i][e] += d0[i][e] * xh0[i][e];
+                db[i][e] += d0[i][e];
+                if (has1) {
+                    dg[i][e] += d1[i][e] * xh1[i][e];
+                    db[i][e] += d1[i][e];
+                }
             }
         }
-        const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a0 += __shfl_xor(a0, o, 64); b0 += __shfl_xor(b0, o, 64);
+            a1 += __shfl_xor(a1, o, 64); b1 += __shfl_xor(b1, o, 64);
+        }
+        const float inv = 1.0f / (float)C;
+        a0 *= inv; b0 *= inv; a1 *= inv; b1 *= inv;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            const int64_t idx = row * C + (int64_t)(lane + 64 * i) * 4;
-            f32x4 o;
+            const int64_t c = (int64_t)(lane + 64 * i) * 4;
+            f32x4 o0, o1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = rs * (d[i][e] * g[i][e] - m1 - xh[i][e] * m2);
-            if (dres) o += load4_as_f32(dres, dres_dt, idx);
-            store4_from_f32(dx, dx_dt, idx, o);
+            for (int e = 0; e < 4; ++e) {
+                o0[e] = rs0 * (d0[i][e] * g[i][e] - a0 - xh0[i][e] * b0);
+                o1[e] = rs1 * (d1[i][e] * g[i][e] - a1 - xh1[i][e] * b1);
+            }
+            if (dres) {
+                o0 += load4_as_f32(dres, dres_dt, row0 * C + c);
+                if (has1) o1 += load4_as_f32(dres, dres_dt, row1 * C + c);
+            }
+            store4_from_f32(dx, dx_dt, row0 * C + c, o0);
+            if (has1) store4_from_f32(dx, dx_dt, row1 * C + c, o1);
         }
     }
-    if (want_affine) {
+    if (want_affine) {     // deterministic block fold: waves park their partials in LDS, then columns are summed in wave order
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = (lane + 64 * i) * 4;
-            *reinterpret_cast<f32x4*>(partial + ((int64_t)gw * 2 + 0) * C + c) = dg[i];
-            *reinterpret_cast<f32x4*>(partial + ((int64_t)gw * 2 + 1) * C + c) = db[i];
+            *reinterpret_cast<f32x4*>(lds_red + (w * 2 + 0) * C + c) = dg[i];
+            *reinterpret_cast<f32x4*>(lds_red + (w * 2 + 1) * C + c) = db[i];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * C; c += LN_THREADS) {
+            const int which = c / C, col = c % C;
+            const float v = (lds_red[(0 * 2 + which) * C + col] + lds_red[(1 * 2 + which) * C + col]) +
+                            (lds_red[(2 * 2 + which) * C + col] + lds_red[(3 * 2 + which) * C + col]);
+            partial[((int64_t)blockIdx.x * 2 + which) * C + col] = v;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int C, int accumulate) {
-    // one block per 64 columns; 4 waves split the partial rows, lanes = columns
+// fold [nrows][2][C] partials: stage 1 (grid.y = LNB_FOLD row groups) -> [LNB_FOLD][2][C]; stage 2 (grid.y = 1) -> outputs
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restrict__ partial, int nrows,
+                                                          float* __restrict__ out_partial, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int C, int accumulate) {
     __shared__ float sh[2][4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
+    const int per = (nrows + gridDim.y - 1) / gridDim.y;
+    const int rb = blockIdx.y * per;
+    const int re = rb + per < nrows ? rb + per : nrows;
     float a = 0.f, b = 0.f;
     if (c < C) {
-        for (int r = w; r < LNB_WAVES; r += 4) {
+        for (int r = rb + w; r < re; r += 4) {
             a += partial[((int64_t)r * 2 + 0) * C + c];
             b += partial[((int64_t)r * 2 + 1) * C + c];
         }
@@ -172,7 +208,10 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     if (w == 0 && c < C) {
         a = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
         b = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
-        if (accumulate) {
+        if (out_partial) {
+            out_partial[((int64_t)blockIdx.y * 2 + 0) * C + c] = a;
+            out_partial[((int64_t)blockIdx.y * 2 + 1) * C + c] = b;
+        } else if (accumulate) {
             dgamma[c] += a;
             dbeta[c] += b;
         } else {
@@ -277,7 +316,9 @@ extern "C" int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     return ME_OK;
 }
 
-extern "C" size_t me_layernorm_bwd_workspace(int cols) { return (size_t)LNB_WAVES * 2 * (size_t)cols * sizeof(float); }
+extern "C" size_t me_layernorm_bwd_workspace(int cols) {
+    return (size_t)(LNB_BLOCKS + LNB_FOLD) * 2 * (size_t)cols * sizeof(float);
+}
 
 extern "C" int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
                                 const float* rstd, const float* gamma, const void* dres, int dres_dtype, void* dx,
@@ -302,9 +343,10 @@ extern "C" int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int
         return ME_OK;
     }
     float* partial = reinterpret_cast<float*>(workspace);
+    const size_t lds_bytes = want_affine ? (size_t)4 * 2 * cols * sizeof(float) : 0;
 #define LN_BWD_CASE(V)                                                                                          \
     case V:                                                                                                     \
-        hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(LNB_BLOCKS), dim3(LN_THREADS), 0, stream, dy, dy_dtype, x,   \
+        hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(LNB_BLOCKS), dim3(LN_THREADS), lds_bytes, stream, dy, dy_dtype, x, \
                            x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, partial, want_affine,    \
                            rows, cols);                                                                         \
         break;
@@ -315,9 +357,13 @@ extern "C" int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int
 #undef LN_BWD_CASE
     ME_CHECK_LAUNCH("me_layernorm_bwd");
     if (want_affine) {
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, stream, partial, dgamma, dbeta,
-                           cols, accumulate_affine);
-        ME_CHECK_LAUNCH("me_layernorm_bwd(reduce)");
+        float* partial2 = partial + (size_t)LNB_BLOCKS * 2 * cols;
+        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((cols + 63) / 64, LNB_FOLD), dim3(256), 0, stream, partial, LNB_BLOCKS,
+                           partial2, nullptr, nullptr, cols, 0);
+        ME_CHECK_LAUNCH("me_layernorm_bwd(fold 1)");
+        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((cols + 63) / 64, 1), dim3(256), 0, stream, partial2, LNB_FOLD,
+                           nullptr, dgamma, dbeta, cols, accumulate_affine);
+        ME_CHECK_LAUNCH("me_layernorm_bwd(fold 2)");
     }
     return ME_OK;
 }

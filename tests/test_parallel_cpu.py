@@ -1,0 +1,87 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient path (flat buckets + one all-reduce per bucket) gives
+sum-over-ranks, the buckets tile the flat buffer exactly once, and the reference-style coalesced helper averages."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from metatransformer_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Linear(40, 96), nn.LayerNorm(96), nn.Linear(96, 33))
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = _model()
+        flat = parallel.FlatParams(m.parameters())
+        # params / grads are views of the flat buffers
+        for p, o in zip(flat.params, flat.offsets):
+            assert p.data.data_ptr() == flat.flat_param.data_ptr() + 4 * o
+            assert p.grad.data_ptr() == flat.flat_grad.data_ptr() + 4 * o
+        x = torch.randn(16, 40, generator=torch.Generator().manual_seed(100 + rank))
+        flat.zero_grad()
+        m(x).square().mean().backward()
+        # autograd accumulated IN PLACE into the flat views
+        assert all(p.grad.data_ptr() == flat.flat_grad.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
+        local = flat.flat_grad.clone()
+        parallel.allreduce_gradients(flat, bucket_bytes=4096)            # several small buckets
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(flat.flat_grad, sum(gathered), atol=1e-6)
+        # bucket slices cover the buffer exactly once, in reverse parameter order
+        bks = flat.buckets(4096)
+        assert sum(b.numel() for b in bks) == flat.numel
+        assert bks[0].data_ptr() > bks[-1].data_ptr()
+        # reference-style helper (dist_utils.py:14-35): average of loose tensors
+        t = [torch.full((7,), float(rank + 1)), torch.full((3, 5), 10.0 * (rank + 1))]
+        parallel.allreduce_coalesced(t, bucket_bytes=16)
+        assert torch.allclose(t[0], torch.full((7,), 1.5)) and torch.allclose(t[1], torch.full((3, 5), 15.0))
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_flatparams_single_process_semantics():
+    m = _model()
+    before = [p.detach().clone() for p in m.parameters()]
+    flat = parallel.FlatParams(m.parameters())
+    assert all(torch.equal(a, b) for a, b in zip(before, m.parameters())), "re-homing must not change values"
+    assert flat.numel % 64 == 0
+    m(torch.randn(4, 40)).sum().backward()
+    assert flat.flat_grad.abs().sum() > 0
+    flat.zero_grad()
+    assert flat.flat_grad.abs().sum() == 0 and all(p.grad is not None for p in m.parameters())
+    parallel.allreduce_gradients(flat)          # no process group: a no-op, not an error

@@ -69,12 +69,15 @@ if __name__ == "__main__":
         run_family(a.family, a.iters)
         sys.exit(0)
     rows = []
-    for fam in a.families.split(","):
+    for fam in a.families.split(","):           # "family[:variant]"
         env = dict(os.environ)
-        if fam != "auto":
-            env["ME_GEMM_KERNEL"] = fam
+        base, _, var = fam.partition(":")
+        if base != "auto":
+            env["ME_GEMM_KERNEL"] = base
         else:
             env.pop("ME_GEMM_KERNEL", None)
+        if var:
+            env["ME_G256_VARIANT"] = var
         r = subprocess.run([sys.executable, __file__, "--family", fam, "--iters", str(a.iters)], env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if not line:
@@ -82,6 +85,8 @@ if __name__ == "__main__":
             continue
         rows.append(json.loads(line[-1]))
     names = [s[0] for s in SHAPES]
-    print(f"{'shape':12s} " + " ".join(f"{r['family']:>22s}" for r in rows))
+    print(f"{'shape':12s} " + " ".join(f"{r['family']:>16s}" for r in rows))
     for n in names:
-        print(f"{n:12s} " + " ".join(f"{r['results'][n]['tflops']:8.1f}TF {r['results'][n]['us']:7.1f}us {r['results'][n]['relerr']:.0e}" for r in rows))
+        print(f"{n:12s} " + " ".join(f"{r['results'][n]['tflops']:7.1f}TF {r['results'][n]['relerr']:.0e}" for r in rows))
+    tot = [sum(r['results'][n]['us'] for n in names) for r in rows]
+    print(f"{'sum us':12s} " + " ".join(f"{t:16.1f}" for t in tot))
