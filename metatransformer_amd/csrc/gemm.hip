@@ -244,51 +244,66 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 }
 
 struct GemmPlan {
-    int family;      // 0 = g128, 1 = g256
-    int bn;          // g256: 256 / 128
+    int family;      // 0 = g128, 1 = g256 (one 8-wave workgroup / CU), 2 = g2b (two 4-wave workgroups / CU)
+    int bn;          // 256 / 128
+    int bm;          // 256 (g256) / 128 (g2b)
+    int kstep;       // 64 / 32
     int split_k;     // >= 1
     int ksteps_per_split;
     size_t ws_bytes;
 };
 
-int forced_family() {   // ME_GEMM_KERNEL = g128 | g256_256 | g256_128   (A/B benchmarking)
-    static int v = -2;
-    if (v == -2) {
+// ME_GEMM_KERNEL = g128 | g256_256 | g256_128 | g2b_256 | g2b_128   (dev A/B switch)
+void forced_family(int& fam, int& bn) {
+    static int f = -2, b = 0;
+    if (f == -2) {
         const char* e = getenv("ME_GEMM_KERNEL");
-        v = -1;
+        f = -1;
         if (e) {
-            if (!strcmp(e, "g128")) v = 0;
-            else if (!strcmp(e, "g256_256")) v = 256;
-            else if (!strcmp(e, "g256_128")) v = 128;
+            if (!strcmp(e, "g128")) f = 0;
+            else if (!strcmp(e, "g256_256")) { f = 1; b = 256; }
+            else if (!strcmp(e, "g256_128")) { f = 1; b = 128; }
+            else if (!strcmp(e, "g2b_256")) { f = 2; b = 256; }
+            else if (!strcmp(e, "g2b_128")) { f = 2; b = 128; }
         }
     }
-    return v;
+    fam = f; bn = b;
 }
 
 GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
-    GemmPlan pl{0, 0, 1, 0, 0};
-    const int force = forced_family();
-    if (d->ab_dtype != ME_BF16 || force == 0 || !g256_supported(p, d->op)) return pl;
-    // tiny problems: one 128x128 tile family is enough
-    if (force < 0 && (d->M < 256 || d->N < 128)) return pl;
-    pl.family = 1;
-    const int64_t tm = (d->M + 255) / 256;
+    GemmPlan pl{0, 0, 128, 0, 1, 0, 0};
+    int ffam, fbn;
+    forced_family(ffam, fbn);
+    if (d->ab_dtype != ME_BF16 || ffam == 0) return pl;
+    const int fam = ffam > 0 ? ffam : 2;                        // default: g2b
+    const bool ok = fam == 2 ? g2b_supported(p, d->op) : g256_supported(p, d->op);
+    if (!ok) {
+        if (fam == 2 && ffam < 0 && g256_supported(p, d->op)) return pl;   // (K % 32 != 0 never passes K % 64)
+        return pl;
+    }
+    if (ffam < 0 && (d->M < 128 || d->N < 128)) return pl;       // tiny problems: g128 is enough
+    pl.family = fam;
+    pl.bm = fam == 2 ? 128 : 256;
+    pl.kstep = fam == 2 ? 32 : 64;
+    const int64_t tm = (d->M + pl.bm - 1) / pl.bm;
     const int64_t t256 = tm * ((d->N + 255) / 256), t128 = tm * ((d->N + 127) / 128);
-    const int nk = (int)(d->K / 64);
-    const int CUS = 256;
+    const int nk = (int)(d->K / pl.kstep);
+    const int SLOTS = fam == 2 ? 512 : 256;                      // co-resident workgroups on the chip
     if (d->op == ME_GEMM_TN) {
-        pl.bn = (force > 0) ? force : ((d->N % 256 == 0 || d->N > 512) ? 256 : 128);
+        pl.bn = fbn ? fbn : ((d->N % 256 == 0 || d->N > 512) ? 256 : 128);
         const int64_t tiles = pl.bn == 256 ? t256 : t128;
-        int s = (int)(CUS / tiles);
+        int s = (int)(SLOTS / tiles);
         if (s < 1) s = 1;
-        while (s > 1 && nk / s < 8) --s;
+        const int min_steps = 512 / pl.kstep;                   // keep >= 512 reduction rows per slice
+        while (s > 1 && nk / s < min_steps) --s;
         pl.ksteps_per_split = (nk + s - 1) / s;
         pl.split_k = (nk + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
         if (pl.split_k > 1) pl.ws_bytes = (size_t)pl.split_k * (size_t)d->M * (size_t)d->N * sizeof(float);
     } else {
-        if (force > 0) pl.bn = force;
+        if (fbn) pl.bn = fbn;
+        else if (fam == 2) pl.bn = d->N > 128 ? 256 : 128;       // measured: g2b_256 beats g2b_128 on every encoder shape
         else {
-            const double c256 = (double)((t256 + CUS - 1) / CUS), c128 = 0.55 * (double)((t128 + CUS - 1) / CUS);
+            const double c256 = (double)((t256 + SLOTS - 1) / SLOTS), c128 = 0.55 * (double)((t128 + SLOTS - 1) / SLOTS);
             pl.bn = c256 <= c128 ? 256 : 128;
         }
         pl.ksteps_per_split = nk;
@@ -353,15 +368,18 @@ extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
     int rc = fill_params(d, p);
     if (rc) return rc;
     GemmPlan pl = plan_gemm(d, p);
-    if (pl.family == 1) {
-        p.tiles_m = (int)((d->M + 255) / 256);
+    if (pl.family >= 1) {
+        auto run = [&](const GemmParams& q) {
+            return pl.family == 2 ? launch_g2b(q, d->op, pl.bn, stream) : launch_g256(q, d->op, pl.bn, stream);
+        };
+        p.tiles_m = (int)((d->M + pl.bm - 1) / pl.bm);
         p.tiles_n = (int)((d->N + pl.bn - 1) / pl.bn);
         p.ksteps_per_split = pl.ksteps_per_split;
         if (pl.split_k > 1 && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes) {
             GemmParams ps = p;
             ps.C = d->workspace;
             ps.split_k = pl.split_k;
-            rc = launch_g256(ps, d->op, pl.bn, stream);
+            rc = run(ps);
             if (rc) return rc;
             const int64_t quads = d->M * (d->N / 4);
             int64_t nb = (quads + 255) / 256;
@@ -372,8 +390,8 @@ extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
             return ME_OK;
         }
         p.split_k = 1;
-        p.ksteps_per_split = (int)(d->K / 64);
-        return launch_g256(p, d->op, pl.bn, stream);
+        p.ksteps_per_split = (int)(d->K / pl.kstep);
+        return run(p);
     }
     if (d->ab_dtype == ME_BF16)
         return d->op == ME_GEMM_NT ? launch_g128<bf16_t, false>(p, stream) : launch_g128<bf16_t, true>(p, stream);
