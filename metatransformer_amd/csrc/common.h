@@ -89,7 +89,7 @@ __device__ __forceinline__ void store1_from_f32(void* base, int dt, int64_t idx,
 // e^{-x^2/2} serves the Gaussian pdf term of the derivative.
 __device__ __forceinline__ void erf_parts(float x, float& erf_z, float& exp_mz2) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));     // 1-ulp v_rcp_f32 (not the IEEE division sequence)
     exp_mz2 = __expf(-z * z);
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);

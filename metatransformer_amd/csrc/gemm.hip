@@ -265,6 +265,7 @@ void forced_family(int& fam, int& bn) {
             else if (!strcmp(e, "g256_128")) { f = 1; b = 128; }
             else if (!strcmp(e, "g2b_256")) { f = 2; b = 256; }
             else if (!strcmp(e, "g2b_128")) { f = 2; b = 128; }
+            else if (!strcmp(e, "g2w")) { f = 3; b = 256; }          // 8 waves, 256x256, K-step 32, 4 stages
         }
     }
     fam = f; bn = b;
@@ -276,7 +277,7 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
     forced_family(ffam, fbn);
     if (d->ab_dtype != ME_BF16 || ffam == 0) return pl;
     const int fam = ffam > 0 ? ffam : 2;                        // default: g2b
-    const bool ok = fam == 2 ? g2b_supported(p, d->op) : g256_supported(p, d->op);
+    const bool ok = fam >= 2 ? g2b_supported(p, d->op) : g256_supported(p, d->op);
     if (!ok) {
         if (fam == 2 && ffam < 0 && g256_supported(p, d->op)) return pl;   // (K % 32 != 0 never passes K % 64)
         return pl;
@@ -284,7 +285,7 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
     if (ffam < 0 && (d->M < 128 || d->N < 128)) return pl;       // tiny problems: g128 is enough
     pl.family = fam;
     pl.bm = fam == 2 ? 128 : 256;
-    pl.kstep = fam == 2 ? 32 : 64;
+    pl.kstep = fam >= 2 ? 32 : 64;
     const int64_t tm = (d->M + pl.bm - 1) / pl.bm;
     const int64_t t256 = tm * ((d->N + 255) / 256), t128 = tm * ((d->N + 127) / 128);
     const int nk = (int)(d->K / pl.kstep);
@@ -370,7 +371,7 @@ extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
     GemmPlan pl = plan_gemm(d, p);
     if (pl.family >= 1) {
         auto run = [&](const GemmParams& q) {
-            return pl.family == 2 ? launch_g2b(q, d->op, pl.bn, stream) : launch_g256(q, d->op, pl.bn, stream);
+            return pl.family >= 2 ? launch_g2b(q, d->op, pl.bm, pl.bn, stream) : launch_g256(q, d->op, pl.bn, stream);
         };
         p.tiles_m = (int)((d->M + pl.bm - 1) / pl.bm);
         p.tiles_n = (int)((d->N + pl.bn - 1) / pl.bn);

@@ -19,10 +19,7 @@
 
 namespace {
 
-constexpr int BM2 = 128;
 constexpr int KS2 = 32;
-constexpr int NTH2 = 256;
-constexpr int NSTAGE = 3;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -33,18 +30,24 @@ __device__ __forceinline__ void glds16(const void* gsrc, lds_char* lds_wave_base
     __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN> struct G2 {
-    static constexpr int A_BYTES = BM2 * KS2 * 2;     // 8 KiB
+// BM = 128: 4 waves (1 x 4), 3 stages, two workgroups per CU ("g2b").
+// BM = 256: 8 waves (2 x 4), 4 stages (DMA three steps ahead), one workgroup per CU with the minimum L2 traffic per
+//           flop a CU can have (256 x 256 accumulators = half the register file) ("g2w").
+template <int BM, int BN> struct G2 {
+    static constexpr int NW = BM / 32;                // waves: 4 / 8
+    static constexpr int NTH = NW * 64;
+    static constexpr int NSTAGE = BM == 128 ? 3 : 4;
+    static constexpr int A_BYTES = BM * KS2 * 2;      // 8 / 16 KiB
     static constexpr int B_BYTES = BN * KS2 * 2;      // 16 / 8 KiB
-    static constexpr int STAGE = A_BYTES + B_BYTES;   // 24 / 16 KiB
+    static constexpr int STAGE = A_BYTES + B_BYTES;
     static constexpr int NI = BN / 128;
-    static constexpr int NDMA = (A_BYTES + B_BYTES) / 1024 / 4;   // DMA instructions per wave per step: 6 / 4
+    static constexpr int NDMA = (A_BYTES + B_BYTES) / 1024 / NW;   // DMA instructions per wave per step
 };
 
 // ---- NT: tile [ROWS][32 k] = 64-byte rows; one DMA instruction = 16 rows; lane -> (row 16q + lane/4, slot lane%4)
-template <int ROWS>
+template <int ROWS, int NW>
 struct NtStager2 {
-    static constexpr int NINS = ROWS / 16 / 4;        // per wave: 2 (128 rows) / 4 (256 rows)
+    static constexpr int NINS = ROWS / 16 / NW;       // DMA instructions per wave
     const bf16_t* src[NINS];
     __device__ __forceinline__ void init(const bf16_t* S, int64_t ld, int64_t nrows, int64_t r0, int wave, int lane) {
 #pragma unroll
@@ -67,10 +70,10 @@ __device__ __forceinline__ bf16x8 nt_frag2(const char* tile, int row, int chunk)
 }
 
 // ---- TN: tile [32 t][COLS]; CPR 16-byte chunks per row; one DMA instruction = 64 chunk slots
-template <int COLS>
+template <int COLS, int NW>
 struct TnStager2 {
     static constexpr int CPR = COLS / 8;
-    static constexpr int NINS = 32 * CPR / 64 / 4;    // per wave: 2 (128 cols) / 4 (256 cols)
+    static constexpr int NINS = 32 * CPR / 64 / NW;   // DMA instructions per wave
     const bf16_t* src[NINS];
     __device__ __forceinline__ void init(const bf16_t* S, int64_t ld, int64_t ncols, int64_t c0, int wave, int lane) {
 #pragma unroll
@@ -104,20 +107,33 @@ __device__ __forceinline__ bf16x8 tn_frag2(const lds_char* tile, int cb, int kk,
     return u.v;
 }
 
-template <int BN, bool TN>
-__global__ __launch_bounds__(NTH2) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g2_kernel(const GemmParams p) {
-    typedef G2<BN> G;
+// K-step schedule (measured best of three, tools/gemm_bench.py): read the substep-0 fragments, issue the DMA while they
+// fly, prefetch the substep-1 fragments, then all 16 MFMAs.  (s_setprio around the MFMAs measured -3 %.)
+//
+// EPI selects a specialised epilogue so that the common cases are small straight-line code:
+//   0 alpha*acc + bias (* colscale)            (QKV forward, dgrad, wgrad / split-K slabs)
+//   1 ... -> (store pre-activation) -> GELU     (fc1 forward)
+//   2 ... + residual                            (proj / fc2 forward)          } one row operand, fetched one pass ahead
+//   3 ... * gelu'(aux)                          (fc2 dgrad -> dH)             }
+//   4 generic: anything include/metaenc.h allows (beta, row remap, pos-embed modulo, combinations)
+//   5 split-K slab: raw fp32 partial sums (folded by splitk_reduce_kernel, which applies the real epilogue)
+constexpr int SCHED = 1;
+template <int BM, int BN, bool TN, int EPI>
+__global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g2_kernel(const GemmParams p) {
+    typedef G2<BM, BN> G;
+    constexpr int NSTAGE = G::NSTAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* lds = (lds_char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = column group
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                        // wave row (BM = 256 only) / column group
     const int l31 = lane & 31, h = lane >> 5;
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int tm = wgid / p.tiles_n, tn = wgid % p.tiles_n;
-    const int64_t m0 = (int64_t)tm * BM2, n0 = (int64_t)tn * BN;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
@@ -135,182 +151,296 @@ __global__ __launch_bounds__(NTH2) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    NtStager2<BM2> nta;
-    NtStager2<BN> ntb;
-    TnStager2<BM2> tna;
-    TnStager2<BN> tnb;
+    NtStager2<BM, G::NW> nta;
+    NtStager2<BN, G::NW> ntb;
+    TnStager2<BM, G::NW> tna;
+    TnStager2<BN, G::NW> tnb;
     if (TN) {
-        tna.init(A, p.lda, p.M, m0, wc, lane);
-        tnb.init(B, p.ldb, p.N, n0, wc, lane);
+        tna.init(A, p.lda, p.M, m0, wave, lane);
+        tnb.init(B, p.ldb, p.N, n0, wave, lane);
     } else {
-        nta.init(A, p.lda, p.M, m0, wc, lane);
-        ntb.init(B, p.ldb, p.N, n0, wc, lane);
+        nta.init(A, p.lda, p.M, m0, wave, lane);
+        ntb.init(B, p.ldb, p.N, n0, wave, lane);
     }
     auto issue = [&](int stage, int kstep) {
         lds_char* sa = lds + stage * G::STAGE;
         lds_char* sb = sa + G::A_BYTES;
         const int64_t k0 = (int64_t)kstep * KS2;
         if (TN) {
-            tna.issue(sa, wc, k0, p.lda);
-            tnb.issue(sb, wc, k0, p.ldb);
+            tna.issue(sa, wave, k0, p.lda);
+            tnb.issue(sb, wave, k0, p.ldb);
         } else {
-            nta.issue(sa, wc, k0);
-            ntb.issue(sb, wc, k0);
+            nta.issue(sa, wave, k0);
+            ntb.issue(sb, wave, k0);
+        }
+    };
+    // counted wait: leave `ahead` younger steps (NDMA instructions each) in flight
+    auto wait_ahead = [&](int ahead) {
+        static_assert(G::NDMA == 6 || G::NDMA == 4 || G::NDMA == 3, "vmcnt immediates below");
+        if (ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (ahead == 1) {
+            if (G::NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (G::NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            if (G::NDMA == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (G::NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         }
     };
 
-    if (nk > 0) issue(0, ks_begin);
-    if (nk > 1) issue(1, ks_begin + 1);
-    int s_cur = 0, s_nxt2 = 2;       // stage of step t, stage of step t+2
+    constexpr int LOOK = NSTAGE - 1;          // steps in flight ahead of the one being computed: 2 / 3
+#pragma unroll
+    for (int i = 0; i < LOOK; ++i)
+        if (i < nk) issue(i, ks_begin + i);
+    int s_cur = 0, s_nxt2 = LOOK;    // stage of step t, stage of step t+LOOK
     for (int t = 0; t < nk; ++t) {
-        // my part of step t has landed (the DMA of step t+1, issued later, may stay in flight) ...
-        if (t + 1 < nk) {
-            if (G::NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // my part of step t has landed (younger steps' DMA may stay in flight) ...
+        int ahead = nk - 1 - t;
+        ahead = ahead < LOOK - 1 ? ahead : LOOK - 1;
+        if (!(p.debug & 8)) wait_ahead(ahead);
         // ... everybody's part has, and every reader of step t-1's stage is done with it
         __builtin_amdgcn_s_barrier();
-        if (t + 2 < nk) issue(s_nxt2, ks_begin + t + 2);
         const char* sa = smem + s_cur * G::STAGE;
         const char* sb = sa + G::A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 xb[4], wa[G::NI];
+        auto load_frags = [&](int kk, bf16x8 (&xb)[4], bf16x8 (&wa)[G::NI]) {
             if (TN) {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) xb[mi] = tn_frag2<BM2>((const lds_char*)sa, mi * 32, kk, lane);
+                for (int mi = 0; mi < 4; ++mi) xb[mi] = tn_frag2<BM>((const lds_char*)sa, wr * 128 + mi * 32, kk, lane);
 #pragma unroll
                 for (int ni = 0; ni < G::NI; ++ni) wa[ni] = tn_frag2<BN>((const lds_char*)sb, wc * (BN / 4) + ni * 32, kk, lane);
             } else {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) xb[mi] = nt_frag2(sa, mi * 32 + l31, 2 * kk + h);
+                for (int mi = 0; mi < 4; ++mi) xb[mi] = nt_frag2(sa, wr * 128 + mi * 32 + l31, 2 * kk + h);
 #pragma unroll
                 for (int ni = 0; ni < G::NI; ++ni) wa[ni] = nt_frag2(sb, wc * (BN / 4) + ni * 32 + l31, 2 * kk + h);
             }
+        };
+        auto mma = [&](const bf16x8 (&xb)[4], const bf16x8 (&wa)[G::NI]) {
+            if (SCHED == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < G::NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ni], xb[mi], acc[mi][ni], 0, 0, 0);
+            if (SCHED == 2) __builtin_amdgcn_s_setprio(0);
+        };
+        if (SCHED == 0) {
+            if (t + LOOK < nk) issue(s_nxt2, ks_begin + t + LOOK);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 xb[4], wa[G::NI];
+                load_frags(kk, xb, wa);
+                mma(xb, wa);
+            }
+        } else {
+            bf16x8 xb0[4], wa0[G::NI], xb1[4], wa1[G::NI];
+            if ((p.debug & 16) && t > 0) {               // dev: no LDS traffic -- reuse whatever the registers hold
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { asm volatile("" : "=v"(xb0[i])); asm volatile("" : "=v"(xb1[i])); }
+#pragma unroll
+                for (int i = 0; i < G::NI; ++i) { asm volatile("" : "=v"(wa0[i])); asm volatile("" : "=v"(wa1[i])); }
+            } else {
+                load_frags(0, xb0, wa0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + LOOK < nk && !(p.debug & 8)) issue(s_nxt2, ks_begin + t + LOOK);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!((p.debug & 16) && t > 0)) load_frags(1, xb1, wa1);
+            mma(xb0, wa0);
+            mma(xb1, wa1);
         }
         s_cur = s_cur == NSTAGE - 1 ? 0 : s_cur + 1;
         s_nxt2 = s_nxt2 == NSTAGE - 1 ? 0 : s_nxt2 + 1;
     }
 
     // ---- epilogue (same scheme as gemm256.hip): accumulators -> per-wave LDS patch -> row-contiguous 16-byte accesses
+    if (p.debug & 1) {                                    // dev: K-loop only
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < G::NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) keep += acc[i][j][e];
+        if (keep == 1.2345e-30f) reinterpret_cast<float*>(p.C)[0] = keep;
+        return;
+    }
+    // ---- epilogue.  A lane owns one output ROW and scattered 4-column quads (MFMA layout); stored directly that is
+    // 16-byte fragments of 32 different lines per instruction.  Each wave therefore transposes 32-row slabs of its
+    // accumulators through its own LDS patch (pitch padded by 16 B: conflict-free 16-byte accesses) and re-reads them
+    // row-contiguous, 8 columns per lane -> full 128-byte lines per row, 16-byte coalesced loads/stores.
+    //
+    // The LDS accesses are INLINE ASM on purpose: vmcnt retires in order and also counts stores, and because LDS-DMA
+    // is "a pending LDS write on the vm counter" hipcc guards every compiler-visible LDS access that follows a DMA with
+    // s_waitcnt vmcnt(0) -- which here would drain the previous slab's global stores four times per tile (measured:
+    // the epilogue then costs 18 us per tile, more than the K-loop at K = 768).  Hidden from the compiler, the slabs'
+    // stores stay in flight; a wave's DS operations execute in order, so write -> read needs no wait in between.
     constexpr int WCOLS = BN / 4;
     constexpr int PITCH = WCOLS * 4 + 16;
-    constexpr int LPR = WCOLS / 8;
-    constexpr int RPI = 64 / LPR;
-    constexpr int NIT = 32 / RPI;
-    __builtin_amdgcn_s_barrier();
-    char* patch = smem + wc * (32 * PITCH);
+    constexpr int LPR = WCOLS / 8;                        // lanes per row in the read phase: 8 / 4
+    constexpr int RPI = 64 / LPR;                         // rows per read instruction: 8 / 16
+    constexpr int NIT = 32 / RPI;                         // read iterations per 32-row slab: 4 / 2
+    __builtin_amdgcn_s_barrier();                         // every wave is done reading the operand stages
+    const uint32_t patch = (uint32_t)(uintptr_t)(lds + wave * (32 * PITCH));
+    const uint32_t waddr = patch + l31 * PITCH + 16 * h;              // + (ni*32 + 8g) * 4
+    const uint32_t raddr = patch + (lane / LPR) * PITCH + 32 * (lane % LPR);   // + RPI*i*PITCH (+16)
     float* slab = p.split_k > 1 ? reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.y * p.M * p.N : nullptr;
     const int c0 = 8 * (lane % LPR);
     const int64_t n = n0 + wc * WCOLS + c0;
-    const bool n_ok = n + 8 <= p.N;
+    const bool n_ok = n + 8 <= p.N;                       // N % 8 == 4 tails take the quad path
+    const int64_t mrow0 = m0 + wr * 128 + (lane / LPR);   // + mi*32 + RPI*i
     f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0, cs0 = {1.f, 1.f, 1.f, 1.f}, cs1 = cs0;
-    if (!slab && n_ok) {
+    if (EPI != 4 && EPI != 5 && n_ok) {
         if (p.bias) { bias0 = *reinterpret_cast<const f32x4*>(p.bias + n); bias1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
         if (p.colscale) { cs0 = *reinterpret_cast<const f32x4*>(p.colscale + n); cs1 = *reinterpret_cast<const f32x4*>(p.colscale + n + 4); }
     }
-    const int n_rowops = (p.residual ? 1 : 0) + (p.aux ? 1 : 0) + (p.beta != 0.0f ? 1 : 0);
-    const bool generic = !slab && (n_rowops > 1 || p.out_group_rows != 0 || p.res_row_mod != 0);
-    const bool piped = !slab && !generic && n_rowops == 1;
-    const void* rop = p.residual ? p.residual : (p.aux ? p.aux : p.C);
-    const int rop_dt = p.residual ? p.res_dtype : (p.aux ? p.aux_dtype : p.c_dtype);
-    const int64_t rop_ld = p.residual ? p.ldres : (p.aux ? p.ldaux : p.ldc);
-    struct RowOp { f32x4 v[NIT][2]; };
-    const int64_t mrow0 = m0 + (lane / LPR);                    // + mi*32 + RPI*i
+    // pin the per-column operands in registers NOW (straight-line code): otherwise hipcc waits for them with vmcnt(0)
+    // inside every guarded store block, which drains the stores of the previous rows each time
+    asm volatile("" ::"v"(bias0), "v"(bias1), "v"(cs0), "v"(cs1));
+    // row operand (EPI 2 / 3): bf16 only on the fast path (fp32 row operands take the generic epilogue); loads are
+    // unconditional with clamped coordinates so that no load -- hence no wait -- sits inside a branch
+    const uint16_t* rop = reinterpret_cast<const uint16_t*>(EPI == 2 ? p.residual : p.aux);
+    const int64_t rop_ld = EPI == 2 ? p.ldres : p.ldaux;
+    const int64_t n_cl = n_ok ? n : 0;
+    struct RowOp { u32x4 raw[NIT]; };
     auto fetch = [&](int mi, RowOp& ro) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int64_t m = mrow0 + mi * 32 + RPI * i;
-            if (m < p.M && n_ok) load8_as_f32(rop, rop_dt, m * rop_ld + n, ro.v[i][0], ro.v[i][1]);
+            int64_t m = mrow0 + mi * 32 + RPI * i;
+            m = m < p.M ? m : p.M - 1;
+            ro.raw[i] = *reinterpret_cast<const u32x4*>(rop + m * rop_ld + n_cl);
         }
     };
-    RowOp cur;
-    // one 32-row pass; called four times with a compile-time accumulator reference (a runtime-indexed acc[] would be
-    // demoted to scratch memory)
-    auto pass = [&](const int mi, const f32x16 (&am)[G::NI]) {
-        // row operand of this pass: issued before the LDS transposition so its latency hides under it (the in-order
-        // vmcnt makes it also wait for the previous pass's stores -- the co-resident workgroup covers that stall)
-        if (piped) fetch(mi, cur);
+    auto unpack = [](const u32x4& r, f32x4& a, f32x4& b) {
+        a[0] = __uint_as_float(r[0] << 16); a[1] = __uint_as_float(r[0] & 0xffff0000u);
+        a[2] = __uint_as_float(r[1] << 16); a[3] = __uint_as_float(r[1] & 0xffff0000u);
+        b[0] = __uint_as_float(r[2] << 16); b[1] = __uint_as_float(r[2] & 0xffff0000u);
+        b[2] = __uint_as_float(r[3] << 16); b[3] = __uint_as_float(r[3] & 0xffff0000u);
+    };
+    RowOp cur, nxt;
+    if (EPI == 2 || EPI == 3) fetch(0, cur);
+    auto slab_pass = [&](const int mi, const f32x16 (&am)[G::NI]) {
 #pragma unroll
         for (int ni = 0; ni < G::NI; ++ni)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v = {am[ni][4 * g], am[ni][4 * g + 1], am[ni][4 * g + 2], am[ni][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(patch + l31 * PITCH + (ni * 32 + 8 * g + 4 * h) * 4) = v;
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(waddr), "v"(v), "i"((ni * 32 + 8 * g) * 4) : "memory");
             }
+        // the next slab's row operand goes out BEFORE this slab's stores (in-order vmcnt: see above)
+        if ((EPI == 2 || EPI == 3) && mi + 1 < 4) fetch(mi + 1, nxt);
+        f32x4 r0[NIT], r1[NIT];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int row = (lane / LPR) + RPI * i;
-            f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + row * PITCH + c0 * 4);
-            f32x4 v1 = *reinterpret_cast<const f32x4*>(patch + row * PITCH + c0 * 4 + 16);
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r0[i]) : "v"(raddr), "i"(RPI * i * PITCH) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r1[i]) : "v"(raddr), "i"(RPI * i * PITCH + 16) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            f32x4 v0 = r0[i], v1 = r1[i];
             const int64_t m = mrow0 + mi * 32 + RPI * i;
-            if (m >= p.M || n >= p.N) continue;
-            if (!n_ok) {
-                if (slab) *reinterpret_cast<f32x4*>(slab + m * p.N + n) = v0;
-                else epilogue_quad(p, m, n, v0);
+            const bool ok = m < p.M && n_ok;              // (N % 8 == 0 is a precondition of this family)
+            if (EPI == 5) {                               // split-K slab: raw fp32 partial sums
+                if (ok) {
+                    *reinterpret_cast<f32x4*>(slab + m * p.N + n) = v0;
+                    *reinterpret_cast<f32x4*>(slab + m * p.N + n + 4) = v1;
+                }
                 continue;
             }
-            if (slab) {
-                *reinterpret_cast<f32x4*>(slab + m * p.N + n) = v0;
-                *reinterpret_cast<f32x4*>(slab + m * p.N + n + 4) = v1;
+            if (EPI == 4) {
+                if (ok) epilogue_oct(p, m, n, v0, v1);
                 continue;
             }
-            if (generic) { epilogue_oct(p, m, n, v0, v1); continue; }
+            // the arithmetic is unconditional (out-of-range rows compute garbage that is never stored): only the
+            // store itself is guarded, so no wait lands inside a branch
             v0 = v0 * p.alpha + bias0;
             v1 = v1 * p.alpha + bias1;
-            if (p.preact) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
-            if (p.act == ME_ACT_GELU) {
+            if (EPI == 1) {
+                if (p.preact && ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v0[e] = gelu_erf(v0[e]); v1[e] = gelu_erf(v1[e]); }
             }
-            if (p.aux) {
+            f32x4 ra, rb;
+            if (EPI == 2 || EPI == 3) unpack(cur.raw[i], ra, rb);
+            if (EPI == 3) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v0[e] *= gelu_erf_grad(cur.v[i][0][e]); v1[e] *= gelu_erf_grad(cur.v[i][1][e]); }
+                for (int e = 0; e < 4; ++e) { v0[e] *= gelu_erf_grad(ra[e]); v1[e] *= gelu_erf_grad(rb[e]); }
             }
             v0 *= cs0; v1 *= cs1;
-            if (p.residual) { v0 += cur.v[i][0]; v1 += cur.v[i][1]; }
-            else if (!p.aux && p.beta != 0.0f) { v0 += p.beta * cur.v[i][0]; v1 += p.beta * cur.v[i][1]; }
-            store8_from_f32(p.C, p.c_dtype, m * p.ldc + n, v0, v1);
+            if (EPI == 2) { v0 += ra; v1 += rb; }
+            if (ok) store8_from_f32(p.C, p.c_dtype, m * p.ldc + n, v0, v1);
         }
+        if ((EPI == 2 || EPI == 3) && mi + 1 < 4) cur = nxt;
     };
-    pass(0, acc[0]);
-    pass(1, acc[1]);
-    pass(2, acc[2]);
-    pass(3, acc[3]);
+    slab_pass(0, acc[0]);
+    slab_pass(1, acc[1]);
+    slab_pass(2, acc[2]);
+    slab_pass(3, acc[3]);
 }
 
-template <int BN, bool TN>
-int launch2(const GemmParams& p, hipStream_t stream) {
-    typedef G2<BN> G;
-    const size_t lds = NSTAGE * G::STAGE;
+template <int BM, int BN, bool TN, int EPI>
+int launch2e(const GemmParams& p, hipStream_t stream) {
+    typedef G2<BM, BN> G;
+    const size_t lds = G::NSTAGE * G::STAGE;
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g2_kernel<BN, TN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g2_kernel<BM, BN, TN, EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         once = true;
     }
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(p.split_k > 1 ? p.split_k : 1));
-    hipLaunchKernelGGL((gemm_g2_kernel<BN, TN>), grid, dim3(NTH2), lds, stream, p);
-    ME_CHECK_LAUNCH("me_gemm(g2b)");
+    hipLaunchKernelGGL((gemm_g2_kernel<BM, BN, TN, EPI>), grid, dim3(G::NTH), lds, stream, p);
+    ME_CHECK_LAUNCH("me_gemm(g2)");
     return ME_OK;
+}
+
+// which specialised epilogue covers this call (4 = generic)
+int pick_epi(const GemmParams& p) {
+    if (p.split_k > 1) return 5;
+    if (p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return 4;
+    const int nrow = (p.residual ? 1 : 0) + (p.aux ? 1 : 0);
+    if (nrow > 1) return 4;
+    if (p.act == ME_ACT_GELU) return (nrow == 0) ? 1 : 4;
+    if (p.preact) return 4;
+    if (p.residual) return p.res_dtype == ME_BF16 ? 2 : 4;
+    if (p.aux) return p.aux_dtype == ME_BF16 ? 3 : 4;
+    return 0;
+}
+
+template <int BM, int BN, bool TN>
+int launch2(const GemmParams& p, hipStream_t stream) {
+    const int epi = pick_epi(p);
+    if (TN) {
+        if (epi == 5) return launch2e<BM, BN, TN, 5>(p, stream);
+        return epi == 0 ? launch2e<BM, BN, TN, 0>(p, stream) : launch2e<BM, BN, TN, 4>(p, stream);
+    }
+    switch (epi) {
+        case 0: return launch2e<BM, BN, TN, 0>(p, stream);
+        case 1: return launch2e<BM, BN, TN, 1>(p, stream);
+        case 2: return launch2e<BM, BN, TN, 2>(p, stream);
+        case 3: return launch2e<BM, BN, TN, 3>(p, stream);
+        case 5: return launch2e<BM, BN, TN, 5>(p, stream);
+        default: return launch2e<BM, BN, TN, 4>(p, stream);
+    }
 }
 
 }  // namespace
 
 bool g2b_supported(const GemmParams& p, int op) {
-    if (p.K % KS2 != 0) return false;
+    if (p.K % KS2 != 0 || p.N % 8 != 0) return false;
     if (op == ME_GEMM_TN) return p.M % 8 == 0 && p.N % 8 == 0 && p.M >= 8 && p.N >= 8;
     return true;
 }
 
-int launch_g2b(const GemmParams& p, int op, int bn, hipStream_t stream) {
-    if (op == ME_GEMM_TN) return bn == 256 ? launch2<256, true>(p, stream) : launch2<128, true>(p, stream);
-    return bn == 256 ? launch2<256, false>(p, stream) : launch2<128, false>(p, stream);
+// bm = 128: two 4-wave workgroups per CU; bm = 256: one 8-wave workgroup, 4 stages
+int launch_g2b(const GemmParams& p, int op, int bm, int bn, hipStream_t stream) {
+    if (bm == 256) {
+        if (op == ME_GEMM_TN) return launch2<256, 256, true>(p, stream);
+        return launch2<256, 256, false>(p, stream);
+    }
+    if (op == ME_GEMM_TN) return bn == 256 ? launch2<128, 256, true>(p, stream) : launch2<128, 128, true>(p, stream);
+    return bn == 256 ? launch2<128, 256, false>(p, stream) : launch2<128, 128, false>(p, stream);
 }

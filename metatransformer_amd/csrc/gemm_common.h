@@ -111,5 +111,5 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
 // kernel families (each in its own translation unit)
 int launch_g256(const GemmParams& p, int op, int bn, hipStream_t stream);
 bool g256_supported(const GemmParams& p, int op);
-int launch_g2b(const GemmParams& p, int op, int bn, hipStream_t stream);
+int launch_g2b(const GemmParams& p, int op, int bm, int bn, hipStream_t stream);
 bool g2b_supported(const GemmParams& p, int op);
