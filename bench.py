@@ -53,8 +53,12 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("ME_BENCH_FORCE_DIST") == "1"     # (forced: exercises the RCCL path on 1 GPU)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     import metatransformer_amd as M
@@ -85,7 +89,7 @@ def main():
             x.grad = None
             y = enc(x)
             y.backward(gy)
-            parallel.allreduce_gradients(flat)
+            parallel.allreduce_gradients(flat, force=use_dist)
             opt.step(grad_scale=1.0 / world)
     else:
         enc.eval()
@@ -95,7 +99,7 @@ def main():
                 enc(x)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -109,7 +113,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -137,7 +141,7 @@ def main():
                                     "share_of_step_time": round(ms2 * 1e-3 / elapsed, 4)}
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -177,7 +181,7 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -144,6 +144,40 @@ template <int HD>
 __device__ __forceinline__ f32x4 ttile_chunk(const float*, const char* lds, int d, int c, int h) {
     return *reinterpret_cast<const f32x4*>(lds + d * Cfg<float, HD>::TROW + (8 * c + 4 * h) * 4);
 }
+// bf16: the same operand straight from a ROW-MAJOR [64][HD] tile with the LDS transpose read (ds_read_b64_tr_b16),
+// no transposed staging at all.  A 16-lane group reads four reduction rows x 16 columns; lane p of the group supplies
+// the address of row +(p>>2), columns +4*(p&3) and receives column +p of the four rows (tools/probe_isa.hip).  Rows are
+// picked so that element e = 4r + j of half h is reduction index 16c + 8r + 4h + j == the accumulator-register mapping
+// above, so P / dS registers still feed the MFMA unchanged.
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_chunk(const char* tile, int dbase, int c, int lane) {
+    const int g = lane >> 4, p = lane & 15, h = g >> 1;
+    const int col = dbase + 16 * (g & 1) + 4 * (p & 3);
+    const uint32_t base = (uint32_t)(uintptr_t)tile + col * 2;
+    union { bf16x4 q[2]; bf16x8 v; } u;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = 16 * c + 8 * r + 4 * h + (p >> 2);
+        u.q[r] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(base + row * Cfg<bf16_t, HD>::RROW));
+    }
+    return u.v;
+}
+// "operand with the reduction index along the tile rows": fp32 -> transposed tile + 16-byte reads, bf16 -> row tile + tr reads
+template <typename T, int HD> struct TRead;
+template <int HD> struct TRead<float, HD> {
+    static constexpr bool kNeedsTransposedTile = true;
+    static __device__ __forceinline__ f32x4 chunk(const char* ttile, const char*, int db, int c, int lane) {
+        return ttile_chunk<HD>((const float*)nullptr, ttile, 32 * db + (lane & 31), c, lane >> 5);
+    }
+};
+template <int HD> struct TRead<bf16_t, HD> {
+    static constexpr bool kNeedsTransposedTile = false;
+    static __device__ __forceinline__ bf16x8 chunk(const char*, const char* rtile, int db, int c, int lane) {
+        return tr_chunk<HD>(rtile, 32 * db, c, lane);
+    }
+};
+
 // B-operand chunk c from the two 32x32 accumulators of a 64-wide tile
 __device__ __forceinline__ bf16x8 pack_chunk(const bf16_t*, const f32x16 (&s)[2], int c) {
     const int u = c >> 1, o = (c & 1) * 8;
@@ -176,8 +210,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
     typedef Cfg<T, HD> C;
     typedef typename Chunk<T>::type chunk_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool TT = TRead<T, HD>::kNeedsTransposedTile;
     char* Ks = smem;
-    char* Vs = smem + C::R_BYTES;
+    char* Vs = smem + C::R_BYTES;              // fp32: transposed [HD][64]; bf16: row-major [64][HD] (read with tr)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
@@ -206,18 +241,18 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
     const bool active = qbase < N;      // wave-uniform
     const int ntiles = (N + KVT - 1) / KVT;
 
-    RowStage<T, HD> ks;
-    TransStage<T, HD> vs;
+    RowStage<T, HD> ks, vrs;
+    TransStage<T, HD> vts;
     ks.load(kptr, ld, 0, N, hd, tid);
-    vs.load(vptr, ld, 0, N, hd, tid);
+    if (TT) vts.load(vptr, ld, 0, N, hd, tid); else vrs.load(vptr, ld, 0, N, hd, tid);
     for (int j = 0; j < ntiles; ++j) {
         __syncthreads();
         ks.store(Ks, tid);
-        vs.store(Vs, tid);
+        if (TT) vts.store(Vs, tid); else vrs.store(Vs, tid);
         __syncthreads();
         if (j + 1 < ntiles) {
             ks.load(kptr, ld, (j + 1) * KVT, N, hd, tid);
-            vs.load(vptr, ld, (j + 1) * KVT, N, hd, tid);
+            if (TT) vts.load(vptr, ld, (j + 1) * KVT, N, hd, tid); else vrs.load(vptr, ld, (j + 1) * KVT, N, hd, tid);
         }
         if (!active) continue;
         f32x16 s[2];
@@ -261,7 +296,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
             const chunk_t pb = pack_chunk((const T*)nullptr, s, c);
 #pragma unroll
             for (int db = 0; db < C::NDB; ++db)
-                o[db] = mma_chunk(ttile_chunk<HD>((const T*)nullptr, Vs, 32 * db + l31, c, h), pb, o[db]);
+                o[db] = mma_chunk(TRead<T, HD>::chunk(Vs, Vs, db, c, lane), pb, o[db]);
         }
     }
     if (!active) return;
@@ -385,25 +420,38 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkdv_kernel(const T* __re
     const bool kv_ok = kvbase + l31 < N;
     const int ntiles = (N + KVT - 1) / KVT;
 
+    constexpr bool TT = TRead<T, HD>::kNeedsTransposedTile;
     RowStage<T, HD> qs, dos;
     TransStage<T, HD> qts, dots;
-    for (int j = 0; j < ntiles; ++j) {
-        const int q0 = j * KVT;
+    float lse_r = INFINITY, del_r = 0.f;
+    auto gload = [&](int q0) {
         qs.load(qptr, ld, q0, N, hd, tid);
         dos.load(doptr, lddo, q0, N, hd, tid);
-        qts.load(qptr, ld, q0, N, hd, tid);
-        dots.load(doptr, lddo, q0, N, hd, tid);
+        if (TT) {
+            qts.load(qptr, ld, q0, N, hd, tid);
+            dots.load(doptr, lddo, q0, N, hd, tid);
+        }
+        if (tid < KVT) {
+            const int q = q0 + tid;
+            lse_r = (q < N) ? lse_bh[q] : INFINITY;          // exp(s - inf) = 0 masks padded queries
+            del_r = (q < N) ? del_bh[q] : 0.f;
+        }
+    };
+    gload(0);
+    for (int j = 0; j < ntiles; ++j) {
         __syncthreads();
         qs.store(Qs, tid);
         dos.store(dOs, tid);
-        qts.store(QTs, tid);
-        dots.store(dOTs, tid);
+        if (TT) {
+            qts.store(QTs, tid);
+            dots.store(dOTs, tid);
+        }
         if (tid < KVT) {
-            const int q = q0 + tid;
-            lse_s[tid] = (q < N) ? lse_bh[q] : INFINITY;     // exp(s - inf) = 0 masks padded queries
-            del_s[tid] = (q < N) ? del_bh[q] : 0.f;
+            lse_s[tid] = lse_r;
+            del_s[tid] = del_r;
         }
         __syncthreads();
+        if (j + 1 < ntiles) gload((j + 1) * KVT);            // next tile's global loads fly during this tile's MFMAs
         if (!active) continue;
         f32x16 s[2], dp[2];
 #pragma unroll
@@ -437,8 +485,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkdv_kernel(const T* __re
             const chunk_t dsb = pack_chunk((const T*)nullptr, dp, c);
 #pragma unroll
             for (int db = 0; db < C::NDB; ++db) {
-                dv[db] = mma_chunk(ttile_chunk<HD>((const T*)nullptr, dOTs, 32 * db + l31, c, h), pb, dv[db]);   // dV^T[d][kv]
-                dk[db] = mma_chunk(ttile_chunk<HD>((const T*)nullptr, QTs, 32 * db + l31, c, h), dsb, dk[db]);  // dK^T[d][kv]
+                dv[db] = mma_chunk(TRead<T, HD>::chunk(dOTs, dOs, db, c, lane), pb, dv[db]);   // dV^T[d][kv]
+                dk[db] = mma_chunk(TRead<T, HD>::chunk(QTs, Qs, db, c, lane), dsb, dk[db]);  // dK^T[d][kv]
             }
         }
     }
@@ -502,18 +550,23 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
     const bool active = qbase < N;
     const int ntiles = (N + KVT - 1) / KVT;
 
+    constexpr bool TT = TRead<T, HD>::kNeedsTransposedTile;
     RowStage<T, HD> ks, vs;
     TransStage<T, HD> kts;
-    for (int j = 0; j < ntiles; ++j) {
-        const int kv0 = j * KVT;
+    auto gload = [&](int kv0) {
         ks.load(kptr, ld, kv0, N, hd, tid);
         vs.load(vptr, ld, kv0, N, hd, tid);
-        kts.load(kptr, ld, kv0, N, hd, tid);
+        if (TT) kts.load(kptr, ld, kv0, N, hd, tid);
+    };
+    gload(0);
+    for (int j = 0; j < ntiles; ++j) {
+        const int kv0 = j * KVT;
         __syncthreads();
         ks.store(Ks, tid);
         vs.store(Vs, tid);
-        kts.store(KTs, tid);
+        if (TT) kts.store(KTs, tid);
         __syncthreads();
+        if (j + 1 < ntiles) gload((j + 1) * KVT);
         if (!active) continue;
         f32x16 s[2], dp[2];
 #pragma unroll
@@ -539,7 +592,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
             const chunk_t dsb = pack_chunk((const T*)nullptr, dp, c);
 #pragma unroll
             for (int db = 0; db < C::NDB; ++db)
-                dq[db] = mma_chunk(ttile_chunk<HD>((const T*)nullptr, KTs, 32 * db + l31, c, h), dsb, dq[db]);   // dQ^T[d][q]
+                dq[db] = mma_chunk(TRead<T, HD>::chunk(KTs, Ks, db, c, lane), dsb, dq[db]);   // dQ^T[d][q]
         }
     }
     if (!active || !q_ok) return;
@@ -562,7 +615,7 @@ template <typename T, int HD>
 int launch_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
                hipStream_t stream) {
     typedef Cfg<T, HD> C;
-    const size_t smem = C::R_BYTES + C::T_BYTES;
+    const size_t smem = C::R_BYTES + (C::T_BYTES > C::R_BYTES ? C::T_BYTES : C::R_BYTES);   // V tile: transposed (fp32) or row-major (bf16)
     static bool once = false;
     if (!once) { set_smem(attn_fwd_kernel<T, HD>, smem); once = true; }
     dim3 grid((N + QPB - 1) / QPB, H, B);

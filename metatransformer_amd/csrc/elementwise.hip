@@ -60,7 +60,19 @@ __global__ __launch_bounds__(EW_THREADS) void add_rows_kernel(const void* __rest
 constexpr int CS_SPLITS = 128;
 // vector path (cols % 4 == 0): a lane owns 4 consecutive columns (8/16-byte loads), a wave covers 256 columns of a
 // row, the 4 waves of a block and blockIdx.y split the rows; 4 rows in flight per wave.
-__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const void* __restrict__ x, int xdt, int64_t ldx,
+// (dtype is a template parameter: a runtime switch around each load would put a vmcnt(0) at every branch join and
+// serialise the four rows in flight)
+template <typename T> __device__ __forceinline__ f32x4 cs_ld4(const void* base, int64_t idx);
+template <> __device__ __forceinline__ f32x4 cs_ld4<float>(const void* base, int64_t idx) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+}
+template <> __device__ __forceinline__ f32x4 cs_ld4<bf16_t>(const void* base, int64_t idx) {
+    const u32x2 raw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+    return f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u), __uint_as_float(raw[1] << 16),
+                 __uint_as_float(raw[1] & 0xffff0000u)};
+}
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const void* __restrict__ x, int64_t ldx,
                                                                  int64_t rows, int64_t cols, float* __restrict__ partial) {
     __shared__ f32x4 sh[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -71,13 +83,14 @@ __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const void* __r
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
     if (c < cols) {
         int64_t r = rb + w;
-        for (; r + 12 < re; r += 16) {
-            a0 += load4_as_f32(x, xdt, r * ldx + c);
-            a1 += load4_as_f32(x, xdt, (r + 4) * ldx + c);
-            a2 += load4_as_f32(x, xdt, (r + 8) * ldx + c);
-            a3 += load4_as_f32(x, xdt, (r + 12) * ldx + c);
+        for (; r + 28 < re; r += 32) {
+            const f32x4 v0 = cs_ld4<T>(x, r * ldx + c), v1 = cs_ld4<T>(x, (r + 4) * ldx + c);
+            const f32x4 v2 = cs_ld4<T>(x, (r + 8) * ldx + c), v3 = cs_ld4<T>(x, (r + 12) * ldx + c);
+            const f32x4 v4 = cs_ld4<T>(x, (r + 16) * ldx + c), v5 = cs_ld4<T>(x, (r + 20) * ldx + c);
+            const f32x4 v6 = cs_ld4<T>(x, (r + 24) * ldx + c), v7 = cs_ld4<T>(x, (r + 28) * ldx + c);
+            a0 += v0 + v4; a1 += v1 + v5; a2 += v2 + v6; a3 += v3 + v7;
         }
-        for (; r < re; r += 4) a0 += load4_as_f32(x, xdt, r * ldx + c);
+        for (; r < re; r += 4) a0 += cs_ld4<T>(x, r * ldx + c);
     }
     sh[w][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
@@ -271,7 +284,10 @@ extern "C" int me_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, 
     float* partial = reinterpret_cast<float*>(workspace);
     if (cols % 4 == 0 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0) {
         dim3 grid((unsigned)((cols + 255) / 256), CS_SPLITS);
-        hipLaunchKernelGGL(colsum_partial_vec_kernel, grid, dim3(256), 0, stream, x, x_dtype, ldx, rows, cols, partial);
+        if (x_dtype == ME_BF16)
+            hipLaunchKernelGGL(colsum_partial_vec_kernel<bf16_t>, grid, dim3(256), 0, stream, x, ldx, rows, cols, partial);
+        else
+            hipLaunchKernelGGL(colsum_partial_vec_kernel<float>, grid, dim3(256), 0, stream, x, ldx, rows, cols, partial);
     } else {
         dim3 grid((unsigned)((cols + 63) / 64), CS_SPLITS);
         hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, stream, x, x_dtype, ldx, rows, cols, partial);

@@ -90,11 +90,32 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_generic_kernel(const void* 
 // Each wave walks rows with a grid stride; a lane always owns the same columns, so the affine partial sums
 // live in registers and are written once per wave to the workspace [n_waves, 2, C]; a second kernel folds
 // them (deterministic, no atomics).
+// compile-time typed 4-element accesses: a runtime dtype switch around every load makes hipcc place a full
+// s_waitcnt vmcnt(0) at each branch join, which serialises the 18 loads a wave has in flight per iteration.
+template <typename T> __device__ __forceinline__ f32x4 ld4(const void* base, int64_t idx);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const void* base, int64_t idx) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+}
+template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const void* base, int64_t idx) {
+    const u32x2 raw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+    return f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u), __uint_as_float(raw[1] << 16),
+                 __uint_as_float(raw[1] & 0xffff0000u)};
+}
+template <typename T> __device__ __forceinline__ void st4(void* base, int64_t idx, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(void* base, int64_t idx, f32x4 v) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(void* base, int64_t idx, f32x4 v) {
+    bf16x4 o;
+    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(base) + idx) = o;
+}
+
 constexpr int LNB_BLOCKS = 1024;
 constexpr int LNB_WAVES = LNB_BLOCKS * (LN_THREADS / 64);
 constexpr int LNB_FOLD = 16;              // second-stage row groups
 
-template <int VPL>
+template <int VPL, typename TX, typename TDY>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restrict__ dy, int dy_dt,
                                                             const void* __restrict__ x, int x_dt,
                                                             const float* __restrict__ mean,
@@ -114,34 +135,41 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
         dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // two rows in flight per wave: the loads of the second row overlap the reductions of the first
+    // two rows in flight per wave; every load of both rows (x, dy and the residual gradient) is issued up front
     for (int64_t row0 = gw; row0 < rows; row0 += 2 * LNB_WAVES) {
         const int64_t row1 = row0 + LNB_WAVES;
         const bool has1 = row1 < rows;
         const int64_t r1 = has1 ? row1 : row0;
         const float mu0 = mean[row0], rs0 = rstd[row0], mu1 = mean[r1], rs1 = rstd[r1];
-        f32x4 xh0[VPL], d0[VPL], xh1[VPL], d1[VPL];
-        float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+        f32x4 xh0[VPL], d0[VPL], xh1[VPL], d1[VPL], q0[VPL], q1[VPL];
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int64_t c = (int64_t)(lane + 64 * i) * 4;
-            const f32x4 xv0 = load4_as_f32(x, x_dt, row0 * C + c);
-            d0[i] = load4_as_f32(dy, dy_dt, row0 * C + c);
-            const f32x4 xv1 = load4_as_f32(x, x_dt, r1 * C + c);
-            d1[i] = load4_as_f32(dy, dy_dt, r1 * C + c);
+            xh0[i] = ld4<TX>(x, row0 * C + c);
+            d0[i] = ld4<TDY>(dy, row0 * C + c);
+            xh1[i] = ld4<TX>(x, r1 * C + c);
+            d1[i] = ld4<TDY>(dy, r1 * C + c);
+            if (dres) {
+                q0[i] = ld4<TX>(dres, row0 * C + c);
+                q1[i] = ld4<TX>(dres, r1 * C + c);
+            } else {
+                q0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                q1[i] = q0[i];
+            }
+        }
+        float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+        const float w1 = has1 ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                xh0[i][e] = (xv0[e] - mu0) * rs0;
-                xh1[i][e] = (xv1[e] - mu1) * rs1;
+                xh0[i][e] = (xh0[i][e] - mu0) * rs0;
+                xh1[i][e] = (xh1[i][e] - mu1) * rs1;
                 const float ge0 = d0[i][e] * g[i][e], ge1 = d1[i][e] * g[i][e];
                 a0 += ge0; b0 += ge0 * xh0[i][e];
                 a1 += ge1; b1 += ge1 * xh1[i][e];
-                dg[i][e] += d0[i][e] * xh0[i][e];
-                db[i][e] += d0[i][e];
-                if (has1) {
-                    dg[i][e] += d1[i][e] * xh1[i][e];
-                    db[i][e] += d1[i][e];
-                }
+                dg[i][e] += d0[i][e] * xh0[i][e] + w1 * d1[i][e] * xh1[i][e];
+                db[i][e] += d0[i][e] + w1 * d1[i][e];
             }
         }
 #pragma unroll
@@ -157,15 +185,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
             f32x4 o0, o1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o0[e] = rs0 * (d0[i][e] * g[i][e] - a0 - xh0[i][e] * b0);
-                o1[e] = rs1 * (d1[i][e] * g[i][e] - a1 - xh1[i][e] * b1);
+                o0[e] = rs0 * (d0[i][e] * g[i][e] - a0 - xh0[i][e] * b0) + q0[i][e];
+                o1[e] = rs1 * (d1[i][e] * g[i][e] - a1 - xh1[i][e] * b1) + q1[i][e];
             }
-            if (dres) {
-                o0 += load4_as_f32(dres, dres_dt, row0 * C + c);
-                if (has1) o1 += load4_as_f32(dres, dres_dt, row1 * C + c);
-            }
-            store4_from_f32(dx, dx_dt, row0 * C + c, o0);
-            if (has1) store4_from_f32(dx, dx_dt, row1 * C + c, o1);
+            st4<TX>(dx, row0 * C + c, o0);
+            if (has1) st4<TX>(dx, row1 * C + c, o1);
         }
     }
     if (want_affine) {     // deterministic block fold: waves park their partials in LDS, then columns are summed in wave order
@@ -331,7 +355,8 @@ extern "C" int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int
     const int want_affine = dgamma != nullptr;
     ME_CHECK_ARG(!want_affine || workspace, "me_layernorm_bwd: workspace required for dgamma/dbeta");
     if (rows == 0) return ME_OK;
-    if (!(cols % 256 == 0 && cols / 256 <= 8)) {
+    const bool same_stream_dtype = dx_dtype == x_dtype && (dres == nullptr || dres_dtype == x_dtype);
+    if (!(cols % 256 == 0 && cols / 256 <= 8) || !same_stream_dtype) {
         hipLaunchKernelGGL(ln_bwd_generic_dx_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(LN_THREADS), 0, stream, dy,
                            dy_dtype, x, x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, rows, cols);
         ME_CHECK_LAUNCH("me_layernorm_bwd(generic dx)");
@@ -344,11 +369,15 @@ extern "C" int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int
     }
     float* partial = reinterpret_cast<float*>(workspace);
     const size_t lds_bytes = want_affine ? (size_t)4 * 2 * cols * sizeof(float) : 0;
-#define LN_BWD_CASE(V)                                                                                          \
-    case V:                                                                                                     \
-        hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(LNB_BLOCKS), dim3(LN_THREADS), lds_bytes, stream, dy, dy_dtype, x, \
-                           x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, partial, want_affine,    \
-                           rows, cols);                                                                         \
+#define LN_BWD_LAUNCH(V, TX, TDY)                                                                                 \
+    hipLaunchKernelGGL((ln_bwd_kernel<V, TX, TDY>), dim3(LNB_BLOCKS), dim3(LN_THREADS), lds_bytes, stream, dy, dy_dtype, \
+                       x, x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, partial, want_affine, rows, cols)
+#define LN_BWD_CASE(V)                                                                                            \
+    case V:                                                                                                       \
+        if (x_dtype == ME_BF16 && dy_dtype == ME_BF16) LN_BWD_LAUNCH(V, bf16_t, bf16_t);                          \
+        else if (x_dtype == ME_BF16) LN_BWD_LAUNCH(V, bf16_t, float);                                             \
+        else if (dy_dtype == ME_BF16) LN_BWD_LAUNCH(V, float, bf16_t);                                            \
+        else LN_BWD_LAUNCH(V, float, float);                                                                      \
         break;
     switch (cols / 256) {
         LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) LN_BWD_CASE(5) LN_BWD_CASE(6) LN_BWD_CASE(7)

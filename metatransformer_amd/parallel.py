@@ -67,10 +67,11 @@ class FlatParams:
         return out
 
 
-def allreduce_gradients(flat: FlatParams, group=None, bucket_bytes: int = 64 << 20, average: bool = False) -> None:
+def allreduce_gradients(flat: FlatParams, group=None, bucket_bytes: int = 64 << 20, average: bool = False,
+                        force: bool = False) -> None:
     """One all_reduce(sum) per flat bucket.  `average=True` divides by the world size afterwards (reference
     semantics, dist_utils.py:31-32); the bench leaves it False and folds 1/world into the optimizer."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in flat.buckets(bucket_bytes)]
     for h in handles:
