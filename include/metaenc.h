@@ -140,6 +140,17 @@ int me_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
 int me_add_rows(const void* x, int x_dtype, const void* pos, int pos_dtype, void* y, int y_dtype,
                 int64_t rows, int64_t pos_rows, int cols, void* stream);
 
+/* Stochastic ops of the Block in training mode (identity in eval / p = 0, where they are never called):
+ *   out[m,c] = (res ? res[m,c] : 0) + path(m / rows_per_sample) * keep(m,c) * v[m,c]
+ * keep = Bernoulli(1-p_drop)/(1-p_drop) per element -- nn.Dropout of Attention.proj_drop / Mlp.drop
+ * (PointCloud/openpoints/models/layers/attention.py:37, mlp.py:32,35); path = Bernoulli(1-p_path)/(1-p_path) per SAMPLE --
+ * DropPath (PointCloud/openpoints/models/layers/drop.py:135-152).  The masks are a counter-based hash of (seed, index):
+ * calling again with the same seed on the incoming gradient (res = NULL) is the backward.  The RNG stream differs
+ * from torch's; distribution and scaling are the reference's. */
+int me_dropout_add(const void* v, int v_dtype, const void* res, int res_dtype, void* out, int out_dtype,
+                   int64_t rows, int cols, int64_t rows_per_sample, float p_drop, float p_path, uint64_t seed,
+                   void* stream);
+
 /* ------------------------------------------------------------------ Data2Seq tokenizers
  * Patch gather ("im2col") for the convolutional patch-embeds; the projection itself is me_gemm (NT) on
  * the gathered matrix with the conv weight viewed as [Cout, Cin*kt*kh*kw].

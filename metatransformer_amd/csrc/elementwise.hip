@@ -223,6 +223,45 @@ __global__ __launch_bounds__(EW_THREADS) void ts_embed_kernel(const float* __res
     }
 }
 
+
+// ---- dropout / drop-path with residual add.  Counter-based RNG (splitmix64 of seed + element index): the same
+// (seed, index) regenerates the same mask in backward, nothing is stored.
+__device__ __forceinline__ float u01_hash(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);      // 24 random bits -> [0, 1)
+}
+__global__ __launch_bounds__(EW_THREADS) void dropout_add_kernel(const void* __restrict__ v, int vdt,
+                                                                 const void* __restrict__ res, int rdt,
+                                                                 void* __restrict__ out, int odt, int64_t rows, int cols,
+                                                                 int64_t rows_per_sample, float p_drop, float p_path,
+                                                                 uint64_t seed) {
+    const int c4 = cols / 4;
+    const int64_t total = rows * c4;
+    const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const float inv_path = p_path > 0.f ? 1.0f / (1.0f - p_path) : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t r = i / c4;
+        const int c = (int)(i % c4) * 4;
+        float rowscale = 1.0f;
+        if (p_path > 0.f) {
+            const uint64_t sample = (uint64_t)(r / rows_per_sample);
+            rowscale = u01_hash(seed ^ 0xD1B54A32D192ED03ull, sample) >= p_path ? inv_path : 0.0f;
+        }
+        f32x4 x = load4_as_f32(v, vdt, r * cols + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float k = rowscale;
+            if (p_drop > 0.f) k = u01_hash(seed, (uint64_t)(r * cols + c + e)) >= p_drop ? k * inv_keep : 0.0f;
+            x[e] *= k;
+        }
+        if (res) x += load4_as_f32(res, rdt, r * cols + c);
+        store4_from_f32(out, odt, r * cols + c, x);
+    }
+}
+
 __global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
@@ -367,5 +406,18 @@ extern "C" int me_adamw_step(float* param, const float* grad, float* exp_avg, fl
     hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, param, grad, exp_avg, exp_avg_sq, n, lr,
                        beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
     ME_CHECK_LAUNCH("me_adamw_step");
+    return ME_OK;
+}
+
+extern "C" int me_dropout_add(const void* v, int v_dtype, const void* res, int res_dtype, void* out, int out_dtype,
+                              int64_t rows, int cols, int64_t rows_per_sample, float p_drop, float p_path, uint64_t seed,
+                              void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(v && out && rows > 0 && cols > 0 && cols % 4 == 0 && rows_per_sample > 0, "me_dropout_add: bad args");
+    ME_CHECK_ARG(me_dtype_ok(v_dtype) && me_dtype_ok(out_dtype) && (!res || me_dtype_ok(res_dtype)), "me_dropout_add: bad dtype");
+    ME_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && p_path >= 0.f && p_path < 1.f, "me_dropout_add: probabilities must be in [0, 1)");
+    hipLaunchKernelGGL(dropout_add_kernel, dim3(ew_blocks(rows * (cols / 4))), dim3(EW_THREADS), 0, stream, v, v_dtype, res,
+                       res_dtype, out, out_dtype, rows, cols, rows_per_sample, p_drop, p_path, seed);
+    ME_CHECK_LAUNCH("me_dropout_add");
     return ME_OK;
 }

@@ -108,7 +108,7 @@ class _BlockFn(torch.autograd.Function):
     """forward + backward of one Block on the HIP kernels.  Restates Block.forward (attention.py:55-58)."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g1, g2, blk, cdt):
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g1, g2, blk, cdt, stoch):
         B, N, C = x.shape
         H = blk.attn.num_heads
         hd = C // H
@@ -122,16 +122,27 @@ class _BlockFn(torch.autograd.Function):
         xn1, mean1, rstd1 = ops.layernorm_fwd(x2, n1w, n1b, blk.eps, cdt, save_stats=need_grad)
         qkv = ops.gemm(xn1, cache.fwd("qkv", qkvw, cdt), bias=qkvb)
         o, lse = ops.attention_fwd(qkv, B, N, H, hd, blk.attn.scale, need_lse=need_grad)
-        x1 = ops.gemm(o, cache.fwd("proj", projw, cdt), bias=projb, residual=x2, out_dtype=rdt, colscale=g1)
+        if stoch is None:
+            x1 = ops.gemm(o, cache.fwd("proj", projw, cdt), bias=projb, residual=x2, out_dtype=rdt, colscale=g1)
+        else:                 # training-mode proj_drop / drop_path: x1 = x + drop_path(dropout(proj(o)))
+            p_drop, p_path, seed = stoch
+            t1 = ops.gemm(o, cache.fwd("proj", projw, cdt), bias=projb, out_dtype=rdt, colscale=g1)
+            x1 = ops.dropout_add(t1, x2, N, p_drop, p_path, seed + 1)
         xn2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, blk.eps, cdt, save_stats=need_grad)
         hpre = torch.empty((M, fc1w.shape[0]), dtype=cdt, device=x.device) if need_grad else None
         a = ops.gemm(xn2, cache.fwd("fc1", fc1w, cdt), bias=fc1b, act=ME_ACT_GELU, preact=hpre)
-        y = ops.gemm(a, cache.fwd("fc2", fc2w, cdt), bias=fc2b, residual=x1, out_dtype=rdt, colscale=g2)
+        if stoch is None:
+            y = ops.gemm(a, cache.fwd("fc2", fc2w, cdt), bias=fc2b, residual=x1, out_dtype=rdt, colscale=g2)
+        else:                 # Mlp: fc1 -> act -> drop -> fc2 -> drop (mlp.py:29-35), then drop_path + residual
+            if p_drop > 0:
+                a = ops.dropout_add(a, None, N, p_drop, 0.0, seed + 2)
+            t2 = ops.gemm(a, cache.fwd("fc2", fc2w, cdt), bias=fc2b, out_dtype=rdt, colscale=g2)
+            y = ops.dropout_add(t2, x1, N, p_drop, p_path, seed + 3)
 
         if need_grad:
             ctx.save_for_backward(x2, mean1, rstd1, xn1, qkv, lse, o, x1, mean2, rstd2, xn2, hpre, a,
                                   n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2)
-            ctx.blk, ctx.cdt, ctx.dims = blk, cdt, (B, N, C, H, hd)
+            ctx.blk, ctx.cdt, ctx.dims, ctx.stoch = blk, cdt, (B, N, C, H, hd), stoch
             ctx.has_bias = (qkvb is not None, projb is not None, fc1b is not None, fc2b is not None)
         return y.reshape(B, N, C)
 
@@ -154,9 +165,16 @@ class _BlockFn(torch.autograd.Function):
         def wgrad(dout, inp, w):      # dW[out,in] = dout^T inp, in the parameter's dtype
             return ops.gemm(dout, inp, op=ME_GEMM_TN, out_dtype=w.dtype)
 
+        stoch = ctx.stoch
+        if stoch is not None:
+            p_drop, p_path, seed = stoch
+
         # ---- MLP branch: y = x1 + fc2(gelu(fc1(LN2(x1))))
-        dy_c = ops.cast(dy2, cdt)
+        # (stochastic training: the branch gradient is the incoming one times the SAME masks, regenerated from the seed)
+        dy_c = ops.cast(dy2 if stoch is None else ops.dropout_add(dy2, None, N, p_drop, p_path, seed + 3), cdt)
         dh = ops.gemm(dy_c, cache.transposed("fc2", fc2w, cdt), aux=hpre)            # dA * gelu'(h)
+        if stoch is not None and p_drop > 0:
+            dh = ops.dropout_add(dh, None, N, p_drop, 0.0, seed + 2)
         d_fc2w = wgrad(dy_c, a, fc2w) if ng[11] else None
         d_fc2b = ops.colsum(dy_c).to(fc2w.dtype) if (ng[12] and ctx.has_bias[3]) else None
         dxn2 = ops.gemm(dh, cache.transposed("fc1", fc1w, cdt))
@@ -166,7 +184,7 @@ class _BlockFn(torch.autograd.Function):
         dx1, d_n2w, d_n2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w, dy2, rdt, need_aff2)
 
         # ---- attention branch: x1 = x + proj(attn(qkv(LN1(x))))
-        dx1_c = ops.cast(dx1, cdt)
+        dx1_c = ops.cast(dx1 if stoch is None else ops.dropout_add(dx1, None, N, p_drop, p_path, seed + 1), cdt)
         do = ops.gemm(dx1_c, cache.transposed("proj", projw, cdt))
         d_projw = wgrad(dx1_c, o, projw) if ng[5] else None
         d_projb = ops.colsum(dx1_c).to(projw.dtype) if (ng[6] and ctx.has_bias[1]) else None
@@ -184,7 +202,7 @@ class _BlockFn(torch.autograd.Function):
                 aff(d_n1w, n1w) if ng[1] else None, aff(d_n1b, n1w) if ng[2] else None,
                 d_qkvw, d_qkvb, d_projw, d_projb,
                 aff(d_n2w, n2w) if ng[7] else None, aff(d_n2b, n2w) if ng[8] else None,
-                d_fc1w, d_fc1b, d_fc2w, d_fc2b, None, None, None, None)
+                d_fc1w, d_fc1b, d_fc2w, d_fc2b, None, None, None, None, None)
 
 
 class Block(nn.Module):
@@ -228,10 +246,18 @@ class Block(nn.Module):
         if not x.is_cuda:
             raise MetaEncError("metatransformer_amd.Block runs on MI355X only: input is a CPU tensor and there is "
                                "no CPU fallback (use oracle/ for CPU reference numbers)")
-        if self.training and (self.attn.attn_drop.p > 0 or self.attn.proj_drop.p > 0 or self.mlp.drop.p > 0
-                              or self.drop_path_prob > 0):
-            raise MetaEncError("stochastic ops (dropout / drop_path with p > 0 in training mode) are not implemented "
-                               "in the HIP path yet; call .eval() or set p = 0")
+        stoch = None
+        if self.training:
+            if self.attn.attn_drop.p > 0:
+                raise MetaEncError("attn_drop > 0 in training mode (dropout on the attention probabilities, used only by "
+                                   "the Graph call site) is not implemented in the fused attention kernel; use .eval() "
+                                   "or attn_drop=0")
+            if self.attn.proj_drop.p != self.mlp.drop.p:
+                raise MetaEncError("proj_drop and mlp drop must be equal (timm's Block passes one `drop` to both)")
+            if self.mlp.drop.p > 0 or self.drop_path_prob > 0:
+                # one seed per call from torch's CPU generator (reproducible under torch.manual_seed)
+                seed = int(torch.empty((), dtype=torch.int64).random_().item())
+                stoch = (float(self.mlp.drop.p), self.drop_path_prob, seed)
         cdt = self._compute_dtype(x)
         if x.dtype not in (torch.float32, torch.bfloat16):
             raise MetaEncError(f"unsupported token dtype {x.dtype}")
@@ -241,7 +267,7 @@ class Block(nn.Module):
         g2 = self.gamma2 if self.layer_scale else None
         return _BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
                               a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
-                              m.fc2.weight, m.fc2.bias, g1, g2, self, cdt)
+                              m.fc2.weight, m.fc2.bias, g1, g2, self, cdt, stoch)
 
 
 def build_encoder(depth: int = 12, dim: int = 768, num_heads: int = 12, mlp_ratio: float = 4., qkv_bias: bool = True,

@@ -212,6 +212,20 @@ def add_rows(x: torch.Tensor, pos: torch.Tensor, out_dtype: Optional[torch.dtype
     return y
 
 
+def dropout_add(v: torch.Tensor, res: Optional[torch.Tensor], rows_per_sample: int, p_drop: float, p_path: float,
+                seed: int, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """res + drop_path(dropout(v)); with res=None and v = incoming gradient this is the backward (same seed)."""
+    lib = _capi.load()
+    _req(v, "v")
+    C = v.shape[-1]
+    rows = v.numel() // C
+    out = torch.empty(v.shape, dtype=out_dtype or (res.dtype if res is not None else v.dtype), device=v.device)
+    check(lib.me_dropout_add(ptr(v), dtype_code(v.dtype), ptr(res), dtype_code(res.dtype) if res is not None else 0,
+                             ptr(out), dtype_code(out.dtype), rows, C, rows_per_sample, float(p_drop), float(p_path),
+                             seed & 0xFFFFFFFFFFFFFFFF, stream_ptr()), "me_dropout_add")
+    return out
+
+
 def patchify(x: torch.Tensor, kt: int, kh: int, kw: int, st: int, sh: int, sw: int, out_dtype: torch.dtype):
     """x [B,Cin,(T,)H,W] -> ([B*tokens, Cin*kt*kh*kw], tokens_per_sample)"""
     lib = _capi.load()

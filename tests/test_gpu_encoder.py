@@ -142,6 +142,52 @@ def test_block_api_behaviours(dev):
     assert rel_err(xr.grad, xr2.grad) < 1e-6
 
 
+def test_stochastic_training_ops(dev):
+    """Dropout(drop) on proj / MLP and DropPath in training mode (attention.py:37,49,56-57; mlp.py:32,35; drop.py:135-152):
+    the RNG stream is our own, so check (i) eval is unaffected, (ii) distribution and 1/keep scaling, (iii) backward uses
+    exactly the forward masks (finite-difference free: linearity of the masked branch in its input gradient)."""
+    from metatransformer_amd import ops
+    # (ii) kernel-level statistics
+    v = torch.ones(64 * 50, 256, device=dev)
+    torch.manual_seed(0)
+    out = ops.dropout_add(v, None, 50, 0.25, 0.0, seed=1234)
+    kept = (out != 0).float().mean().item()
+    assert abs(kept - 0.75) < 0.01 and torch.allclose(out[out != 0], torch.tensor(1 / 0.75, device=dev))
+    out = ops.dropout_add(v, None, 50, 0.0, 0.3, seed=99)
+    per_sample = out.reshape(64, 50, 256)
+    assert all(bool((s == 0).all() or torch.allclose(s, torch.tensor(1 / 0.7, device=dev))) for s in per_sample), "drop-path is per sample"
+    assert 0 < int(sum(bool((s == 0).all()) for s in per_sample)) < 64
+    assert torch.equal(ops.dropout_add(v, None, 50, 0.25, 0.3, seed=7), ops.dropout_add(v, None, 50, 0.25, 0.3, seed=7))
+    res = torch.randn_like(v)
+    assert torch.allclose(ops.dropout_add(v, res, 50, 0.25, 0.0, seed=1234), ops.dropout_add(v, None, 50, 0.25, 0.0, seed=1234) + res)
+    # (i) + (iii) module level
+    blk = M.Block(128, 2, qkv_bias=True, drop=0.2, drop_path=0.25).to(dev)
+    x = torch.randn(16, 20, 128, device=dev)
+    blk.eval()
+    with torch.no_grad():
+        sd = {k: v.cpu() for k, v in blk.state_dict().items()}
+        assert rel_err(blk(x), bo.block_forward(x.cpu(), sd, 2)) < TOL_F32
+    blk.train()
+    torch.manual_seed(5); y1 = blk(x)
+    torch.manual_seed(5); y2 = blk(x)
+    torch.manual_seed(6); y3 = blk(x)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    dropped = [(y1[b] - x[b]).abs().max().item() == 0 for b in range(16)]     # both branches dropped for a sample: y == x
+    torch.manual_seed(5)
+    xr = x.clone().requires_grad_(True)
+    y = blk(xr)
+    g1, g2 = torch.randn_like(y), torch.randn_like(y)
+    (ga,) = torch.autograd.grad(y, xr, g1, retain_graph=True)
+    (gb,) = torch.autograd.grad(y, xr, g2, retain_graph=True)
+    (gab,) = torch.autograd.grad(y, xr, g1 + 2 * g2)
+    assert rel_err(gab, ga + 2 * gb) < 1e-4, "backward must be linear in the incoming gradient (same masks every time)"
+    for b, d in enumerate(dropped):
+        if d:
+            assert torch.equal(ga[b], g1[b]), "a sample whose branches are dropped passes its gradient through unchanged"
+    with pytest.raises(M.MetaEncError):
+        M.Block(128, 2, attn_drop=0.1).to(dev).train()(x)
+
+
 def test_layer_scale_variant(dev):
     blk = M.Block(128, 2, qkv_bias=True, layer_scale=True).to(dev).eval()
     with torch.no_grad():
