@@ -276,12 +276,12 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
     int ffam, fbn;
     forced_family(ffam, fbn);
     if (d->ab_dtype != ME_BF16 || ffam == 0) return pl;
-    const int fam = ffam > 0 ? ffam : 2;                        // default: g2b
+    // default (measured on the encoder's shapes, tools/gemm_bench.py): NT -> the staggered 8-wave 256x256 kernel ("g2w",
+    // family 3) except small N x small K where the two-workgroup kernel's overlapped epilogue wins; TN (wgrad) -> g2b.
+    int fam = ffam > 0 ? ffam : 2;
+    if (ffam < 0 && d->op == ME_GEMM_NT && d->M >= 256 && d->N >= 256 && !(d->N <= 768 && d->K <= 1024)) fam = 3;
     const bool ok = fam >= 2 ? g2b_supported(p, d->op) : g256_supported(p, d->op);
-    if (!ok) {
-        if (fam == 2 && ffam < 0 && g256_supported(p, d->op)) return pl;   // (K % 32 != 0 never passes K % 64)
-        return pl;
-    }
+    if (!ok) return pl;
     if (ffam < 0 && (d->M < 128 || d->N < 128)) return pl;       // tiny problems: g128 is enough
     pl.family = fam;
     pl.bm = fam == 2 ? 128 : 256;
@@ -302,6 +302,7 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         if (pl.split_k > 1) pl.ws_bytes = (size_t)pl.split_k * (size_t)d->M * (size_t)d->N * sizeof(float);
     } else {
         if (fbn) pl.bn = fbn;
+        else if (fam == 3) pl.bn = 256;
         else if (fam == 2) pl.bn = d->N > 128 ? 256 : 128;       // measured: g2b_256 beats g2b_128 on every encoder shape
         else {
             const double c256 = (double)((t256 + SLOTS - 1) / SLOTS), c128 = 0.55 * (double)((t128 + SLOTS - 1) / SLOTS);

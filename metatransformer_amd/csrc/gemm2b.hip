@@ -193,65 +193,79 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int i = 0; i < LOOK; ++i)
         if (i < nk) issue(i, ks_begin + i);
-    int s_cur = 0, s_nxt2 = LOOK;    // stage of step t, stage of step t+LOOK
-    for (int t = 0; t < nk; ++t) {
-        // my part of step t has landed (younger steps' DMA may stay in flight) ...
+
+    struct Frags { bf16x8 xb[2][4]; bf16x8 wa[2][G::NI]; };
+    // my part of step t has landed (younger steps' DMA may stay in flight); then everybody's part has, and every reader
+    // of step t-1's stage is done with it
+    auto step_sync = [&](int t) {
         int ahead = nk - 1 - t;
         ahead = ahead < LOOK - 1 ? ahead : LOOK - 1;
-        if (!(p.debug & 8)) wait_ahead(ahead);
-        // ... everybody's part has, and every reader of step t-1's stage is done with it
+        wait_ahead(ahead);
         __builtin_amdgcn_s_barrier();
-        const char* sa = smem + s_cur * G::STAGE;
+    };
+    auto load_sub = [&](int stage, int kk, Frags& f) {
+        const char* sa = smem + stage * G::STAGE;
         const char* sb = sa + G::A_BYTES;
-        auto load_frags = [&](int kk, bf16x8 (&xb)[4], bf16x8 (&wa)[G::NI]) {
-            if (TN) {
+        if (TN) {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) xb[mi] = tn_frag2<BM>((const lds_char*)sa, wr * 128 + mi * 32, kk, lane);
+            for (int mi = 0; mi < 4; ++mi) f.xb[kk][mi] = tn_frag2<BM>((const lds_char*)sa, wr * 128 + mi * 32, kk, lane);
 #pragma unroll
-                for (int ni = 0; ni < G::NI; ++ni) wa[ni] = tn_frag2<BN>((const lds_char*)sb, wc * (BN / 4) + ni * 32, kk, lane);
-            } else {
+            for (int ni = 0; ni < G::NI; ++ni) f.wa[kk][ni] = tn_frag2<BN>((const lds_char*)sb, wc * (BN / 4) + ni * 32, kk, lane);
+        } else {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) xb[mi] = nt_frag2(sa, wr * 128 + mi * 32 + l31, 2 * kk + h);
+            for (int mi = 0; mi < 4; ++mi) f.xb[kk][mi] = nt_frag2(sa, wr * 128 + mi * 32 + l31, 2 * kk + h);
 #pragma unroll
-                for (int ni = 0; ni < G::NI; ++ni) wa[ni] = nt_frag2(sb, wc * (BN / 4) + ni * 32 + l31, 2 * kk + h);
-            }
-        };
-        auto mma = [&](const bf16x8 (&xb)[4], const bf16x8 (&wa)[G::NI]) {
-            if (SCHED == 2) __builtin_amdgcn_s_setprio(1);
+            for (int ni = 0; ni < G::NI; ++ni) f.wa[kk][ni] = nt_frag2(sb, wc * (BN / 4) + ni * 32 + l31, 2 * kk + h);
+        }
+    };
+    auto mma_step = [&](const Frags& f) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < G::NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ni], xb[mi], acc[mi][ni], 0, 0, 0);
-            if (SCHED == 2) __builtin_amdgcn_s_setprio(0);
-        };
-        if (SCHED == 0) {
-            if (t + LOOK < nk) issue(s_nxt2, ks_begin + t + LOOK);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 xb[4], wa[G::NI];
-                load_frags(kk, xb, wa);
-                mma(xb, wa);
-            }
-        } else {
-            bf16x8 xb0[4], wa0[G::NI], xb1[4], wa1[G::NI];
-            if ((p.debug & 16) && t > 0) {               // dev: no LDS traffic -- reuse whatever the registers hold
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { asm volatile("" : "=v"(xb0[i])); asm volatile("" : "=v"(xb1[i])); }
-#pragma unroll
-                for (int i = 0; i < G::NI; ++i) { asm volatile("" : "=v"(wa0[i])); asm volatile("" : "=v"(wa1[i])); }
-            } else {
-                load_frags(0, xb0, wa0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + LOOK < nk && !(p.debug & 8)) issue(s_nxt2, ks_begin + t + LOOK);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!((p.debug & 16) && t > 0)) load_frags(1, xb1, wa1);
-            mma(xb0, wa0);
-            mma(xb1, wa1);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wa[kk][ni], f.xb[kk][mi], acc[mi][ni], 0, 0, 0);
+    };
+    // fragments of substep 0, then the DMA issue while they fly, then substep 1 (measured best order)
+    auto load_and_issue = [&](int t, int stage, int stage_ahead, Frags& f) {
+        load_sub(stage, 0, f);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + LOOK < nk) issue(stage_ahead, ks_begin + t + LOOK);
+        __builtin_amdgcn_sched_barrier(0);
+        load_sub(stage, 1, f);
+    };
+    auto next_stage = [&](int s) { return s == NSTAGE - 1 ? 0 : s + 1; };
+
+    // The 8-wave workgroup (BM = 256) runs its two wave rows STAGGERED by the MFMA phase: each SIMD hosts one wave of
+    // row 0 and one of row 1; after barrier t row 0 reads its fragments / issues DMA while row 1 still executes the
+    // MFMAs of step t-1 on fragments it kept in registers, then they swap -- LDS/DMA phases of one wave sit under the
+    // MFMA phase of its SIMD partner instead of all eight waves doing the same thing at the same time.
+    const bool trailing = (BM == 256) && wr == 1 && !(p.debug & 64);
+    int s_cur = 0, s_ahead = LOOK;
+    if (!trailing) {
+        for (int t = 0; t < nk; ++t) {
+            step_sync(t);
+            Frags f;
+            load_and_issue(t, s_cur, s_ahead, f);
+            mma_step(f);
+            s_cur = next_stage(s_cur);
+            s_ahead = next_stage(s_ahead);
         }
-        s_cur = s_cur == NSTAGE - 1 ? 0 : s_cur + 1;
-        s_nxt2 = s_nxt2 == NSTAGE - 1 ? 0 : s_nxt2 + 1;
+    } else if (nk > 0) {
+        // one fragment set is enough: once the 16 MFMAs of step t-1 have ISSUED their operands are read, and the
+        // reads of step t may overwrite the registers while the matrix pipe is still busy
+        Frags f;
+        step_sync(0);
+        load_and_issue(0, s_cur, s_ahead, f);
+        for (int t = 1; t < nk; ++t) {
+            s_cur = next_stage(s_cur);
+            s_ahead = next_stage(s_ahead);
+            step_sync(t);
+            mma_step(f);
+            load_and_issue(t, s_cur, s_ahead, f);
+        }
+        mma_step(f);
     }
 
     // ---- epilogue (same scheme as gemm256.hip): accumulators -> per-wave LDS patch -> row-contiguous 16-byte accesses
@@ -276,6 +290,24 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // s_waitcnt vmcnt(0) -- which here would drain the previous slab's global stores four times per tile (measured:
     // the epilogue then costs 18 us per tile, more than the K-loop at K = 768).  Hidden from the compiler, the slabs'
     // stores stay in flight; a wave's DS operations execute in order, so write -> read needs no wait in between.
+    if (EPI == 6) {
+        // dev experiment: no LDS transposition, no barrier -- every lane stores its own row's 4-column quads (8 bytes
+        // in bf16); the two half-waves make 16 contiguous bytes per row per instruction
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int64_t m = m0 + wr * 128 + mi * 32 + l31;
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int64_t nn = n0 + wc * (BN / 4) + ni * 32 + 8 * g + 4 * h;
+                    f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+                    if (p.bias) v = v * p.alpha + *reinterpret_cast<const f32x4*>(p.bias + (nn < p.N ? nn : 0));
+                    if (m < p.M && nn < p.N) store4_from_f32(p.C, p.c_dtype, m * p.ldc + nn, v);
+                }
+        }
+        return;
+    }
     constexpr int WCOLS = BN / 4;
     constexpr int PITCH = WCOLS * 4 + 16;
     constexpr int LPR = WCOLS / 8;                        // lanes per row in the read phase: 8 / 4
@@ -418,7 +450,7 @@ int launch2(const GemmParams& p, hipStream_t stream) {
         return epi == 0 ? launch2e<BM, BN, TN, 0>(p, stream) : launch2e<BM, BN, TN, 4>(p, stream);
     }
     switch (epi) {
-        case 0: return launch2e<BM, BN, TN, 0>(p, stream);
+        case 0: return (p.debug & 32) ? launch2e<BM, BN, TN, 6>(p, stream) : launch2e<BM, BN, TN, 0>(p, stream);
         case 1: return launch2e<BM, BN, TN, 1>(p, stream);
         case 2: return launch2e<BM, BN, TN, 2>(p, stream);
         case 3: return launch2e<BM, BN, TN, 3>(p, stream);

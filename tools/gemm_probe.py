@@ -39,9 +39,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child(); sys.exit(0)
     base = {"ME_G2_SCHED": "1", "ME_GEMM_KERNEL": os.environ.get("PROBE_KERNEL", "g2b_256")}
-    for env_name, env in (("default", {}), ("no-epilogue", {"ME_G256_DEBUG": "1"}),
-                          ("no-epi no-dma", {"ME_G256_DEBUG": "9"}), ("no-epi no-dma no-lds", {"ME_G256_DEBUG": "25"}),
-                          ("no-epi no-lds", {"ME_G256_DEBUG": "17"})):
+    for env_name, env in (("staggered", {}), ("lockstep", {"ME_G256_DEBUG": "64"}), ("staggered no-epi", {"ME_G256_DEBUG": "1"}),
+                          ("lockstep no-epi", {"ME_G256_DEBUG": "65"})):
         env = dict(base, **env)
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, __file__, "child"], env=e, capture_output=True, text=True)
