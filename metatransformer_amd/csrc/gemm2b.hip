@@ -218,7 +218,9 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int ni = 0; ni < G::NI; ++ni) f.wa[kk][ni] = nt_frag2(sb, wc * (BN / 4) + ni * 32 + l31, 2 * kk + h);
         }
     };
+    const bool prio_mma = (p.debug & 256) != 0;
     auto mma_step = [&](const Frags& f) {
+        if (prio_mma) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int ni = 0; ni < G::NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wa[kk][ni], f.xb[kk][mi], acc[mi][ni], 0, 0, 0);
+        if (prio_mma) __builtin_amdgcn_s_setprio(0);
     };
     // fragments of substep 0, then the DMA issue while they fly, then substep 1 (measured best order)
     auto load_and_issue = [&](int t, int stage, int stage_ahead, Frags& f) {
@@ -242,6 +245,9 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // MFMAs of step t-1 on fragments it kept in registers, then they swap -- LDS/DMA phases of one wave sit under the
     // MFMA phase of its SIMD partner instead of all eight waves doing the same thing at the same time.
     const bool trailing = (BM == 256) && wr == 1 && !(p.debug & 64);
+    // static priority for the later-dispatched wave row (it loses VALU arbitration to the older row otherwise; measured
+    // +2..5 %; per-MFMA-group s_setprio flips measured neutral) -- wave-uniform condition, scalar branch
+    if (trailing && !(p.debug & 128)) __builtin_amdgcn_s_setprio(1);
     int s_cur = 0, s_ahead = LOOK;
     if (!trailing) {
         for (int t = 0; t < nk; ++t) {

@@ -108,15 +108,16 @@ class _BlockFn(torch.autograd.Function):
     """forward + backward of one Block on the HIP kernels.  Restates Block.forward (attention.py:55-58)."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g1, g2, blk, cdt, stoch):
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g1, g2, blk, cdt, stoch, grad_mode):
         B, N, C = x.shape
         H = blk.attn.num_heads
         hd = C // H
         M = B * N
         rdt = x.dtype                      # residual-stream dtype
         cache: _WeightCache = blk._wcache
-        # grad mode is always off inside Function.forward; needs_input_grad says whether a backward can follow
-        need_grad = any(ctx.needs_input_grad)
+        # grad mode is always off inside Function.forward and needs_input_grad ignores torch.no_grad(): the caller
+        # samples torch.is_grad_enabled() and passes it in, so inference saves nothing (no stats / LSE / pre-activation)
+        need_grad = grad_mode and any(ctx.needs_input_grad)
         x2 = x.reshape(M, C)
 
         xn1, mean1, rstd1 = ops.layernorm_fwd(x2, n1w, n1b, blk.eps, cdt, save_stats=need_grad)
@@ -202,7 +203,7 @@ class _BlockFn(torch.autograd.Function):
                 aff(d_n1w, n1w) if ng[1] else None, aff(d_n1b, n1w) if ng[2] else None,
                 d_qkvw, d_qkvb, d_projw, d_projb,
                 aff(d_n2w, n2w) if ng[7] else None, aff(d_n2b, n2w) if ng[8] else None,
-                d_fc1w, d_fc1b, d_fc2w, d_fc2b, None, None, None, None, None)
+                d_fc1w, d_fc1b, d_fc2w, d_fc2b, None, None, None, None, None, None)
 
 
 class Block(nn.Module):
@@ -267,7 +268,7 @@ class Block(nn.Module):
         g2 = self.gamma2 if self.layer_scale else None
         return _BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
                               a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
-                              m.fc2.weight, m.fc2.bias, g1, g2, self, cdt, stoch)
+                              m.fc2.weight, m.fc2.bias, g1, g2, self, cdt, stoch, torch.is_grad_enabled())
 
 
 def build_encoder(depth: int = 12, dim: int = 768, num_heads: int = 12, mlp_ratio: float = 4., qkv_bias: bool = True,

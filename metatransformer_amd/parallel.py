@@ -80,6 +80,61 @@ def allreduce_gradients(flat: FlatParams, group=None, bucket_bytes: int = 64 << 
         flat.flat_grad.div_(dist.get_world_size(group))
 
 
+class OverlappedGradReducer:
+    """All-reduce each flat bucket as soon as backward has finished writing it, overlapping RCCL with the rest of
+    backward (what DDP does with its 25 MB buckets, Video/run_class_finetuning.py:739-742; here the buckets are slices
+    of the FlatParams gradient buffer, last layers first, so nothing is copied).
+
+    Every parameter gets a post-accumulate-grad hook; a bucket launches ``all_reduce(async_op=True)`` when its last
+    parameter has fired.  ``finish()`` waits for the handles (call it before the optimizer step)."""
+
+    def __init__(self, flat: FlatParams, group=None, bucket_bytes: int = 64 << 20, force: bool = False):
+        self.flat, self.group, self.force = flat, group, force
+        es = flat.flat_grad.element_size()
+        # same partition as FlatParams.buckets(): walk parameters in reverse order
+        self.bucket_of, self.bucket_slices, self.bucket_left = {}, [], []
+        cur_end, members = flat.numel, []
+        for i in range(len(flat.params) - 1, -1, -1):
+            members.append(i)
+            if (cur_end - flat.offsets[i]) * es >= bucket_bytes or i == 0:
+                b = len(self.bucket_slices)
+                self.bucket_slices.append(flat.flat_grad[flat.offsets[i]:cur_end])
+                self.bucket_left.append(len(members))
+                for m in members:
+                    self.bucket_of[m] = b
+                cur_end, members = flat.offsets[i], []
+        self._initial = list(self.bucket_left)
+        self.handles = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(flat.params)]
+
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
+
+    def _make_hook(self, idx):
+        def hook(param):
+            b = self.bucket_of[idx]
+            self.bucket_left[b] -= 1
+            if self.bucket_left[b] == 0 and self._active():
+                self.handles.append(dist.all_reduce(self.bucket_slices[b], op=dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True))
+        return hook
+
+    def finish(self) -> None:
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if any(left != 0 for left in self.bucket_left) and self._active():
+            # a parameter received no gradient this step (unused / frozen late): reduce what was not launched
+            for b, left in enumerate(self.bucket_left):
+                if left != 0:
+                    dist.all_reduce(self.bucket_slices[b], op=dist.ReduceOp.SUM, group=self.group)
+        self.bucket_left = list(self._initial)
+
+    def remove(self) -> None:
+        for h in self._hooks:
+            h.remove()
+
+
 def allreduce_coalesced(tensors: Sequence[torch.Tensor], group=None, bucket_bytes: int = 64 << 20) -> None:
     """Generic form for gradients that do NOT live in a FlatParams (tokenizer / head parameters of the frozen-encoder
     pipelines): bucket -> flatten -> all_reduce -> /world -> copy back, exactly dist_utils.py:14-35."""

@@ -50,6 +50,15 @@ def _worker(rank, world, port, q):
         bks = flat.buckets(4096)
         assert sum(b.numel() for b in bks) == flat.numel
         assert bks[0].data_ptr() > bks[-1].data_ptr()
+        # overlapped reducer: hooks fire during backward, result == plain sum, and it is reusable step after step
+        red = parallel.OverlappedGradReducer(flat, bucket_bytes=4096)
+        for it in range(2):
+            flat.zero_grad()
+            m(x).square().mean().backward()
+            local2 = None
+            red.finish()
+            assert torch.allclose(flat.flat_grad, sum(gathered), atol=1e-6), it
+        red.remove()
         # reference-style helper (dist_utils.py:14-35): average of loose tensors
         t = [torch.full((7,), float(rank + 1)), torch.full((3, 5), 10.0 * (rank + 1))]
         parallel.allreduce_coalesced(t, bucket_bytes=16)

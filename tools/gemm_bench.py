@@ -12,7 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 M = 256 * 197
-SHAPES = [  # (name, op, M, N, K)
+SHAPES = [  # (name, op, M, N, K)   names ending in _gelu / _res / _aux use that fused epilogue
+    ("fc1_fwd_gelu", "nt", M, 3072, 768), ("fc2_fwd_res", "nt", M, 768, 3072), ("proj_fwd_res", "nt", M, 768, 768),
+    ("fc2_dgrad_aux", "nt", M, 3072, 768),
     ("qkv_fwd", "nt", M, 2304, 768), ("proj_fwd", "nt", M, 768, 768), ("fc1_fwd", "nt", M, 3072, 768),
     ("fc2_fwd", "nt", M, 768, 3072), ("fc1_dgrad", "nt", M, 768, 3072), ("fc2_dgrad", "nt", M, 3072, 768),
     ("qkv_dgrad", "nt", M, 768, 2304),
@@ -49,8 +51,22 @@ def run_family(family, iters):
         out_dtype = torch.bfloat16 if op == "nt" else torch.float32
         outs = [torch.empty((m, n), dtype=out_dtype, device=dev) for _ in range(NSET)]
         kw = dict(op=code, bias=bias if op == "nt" else None)
+        extra = None
+        if name.endswith("_gelu"):
+            kw["act"] = _capi.ME_ACT_GELU
+        elif name.endswith("_res"):
+            extra = torch.randn(m, n, device=dev).bfloat16(); kw["residual"] = extra
+        elif name.endswith("_aux"):
+            extra = torch.randn(m, n, device=dev).bfloat16(); kw["aux"] = extra; kw["bias"] = None
         c = ops.gemm(As[0], Bs[0], out=outs[0], **kw)
-        r = ref() + (bias if op == "nt" else 0)
+        r = ref() + (bias if (op == "nt" and kw.get("bias") is not None) else 0)
+        if name.endswith("_gelu"):
+            r = torch.nn.functional.gelu(r)
+        elif name.endswith("_res"):
+            r = r + extra[:512].float()
+        elif name.endswith("_aux"):
+            xa = extra[:512].float()
+            r = r * (0.5 * (1 + torch.erf(xa / 2 ** 0.5)) + xa * torch.exp(-0.5 * xa * xa) / (2 * 3.141592653589793) ** 0.5)
         err = float((sl(c).float() - r).abs().max() / r.abs().max())
         for i in range(3):
             ops.gemm(As[i % NSET], Bs[i % NSET], out=outs[i % NSET], **kw)

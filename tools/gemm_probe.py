@@ -39,8 +39,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child(); sys.exit(0)
     base = {"ME_G2_SCHED": "1", "ME_GEMM_KERNEL": os.environ.get("PROBE_KERNEL", "g2b_256")}
-    for env_name, env in (("staggered", {}), ("lockstep", {"ME_G256_DEBUG": "64"}), ("staggered no-epi", {"ME_G256_DEBUG": "1"}),
-                          ("lockstep no-epi", {"ME_G256_DEBUG": "65"})):
+    for env_name, env in (("staggered", {}), ("+static prio trailing", {"ME_G256_DEBUG": "128"}), ("+setprio around mfma", {"ME_G256_DEBUG": "256"}),
+                          ("both", {"ME_G256_DEBUG": "384"}), ("staggered again", {})):
         env = dict(base, **env)
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, __file__, "child"], env=e, capture_output=True, text=True)

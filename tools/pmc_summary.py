@@ -1,0 +1,43 @@
+"""Fold the rocprofv3 --pmc passes of tools/pmc_bench.sh into one JSON per mode (per-kernel averages per launch).
+HBM traffic = 2 * FETCH_SIZE + WRITE_SIZE  (KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced
+streams -- MI355X_MICROARCH.md "HBM" -- hence the factor 2; WRITE_SIZE is uncalibrated and taken as reported)."""
+import collections, csv, glob, json, re, sys
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return re.sub(r"\(.*", "", name)
+
+def main(mode):
+    base = f"gpurun_out/pmc_bench_{mode}"
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for p in sorted(glob.glob(f"{base}/p*/p_counter_collection.csv")):
+        for r in csv.DictReader(open(p)):
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for r in csv.DictReader(open(f"{base}/p1/p_kernel_trace.csv")):
+        dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out = {}
+    for k, cs in agg.items():
+        c = {n: sum(v) / len(v) for n, v in cs.items()}
+        e = {"launches": len(dur.get(k, [])), "avg_us_profiled": round(sum(dur[k]) / max(1, len(dur[k])), 1)}
+        if "FETCH_SIZE" in c:
+            e["fetch_MB"] = round(2 * c["FETCH_SIZE"] / 1024, 1)
+            e["write_MB"] = round(c.get("WRITE_SIZE", 0) / 1024, 1)
+            e["hbm_traffic_MB"] = round(e["fetch_MB"] + e["write_MB"], 1)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            e["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 256 * 4), 4)
+        if "SQ_WAVE_CYCLES" in c:
+            wc = c["SQ_WAVE_CYCLES"]
+            e["wave_cycles"] = {"wait_any": round(c["SQ_WAIT_ANY"] / wc, 3), "wait_inst": round(c["SQ_WAIT_INST_ANY"] / wc, 3),
+                                "active": round(c["SQ_ACTIVE_INST_ANY"] / wc, 3)}
+        if "TCC_HIT_sum" in c:
+            e["l2_hit"] = round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3)
+        out[k] = e
+    json.dump(out, open(f"profiles/r01_pmc_{mode}.json", "w"), indent=1, sort_keys=True)
+    for k, e in sorted(out.items(), key=lambda kv: -kv[1]["launches"] * kv[1]["avg_us_profiled"])[:12]:
+        print(f"{k[:60]:60s}", {x: e[x] for x in e if x != "wave_cycles"})
+
+if __name__ == "__main__":
+    for m in sys.argv[1:] or ["fwd", "train"]:
+        print("==", m); main(m)
