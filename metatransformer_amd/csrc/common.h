@@ -84,29 +84,47 @@ __device__ __forceinline__ void store1_from_f32(void* base, int dt, int64_t idx,
 }
 
 // exact-erf GELU and its derivative (nn.GELU(approximate='none')).
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, branch-free: 1 rcp + 1 exp + 6 fma) instead of libm's erff,
-// which costs several times more VALU in the GEMM epilogues.  With z = x/sqrt(2) the same exponential e^{-z^2} =
-// e^{-x^2/2} serves the Gaussian pdf term of the derivative.
-__device__ __forceinline__ void erf_parts(float x, float& erf_z, float& exp_mz2) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));     // 1-ulp v_rcp_f32 (not the IEEE division sequence)
-    exp_mz2 = __expf(-z * z);
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    erf_z = copysignf(1.0f - poly * t * exp_mz2, x);
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, branch-free) instead of libm's erff, which costs several times
+// more VALU in the GEMM epilogues.  Written on 4-wide vectors so hipcc emits packed fp32 math (v_pk_fma_f32 /
+// v_pk_mul_f32: two lanes-elements per instruction); only rcp and exp2 are per element.  Constants are folded so that
+//   w = |x| * sqrt(log2(e)/2)            ->  e^{-x^2/2} = 2^{-w^2}          (one v_exp_f32, no extra scale)
+//   t = 1 / (1 + p*|x|/sqrt(2))          =   rcp(fma(w, p/sqrt(log2 e), 1))
+//   q = 0.5 * poly(t) * 2^{-w^2}         =   1 - Phi(|x|)                    (0.5 folded into the coefficients)
+//   Phi(x) = 0.5 + copysign(0.5 - q, x);   gelu = x*Phi ;   gelu' = Phi + x * e^{-x^2/2} / sqrt(2 pi)
+// The same exponential serves the Gaussian term of the derivative.
+__device__ __forceinline__ void phi_parts4(f32x4 x, f32x4& phi, f32x4& gauss) {
+    const f32x4 ax = {fabsf(x[0]), fabsf(x[1]), fabsf(x[2]), fabsf(x[3])};
+    const f32x4 w = ax * 0.84932180028801907f;                    // sqrt(log2(e) / 2)
+    const f32x4 u = w * 0.27273748087922245f + 1.0f;              // 0.3275911 / sqrt(2) / sqrt(log2(e)/2) ... = p*|x|/sqrt2
+    const f32x4 nw2 = -(w * w);
+    f32x4 t, e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t[i] = __builtin_amdgcn_rcpf(u[i]);
+        e[i] = __builtin_amdgcn_exp2f(nw2[i]);
+    }
+    f32x4 poly = t * 0.5307027145f - 0.7265760135f;               // 0.5 * {1.061405429, -1.453152027, ...}
+    poly = poly * t + 0.7107068705f;
+    poly = poly * t - 0.142248368f;
+    poly = poly * t + 0.127414796f;
+    const f32x4 q = poly * t * e;                                 // 1 - Phi(|x|)
+    const f32x4 hmq = 0.5f - q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) phi[i] = 0.5f + copysignf(hmq[i], x[i]);
+    gauss = e;
 }
-__device__ __forceinline__ float gelu_erf(float x) {
-    float e, g;
-    erf_parts(x, e, g);
-    return 0.5f * x * (1.0f + e);
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 x) {
+    f32x4 phi, g;
+    phi_parts4(x, phi, g);
+    return x * phi;
 }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    float e, g;
-    erf_parts(x, e, g);
-    return 0.5f * (1.0f + e) + x * 0.3989422804014327f * g;
+__device__ __forceinline__ f32x4 gelu_erf_grad4(f32x4 x) {
+    f32x4 phi, g;
+    phi_parts4(x, phi, g);
+    return phi + x * g * 0.3989422804014327f;
 }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf4(f32x4{x, x, x, x})[0]; }
+__device__ __forceinline__ float gelu_erf_grad(float x) { return gelu_erf_grad4(f32x4{x, x, x, x})[0]; }
 
 // ---- MFMA "16-byte chunk" abstraction.
 // A chunk is 16 bytes of an operand row along the reduction dimension: 8 bf16 or 4 fp32.

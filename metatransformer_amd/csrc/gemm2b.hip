@@ -398,14 +398,14 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             v1 = v1 * p.alpha + bias1;
             if (EPI == 1) {
                 if (p.preact && ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v0[e] = gelu_erf(v0[e]); v1[e] = gelu_erf(v1[e]); }
+v0 = gelu_erf4(v0);
+                v1 = gelu_erf4(v1);
             }
             f32x4 ra, rb;
             if (EPI == 2 || EPI == 3) unpack(cur.raw[i], ra, rb);
             if (EPI == 3) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v0[e] *= gelu_erf_grad(ra[e]); v1[e] *= gelu_erf_grad(rb[e]); }
+v0 *= gelu_erf_grad4(ra);
+                v1 *= gelu_erf_grad4(rb);
             }
             v0 *= cs0; v1 *= cs1;
             if (EPI == 2) { v0 += ra; v1 += rb; }

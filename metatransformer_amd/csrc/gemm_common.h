@@ -24,13 +24,11 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, in
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.preact) store4_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v);
     if (p.act == ME_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+v = gelu_erf4(v);
     }
     if (p.aux) {
         const f32x4 a = load4_as_f32(p.aux, p.aux_dtype, m * p.ldaux + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a[e]);
+v *= gelu_erf_grad4(a);
     }
     if (p.colscale) v *= *reinterpret_cast<const f32x4*>(p.colscale + n);
     if (p.residual) {
@@ -78,14 +76,14 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
     }
     if (p.preact) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
     if (p.act == ME_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v0[e] = gelu_erf(v0[e]); v1[e] = gelu_erf(v1[e]); }
+v0 = gelu_erf4(v0);
+                v1 = gelu_erf4(v1);
     }
     if (p.aux) {
         f32x4 a0, a1;
         load8_as_f32(p.aux, p.aux_dtype, m * p.ldaux + n, a0, a1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v0[e] *= gelu_erf_grad(a0[e]); v1[e] *= gelu_erf_grad(a1[e]); }
+v0 *= gelu_erf_grad4(a0);
+        v1 *= gelu_erf_grad4(a1);
     }
     if (p.colscale) {
         v0 *= *reinterpret_cast<const f32x4*>(p.colscale + n);
