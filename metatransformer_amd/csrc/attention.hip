@@ -15,6 +15,7 @@
 // fp32 runs the same code on the exact-fp32 MFMA (parity mode); bf16 is the performance mode.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -607,8 +608,500 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
         }
 }
 
+
+// =====================================================================================================
+// small-sequence kernels (bf16, head_dim <= 64, N <= 256): ONE workgroup of 8 waves per (batch, head), the whole
+// sequence resident in LDS.  At the encoder's N = 197 the tiled kernels above are bound by staging, not math: two
+// query blocks per head re-fetch K/V through different XCD L2s, every 64-key tile costs two barriers, and the
+// 128-query / 64-key tiling pads 197 to 256 both ways.  Here each array is fetched exactly once with all loads in
+// flight together, rows are padded only to a multiple of 32, and the per-wave loops over key (query) sub-tiles run
+// without any barrier.  The backward is ONE kernel: phase A (a wave owns 32 queries) computes delta = rowsum(dO*O)
+// and dQ, phase B (a wave owns 32 keys) computes dK and dV from the same resident tiles -- no delta kernel, no second
+// pass over HBM.  Both phases recompute S and dP (7 MFMA products instead of the minimal 5); results are
+// deterministic (no atomics).
+// =====================================================================================================
+// developer instrumentation (tools/attn_trace.hip defines ME_ATTN_TRACE and includes this file): per-workgroup
+// s_memtime stamps at the phase boundaries; compiled out of libmetaenc.so
+#ifdef ME_ATTN_TRACE
+__device__ long long g_trace[1 << 16];
+#define TRACE_STAMP(slot, k) do { if (threadIdx.x == 0 && (slot) < (1 << 12)) g_trace[(slot) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE_STAMP(slot, k) do { } while (0)
+#endif
+
+constexpr int SM_THREADS = 512;
+constexpr int SM_MAXN = 256;
+constexpr int SM_MINN = 64;      // at or below one 64-key tile the tiled kernels (more workgroups per CU) win
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+template <int HD, int NARR> struct SmallStage {
+    static constexpr int CPR = HD / 8;
+    static constexpr int ITEMS = (SM_MAXN * CPR) / SM_THREADS;
+    u32x4 v[NARR][ITEMS];
+    // branch-free: out-of-range rows / chunks read a clamped (valid) address and are zeroed afterwards, so every load
+    // of every array is in flight before the first use
+    __device__ __forceinline__ void load(const bf16_t* const (&base)[NARR], const int64_t (&ld)[NARR], int N, int hd, int tid) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int it = tid + SM_THREADS * i;
+            const int chunk = it % CPR, row = it / CPR;
+            const bool ok = (row < N) && (chunk * 8 < hd);
+            const int rc = ok ? row : 0, cc = ok ? chunk : 0;
+#pragma unroll
+            for (int a = 0; a < NARR; ++a) v[a][i] = *reinterpret_cast<const u32x4*>(base[a] + (int64_t)rc * ld[a] + cc * 8);
+#pragma unroll
+            for (int a = 0; a < NARR; ++a) v[a][i] = ok ? v[a][i] : zero4();
+        }
+    }
+    __device__ __forceinline__ void store(char* const (&lds)[NARR], int NR, int tid) const {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int it = tid + SM_THREADS * i;
+            const int chunk = it % CPR, row = it / CPR;
+            if (row < NR) {
+#pragma unroll
+                for (int a = 0; a < NARR; ++a)
+                    *reinterpret_cast<u32x4*>(lds[a] + row * Cfg<bf16_t, HD>::RROW + chunk * 16) = v[a][i];
+            }
+        }
+    }
+};
+
+// Write one wave's 32 x HD result (accumulators in the transposed layout: lane = row l31, registers = d) as bf16 rows.
+// Straight from registers this is a row-per-lane scatter of 8-byte pieces (64 rows touched per store instruction), which
+// is store-issue bound; instead the wave transposes through a private [32][HD] LDS scratch and stores whole 128-byte
+// rows: 16 bytes per lane, 64/CPR rows per instruction.
+template <int HD>
+__device__ __forceinline__ void store_rows_via_lds(char* scr, const f32x16 (&acc)[Cfg<bf16_t, HD>::NDB], float mul,
+                                                   bf16_t* __restrict__ grow0, int64_t ldg, int rows_valid, int hd,
+                                                   int lane) {
+    typedef Cfg<bf16_t, HD> C;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[db][4 * g + e] * mul);
+            *reinterpret_cast<bf16x4*>(scr + l31 * C::RROW + (32 * db + 8 * g + 4 * h) * 2) = o;
+        }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int RPI = 64 / C::CPR;      // rows per instruction
+    const int chunk = lane % C::CPR, r0 = lane / C::CPR;
+#pragma unroll
+    for (int k = 0; k < 32 / RPI; ++k) {
+        const int r = r0 + RPI * k;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(scr + r * C::RROW + chunk * 16);
+        if (r < rows_valid && chunk * 8 < hd) *reinterpret_cast<u32x4*>(grow0 + (int64_t)r * ldg + chunk * 8) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// one step of the forward over NU 32-key sub-tiles starting at key kv0 (Kt / Vt point at that row of the resident tiles)
+template <int HD, int NU, bool MASK>
+__device__ __forceinline__ void fwd_small_step(const char* Kt, const char* Vt, int kv0, int N,
+                                               const bf16x8 (&qf)[Cfg<bf16_t, HD>::NKK], float sl, float& m_run,
+                                               float& l_run, f32x16 (&o)[Cfg<bf16_t, HD>::NDB], int lane) {
+    typedef Cfg<bf16_t, HD> C;
+    const int l31 = lane & 31, h = lane >> 5;
+    f32x16 s[2];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk)
+            s[u] = mma_chunk(rtile_chunk<bf16_t, HD>(Kt, 32 * u + l31, 2 * kk + h), qf[kk], s[u]);
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (MASK) s[u][r] = (kv0 + 32 * u + acc_row(r, h) < N) ? s[u][r] : -INFINITY;
+            mt = fmaxf(mt, s[u][r]);
+        }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * sl;          // log2 domain; every step holds at least one valid key
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[u][r] * sl - m_new);
+            s[u][r] = p;
+            ps += p;
+        }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) o[db] *= alpha;
+#pragma unroll
+    for (int c = 0; c < 2 * NU; ++c) {
+        const bf16x8 pb = pack_chunk((const bf16_t*)nullptr, s, c);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) o[db] = mma_chunk(tr_chunk<HD>(Vt, 32 * db, c, lane), pb, o[db]);
+    }
+}
+
+// Persistent: a workgroup walks (batch, head) items with stride gridDim.x.  While item i is computed, the K/V rows and
+// Q fragments of item i+1 are already in flight into registers; they are parked in LDS once every wave is done with
+// item i -- HBM latency and the bursty all-CUs-load-at-once phase hide behind the math.
+template <int HD>
+__global__ __launch_bounds__(SM_THREADS) void attn_fwd_small_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                    bf16_t* __restrict__ out, int64_t ldo,
+                                                                    float* __restrict__ lse, int N, int H, int hd,
+                                                                    float scale, int items) {
+    typedef Cfg<bf16_t, HD> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NS = (N + 31) >> 5, NR = NS * 32;
+    const int tile_bytes = NR * C::RROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    char* Ks = smem;
+    char* Vs = smem + tile_bytes;
+    char* scr = smem + 2 * tile_bytes + wave * 32 * C::RROW;      // per-wave output transposition scratch
+    const int Cdim = H * hd;
+    const int q = 32 * wave + l31;
+    const int qrow = (q < N) ? q : N - 1;
+    const bool active = 32 * wave < N;      // wave-uniform
+    const float sl = scale * LOG2E;
+    const int64_t ldv[2] = {ld, ld};
+
+    SmallStage<HD, 2> st;
+    bf16x8 qf[C::NKK], qn[C::NKK];
+    auto fresh_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+    auto issue = [&](int it, bf16x8 (&qdst)[C::NKK]) {
+        const bf16_t* qptr = qkv + (int64_t)(it / H) * N * ld + (it % H) * hd;
+        const bf16_t* const bases[2] = {qptr + Cdim, qptr + 2 * Cdim};
+        st.load(bases, ldv, N, hd, fresh_tid());
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            const int d = (2 * kk + h) * 8;
+            const bool ok = d < hd;
+            u32x4 raw = *reinterpret_cast<const u32x4*>(qptr + (int64_t)qrow * ld + (ok ? d : 0));
+            raw = ok ? raw : zero4();
+            qdst[kk] = *reinterpret_cast<bf16x8*>(&raw);
+        }
+    };
+    auto park = [&]() {
+        char* const tiles[2] = {Ks, Vs};
+        st.store(tiles, NR, fresh_tid());
+    };
+    int it = blockIdx.x;
+    issue(it, qf);
+    park();
+    __syncthreads();
+    for (; it < items; it += gridDim.x) {
+        const int nxt = (it + (int)gridDim.x < items) ? it + (int)gridDim.x : it;
+        TRACE_STAMP(it, 0);
+        issue(nxt, qn);
+        if (active) {
+            f32x16 o[C::NDB];
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+            float m_run = -INFINITY, l_run = 0.f;
+            int t = 0;
+            for (; 32 * (t + 2) <= N; t += 2)      // full 64-key steps
+                fwd_small_step<HD, 2, false>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, 32 * t, N, qf, sl, m_run, l_run, o, lane);
+            if (t + 2 <= NS) {
+                fwd_small_step<HD, 2, true>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, 32 * t, N, qf, sl, m_run, l_run, o, lane);
+            } else if (t < NS) {
+                fwd_small_step<HD, 1, true>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, 32 * t, N, qf, sl, m_run, l_run, o, lane);
+            }
+            TRACE_STAMP(it, 1);
+            const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+            const float inv = 1.0f / l_tot;
+            const int b = it / H, head = it % H;
+            store_rows_via_lds<HD>(scr, o, inv, out + ((int64_t)b * N + 32 * wave) * ldo + head * hd, ldo, N - 32 * wave, hd, lane);
+            if (lse && h == 0 && q < N) lse[((int64_t)b * H + head) * N + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
+        }
+        TRACE_STAMP(it, 2);
+        __syncthreads();      // every wave is done with the K/V tiles of this item
+        TRACE_STAMP(it, 3);
+        park();
+        TRACE_STAMP(it, 4);
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) qf[kk] = qn[kk];
+        __syncthreads();
+        TRACE_STAMP(it, 5);
+    }
+}
+
+// phase A step (wave owns 32 queries): NU 32-key sub-tiles starting at kv0
+template <int HD, int NU, bool MASK>
+__device__ __forceinline__ void bwd_small_q_step(const char* Kt, const char* Vt, int kv0, int N,
+                                                 const bf16x8 (&qf)[Cfg<bf16_t, HD>::NKK],
+                                                 const bf16x8 (&dof)[Cfg<bf16_t, HD>::NKK], float sl, float lse2,
+                                                 float del, f32x16 (&dq)[Cfg<bf16_t, HD>::NDB], int lane) {
+    typedef Cfg<bf16_t, HD> C;
+    const int l31 = lane & 31, h = lane >> 5;
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[u][r] = 0.f; dp[u][r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            s[u] = mma_chunk(rtile_chunk<bf16_t, HD>(Kt, 32 * u + l31, 2 * kk + h), qf[kk], s[u]);      // S^T[kv][q]
+            dp[u] = mma_chunk(rtile_chunk<bf16_t, HD>(Vt, 32 * u + l31, 2 * kk + h), dof[kk], dp[u]);   // dP^T[kv][q]
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = __builtin_amdgcn_exp2f(s[u][r] * sl - lse2);
+            if (MASK) p = (kv0 + 32 * u + acc_row(r, h) < N) ? p : 0.f;
+            dp[u][r] = p * (dp[u][r] - del);                                   // dS^T / scale (scale applied to dQ once)
+        }
+#pragma unroll
+    for (int c = 0; c < 2 * NU; ++c) {
+        const bf16x8 dsb = pack_chunk((const bf16_t*)nullptr, dp, c);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) dq[db] = mma_chunk(tr_chunk<HD>(Kt, 32 * db, c, lane), dsb, dq[db]);   // dQ^T[d][q]
+    }
+}
+
+// phase B step (wave owns 32 keys): NU 32-query sub-tiles starting at q0; lse_t / del_t point at q0 (log2-scaled lse,
+// +inf on padded queries so that P = 0 there).  Padded KEYS need no mask: a key is a lane here, and whatever a padded
+// lane accumulates stays in its own dK/dV columns, which are never stored.
+template <int HD, int NU>
+__device__ __forceinline__ void bwd_small_kv_step(const char* Qt, const char* dOt, const float* lse_t, const float* del_t,
+                                                  const bf16x8 (&kf)[Cfg<bf16_t, HD>::NKK],
+                                                  const bf16x8 (&vf)[Cfg<bf16_t, HD>::NKK], float sl,
+                                                  f32x16 (&dk)[Cfg<bf16_t, HD>::NDB], f32x16 (&dv)[Cfg<bf16_t, HD>::NDB],
+                                                  int lane) {
+    typedef Cfg<bf16_t, HD> C;
+    const int l31 = lane & 31, h = lane >> 5;
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[u][r] = 0.f; dp[u][r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            s[u] = mma_chunk(rtile_chunk<bf16_t, HD>(Qt, 32 * u + l31, 2 * kk + h), kf[kk], s[u]);      // S[q][kv]
+            dp[u] = mma_chunk(rtile_chunk<bf16_t, HD>(dOt, 32 * u + l31, 2 * kk + h), vf[kk], dp[u]);   // dP[q][kv]
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 L = *reinterpret_cast<const f32x4*>(lse_t + 32 * u + 8 * g + 4 * h);
+            const f32x4 D = *reinterpret_cast<const f32x4*>(del_t + 32 * u + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const float p = __builtin_amdgcn_exp2f(s[u][r] * sl - L[e]);
+                s[u][r] = p;                                   // P
+                dp[u][r] = p * (dp[u][r] - D[e]);              // dS / scale (scale applied to dK once)
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < 2 * NU; ++c) {
+        const bf16x8 pb = pack_chunk((const bf16_t*)nullptr, s, c);
+        const bf16x8 dsb = pack_chunk((const bf16_t*)nullptr, dp, c);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) {
+            dv[db] = mma_chunk(tr_chunk<HD>(dOt, 32 * db, c, lane), pb, dv[db]);    // dV^T[d][kv]
+            dk[db] = mma_chunk(tr_chunk<HD>(Qt, 32 * db, c, lane), dsb, dk[db]);    // dK^T[d][kv]
+        }
+    }
+}
+
+// One workgroup per (batch, head); LDS holds {Q, K, V, dO} (4 x 32 KB at N = 197).  Once every wave has lifted its K/V row
+// fragments for phase B the K/V tiles are dead, and wave w reuses rows [32w, 32w+32) of them as its private scratch for
+// the coalesced row stores of dQ, dK and dV.
+template <int HD>
+__global__ __launch_bounds__(SM_THREADS) void attn_bwd_small_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                    const bf16_t* __restrict__ out, int64_t ldo,
+                                                                    const bf16_t* __restrict__ dout, int64_t lddo,
+                                                                    const float* __restrict__ lse,
+                                                                    float* __restrict__ delta,
+                                                                    bf16_t* __restrict__ dqkv, int64_t lddq, int N, int H,
+                                                                    int hd, float scale) {
+    typedef Cfg<bf16_t, HD> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NS = (N + 31) >> 5, NR = NS * 32;
+    char* Qs = smem;
+    char* Ks = Qs + NR * C::RROW;
+    char* Vs = Ks + NR * C::RROW;
+    char* dOs = Vs + NR * C::RROW;
+    float* lse_s = reinterpret_cast<float*>(dOs + NR * C::RROW);   // [SM_MAXN]  lse * log2(e), +inf on padded rows
+    float* del_s = lse_s + SM_MAXN;                                // [SM_MAXN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int Cdim = H * hd;
+    const bf16_t* qptr = qkv + (int64_t)b * N * ld + head * hd;
+    const bf16_t* doptr = dout + (int64_t)b * N * lddo + head * hd;
+    const int64_t bh = ((int64_t)b * H + head) * N;
+    const int row = 32 * wave + l31;        // the query (phase A) / key (phase B) this lane owns
+    const bool row_ok = row < N;
+    const int rowc = row_ok ? row : N - 1;
+    const bool active = 32 * wave < N;      // wave-uniform
+    const float sl = scale * LOG2E;
+
+    const int trace_slot = blockIdx.y * gridDim.x + blockIdx.x;
+    (void)trace_slot;
+    TRACE_STAMP(trace_slot, 0);
+    SmallStage<HD, 4> st;
+    {
+        const bf16_t* const bases[4] = {qptr, qptr + Cdim, qptr + 2 * Cdim, doptr};
+        const int64_t ldv[4] = {ld, ld, ld, lddo};
+        st.load(bases, ldv, N, hd, tid);
+    }
+    u32x4 of[C::NKK];      // O row fragments for delta: the same d-slices as the dO operand fragments
+    {
+        const bf16_t* optr = out + ((int64_t)b * N + rowc) * ldo + head * hd;
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            const int d = (2 * kk + h) * 8;
+            const bool ok = d < hd;
+            of[kk] = *reinterpret_cast<const u32x4*>(optr + (ok ? d : 0));
+            of[kk] = ok ? of[kk] : zero4();
+        }
+    }
+    const float lse_mine = (tid < N && tid < SM_MAXN) ? lse[bh + tid] * LOG2E : INFINITY;
+    {
+        char* const tiles[4] = {Qs, Ks, Vs, dOs};
+        st.store(tiles, NR, tid);
+    }
+    if (tid < SM_MAXN) lse_s[tid] = lse_mine;
+    __syncthreads();
+    TRACE_STAMP(trace_slot, 1);
+
+    // ---- phase A: delta and dQ for the 32 queries of this wave
+    f32x16 dq[C::NDB];
+    if (active) {
+        bf16x8 qf[C::NKK], dof[C::NKK];
+        float del = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            qf[kk] = rtile_chunk<bf16_t, HD>(Qs, row, 2 * kk + h);
+            dof[kk] = rtile_chunk<bf16_t, HD>(dOs, row, 2 * kk + h);
+            const u32x4 rd = *reinterpret_cast<const u32x4*>(&dof[kk]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                del += __uint_as_float(of[kk][e] << 16) * __uint_as_float(rd[e] << 16) +
+                       __uint_as_float(of[kk][e] & 0xffff0000u) * __uint_as_float(rd[e] & 0xffff0000u);
+        }
+        del += __shfl_xor(del, 32, 64);
+        if (h == 0) {
+            del_s[row] = del;
+            if (row_ok && delta) delta[bh + row] = del;
+        }
+        const float lse2 = lse_s[row];      // +inf on padded queries -> P = 0
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+        int t = 0;
+        for (; 32 * (t + 2) <= N; t += 2)
+            bwd_small_q_step<HD, 2, false>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, 32 * t, N, qf, dof, sl, lse2, del, dq, lane);
+        if (t + 2 <= NS)
+            bwd_small_q_step<HD, 2, true>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, 32 * t, N, qf, dof, sl, lse2, del, dq, lane);
+        else if (t < NS)
+            bwd_small_q_step<HD, 1, true>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, 32 * t, N, qf, dof, sl, lse2, del, dq, lane);
+    }
+    TRACE_STAMP(trace_slot, 2);
+    __syncthreads();      // del_s complete; every phase-A loop over the K/V tiles is finished
+    if (!active) {
+        __syncthreads();
+        return;
+    }
+    bf16x8 kf[C::NKK], vf[C::NKK];
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk) {
+        kf[kk] = rtile_chunk<bf16_t, HD>(Ks, row, 2 * kk + h);
+        vf[kk] = rtile_chunk<bf16_t, HD>(Vs, row, 2 * kk + h);
+    }
+    __syncthreads();      // K/V tiles are dead: rows [32 wave, +32) of each are this wave's scratch from here on
+    TRACE_STAMP(trace_slot, 3);
+    char* scr0 = Ks + 32 * wave * C::RROW;
+    char* scr1 = Vs + 32 * wave * C::RROW;
+    bf16_t* grow0 = dqkv + ((int64_t)b * N + 32 * wave) * lddq + head * hd;
+    store_rows_via_lds<HD>(scr0, dq, scale, grow0, lddq, N - 32 * wave, hd, lane);
+
+    TRACE_STAMP(trace_slot, 4);
+    // ---- phase B: dK and dV for the 32 keys of this wave
+    f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    int t = 0;
+    for (; t + 2 <= NS; t += 2)
+        bwd_small_kv_step<HD, 2>(Qs + 32 * t * C::RROW, dOs + 32 * t * C::RROW, lse_s + 32 * t, del_s + 32 * t, kf, vf, sl, dk, dv, lane);
+    if (t < NS)
+        bwd_small_kv_step<HD, 1>(Qs + 32 * t * C::RROW, dOs + 32 * t * C::RROW, lse_s + 32 * t, del_s + 32 * t, kf, vf, sl, dk, dv, lane);
+    TRACE_STAMP(trace_slot, 5);
+    store_rows_via_lds<HD>(scr0, dk, scale, grow0 + Cdim, lddq, N - 32 * wave, hd, lane);
+    store_rows_via_lds<HD>(scr1, dv, 1.0f, grow0 + 2 * Cdim, lddq, N - 32 * wave, hd, lane);
+    TRACE_STAMP(trace_slot, 6);
+}
+
 template <typename K> void set_smem(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+bool small_path_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ME_ATTN_SMALL");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+int device_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+constexpr size_t LDS_PER_CU = 160 * 1024;
+
+template <int HD>
+int launch_fwd_small(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
+                     hipStream_t stream) {
+    typedef Cfg<bf16_t, HD> C;
+    const size_t smem = (size_t)(2 * ((N + 31) / 32 * 32) + SM_THREADS / 2) * C::RROW;      // {K, V} + per-wave [32][HD] scratch
+    static bool once = false;
+    if (!once) { set_smem(attn_fwd_small_kernel<HD>, (size_t)(2 * SM_MAXN + SM_THREADS / 2) * C::RROW); once = true; }
+    const int64_t items = (int64_t)B * H;
+    int per_cu = (int)(LDS_PER_CU / smem);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int64_t slots = (int64_t)device_cus() * per_cu;
+    const unsigned grid = (unsigned)(items < slots ? items : slots);
+    hipLaunchKernelGGL((attn_fwd_small_kernel<HD>), dim3(grid), dim3(SM_THREADS), smem, stream,
+                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale,
+                       (int)items);
+    ME_CHECK_LAUNCH("me_attention_fwd(small)");
+    return ME_OK;
+}
+template <int HD>
+int launch_bwd_small(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                     float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
+    typedef Cfg<bf16_t, HD> C;
+    const size_t smem = (size_t)4 * ((N + 31) / 32 * 32) * C::RROW + 2 * SM_MAXN * sizeof(float);
+    static bool once = false;
+    if (!once) { set_smem(attn_bwd_small_kernel<HD>, (size_t)4 * SM_MAXN * C::RROW + 2 * SM_MAXN * sizeof(float)); once = true; }
+    hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), dim3(H, B), dim3(SM_THREADS), smem, stream,
+                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<const bf16_t*>(out), ldo,
+                       reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd,
+                       scale);
+    ME_CHECK_LAUNCH("me_attention_bwd(small)");
+    return ME_OK;
 }
 
 template <typename T, int HD>
@@ -682,6 +1175,10 @@ extern "C" int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int6
     int rc = check_attn_args("me_attention_fwd", ld_qkv, B, N, H, head_dim, dtype);
     if (rc) return rc;
     ME_CHECK_ARG(ld_out % 4 == 0, "me_attention_fwd: ld_out must be a multiple of 4");
+    if (dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN && small_path_enabled()) {
+        if (head_dim <= 32) return launch_fwd_small<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+        return launch_fwd_small<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+    }
     ATTN_DISPATCH(launch_fwd, qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
 }
 
@@ -694,6 +1191,13 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
     if (rc) return rc;
     const int E = dtype == ME_BF16 ? 8 : 4;
     ME_CHECK_ARG(ld_dout % E == 0 && ld_dqkv % 4 == 0, "me_attention_bwd: bad strides");
+    if (dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN && ld_out % 8 == 0 && small_path_enabled()) {
+        if (head_dim <= 32)
+            return launch_bwd_small<32>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim,
+                                        scale, stream);
+        return launch_bwd_small<64>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale,
+                                    stream);
+    }
     const int64_t rows = (int64_t)B * N;
     const int64_t nw = rows * H;
     const int lph = head_dim / 8;
