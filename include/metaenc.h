@@ -99,12 +99,18 @@ typedef struct me_gemm_desc {
     int64_t res_row_mod;
     int64_t out_group_rows, out_group_stride, out_row_offset;
     void* workspace; int64_t workspace_bytes;               /* optional scratch (split-K slabs), see below */
+    float* colsum_a;       /* optional, ME_GEMM_TN only: receives sum_k A[k, m] for m in [0, M) -- the bias gradient
+                            * that goes with a weight gradient dW = dY^T X (A = dY), computed on the matrix pipe from
+                            * the operand tiles the kernel stages anyway instead of a second pass over dY.  Only when
+                            * me_gemm_fuses_colsum(d) != 0; otherwise me_gemm rejects the descriptor (use me_colsum). */
 } me_gemm_desc;
 
 /* Scratch the kernel selected for this problem can use (0 = none).  wgrad-shaped problems (tiny output, very long
  * reduction) split the reduction over workgroups and fold fp32 slabs deterministically; without a workspace of this
  * size they still run, unsplit and slower. */
 size_t me_gemm_workspace_bytes(const me_gemm_desc* d);
+/* 1 if me_gemm(d) with d->colsum_a set (and a workspace of me_gemm_workspace_bytes(d)) will produce the column sums */
+int me_gemm_fuses_colsum(const me_gemm_desc* d);
 int me_gemm(const me_gemm_desc* d, void* stream);
 
 /* column sums of a [rows, cols] matrix -> out[cols] fp32 (bias gradients).  accumulate != 0 adds into out.

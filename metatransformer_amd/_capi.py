@@ -46,6 +46,7 @@ class GemmDesc(ctypes.Structure):
         ("res_row_mod", c_int64),
         ("out_group_rows", c_int64), ("out_group_stride", c_int64), ("out_row_offset", c_int64),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
+        ("colsum_a", c_void_p),
     ]
 
 
@@ -63,6 +64,7 @@ SIGNATURES = {
                                  c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                  c_int64, c_int, c_void_p, c_void_p]),
     "me_gemm_workspace_bytes": (c_size_t, [POINTER(GemmDesc)]),
+    "me_gemm_fuses_colsum": (c_int, [POINTER(GemmDesc)]),
     "me_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
     "me_colsum_workspace": (c_size_t, [c_int64]),
     "me_colsum": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p]),

@@ -232,7 +232,35 @@ int launch_g128(const GemmParams& p, hipStream_t stream) {
 }
 
 // ---- split-K fold: sum the fp32 slabs [S][M][N] and apply the real epilogue
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ slabs, int S) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ slabs, int S,
+                                                            const float* __restrict__ cs_part, int n_part,
+                                                            float* __restrict__ colsum_out) {
+    if (colsum_out) {
+        // fold the partial column sums of A (fixed order: deterministic).  The LAST workgroups of the grid take 32 columns
+        // each, eight threads per column striding over the partial rows, then a fixed-order fold through LDS -- kept off
+        // the first workgroups so it overlaps the slab fold instead of delaying it.
+        __shared__ float red[8][32];
+        const int nblk = (int)((p.M + 31) / 32);
+        const int b = (int)gridDim.x - 1 - (int)blockIdx.x;
+        if (b < nblk || gridDim.x < (unsigned)nblk) {
+            for (int cb = b; cb < nblk; cb += (int)gridDim.x) {
+                const int64_t m = (int64_t)cb * 32 + (threadIdx.x & 31);
+                const int jg = threadIdx.x >> 5;
+                float s = 0.f;
+                if (m < p.M)
+                    for (int j = jg; j < n_part; j += 8) s += cs_part[(int64_t)j * p.M + m];
+                red[jg][threadIdx.x & 31] = s;
+                __syncthreads();
+                if (threadIdx.x < 32 && m < p.M) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
+                    colsum_out[m] = t;
+                }
+                __syncthreads();
+            }
+        }
+    }
     const int64_t nq = p.N / 4;
     const int64_t total = p.M * nq;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -299,7 +327,11 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         while (s > 1 && nk / s < min_steps) --s;
         pl.ksteps_per_split = (nk + s - 1) / s;
         pl.split_k = (nk + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
-        if (pl.split_k > 1) pl.ws_bytes = (size_t)pl.split_k * (size_t)d->M * (size_t)d->N * sizeof(float);
+        if (pl.split_k > 1) {
+            pl.ws_bytes = (size_t)pl.split_k * (size_t)d->M * (size_t)d->N * sizeof(float);
+            if (d->colsum_a && fam == 2)      // partial column sums of A: one [M] row per (split, N-tile)
+                pl.ws_bytes += (size_t)pl.split_k * (size_t)((d->N + pl.bn - 1) / pl.bn) * (size_t)d->M * sizeof(float);
+        }
     } else {
         if (fbn) pl.bn = fbn;
         else if (fam == 3) pl.bn = 256;
@@ -345,6 +377,8 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     p.res_row_mod = d->res_row_mod; p.out_group_rows = d->out_group_rows;
     p.out_group_stride = d->out_group_stride; p.out_row_offset = d->out_row_offset;
     p.split_k = 1; p.ksteps_per_split = 0;
+    p.colsum_ws = nullptr;
+    if (d->colsum_a) ME_CHECK_ARG(d->op == ME_GEMM_TN, "me_gemm: colsum_a is defined for ME_GEMM_TN only");
     {
         static int dbg = -1;
         if (dbg < 0) { const char* e = getenv("ME_G256_DEBUG"); dbg = e ? atoi(e) : 0; }
@@ -364,12 +398,22 @@ extern "C" size_t me_gemm_workspace_bytes(const me_gemm_desc* d) {
     return plan_gemm(d, p).ws_bytes;
 }
 
+extern "C" int me_gemm_fuses_colsum(const me_gemm_desc* d) {
+    GemmParams p;
+    if (!d || d->op != ME_GEMM_TN || fill_params(d, p) != ME_OK) return 0;
+    const GemmPlan pl = plan_gemm(d, p);
+    return pl.family == 2 && pl.split_k > 1;
+}
+
 extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     GemmParams p;
     int rc = fill_params(d, p);
     if (rc) return rc;
     GemmPlan pl = plan_gemm(d, p);
+    if (d->colsum_a)
+        ME_CHECK_ARG(pl.family == 2 && pl.split_k > 1 && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes,
+                     "me_gemm: colsum_a needs the split-K wgrad kernel and its workspace (see me_gemm_fuses_colsum)");
     if (pl.family >= 1) {
         auto run = [&](const GemmParams& q) {
             return pl.family >= 2 ? launch_g2b(q, d->op, pl.bm, pl.bn, stream) : launch_g256(q, d->op, pl.bn, stream);
@@ -381,13 +425,17 @@ extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
             GemmParams ps = p;
             ps.C = d->workspace;
             ps.split_k = pl.split_k;
+            const int n_part = pl.split_k * p.tiles_n;
+            if (d->colsum_a)
+                ps.colsum_ws = reinterpret_cast<float*>(d->workspace) + (size_t)pl.split_k * (size_t)d->M * (size_t)d->N;
             rc = run(ps);
             if (rc) return rc;
             const int64_t quads = d->M * (d->N / 4);
             int64_t nb = (quads + 255) / 256;
             if (nb > 2048) nb = 2048;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p,
-                               reinterpret_cast<const float*>(d->workspace), pl.split_k);
+                               reinterpret_cast<const float*>(d->workspace), pl.split_k, ps.colsum_ws, n_part,
+                               d->colsum_a);
             ME_CHECK_LAUNCH("me_gemm(splitk reduce)");
             return ME_OK;
         }

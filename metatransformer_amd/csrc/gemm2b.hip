@@ -135,6 +135,15 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int tm = wgid / p.tiles_n, tn = wgid % p.tiles_n;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
+    if (BM == 128 && (p.debug & (512 | 1024))) {
+        // dev experiment: de-phase the two workgroups that share a CU so that one's epilogue runs under the other's
+        // K-loop (they are dispatched together and otherwise stay in lock-step): first-round workgroups of odd parity
+        // start late by (debug >> 16) x 8128 cycles.  512: parity = slot within the XCD; 1024: parity = slot / 32.
+        const int slot = bid >> 3;
+        const bool odd = (p.debug & 512) ? (slot & 1) : ((slot >> 5) & 1);
+        if (bid < 512 && odd)
+            for (int i = 0; i < (p.debug >> 16); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
     const int nk_total = (int)(p.K / KS2);
@@ -218,8 +227,35 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int ni = 0; ni < G::NI; ++ni) f.wa[kk][ni] = nt_frag2(sb, wc * (BN / 4) + ni * 32 + l31, 2 * kk + h);
         }
     };
+    // wgrad bias gradient: column sums of A (= dY) over this workgroup's reduction range, on the matrix pipe from the
+    // fragments already in registers: D = ones x A-fragment puts sum_k A[k, m] in every row of column m.  The four waves
+    // take one 32-row m-subtile each, and the N-tiles of the same (M-tile, split) -- which all stage the same A rows --
+    // share the steps round-robin, so the extra work is 2/tiles_n MFMAs per wave and step, evenly spread.
+    const bool do_cs = TN && BM == 128 && p.colsum_ws != nullptr;
+    f32x16 cs;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[e] = 0.0f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+    int cs_turn = do_cs ? (tn - ks_begin % p.tiles_n + p.tiles_n) % p.tiles_n : -1;      // steps until my next turn
     const bool prio_mma = (p.debug & 256) != 0;
     auto mma_step = [&](const Frags& f) {
+        if (do_cs) {
+            if (cs_turn == 0) {
+                // wc is wave-uniform: a scalar switch keeps the fragment index static (a runtime index would demote
+                // the fragment array to scratch)
+#define ME_CS_CASE(W)                                                                                          \
+    case W:                                                                                                    \
+        cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, f.xb[0][W], cs, 0, 0, 0);                           \
+        cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, f.xb[1][W], cs, 0, 0, 0);                           \
+        break;
+                switch (wc) { ME_CS_CASE(0) ME_CS_CASE(1) ME_CS_CASE(2) default: ME_CS_CASE(3) }
+#undef ME_CS_CASE
+                cs_turn = p.tiles_n;
+            }
+            --cs_turn;
+        }
         if (prio_mma) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -274,6 +310,10 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         mma_step(f);
     }
 
+    if (do_cs && h == 0) {      // every accumulator row holds the same sums: register 0 of the lower half-wave
+        const int64_t m = m0 + wc * 32 + l31;
+        if (m < p.M) p.colsum_ws[((int64_t)blockIdx.y * p.tiles_n + tn) * p.M + m] = cs[0];
+    }
     // ---- epilogue (same scheme as gemm256.hip): accumulators -> per-wave LDS patch -> row-contiguous 16-byte accesses
     if (p.debug & 1) {                                    // dev: K-loop only
         float keep = 0.f;

@@ -15,6 +15,7 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int debug;                              // dev switches (ME_G256_DEBUG): 1 = skip the epilogue
     int split_k, ksteps_per_split;          // split-K (wgrad): grid.y = split_k, slab z written to C + z*M*ldc
+    float* colsum_ws;                       // TN only: partial column sums of A, [split_k * tiles_n][M] (null = off)
 };
 
 

@@ -163,8 +163,22 @@ class _BlockFn(torch.autograd.Function):
         if g1 is not None or g2 is not None:
             raise MetaEncError("backward through layer-scale (gamma1/gamma2) is not implemented yet")
 
-        def wgrad(dout, inp, w):      # dW[out,in] = dout^T inp, in the parameter's dtype
-            return ops.gemm(dout, inp, op=ME_GEMM_TN, out_dtype=w.dtype)
+        def wgrad(dout, inp, lin, need_w, need_b):
+            """dW[out,in] = dout^T inp in the parameter's dtype, db = column sums of dout (fused into the same kernel).
+            When the parameters live in a parallel.FlatParams the weight gradient is ACCUMULATED in place into its flat
+            view by the GEMM epilogue (beta = 1) and autograd gets None for it -- no separate `grad += dW` pass."""
+            w = lin.weight
+            if not need_w:
+                return None, (ops.colsum(dout).to(w.dtype) if need_b else None)
+            flat = getattr(w, "_me_flat", None)
+            tgt = flat.direct_grad(w) if (flat is not None and w.dtype == torch.float32) else None
+            res = ops.gemm(dout, inp, op=ME_GEMM_TN, out=tgt, out_dtype=w.dtype, beta=1.0 if tgt is not None else 0.0,
+                           want_colsum_a=need_b)
+            dw, db = res if need_b else (res, None)
+            if tgt is not None:
+                flat.grad_written(w)
+                dw = None
+            return dw, (db.to(w.dtype) if db is not None else None)
 
         stoch = ctx.stoch
         if stoch is not None:
@@ -176,23 +190,19 @@ class _BlockFn(torch.autograd.Function):
         dh = ops.gemm(dy_c, cache.transposed("fc2", fc2w, cdt), aux=hpre)            # dA * gelu'(h)
         if stoch is not None and p_drop > 0:
             dh = ops.dropout_add(dh, None, N, p_drop, 0.0, seed + 2)
-        d_fc2w = wgrad(dy_c, a, fc2w) if ng[11] else None
-        d_fc2b = ops.colsum(dy_c).to(fc2w.dtype) if (ng[12] and ctx.has_bias[3]) else None
+        d_fc2w, d_fc2b = wgrad(dy_c, a, blk.mlp.fc2, ng[11], ng[12] and ctx.has_bias[3])
         dxn2 = ops.gemm(dh, cache.transposed("fc1", fc1w, cdt))
-        d_fc1w = wgrad(dh, xn2, fc1w) if ng[9] else None
-        d_fc1b = ops.colsum(dh).to(fc1w.dtype) if (ng[10] and ctx.has_bias[2]) else None
+        d_fc1w, d_fc1b = wgrad(dh, xn2, blk.mlp.fc1, ng[9], ng[10] and ctx.has_bias[2])
         need_aff2 = ng[7] or ng[8]
         dx1, d_n2w, d_n2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w, dy2, rdt, need_aff2)
 
         # ---- attention branch: x1 = x + proj(attn(qkv(LN1(x))))
         dx1_c = ops.cast(dx1 if stoch is None else ops.dropout_add(dx1, None, N, p_drop, p_path, seed + 1), cdt)
         do = ops.gemm(dx1_c, cache.transposed("proj", projw, cdt))
-        d_projw = wgrad(dx1_c, o, projw) if ng[5] else None
-        d_projb = ops.colsum(dx1_c).to(projw.dtype) if (ng[6] and ctx.has_bias[1]) else None
+        d_projw, d_projb = wgrad(dx1_c, o, blk.attn.proj, ng[5], ng[6] and ctx.has_bias[1])
         dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, hd, blk.attn.scale)
         dxn1 = ops.gemm(dqkv, cache.transposed("qkv", qkvw, cdt))
-        d_qkvw = wgrad(dqkv, xn1, qkvw) if ng[3] else None
-        d_qkvb = ops.colsum(dqkv).to(qkvw.dtype) if (ng[4] and ctx.has_bias[0]) else None
+        d_qkvw, d_qkvb = wgrad(dqkv, xn1, blk.attn.qkv, ng[3], ng[4] and ctx.has_bias[0])
         need_aff1 = ng[1] or ng[2]
         dx, d_n1w, d_n1b = ops.layernorm_bwd(dxn1, x2, mean1, rstd1, n1w, dx1, rdt, need_aff1)
 

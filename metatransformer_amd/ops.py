@@ -80,8 +80,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
          out_dtype: Optional[torch.dtype] = None, bias: Optional[torch.Tensor] = None, act: int = _capi.ME_ACT_NONE,
          residual: Optional[torch.Tensor] = None, res_row_mod: int = 0, preact: Optional[torch.Tensor] = None,
          aux: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, alpha: float = 1.0,
-         beta: float = 0.0, out_rows: Optional[int] = None, out_group: Tuple[int, int, int] = (0, 0, 0)) -> torch.Tensor:
-    """NT: out[M,N] = a[M,K] @ b[N,K]^T ;  TN: out[M,N] = a[K,M]^T @ b[K,N]; fused epilogue per include/metaenc.h."""
+         beta: float = 0.0, out_rows: Optional[int] = None, out_group: Tuple[int, int, int] = (0, 0, 0),
+         want_colsum_a: bool = False):
+    """NT: out[M,N] = a[M,K] @ b[N,K]^T ;  TN: out[M,N] = a[K,M]^T @ b[K,N]; fused epilogue per include/metaenc.h.
+    want_colsum_a (TN): also return sum_k a[k, :] (fp32 [M]) -- the bias gradient that goes with a weight gradient --
+    from the same kernel when the library can fuse it, else from me_colsum; the result is then (out, colsum)."""
     lib = _capi.load()
     _req(a, "a"); _req(b, "b")
     if a.dtype != b.dtype:
@@ -124,6 +127,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
         d.residual, d.ldres, d.res_dtype = ptr(residual), residual.stride(-2), dtype_code(residual.dtype)
         d.res_row_mod = res_row_mod
     d.out_group_rows, d.out_group_stride, d.out_row_offset = out_group
+    cs = None
+    if want_colsum_a:
+        if op != _capi.ME_GEMM_TN:
+            raise MetaEncError("gemm: want_colsum_a is defined for ME_GEMM_TN")
+        if lib.me_gemm_fuses_colsum(ctypes.byref(d)):
+            cs = torch.empty(M, dtype=torch.float32, device=a.device); keep.append(cs)
+            d.colsum_a = ptr(cs)
     ws_bytes = lib.me_gemm_workspace_bytes(ctypes.byref(d))
     if ws_bytes:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device); keep.append(ws)
@@ -134,8 +144,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
         check(lib.me_gemm(ctypes.byref(d), stream_ptr()), "me_gemm")
         e1.record()
         GEMM_PROFILE.append((op, d.ab_dtype, M, N, K, e0, e1))
-        return out
-    check(lib.me_gemm(ctypes.byref(d), stream_ptr()), "me_gemm")
+    else:
+        check(lib.me_gemm(ctypes.byref(d), stream_ptr()), "me_gemm")
+    if want_colsum_a:
+        return out, (cs if cs is not None else colsum(a2))
     return out
 
 

@@ -26,7 +26,10 @@ from ._capi import MetaEncError
 class FlatParams:
     """Re-homes parameters (and their gradients) into flat fp32 buffers; `p.data` / `p.grad` become views."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], fused_accumulate: bool = True):
+        """fused_accumulate: let the Block backward accumulate weight gradients straight into the flat buffer (see
+        direct_grad).  Turn it off if you call torch.autograd.grad() on encoder weights (they would come back None)."""
+        self.fused_accumulate = fused_accumulate
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise MetaEncError("FlatParams: no trainable parameters")
@@ -42,10 +45,32 @@ class FlatParams:
         self.numel = off
         self.flat_param = torch.zeros(off, dtype=dt, device=dev)
         self.flat_grad = torch.zeros(off, dtype=dt, device=dev)
-        for p, o in zip(self.params, self.offsets):
+        self._index = {}
+        self._listeners = []        # callables(param_index): a gradient was written straight into the flat buffer
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             self.flat_param[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat_param[o:o + p.numel()].view(p.shape)
             p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+            self._index[id(p)] = i
+            p._me_flat = self       # lets the fused Block backward accumulate weight gradients in place (direct_grad)
+
+    def direct_grad(self, p: torch.nn.Parameter) -> Optional[torch.Tensor]:
+        """The flat-buffer view that IS p.grad, or None if something replaced it.  The Block backward accumulates weight
+        (and bias) gradients into it from the GEMM epilogue (beta = 1) and returns None to autograd for that parameter,
+        which saves autograd's `grad += new` pass over every weight; `grad_written` then stands in for the
+        post-accumulate hook."""
+        i = self._index.get(id(p))
+        if i is None or p.grad is None or not self.fused_accumulate:
+            return None
+        o = self.offsets[i]
+        if p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size() or p.grad.shape != p.shape:
+            return None
+        return p.grad
+
+    def grad_written(self, p: torch.nn.Parameter) -> None:
+        i = self._index[id(p)]
+        for cb in self._listeners:
+            cb(i)
 
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
@@ -106,17 +131,22 @@ class OverlappedGradReducer:
         self._initial = list(self.bucket_left)
         self.handles = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(flat.params)]
+        self._direct = lambda i: self._fire(i)          # gradients the fused backward wrote in place (FlatParams.direct_grad)
+        flat._listeners.append(self._direct)
 
     def _active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
 
+    def _fire(self, idx) -> None:
+        b = self.bucket_of[idx]
+        self.bucket_left[b] -= 1
+        if self.bucket_left[b] == 0 and self._active():
+            self.handles.append(dist.all_reduce(self.bucket_slices[b], op=dist.ReduceOp.SUM, group=self.group,
+                                                async_op=True))
+
     def _make_hook(self, idx):
         def hook(param):
-            b = self.bucket_of[idx]
-            self.bucket_left[b] -= 1
-            if self.bucket_left[b] == 0 and self._active():
-                self.handles.append(dist.all_reduce(self.bucket_slices[b], op=dist.ReduceOp.SUM, group=self.group,
-                                                    async_op=True))
+            self._fire(idx)
         return hook
 
     def finish(self) -> None:
@@ -133,6 +163,8 @@ class OverlappedGradReducer:
     def remove(self) -> None:
         for h in self._hooks:
             h.remove()
+        if self._direct in self.flat._listeners:
+            self.flat._listeners.remove(self._direct)
 
 
 def allreduce_coalesced(tensors: Sequence[torch.Tensor], group=None, bucket_bytes: int = 64 << 20) -> None:

@@ -52,7 +52,7 @@ def test_gemm_desc_layout_matches_c():
 int main(void){ printf("size %zu\n", sizeof(me_gemm_desc));
 P(op);P(ab_dtype);P(M);P(N);P(K);P(A);P(lda);P(B);P(ldb);P(C);P(ldc);P(c_dtype);P(act);P(alpha);P(beta);P(bias);
 P(colscale);P(preact);P(ldpre);P(preact_dtype);P(aux_dtype);P(aux);P(ldaux);P(residual);P(ldres);P(res_dtype);
-P(reserved0);P(res_row_mod);P(out_group_rows);P(out_group_stride);P(out_row_offset);P(workspace);P(workspace_bytes); return 0; }
+P(reserved0);P(res_row_mod);P(out_group_rows);P(out_group_stride);P(out_row_offset);P(workspace);P(workspace_bytes);P(colsum_a); return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")

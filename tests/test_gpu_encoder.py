@@ -95,6 +95,30 @@ def test_backward_full_parity_vs_oracle(dev):
             assert rel_err(p.grad, dp_ref[k]) < t, (k, dt)
 
 
+def test_flat_params_fused_gradient_accumulation(dev):
+    """parallel.FlatParams: weight gradients accumulated in place by the wgrad epilogue == autograd's own accumulation,
+    over two backward passes (gradient accumulation), and the direct-write listeners fire once per weight per pass"""
+    from metatransformer_amd import parallel
+    c = dict(depth=2, dim=256, heads=4, eps=1e-5, seed=7)
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(2, 300, 256, generator=g).to(dev) for _ in range(2)]
+    grads = {}
+    for fused in (False, True):
+        enc = make_encoder(c, dev).train()
+        flat = parallel.FlatParams(enc.parameters(), fused_accumulate=fused)
+        fired = []
+        flat._listeners.append(fired.append)
+        flat.zero_grad()
+        for x in xs:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                enc(x).float().square().mean().backward()
+        grads[fused] = flat.flat_grad.clone()
+        assert len(fired) == (2 * 4 * c["depth"] if fused else 0)
+        for p in enc.parameters():
+            assert flat.direct_grad(p) is not None or not fused       # .grad views were not replaced
+    assert rel_err(grads[True], grads[False]) < 1e-6
+
+
 def test_frozen_encoder_passes_input_grad_only(dev):
     """most reference pipelines freeze the encoder but train the tokenizer in front of it."""
     c = dict(depth=1, dim=128, heads=2, eps=1e-5, seed=6)

@@ -123,6 +123,21 @@ def test_gemm_tn_wgrad(dev, T, M, N, dt):
     assert rel_err(c, ref) < 1e-5
 
 
+@pytest.mark.parametrize("T,M,N", [(256 * 197, 768, 768), (256 * 197, 2304, 768), (8192, 768, 3072), (4096 + 32, 256, 512),
+                                   (640, 128, 256)])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_tn_fused_bias_gradient(dev, T, M, N, dt):
+    """wgrad with the bias gradient (column sums of dY) from the same kernel; falls back to me_colsum when not fusable"""
+    dy = rnd(T, M, seed=5).to(dt)
+    x = rnd(T, N, seed=6).to(dt)
+    dw, db = ops.gemm(dy.to(dev), x.to(dev), op=_capi.ME_GEMM_TN, out_dtype=torch.float32, want_colsum_a=True)
+    assert rel_err(dw, dy.double().t() @ x.double()) < 3e-5      # reduction length up to 50 432
+    ref = dy.double().sum(0)
+    assert (db.double().cpu() - ref).abs().max() / ref.abs().max() < 1e-5
+    dw2, db2 = ops.gemm(dy.to(dev), x.to(dev), op=_capi.ME_GEMM_TN, out_dtype=torch.float32, want_colsum_a=True)
+    assert torch.equal(db, db2) and torch.equal(dw, dw2), "deterministic"
+
+
 def test_gemm_rejects_bad_args(dev):
     a = torch.zeros(4, 12, device=dev, dtype=torch.bfloat16)
     with pytest.raises(_capi.MetaEncError, match="multiples"):

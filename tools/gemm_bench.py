@@ -95,7 +95,10 @@ if __name__ == "__main__":
     rows = []
     for fam in a.families.split(","):           # "family[:variant]"
         env = dict(os.environ)
-        base, _, var = fam.partition(":")
+        base, _, rest = fam.partition(":")
+        var, _, dbg = rest.partition(":")
+        if dbg:
+            env["ME_G256_DEBUG"] = dbg
         if base != "auto":
             env["ME_GEMM_KERNEL"] = base
         else:
