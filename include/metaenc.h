@@ -101,7 +101,8 @@ typedef struct me_gemm_desc {
     void* workspace; int64_t workspace_bytes;               /* optional scratch (split-K slabs), see below */
     float* colsum_a;       /* optional, ME_GEMM_TN only: receives sum_k A[k, m] for m in [0, M) -- the bias gradient
                             * that goes with a weight gradient dW = dY^T X (A = dY), computed on the matrix pipe from
-                            * the operand tiles the kernel stages anyway instead of a second pass over dY.  Only when
+                            * the operand tiles the kernel stages anyway instead of a second pass over dY; accumulated like C
+                            * (colsum_a = beta * colsum_a + sums).  Only when
                             * me_gemm_fuses_colsum(d) != 0; otherwise me_gemm rejects the descriptor (use me_colsum). */
 } me_gemm_desc;
 

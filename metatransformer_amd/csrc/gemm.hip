@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
                     float t = 0.f;
 #pragma unroll
                     for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
-                    colsum_out[m] = t;
+                    colsum_out[m] = p.beta != 0.0f ? t + p.beta * colsum_out[m] : t;      // follows C's beta
                 }
                 __syncthreads();
             }

@@ -172,13 +172,35 @@ class _BlockFn(torch.autograd.Function):
                 return None, (ops.colsum(dout).to(w.dtype) if need_b else None)
             flat = getattr(w, "_me_flat", None)
             tgt = flat.direct_grad(w) if (flat is not None and w.dtype == torch.float32) else None
+            tgt_b = None
+            if tgt is not None and need_b and getattr(lin.bias, "_me_flat", None) is flat and lin.bias.dtype == torch.float32:
+                tgt_b = flat.direct_grad(lin.bias)
+            # the fused column sums share C's beta: usable when both accumulate in place or neither does
+            fuse_b = need_b and (tgt is None or tgt_b is not None)
             res = ops.gemm(dout, inp, op=ME_GEMM_TN, out=tgt, out_dtype=w.dtype, beta=1.0 if tgt is not None else 0.0,
-                           want_colsum_a=need_b)
-            dw, db = res if need_b else (res, None)
+                           want_colsum_a=fuse_b, colsum_out=tgt_b)
+            dw, db = res if fuse_b else (res, ops.colsum(dout) if need_b else None)
             if tgt is not None:
                 flat.grad_written(w)
                 dw = None
+            if tgt_b is not None:
+                flat.grad_written(lin.bias)
+                db = None
             return dw, (db.to(w.dtype) if db is not None else None)
+
+        def ln_bwd(dyn, xin, mean, rstd, norm, dres, need_aff):
+            """LayerNorm backward; affine gradients accumulated in place when the parameters live in a FlatParams"""
+            flat = getattr(norm.weight, "_me_flat", None)
+            acc = None
+            if need_aff and flat is not None and getattr(norm.bias, "_me_flat", None) is flat and norm.weight.dtype == torch.float32:
+                gw, gb = flat.direct_grad(norm.weight), flat.direct_grad(norm.bias)
+                if gw is not None and gb is not None:
+                    acc = (gw, gb)
+            dxo, dg, db = ops.layernorm_bwd(dyn, xin, mean, rstd, norm.weight, dres, rdt, need_aff, affine_accum=acc)
+            if acc is not None:
+                flat.grad_written(norm.weight)
+                flat.grad_written(norm.bias)
+            return dxo, dg, db
 
         stoch = ctx.stoch
         if stoch is not None:
@@ -193,8 +215,7 @@ class _BlockFn(torch.autograd.Function):
         d_fc2w, d_fc2b = wgrad(dy_c, a, blk.mlp.fc2, ng[11], ng[12] and ctx.has_bias[3])
         dxn2 = ops.gemm(dh, cache.transposed("fc1", fc1w, cdt))
         d_fc1w, d_fc1b = wgrad(dh, xn2, blk.mlp.fc1, ng[9], ng[10] and ctx.has_bias[2])
-        need_aff2 = ng[7] or ng[8]
-        dx1, d_n2w, d_n2b = ops.layernorm_bwd(dxn2, x1, mean2, rstd2, n2w, dy2, rdt, need_aff2)
+        dx1, d_n2w, d_n2b = ln_bwd(dxn2, x1, mean2, rstd2, blk.norm2, dy2, ng[7] or ng[8])
 
         # ---- attention branch: x1 = x + proj(attn(qkv(LN1(x))))
         dx1_c = ops.cast(dx1 if stoch is None else ops.dropout_add(dx1, None, N, p_drop, p_path, seed + 1), cdt)
@@ -203,8 +224,7 @@ class _BlockFn(torch.autograd.Function):
         dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, hd, blk.attn.scale)
         dxn1 = ops.gemm(dqkv, cache.transposed("qkv", qkvw, cdt))
         d_qkvw, d_qkvb = wgrad(dqkv, xn1, blk.attn.qkv, ng[3], ng[4] and ctx.has_bias[0])
-        need_aff1 = ng[1] or ng[2]
-        dx, d_n1w, d_n1b = ops.layernorm_bwd(dxn1, x2, mean1, rstd1, n1w, dx1, rdt, need_aff1)
+        dx, d_n1w, d_n1b = ln_bwd(dxn1, x2, mean1, rstd1, blk.norm1, dx1, ng[1] or ng[2])
 
         def aff(g, p):
             return None if g is None else g.to(p.dtype)

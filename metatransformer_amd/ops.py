@@ -55,22 +55,31 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
 
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor,
-                  dres: Optional[torch.Tensor], dx_dtype: torch.dtype, need_affine: bool):
+                  dres: Optional[torch.Tensor], dx_dtype: torch.dtype, need_affine: bool,
+                  affine_accum: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    """affine_accum = (dgamma, dbeta) fp32 [C] buffers to ACCUMULATE the affine gradients into (then returned as None)."""
     lib = _capi.load()
     _req(dy, "dy"); _req(x, "x")
     C = x.shape[-1]
     rows = x.numel() // C
     dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)
     g = _f32(gamma).contiguous()
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if need_affine else None
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if need_affine else None
+    accumulate = 0
+    if need_affine and affine_accum is not None:
+        dgamma, dbeta = affine_accum
+        accumulate = 1
+    else:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if need_affine else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if need_affine else None
     ws = None
     if need_affine:
         ws = torch.empty(lib.me_layernorm_bwd_workspace(C), dtype=torch.uint8, device=x.device)
     check(lib.me_layernorm_bwd(ptr(dy), dtype_code(dy.dtype), ptr(x), dtype_code(x.dtype), ptr(mean), ptr(rstd), ptr(g),
                                ptr(dres), dtype_code(dres.dtype) if dres is not None else 0,
-                               ptr(dx), dtype_code(dx_dtype), ptr(dgamma), ptr(dbeta), 0, rows, C, ptr(ws),
+                               ptr(dx), dtype_code(dx_dtype), ptr(dgamma), ptr(dbeta), accumulate, rows, C, ptr(ws),
                                stream_ptr()), "me_layernorm_bwd")
+    if accumulate:
+        return dx, None, None
     return dx, dgamma, dbeta
 
 
@@ -81,10 +90,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
          residual: Optional[torch.Tensor] = None, res_row_mod: int = 0, preact: Optional[torch.Tensor] = None,
          aux: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, alpha: float = 1.0,
          beta: float = 0.0, out_rows: Optional[int] = None, out_group: Tuple[int, int, int] = (0, 0, 0),
-         want_colsum_a: bool = False):
+         want_colsum_a: bool = False, colsum_out: Optional[torch.Tensor] = None):
     """NT: out[M,N] = a[M,K] @ b[N,K]^T ;  TN: out[M,N] = a[K,M]^T @ b[K,N]; fused epilogue per include/metaenc.h.
     want_colsum_a (TN): also return sum_k a[k, :] (fp32 [M]) -- the bias gradient that goes with a weight gradient --
-    from the same kernel when the library can fuse it, else from me_colsum; the result is then (out, colsum)."""
+    from the same kernel when the library can fuse it, else from me_colsum; the result is then (out, colsum).
+    colsum_out: fp32 [M] buffer for it, accumulated with the same beta as out (only used when the kernel fuses it)."""
     lib = _capi.load()
     _req(a, "a"); _req(b, "b")
     if a.dtype != b.dtype:
@@ -132,8 +142,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
         if op != _capi.ME_GEMM_TN:
             raise MetaEncError("gemm: want_colsum_a is defined for ME_GEMM_TN")
         if lib.me_gemm_fuses_colsum(ctypes.byref(d)):
-            cs = torch.empty(M, dtype=torch.float32, device=a.device); keep.append(cs)
+            cs = colsum_out if colsum_out is not None else torch.empty(M, dtype=torch.float32, device=a.device)
+            keep.append(cs)
             d.colsum_a = ptr(cs)
+
     ws_bytes = lib.me_gemm_workspace_bytes(ctypes.byref(d))
     if ws_bytes:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device); keep.append(ws)
@@ -147,19 +159,22 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
     else:
         check(lib.me_gemm(ctypes.byref(d), stream_ptr()), "me_gemm")
     if want_colsum_a:
-        return out, (cs if cs is not None else colsum(a2))
+        if cs is None:      # not fusable for this problem: separate pass over a
+            cs = colsum(a2, out=colsum_out, accumulate=beta != 0.0)
+        return out, cs
     return out
 
 
-def colsum(x: torch.Tensor) -> torch.Tensor:
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     lib = _capi.load()
     _req(x, "x")
     x2 = x.reshape(-1, x.shape[-1])
     rows, cols = x2.shape
-    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    if out is None:
+        out, accumulate = torch.empty(cols, dtype=torch.float32, device=x.device), False
     ws = torch.empty(lib.me_colsum_workspace(cols), dtype=torch.uint8, device=x.device)
-    check(lib.me_colsum(ptr(x2), dtype_code(x.dtype), x2.stride(0), rows, cols, ptr(out), 0, ptr(ws), stream_ptr()),
-          "me_colsum")
+    check(lib.me_colsum(ptr(x2), dtype_code(x.dtype), x2.stride(0), rows, cols, ptr(out), 1 if accumulate else 0, ptr(ws),
+                        stream_ptr()), "me_colsum")
     return out
 
 
