@@ -279,7 +279,16 @@ struct GemmPlan {
     int split_k;     // >= 1
     int ksteps_per_split;
     size_t ws_bytes;
+    // NT tail split: the last tail_rows rows run as their own split-K problem (see plan_gemm)
+    int64_t tail_rows;
+    int tail_split, tail_ksteps;
 };
+
+bool tail_split_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ME_GEMM_TAILSPLIT"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 
 // ME_GEMM_KERNEL = g128 | g256_256 | g256_128 | g2b_256 | g2b_128   (dev A/B switch)
 void forced_family(int& fam, int& bn) {
@@ -300,7 +309,7 @@ void forced_family(int& fam, int& bn) {
 }
 
 GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
-    GemmPlan pl{0, 0, 128, 0, 1, 0, 0};
+    GemmPlan pl{0, 0, 128, 0, 1, 0, 0, 0, 1, 0};
     int ffam, fbn;
     forced_family(ffam, fbn);
     if (d->ab_dtype != ME_BF16 || ffam == 0) return pl;
@@ -341,6 +350,28 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
             pl.bn = c256 <= c128 ? 256 : 128;
         }
         pl.ksteps_per_split = nk;
+        // Tile quantisation: T tiles on SLOTS co-resident workgroups take ceil(T / SLOTS) rounds; the encoder's N = 768
+        // outputs give 591 tiles = 2.31 rounds -> 3 (23 % idle), N = 3072 gives 9.23 -> 10.  When the last round is
+        // mostly empty, the rows of that round are carved off as a second problem whose reduction is split over the idle
+        // workgroups (fp32 slabs + the deterministic fold that also applies the epilogue): 2 rounds + 1/3 instead of 3.
+        // Measured (tools/gemm_bench.py): +4..5 % on the 256x256 kernel at N = 768 (fc2 forward, fc1 / qkv dgrad); a loss
+        // at N = 3072 (one sparse round in ten is cheap: its workgroups run faster on an emptier chip) and on the
+        // two-workgroup kernel at K = 768 (slices too short) -- hence the fam == 3 / N <= 1024 gate.
+        const int64_t tn_ = (d->N + pl.bn - 1) / pl.bn, tiles = tm * tn_;
+        const int64_t R = tiles / SLOTS, rem = tiles - R * SLOTS;
+        if (fam == 3 && d->N <= 1024 && tail_split_enabled() && R >= 1 && rem * 20 >= SLOTS && rem * 10 <= SLOTS * 6 &&
+            d->res_row_mod == 0 && d->out_group_rows == 0 && d->M % pl.bm == 0) {
+            const int64_t m_main = (R * SLOTS) / tn_;
+            const int64_t tail_tiles = (tm - m_main) * tn_;
+            int s = (int)(SLOTS / tail_tiles);
+            while (s > 1 && nk / s < 8) --s;                     // >= 8 K-steps (256 reduction elements) per slice
+            if (s >= 2 && m_main >= 1) {
+                pl.tail_rows = (tm - m_main) * pl.bm;
+                pl.tail_ksteps = (nk + s - 1) / s;
+                pl.tail_split = (nk + pl.tail_ksteps - 1) / pl.tail_ksteps;
+                pl.ws_bytes = (size_t)pl.tail_split * (size_t)pl.tail_rows * (size_t)d->N * sizeof(float);
+            }
+        }
     }
     return pl;
 }
@@ -441,6 +472,35 @@ extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
         }
         p.split_k = 1;
         p.ksteps_per_split = (int)(d->K / pl.kstep);
+        if (pl.tail_rows > 0 && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes) {
+            const int64_t m1 = d->M - pl.tail_rows;
+            GemmParams pm = p;                       // main part: rows [0, m1), fused epilogue as usual
+            pm.M = m1;
+            pm.tiles_m = (int)(m1 / pl.bm);
+            rc = run(pm);
+            if (rc) return rc;
+            GemmParams pt = p;                       // tail: rows [m1, M) -- every row-indexed operand moves down by m1
+            pt.M = pl.tail_rows;
+            pt.tiles_m = (int)(pl.tail_rows / pl.bm);
+            pt.A = reinterpret_cast<const char*>(p.A) + (size_t)m1 * p.lda * me_dtype_size(d->ab_dtype);
+            pt.C = reinterpret_cast<char*>(p.C) + (size_t)m1 * p.ldc * me_dtype_size(p.c_dtype);
+            if (p.preact) pt.preact = reinterpret_cast<char*>(p.preact) + (size_t)m1 * p.ldpre * me_dtype_size(p.preact_dtype);
+            if (p.aux) pt.aux = reinterpret_cast<const char*>(p.aux) + (size_t)m1 * p.ldaux * me_dtype_size(p.aux_dtype);
+            if (p.residual) pt.residual = reinterpret_cast<const char*>(p.residual) + (size_t)m1 * p.ldres * me_dtype_size(p.res_dtype);
+            GemmParams ps = pt;                      // the split launch writes slabs [S][tail_rows][N]
+            ps.C = d->workspace;
+            ps.split_k = pl.tail_split;
+            ps.ksteps_per_split = pl.tail_ksteps;
+            rc = run(ps);
+            if (rc) return rc;
+            const int64_t quads = pt.M * (d->N / 4);
+            int64_t nb = (quads + 255) / 256;
+            if (nb > 2048) nb = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, pt,
+                               reinterpret_cast<const float*>(d->workspace), pl.tail_split, nullptr, 0, nullptr);
+            ME_CHECK_LAUNCH("me_gemm(tail fold)");
+            return ME_OK;
+        }
         return run(p);
     }
     if (d->ab_dtype == ME_BF16)
