@@ -119,6 +119,10 @@ int me_gemm(const me_gemm_desc* d, void* stream);
 size_t me_colsum_workspace(int64_t cols);
 int me_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, int64_t cols,
               float* out, int accumulate, void* workspace, void* stream);
+/* out[c] = sum_r x[r,c] * y[r,c] -- gradient of a per-channel scale: d gamma1/gamma2 of the layer-scale Block variant
+ * (Image/detection/mmdet_custom/models/backbones/base/vit.py:313-316) = colsum(dy * branch_output).  Same workspace. */
+int me_colsum_mul(const void* x, int x_dtype, int64_t ldx, const void* y, int y_dtype, int64_t ldy,
+                  int64_t rows, int64_t cols, float* out, int accumulate, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------ Multi-head self-attention core
  * Replaces attention.py:28-35: the reshape/permute of qkv into heads, (q @ k^T) * scale, softmax(-1),
@@ -153,10 +157,11 @@ int me_add_rows(const void* x, int x_dtype, const void* pos, int pos_dtype, void
  * (PointCloud/openpoints/models/layers/attention.py:37, mlp.py:32,35); path = Bernoulli(1-p_path)/(1-p_path) per SAMPLE --
  * DropPath (PointCloud/openpoints/models/layers/drop.py:135-152).  The masks are a counter-based hash of (seed, index):
  * calling again with the same seed on the incoming gradient (res = NULL) is the backward.  The RNG stream differs
- * from torch's; distribution and scaling are the reference's. */
+ * from torch's; distribution and scaling are the reference's.  colscale ([cols] fp32 or NULL) multiplies the masked value
+ * per channel (layer-scale gamma applied outside the GEMM when its un-scaled branch output must be kept for d gamma). */
 int me_dropout_add(const void* v, int v_dtype, const void* res, int res_dtype, void* out, int out_dtype,
                    int64_t rows, int cols, int64_t rows_per_sample, float p_drop, float p_path, uint64_t seed,
-                   void* stream);
+                   const float* colscale, void* stream);
 
 /* ------------------------------------------------------------------ Data2Seq tokenizers
  * Patch gather ("im2col") for the convolutional patch-embeds; the projection itself is me_gemm (NT) on

@@ -68,6 +68,8 @@ SIGNATURES = {
     "me_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
     "me_colsum_workspace": (c_size_t, [c_int64]),
     "me_colsum": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    "me_colsum_mul": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int,
+                              c_void_p, c_void_p]),
     "me_attention_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int,
                                  c_float, c_int, c_void_p]),
     "me_attention_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
@@ -76,7 +78,7 @@ SIGNATURES = {
     "me_transpose_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "me_add_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "me_dropout_add": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_float, c_float,
-                               ctypes.c_uint64, c_void_p]),
+                               ctypes.c_uint64, c_void_p, c_void_p]),
     "me_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 11 + [c_void_p]),
     "me_unpatchify_add": (c_int, [c_void_p, c_int, c_void_p] + [c_int] * 11 + [c_void_p]),
     "me_timeseries_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_void_p), POINTER(c_int32),

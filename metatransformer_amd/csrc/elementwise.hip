@@ -123,6 +123,25 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     out[c] = accumulate ? out[c] + a : a;
 }
 
+// out[c] = sum_r x[r,c] * y[r,c]  (layer-scale gradients: d gamma = colsum(dy * branch)); same split / fold as colsum
+__global__ __launch_bounds__(256) void colsum_mul_partial_kernel(const void* __restrict__ x, int xdt, int64_t ldx,
+                                                                 const void* __restrict__ y, int ydt, int64_t ldy,
+                                                                 int64_t rows, int64_t cols, float* __restrict__ partial) {
+    __shared__ f32x4 sh[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    const int64_t rows_per = (rows + CS_SPLITS - 1) / CS_SPLITS;
+    const int64_t rb = (int64_t)blockIdx.y * rows_per;
+    const int64_t re = rb + rows_per < rows ? rb + rows_per : rows;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols)
+        for (int64_t r = rb + w; r < re; r += 4) a += load4_as_f32(x, xdt, r * ldx + c) * load4_as_f32(y, ydt, r * ldy + c);
+    sh[w][lane] = a;
+    __syncthreads();
+    if (w == 0 && c < cols)
+        *reinterpret_cast<f32x4*>(partial + (int64_t)blockIdx.y * cols + c) = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+
 // ---- patch gather: cols[(b, pt, py, px), (c, dt, dy, dx)] = x[b, c, pt*st+dt, py*sh+dy, px*sw+dx]
 struct PatchGeom {
     int B, Cin, T, H, W, kt, kh, kw, st, sh, sw, gt, gh, gw;
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(EW_THREADS) void dropout_add_kernel(const void* __r
                                                                  const void* __restrict__ res, int rdt,
                                                                  void* __restrict__ out, int odt, int64_t rows, int cols,
                                                                  int64_t rows_per_sample, float p_drop, float p_path,
-                                                                 uint64_t seed) {
+                                                                 uint64_t seed, const float* __restrict__ colscale) {
     const int c4 = cols / 4;
     const int64_t total = rows * c4;
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
@@ -257,6 +276,7 @@ __global__ __launch_bounds__(EW_THREADS) void dropout_add_kernel(const void* __r
             if (p_drop > 0.f) k = u01_hash(seed, (uint64_t)(r * cols + c + e)) >= p_drop ? k * inv_keep : 0.0f;
             x[e] *= k;
         }
+        if (colscale) x *= *reinterpret_cast<const f32x4*>(colscale + c);
         if (res) x += load4_as_f32(res, rdt, r * cols + c);
         store4_from_f32(out, odt, r * cols + c, x);
     }
@@ -338,6 +358,22 @@ extern "C" int me_colsum(const void* x, int x_dtype, int64_t ldx, int64_t rows, 
     return ME_OK;
 }
 
+extern "C" int me_colsum_mul(const void* x, int x_dtype, int64_t ldx, const void* y, int y_dtype, int64_t ldy, int64_t rows,
+                             int64_t cols, float* out, int accumulate, void* workspace, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(x && y && out && workspace && rows > 0 && cols > 0, "me_colsum_mul: bad args");
+    ME_CHECK_ARG(me_dtype_ok(x_dtype) && me_dtype_ok(y_dtype), "me_colsum_mul: bad dtype");
+    ME_CHECK_ARG(cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "me_colsum_mul: cols and row strides must be multiples of 4");
+    float* partial = reinterpret_cast<float*>(workspace);
+    dim3 grid((unsigned)((cols + 255) / 256), CS_SPLITS);
+    hipLaunchKernelGGL(colsum_mul_partial_kernel, grid, dim3(256), 0, stream, x, x_dtype, ldx, y, y_dtype, ldy, rows, cols, partial);
+    ME_CHECK_LAUNCH("me_colsum_mul(partial)");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, partial, cols, out,
+                       accumulate);
+    ME_CHECK_LAUNCH("me_colsum_mul(final)");
+    return ME_OK;
+}
+
 static int make_geom(PatchGeom& g, int B, int Cin, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw) {
     ME_CHECK_ARG(B > 0 && Cin > 0 && T > 0 && H > 0 && W > 0 && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
                  "patchify: bad geometry");
@@ -410,14 +446,14 @@ extern "C" int me_adamw_step(float* param, const float* grad, float* exp_avg, fl
 }
 
 extern "C" int me_dropout_add(const void* v, int v_dtype, const void* res, int res_dtype, void* out, int out_dtype,
-                              int64_t rows, int cols, int64_t rows_per_sample, float p_drop, float p_path, uint64_t seed,
+                              int64_t rows, int cols, int64_t rows_per_sample, float p_drop, float p_path, uint64_t seed, const float* colscale,
                               void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ME_CHECK_ARG(v && out && rows > 0 && cols > 0 && cols % 4 == 0 && rows_per_sample > 0, "me_dropout_add: bad args");
     ME_CHECK_ARG(me_dtype_ok(v_dtype) && me_dtype_ok(out_dtype) && (!res || me_dtype_ok(res_dtype)), "me_dropout_add: bad dtype");
     ME_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && p_path >= 0.f && p_path < 1.f, "me_dropout_add: probabilities must be in [0, 1)");
     hipLaunchKernelGGL(dropout_add_kernel, dim3(ew_blocks(rows * (cols / 4))), dim3(EW_THREADS), 0, stream, v, v_dtype, res,
-                       res_dtype, out, out_dtype, rows, cols, rows_per_sample, p_drop, p_path, seed);
+                       res_dtype, out, out_dtype, rows, cols, rows_per_sample, p_drop, p_path, seed, colscale);
     ME_CHECK_LAUNCH("me_dropout_add");
     return ME_OK;
 }

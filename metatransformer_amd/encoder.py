@@ -123,26 +123,32 @@ class _BlockFn(torch.autograd.Function):
         xn1, mean1, rstd1 = ops.layernorm_fwd(x2, n1w, n1b, blk.eps, cdt, save_stats=need_grad)
         qkv = ops.gemm(xn1, cache.fwd("qkv", qkvw, cdt), bias=qkvb)
         o, lse = ops.attention_fwd(qkv, B, N, H, hd, blk.attn.scale, need_lse=need_grad)
-        if stoch is None:
+        # layer-scale with gradients: d gamma = colsum(dy * UNSCALED branch output), so the branch output is kept and
+        # gamma is applied by the residual kernel instead of the GEMM epilogue
+        ls_grad = need_grad and g1 is not None
+        p_drop, p_path, seed = stoch if stoch is not None else (0.0, 0.0, 0)
+        t1 = t2 = None
+        if stoch is None and not ls_grad:
             x1 = ops.gemm(o, cache.fwd("proj", projw, cdt), bias=projb, residual=x2, out_dtype=rdt, colscale=g1)
-        else:                 # training-mode proj_drop / drop_path: x1 = x + drop_path(dropout(proj(o)))
-            p_drop, p_path, seed = stoch
-            t1 = ops.gemm(o, cache.fwd("proj", projw, cdt), bias=projb, out_dtype=rdt, colscale=g1)
-            x1 = ops.dropout_add(t1, x2, N, p_drop, p_path, seed + 1)
+        else:                 # training-mode proj_drop / drop_path: x1 = x + drop_path(gamma1 * dropout(proj(o)))
+            t1 = ops.gemm(o, cache.fwd("proj", projw, cdt), bias=projb, out_dtype=rdt, colscale=None if ls_grad else g1)
+            x1 = ops.dropout_add(t1, x2, N, p_drop, p_path, seed + 1, colscale=g1 if ls_grad else None)
         xn2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, blk.eps, cdt, save_stats=need_grad)
         hpre = torch.empty((M, fc1w.shape[0]), dtype=cdt, device=x.device) if need_grad else None
         a = ops.gemm(xn2, cache.fwd("fc1", fc1w, cdt), bias=fc1b, act=ME_ACT_GELU, preact=hpre)
-        if stoch is None:
+        if stoch is None and not ls_grad:
             y = ops.gemm(a, cache.fwd("fc2", fc2w, cdt), bias=fc2b, residual=x1, out_dtype=rdt, colscale=g2)
         else:                 # Mlp: fc1 -> act -> drop -> fc2 -> drop (mlp.py:29-35), then drop_path + residual
             if p_drop > 0:
                 a = ops.dropout_add(a, None, N, p_drop, 0.0, seed + 2)
-            t2 = ops.gemm(a, cache.fwd("fc2", fc2w, cdt), bias=fc2b, out_dtype=rdt, colscale=g2)
-            y = ops.dropout_add(t2, x1, N, p_drop, p_path, seed + 3)
+            t2 = ops.gemm(a, cache.fwd("fc2", fc2w, cdt), bias=fc2b, out_dtype=rdt, colscale=None if ls_grad else g2)
+            y = ops.dropout_add(t2, x1, N, p_drop, p_path, seed + 3, colscale=g2 if ls_grad else None)
+        if not ls_grad:
+            t1 = t2 = None
 
         if need_grad:
             ctx.save_for_backward(x2, mean1, rstd1, xn1, qkv, lse, o, x1, mean2, rstd2, xn2, hpre, a,
-                                  n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2)
+                                  n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2, t1, t2)
             ctx.blk, ctx.cdt, ctx.dims, ctx.stoch = blk, cdt, (B, N, C, H, hd), stoch
             ctx.has_bias = (qkvb is not None, projb is not None, fc1b is not None, fc2b is not None)
         return y.reshape(B, N, C)
@@ -150,7 +156,7 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x2, mean1, rstd1, xn1, qkv, lse, o, x1, mean2, rstd2, xn2, hpre, a,
-         n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2) = ctx.saved_tensors
+         n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2, t1, t2) = ctx.saved_tensors
         blk, cdt = ctx.blk, ctx.cdt
         B, N, C, H, hd = ctx.dims
         M = B * N
@@ -160,8 +166,6 @@ class _BlockFn(torch.autograd.Function):
         dy2 = dy.contiguous().reshape(M, C)
         if dy2.dtype != rdt:
             dy2 = ops.cast(dy2, rdt)
-        if g1 is not None or g2 is not None:
-            raise MetaEncError("backward through layer-scale (gamma1/gamma2) is not implemented yet")
 
         def wgrad(dout, inp, lin, need_w, need_b):
             """dW[out,in] = dout^T inp in the parameter's dtype, db = column sums of dout (fused into the same kernel).
@@ -203,12 +207,19 @@ class _BlockFn(torch.autograd.Function):
             return dxo, dg, db
 
         stoch = ctx.stoch
-        if stoch is not None:
-            p_drop, p_path, seed = stoch
+        p_drop, p_path, seed = stoch if stoch is not None else (0.0, 0.0, 0)
 
-        # ---- MLP branch: y = x1 + fc2(gelu(fc1(LN2(x1))))
-        # (stochastic training: the branch gradient is the incoming one times the SAME masks, regenerated from the seed)
-        dy_c = ops.cast(dy2 if stoch is None else ops.dropout_add(dy2, None, N, p_drop, p_path, seed + 3), cdt)
+        def branch_grad(dout, t, g, sd):
+            """gradient entering a residual branch y = x + drop_path(gamma * dropout(t)): (d t in compute dtype, d gamma).
+            Stochastic training: the SAME masks, regenerated from the seed; layer-scale: d gamma = colsum(masked dy * t)."""
+            dm = dout if stoch is None else ops.dropout_add(dout, None, N, p_drop, p_path, sd)
+            if g is None:
+                return ops.cast(dm, cdt), None
+            dg = ops.colsum_mul(dm, t)
+            return ops.dropout_add(dm, None, N, 0.0, 0.0, 0, out_dtype=cdt, colscale=g), dg
+
+        # ---- MLP branch: y = x1 + gamma2 * fc2(gelu(fc1(LN2(x1))))
+        dy_c, d_g2 = branch_grad(dy2, t2, g2, seed + 3)
         dh = ops.gemm(dy_c, cache.transposed("fc2", fc2w, cdt), aux=hpre)            # dA * gelu'(h)
         if stoch is not None and p_drop > 0:
             dh = ops.dropout_add(dh, None, N, p_drop, 0.0, seed + 2)
@@ -218,7 +229,7 @@ class _BlockFn(torch.autograd.Function):
         dx1, d_n2w, d_n2b = ln_bwd(dxn2, x1, mean2, rstd2, blk.norm2, dy2, ng[7] or ng[8])
 
         # ---- attention branch: x1 = x + proj(attn(qkv(LN1(x))))
-        dx1_c = ops.cast(dx1 if stoch is None else ops.dropout_add(dx1, None, N, p_drop, p_path, seed + 1), cdt)
+        dx1_c, d_g1 = branch_grad(dx1, t1, g1, seed + 1)
         do = ops.gemm(dx1_c, cache.transposed("proj", projw, cdt))
         d_projw, d_projb = wgrad(dx1_c, o, blk.attn.proj, ng[5], ng[6] and ctx.has_bias[1])
         dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, hd, blk.attn.scale)
@@ -233,7 +244,9 @@ class _BlockFn(torch.autograd.Function):
                 aff(d_n1w, n1w) if ng[1] else None, aff(d_n1b, n1w) if ng[2] else None,
                 d_qkvw, d_qkvb, d_projw, d_projb,
                 aff(d_n2w, n2w) if ng[7] else None, aff(d_n2b, n2w) if ng[8] else None,
-                d_fc1w, d_fc1b, d_fc2w, d_fc2b, None, None, None, None, None, None)
+                d_fc1w, d_fc1b, d_fc2w, d_fc2b,
+                d_g1.to(g1.dtype) if (d_g1 is not None and ng[13]) else None,
+                d_g2.to(g2.dtype) if (d_g2 is not None and ng[14]) else None, None, None, None, None)
 
 
 class Block(nn.Module):

@@ -240,16 +240,33 @@ def add_rows(x: torch.Tensor, pos: torch.Tensor, out_dtype: Optional[torch.dtype
 
 
 def dropout_add(v: torch.Tensor, res: Optional[torch.Tensor], rows_per_sample: int, p_drop: float, p_path: float,
-                seed: int, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """res + drop_path(dropout(v)); with res=None and v = incoming gradient this is the backward (same seed)."""
+                seed: int, out_dtype: Optional[torch.dtype] = None, colscale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """res + colscale * drop_path(dropout(v)); with res=None and v = incoming gradient this is the backward (same seed).
+    p_drop = p_path = 0 makes it the plain fused `res + colscale * v`."""
     lib = _capi.load()
     _req(v, "v")
     C = v.shape[-1]
     rows = v.numel() // C
     out = torch.empty(v.shape, dtype=out_dtype or (res.dtype if res is not None else v.dtype), device=v.device)
+    cs = _f32(colscale).contiguous() if colscale is not None else None
     check(lib.me_dropout_add(ptr(v), dtype_code(v.dtype), ptr(res), dtype_code(res.dtype) if res is not None else 0,
                              ptr(out), dtype_code(out.dtype), rows, C, rows_per_sample, float(p_drop), float(p_path),
-                             seed & 0xFFFFFFFFFFFFFFFF, stream_ptr()), "me_dropout_add")
+                             seed & 0xFFFFFFFFFFFFFFFF, ptr(cs), stream_ptr()), "me_dropout_add")
+    return out
+
+
+def colsum_mul(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """out[c] = sum_r x[r,c] * y[r,c]  (fp32)"""
+    lib = _capi.load()
+    _req(x, "x"); _req(y, "y")
+    x2, y2 = x.reshape(-1, x.shape[-1]), y.reshape(-1, y.shape[-1])
+    if x2.shape != y2.shape:
+        raise MetaEncError(f"colsum_mul: shapes differ ({tuple(x2.shape)} vs {tuple(y2.shape)})")
+    rows, cols = x2.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.me_colsum_workspace(cols), dtype=torch.uint8, device=x.device)
+    check(lib.me_colsum_mul(ptr(x2), dtype_code(x.dtype), x2.stride(0), ptr(y2), dtype_code(y.dtype), y2.stride(0), rows, cols,
+                            ptr(out), 0, ptr(ws), stream_ptr()), "me_colsum_mul")
     return out
 
 

@@ -222,6 +222,29 @@ def test_layer_scale_variant(dev):
         assert rel_err(blk(x), ref) < TOL_F32
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_F32), (torch.bfloat16, 5e-2)])
+def test_layer_scale_backward_vs_oracle(dev, dt, tol):
+    """gamma1/gamma2 of the Image pipelines (vit.py:313-316): every gradient incl. d gamma against autograd through the
+    oracle's restatement"""
+    torch.manual_seed(11)
+    blk = M.Block(256, 4, qkv_bias=True, layer_scale=True).to(dev).train()
+    with torch.no_grad():
+        blk.gamma1.uniform_(0.2, 1.5); blk.gamma2.uniform_(0.2, 1.5)
+    x = torch.randn(2, 70, 256)
+    go = torch.randn(2, 70, 256)
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xr = x.double().requires_grad_(True)
+    y_ref = bo.block_forward(xr, sd, 4, gamma1=sd["gamma1"], gamma2=sd["gamma2"])
+    (y_ref * go.double()).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+        y = blk(xd)
+    (y * go.to(dev)).sum().backward()
+    assert rel_err(y, y_ref) < tol and rel_err(xd.grad, xr.grad) < tol
+    for k, p in blk.named_parameters():
+        assert rel_err(p.grad, sd[k].grad) < tol, k
+
+
 # ----------------------------------------------------------------------------- BASELINE-size properties
 
 def test_base_config2_shape_properties(dev):
