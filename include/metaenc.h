@@ -151,6 +151,16 @@ int me_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
 int me_add_rows(const void* x, int x_dtype, const void* pos, int pos_dtype, void* y, int y_dtype,
                 int64_t rows, int64_t pos_rows, int cols, void* stream);
 
+/* Window partition (merge = 0) / merge (merge = 1) of token rows for windowed attention
+ * (Image/detection/mmdet_custom/models/backbones/base/vit.py:160-190: qkv is zero-padded to multiples of the window AFTER
+ * the Linear, unfolded into ws x ws windows, attended per window, folded back and cropped).
+ *   partition: src [B*H*W, cols] -> dst [B*gh*gw*ws*ws, cols], gh = ceil(H/ws), gw = ceil(W/ws); window (wy, wx) row-major,
+ *              inside a window (iy, ix) row-major; positions outside the H x W grid are zero rows
+ *   merge:     src [B*gh*gw*ws*ws, cols] -> dst [B*H*W, cols]  (padded rows dropped)
+ * Same dtype both sides, row size a multiple of 16 bytes.  Integer index arithmetic only: bit-exact. */
+int me_window_rows(const void* src, void* dst, int dtype, int B, int H, int W, int window, int cols, int merge,
+                   void* stream);
+
 /* Stochastic ops of the Block in training mode (identity in eval / p = 0, where they are never called):
  *   out[m,c] = (res ? res[m,c] : 0) + path(m / rows_per_sample) * keep(m,c) * v[m,c]
  * keep = Bernoulli(1-p_drop)/(1-p_drop) per element -- nn.Dropout of Attention.proj_drop / Mlp.drop

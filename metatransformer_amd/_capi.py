@@ -77,6 +77,7 @@ SIGNATURES = {
     "me_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "me_transpose_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "me_add_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "me_window_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "me_dropout_add": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_float, c_float,
                                ctypes.c_uint64, c_void_p, c_void_p]),
     "me_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 11 + [c_void_p]),

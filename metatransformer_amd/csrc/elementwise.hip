@@ -142,6 +142,36 @@ __global__ __launch_bounds__(256) void colsum_mul_partial_kernel(const void* __r
         *reinterpret_cast<f32x4*>(partial + (int64_t)blockIdx.y * cols + c) = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
 
+
+// ---- window partition / merge of token rows (windowed attention, Image/detection/.../base/vit.py:160-190).
+// Tokens of one image are rows (y, x) of an H x W grid; windows of ws x ws tile the grid padded up to multiples of ws.
+// partition: win[(b, wy, wx), (iy, ix)] = tok[b, wy*ws + iy, wx*ws + ix]  or 0 outside the grid (the reference zero-pads
+// q, k, v AFTER the qkv Linear, so padded keys take part in the softmax with score 0 and value 0); merge is the inverse
+// gather (padded rows are dropped).  Same-dtype 16-byte row-chunk copies; pure integer index arithmetic (bit-exact).
+__global__ __launch_bounds__(EW_THREADS) void window_rows_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int B,
+                                                                 int H, int W, int ws, int chunks, int merge) {
+    const int gh = (H + ws - 1) / ws, gw = (W + ws - 1) / ws;
+    const int64_t win_rows = (int64_t)B * gh * gw * ws * ws, tok_rows = (int64_t)B * H * W;
+    const int64_t total = (merge ? tok_rows : win_rows) * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i % chunks);
+        if (merge) {
+            const int x = (int)(r % W), y = (int)((r / W) % H);
+            const int64_t b = r / ((int64_t)W * H);
+            const int64_t wr = (((b * gh + y / ws) * gw + x / ws) * ws + y % ws) * ws + x % ws;
+            dst[i] = src[wr * chunks + c];
+        } else {
+            const int ix = (int)(r % ws), iy = (int)((r / ws) % ws);
+            const int64_t w = r / ((int64_t)ws * ws);
+            const int wx = (int)(w % gw), wy = (int)((w / gw) % gh);
+            const int64_t b = w / ((int64_t)gw * gh);
+            const int y = wy * ws + iy, x = wx * ws + ix;
+            dst[i] = (y < H && x < W) ? src[((b * H + y) * W + x) * chunks + c] : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+}
+
 // ---- patch gather: cols[(b, pt, py, px), (c, dt, dy, dx)] = x[b, c, pt*st+dt, py*sh+dy, px*sw+dx]
 struct PatchGeom {
     int B, Cin, T, H, W, kt, kh, kw, st, sh, sw, gt, gh, gw;
@@ -330,6 +360,23 @@ extern "C" int me_add_rows(const void* x, int x_dtype, const void* pos, int pos_
     hipLaunchKernelGGL(add_rows_kernel, dim3(ew_blocks(rows * (cols / 4))), dim3(EW_THREADS), 0, stream, x, x_dtype, pos,
                        pos_dtype, y, y_dtype, rows, pos_rows, cols);
     ME_CHECK_LAUNCH("me_add_rows");
+    return ME_OK;
+}
+
+extern "C" int me_window_rows(const void* src, void* dst, int dtype, int B, int H, int W, int window, int cols, int merge,
+                              void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(src && dst && B > 0 && H > 0 && W > 0 && window > 0 && cols > 0, "me_window_rows: bad args");
+    ME_CHECK_ARG(me_dtype_ok(dtype), "me_window_rows: bad dtype");
+    const int64_t row_bytes = (int64_t)cols * (int64_t)me_dtype_size(dtype);
+    ME_CHECK_ARG(row_bytes % 16 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0,
+                 "me_window_rows: rows must be multiples of 16 bytes, 16-byte aligned");
+    const int chunks = (int)(row_bytes / 16);
+    const int gh = (H + window - 1) / window, gw = (W + window - 1) / window;
+    const int64_t rows = merge ? (int64_t)B * H * W : (int64_t)B * gh * gw * window * window;
+    hipLaunchKernelGGL(window_rows_kernel, dim3(ew_blocks(rows * chunks)), dim3(EW_THREADS), 0, stream,
+                       reinterpret_cast<const u32x4*>(src), reinterpret_cast<u32x4*>(dst), B, H, W, window, chunks, merge);
+    ME_CHECK_LAUNCH("me_window_rows");
     return ME_OK;
 }
 

@@ -108,7 +108,8 @@ class _BlockFn(torch.autograd.Function):
     """forward + backward of one Block on the HIP kernels.  Restates Block.forward (attention.py:55-58)."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g1, g2, blk, cdt, stoch, grad_mode):
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g1, g2, blk, cdt, stoch, grad_mode,
+                win=None):
         B, N, C = x.shape
         H = blk.attn.num_heads
         hd = C // H
@@ -122,7 +123,17 @@ class _BlockFn(torch.autograd.Function):
 
         xn1, mean1, rstd1 = ops.layernorm_fwd(x2, n1w, n1b, blk.eps, cdt, save_stats=need_grad)
         qkv = ops.gemm(xn1, cache.fwd("qkv", qkvw, cdt), bias=qkvb)
-        o, lse = ops.attention_fwd(qkv, B, N, H, hd, blk.attn.scale, need_lse=need_grad)
+        if win is None:
+            o, lse = ops.attention_fwd(qkv, B, N, H, hd, blk.attn.scale, need_lse=need_grad)
+            o_att = o
+        else:
+            # windowed attention (Image/detection/.../base/vit.py:160-190): qkv rows regrouped into ws x ws windows
+            # (zero rows where the padded grid exceeds the image), plain attention per window, rows gathered back
+            gh_, gw_, ws = win
+            nwin = -(-gh_ // ws) * -(-gw_ // ws)
+            qkv = ops.window_rows(qkv, B, gh_, gw_, ws, merge=False)
+            o_att, lse = ops.attention_fwd(qkv, B * nwin, ws * ws, H, hd, blk.attn.scale, need_lse=need_grad)
+            o = ops.window_rows(o_att, B, gh_, gw_, ws, merge=True)
         # layer-scale with gradients: d gamma = colsum(dy * UNSCALED branch output), so the branch output is kept and
         # gamma is applied by the residual kernel instead of the GEMM epilogue
         ls_grad = need_grad and g1 is not None
@@ -148,15 +159,15 @@ class _BlockFn(torch.autograd.Function):
 
         if need_grad:
             ctx.save_for_backward(x2, mean1, rstd1, xn1, qkv, lse, o, x1, mean2, rstd2, xn2, hpre, a,
-                                  n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2, t1, t2)
-            ctx.blk, ctx.cdt, ctx.dims, ctx.stoch = blk, cdt, (B, N, C, H, hd), stoch
+                                  n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2, t1, t2, o_att if win is not None else None)
+            ctx.blk, ctx.cdt, ctx.dims, ctx.stoch, ctx.win = blk, cdt, (B, N, C, H, hd), stoch, win
             ctx.has_bias = (qkvb is not None, projb is not None, fc1b is not None, fc2b is not None)
         return y.reshape(B, N, C)
 
     @staticmethod
     def backward(ctx, dy):
         (x2, mean1, rstd1, xn1, qkv, lse, o, x1, mean2, rstd2, xn2, hpre, a,
-         n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2, t1, t2) = ctx.saved_tensors
+         n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2, t1, t2, o_att) = ctx.saved_tensors
         blk, cdt = ctx.blk, ctx.cdt
         B, N, C, H, hd = ctx.dims
         M = B * N
@@ -232,7 +243,14 @@ class _BlockFn(torch.autograd.Function):
         dx1_c, d_g1 = branch_grad(dx1, t1, g1, seed + 1)
         do = ops.gemm(dx1_c, cache.transposed("proj", projw, cdt))
         d_projw, d_projb = wgrad(dx1_c, o, blk.attn.proj, ng[5], ng[6] and ctx.has_bias[1])
-        dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, hd, blk.attn.scale)
+        if ctx.win is None:
+            dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, hd, blk.attn.scale)
+        else:                 # the same regrouping on the gradient; padded rows are constants (no gradient leaves them)
+            gh_, gw_, ws = ctx.win
+            nwin = -(-gh_ // ws) * -(-gw_ // ws)
+            do_w = ops.window_rows(do, B, gh_, gw_, ws, merge=False)
+            dqkv_w = ops.attention_bwd(qkv, o_att, do_w, lse, B * nwin, ws * ws, H, hd, blk.attn.scale)
+            dqkv = ops.window_rows(dqkv_w, B, gh_, gw_, ws, merge=True)
         dxn1 = ops.gemm(dqkv, cache.transposed("qkv", qkvw, cdt))
         d_qkvw, d_qkvb = wgrad(dqkv, xn1, blk.attn.qkv, ng[3], ng[4] and ctx.has_bias[0])
         dx, d_n1w, d_n1b = ln_bwd(dxn1, x2, mean1, rstd1, blk.norm1, dx1, ng[1] or ng[2])
@@ -246,19 +264,23 @@ class _BlockFn(torch.autograd.Function):
                 aff(d_n2w, n2w) if ng[7] else None, aff(d_n2b, n2w) if ng[8] else None,
                 d_fc1w, d_fc1b, d_fc2w, d_fc2b,
                 d_g1.to(g1.dtype) if (d_g1 is not None and ng[13]) else None,
-                d_g2.to(g2.dtype) if (d_g2 is not None and ng[14]) else None, None, None, None, None)
+                d_g2.to(g2.dtype) if (d_g2 is not None and ng[14]) else None, None, None, None, None, None)
 
 
 class Block(nn.Module):
     """timm.models.vision_transformer.Block, served by HIP kernels.
 
     Signature follows timm 0.4.12 (the version the reference pins); ``layer_scale`` adds the per-channel
-    gamma1/gamma2 of the Image pipelines (Image/detection/mmdet_custom/models/backbones/base/vit.py:298-320).
+    gamma1/gamma2 of the Image pipelines (Image/detection/mmdet_custom/models/backbones/base/vit.py:298-320);
+    ``windowed`` / ``window_size`` select that file's WindowedAttention (:148-192), whose forward takes the token grid:
+    ``blk(x, H, W)`` (the detection backbone calls every block that way, :312-329; H, W are ignored by global blocks).
     """
 
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
-                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, layer_scale=False):
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, layer_scale=False, windowed=False,
+                 window_size=14):
         super().__init__()
+        self.windowed, self.window_size = bool(windowed), int(window_size)
         self.eps = _resolve_eps(norm_layer)
         self.norm1 = nn.LayerNorm(dim, eps=self.eps)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
@@ -284,7 +306,13 @@ class Block(nn.Module):
             return dt
         return self.attn.qkv.weight.dtype
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, H: Optional[int] = None, W: Optional[int] = None) -> torch.Tensor:
+        win = None
+        if self.windowed:
+            if H is None or W is None or H * W != x.shape[1]:
+                raise MetaEncError(f"windowed Block needs the token grid: blk(x, H, W) with H*W == N (got H={H}, W={W}, "
+                                   f"N={x.shape[1] if x.dim() == 3 else '?'})")
+            win = (int(H), int(W), self.window_size)
         if x.dim() != 3:
             raise MetaEncError(f"Block expects [B, N, C] tokens, got shape {tuple(x.shape)}")
         if not x.is_cuda:
@@ -311,7 +339,7 @@ class Block(nn.Module):
         g2 = self.gamma2 if self.layer_scale else None
         return _BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
                               a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
-                              m.fc2.weight, m.fc2.bias, g1, g2, self, cdt, stoch, torch.is_grad_enabled())
+                              m.fc2.weight, m.fc2.bias, g1, g2, self, cdt, stoch, torch.is_grad_enabled(), win)
 
 
 def build_encoder(depth: int = 12, dim: int = 768, num_heads: int = 12, mlp_ratio: float = 4., qkv_bias: bool = True,

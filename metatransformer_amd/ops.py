@@ -255,6 +255,22 @@ def dropout_add(v: torch.Tensor, res: Optional[torch.Tensor], rows_per_sample: i
     return out
 
 
+def window_rows(x: torch.Tensor, B: int, H: int, W: int, window: int, merge: bool) -> torch.Tensor:
+    """partition ([B*H*W, C] -> [B*gh*gw*ws*ws, C], zero rows outside the grid) or merge (inverse) -- me_window_rows"""
+    lib = _capi.load()
+    _req(x, "x")
+    C = x.shape[-1]
+    gh, gw = -(-H // window), -(-W // window)
+    rows_tok, rows_win = B * H * W, B * gh * gw * window * window
+    x2 = x.reshape(-1, C)
+    if x2.shape[0] != (rows_win if merge else rows_tok):
+        raise MetaEncError(f"window_rows: {x2.shape[0]} rows, expected {rows_win if merge else rows_tok}")
+    out = torch.empty((rows_tok if merge else rows_win, C), dtype=x.dtype, device=x.device)
+    check(lib.me_window_rows(ptr(x2), ptr(out), dtype_code(x.dtype), B, H, W, window, C, 1 if merge else 0, stream_ptr()),
+          "me_window_rows")
+    return out
+
+
 def colsum_mul(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """out[c] = sum_r x[r,c] * y[r,c]  (fp32)"""
     lib = _capi.load()

@@ -133,15 +133,43 @@ def mlp(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str = "mlp.") -> to
     return linear(gelu_erf(h), p[prefix + "fc2.weight"], p[prefix + "fc2.bias"])
 
 
+def windowed_attention(x: torch.Tensor, p: Dict[str, torch.Tensor], num_heads: int, H: int, W: int, window: int) -> torch.Tensor:
+    """WindowedAttention.forward, Image/detection/mmdet_custom/models/backbones/base/vit.py:160-190, restated with plain
+    indexing instead of F.unfold / F.fold: qkv Linear on every token (:166); the [B, H, W, 3C] grid is zero-padded on the
+    bottom/right to multiples of the window (:167-168) -- so padded positions hold q = k = v = 0 and DO take part in the
+    softmax as keys with score 0; windows are (wy, wx) row-major with (iy, ix) row-major inside (:170-175); attention per
+    window and head (:179-183); fold back, crop to H x W (:185-189); proj (:190)."""
+    B, N, C = x.shape
+    hd = C // num_heads
+    scale = hd ** -0.5
+    gh, gw = -(-H // window), -(-W // window)
+    qkv = x @ p["attn.qkv.weight"].t()
+    if "attn.qkv.bias" in p and p["attn.qkv.bias"] is not None:
+        qkv = qkv + p["attn.qkv.bias"]
+    grid = qkv.new_zeros(B, gh * window, gw * window, 3 * C)
+    grid[:, :H, :W] = qkv.reshape(B, H, W, 3 * C)
+    wins = grid.reshape(B, gh, window, gw, window, 3, num_heads, hd).permute(5, 0, 1, 3, 6, 2, 4, 7)
+    wins = wins.reshape(3, B, gh * gw, num_heads, window * window, hd)
+    q, k, v = wins[0], wins[1], wins[2]
+    attn = torch.softmax((q @ k.transpose(-2, -1)) * scale, dim=-1)
+    o = attn @ v                                                            # [B, L, heads, ws*ws, hd]
+    o = o.reshape(B, gh, gw, num_heads, window, window, hd).permute(0, 1, 4, 2, 5, 3, 6)
+    o = o.reshape(B, gh * window, gw * window, C)[:, :H, :W].reshape(B, N, C)
+    return o @ p["attn.proj.weight"].t() + p["attn.proj.bias"]
+
+
 def block_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], num_heads: int, eps: float = 1e-5,
                   gamma1: Optional[torch.Tensor] = None, gamma2: Optional[torch.Tensor] = None,
-                  pre_scale_q: bool = False) -> torch.Tensor:
+                  pre_scale_q: bool = False, window: Optional[tuple] = None) -> torch.Tensor:
     """Block.forward, PointCloud/openpoints/models/layers/attention.py:55-58:
         x = x + drop_path(attn(norm1(x)));  x = x + drop_path(mlp(norm2(x)))
     gamma1/gamma2 restate the layer-scale variant
     (Image/detection/mmdet_custom/models/backbones/base/vit.py:313-316)."""
-    a = attention(layer_norm(x, p["norm1.weight"], p["norm1.bias"], eps), p, num_heads,
-                  pre_scale_q=pre_scale_q)
+    if window is not None:      # (H, W, window_size): the windowed blocks of the detection backbone (vit.py:284-287)
+        a = windowed_attention(layer_norm(x, p["norm1.weight"], p["norm1.bias"], eps), p, num_heads, *window)
+    else:
+        a = attention(layer_norm(x, p["norm1.weight"], p["norm1.bias"], eps), p, num_heads,
+                      pre_scale_q=pre_scale_q)
     x = x + (a if gamma1 is None else gamma1 * a)
     m = mlp(layer_norm(x, p["norm2.weight"], p["norm2.bias"], eps), p)
     x = x + (m if gamma2 is None else gamma2 * m)

@@ -245,6 +245,45 @@ def test_layer_scale_backward_vs_oracle(dev, dt, tol):
         assert rel_err(p.grad, sd[k].grad) < tol, k
 
 
+@pytest.mark.parametrize("B,H,W,ws,C", [(2, 5, 9, 4, 64), (1, 28, 28, 14, 128), (3, 20, 31, 14, 32)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_window_rows_bit_exact(dev, B, H, W, ws, C, dt):
+    from metatransformer_amd import ops
+    x = torch.randn(B * H * W, C).to(dt)
+    gh, gw = -(-H // ws), -(-W // ws)
+    grid = torch.zeros(B, gh * ws, gw * ws, C, dtype=dt)
+    grid[:, :H, :W] = x.reshape(B, H, W, C)
+    ref = grid.reshape(B, gh, ws, gw, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, C)
+    win = ops.window_rows(x.to(dev), B, H, W, ws, merge=False)
+    assert torch.equal(win.cpu(), ref)
+    back = ops.window_rows(win, B, H, W, ws, merge=True)
+    assert torch.equal(back.cpu(), x)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_F32), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("H,W,ws", [(20, 31, 14), (28, 28, 14), (9, 5, 4)])
+def test_windowed_block_vs_oracle(dev, dt, tol, H, W, ws):
+    """row f3: WindowedAttention blocks of the detection backbone (vit.py:148-192, 284-287) -- forward, dL/dx and every
+    parameter gradient against autograd through the oracle restatement; grids that are not multiples of the window
+    exercise the zero-padded keys"""
+    torch.manual_seed(5)
+    blk = M.Block(128, 4, qkv_bias=True, windowed=True, window_size=ws).to(dev).train()
+    x, go = torch.randn(2, H * W, 128), torch.randn(2, H * W, 128)
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xr = x.double().requires_grad_(True)
+    y_ref = bo.block_forward(xr, sd, 4, window=(H, W, ws))
+    (y_ref * go.double()).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+        y = blk(xd, H, W)
+    (y * go.to(dev)).sum().backward()
+    assert rel_err(y, y_ref) < tol and rel_err(xd.grad, xr.grad) < tol
+    for k, p in blk.named_parameters():
+        assert rel_err(p.grad, sd[k].grad) < tol, k
+    with pytest.raises(M.MetaEncError):
+        blk(xd)                                    # the token grid is mandatory for a windowed block
+
+
 # ----------------------------------------------------------------------------- BASELINE-size properties
 
 def test_base_config2_shape_properties(dev):
