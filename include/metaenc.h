@@ -32,7 +32,8 @@ extern "C" {
 
 #define ME_ABI_VERSION 1
 
-enum { ME_F32 = 0, ME_BF16 = 1 };
+enum { ME_F32 = 0, ME_BF16 = 1,
+       ME_F16 = 2 /* storage only: accepted by me_cast / me_transpose_cast, which convert fp16 tensors at the boundary */ };
 
 enum { ME_OK = 0, ME_ERR_ARG = -1, ME_ERR_UNSUPPORTED = -2, ME_ERR_HIP = -3, ME_ERR_WORKSPACE = -4 };
 

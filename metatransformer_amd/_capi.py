@@ -17,7 +17,7 @@ import torch  # noqa: F401  (imported first so libamdhip64.so.7 resolves to the 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmetaenc.so")
 
-ME_F32, ME_BF16 = 0, 1
+ME_F32, ME_BF16, ME_F16 = 0, 1, 2      # ME_F16: storage dtype of me_cast / me_transpose_cast only
 ME_GEMM_NT, ME_GEMM_TN = 0, 1
 ME_ACT_NONE, ME_ACT_GELU = 0, 1
 
@@ -121,12 +121,15 @@ def check(rc: int, what: str = "") -> None:
         raise MetaEncError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
 
 
-def dtype_code(dt: torch.dtype) -> int:
+def dtype_code(dt: torch.dtype, storage: bool = False) -> int:
     if dt == torch.float32:
         return ME_F32
     if dt == torch.bfloat16:
         return ME_BF16
-    raise MetaEncError(f"unsupported dtype {dt}: libmetaenc computes in float32 or bfloat16")
+    if storage and dt == torch.float16:
+        return ME_F16
+    raise MetaEncError(f"unsupported dtype {dt}: libmetaenc computes in float32 or bfloat16"
+                       + ("" if storage else " (float16 tensors are converted with ops.cast at the boundary)"))
 
 
 def ptr(t) -> int:

@@ -35,8 +35,9 @@ void me_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
-static inline size_t me_dtype_size(int dt) { return dt == ME_BF16 ? 2 : 4; }
-static inline bool me_dtype_ok(int dt) { return dt == ME_F32 || dt == ME_BF16; }
+static inline size_t me_dtype_size(int dt) { return dt == ME_F32 ? 4 : 2; }
+static inline bool me_dtype_ok(int dt) { return dt == ME_F32 || dt == ME_BF16; }                    // compute dtypes
+static inline bool me_storage_dtype_ok(int dt) { return me_dtype_ok(dt) || dt == ME_F16; }          // me_cast only
 
 // ---- device helpers
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __uint_as_float(lo16 << 16); }

@@ -13,6 +13,22 @@ inline unsigned ew_blocks(int64_t work_items) {
     return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+// fp16 exists at the boundary only (ME_F16: storage dtype of me_cast / me_transpose_cast -- `.half()` checkpoints and
+// fp16-autocast call sites are converted to bf16 / fp32 on the way in and back on the way out; no kernel computes in it)
+__device__ __forceinline__ float ld1_any(const void* base, int dt, int64_t i) {
+    if (dt == ME_F16) return (float)reinterpret_cast<const _Float16*>(base)[i];
+    return load1_as_f32(base, dt, i);
+}
+__device__ __forceinline__ void st1_any(void* base, int dt, int64_t i, float v) {
+    if (dt == ME_F16) reinterpret_cast<_Float16*>(base)[i] = (_Float16)v;
+    else store1_from_f32(base, dt, i, v);
+}
+__global__ __launch_bounds__(EW_THREADS) void cast_any_kernel(const void* __restrict__ src, int sdt, void* __restrict__ dst,
+                                                              int ddt, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
+        st1_any(dst, ddt, i, ld1_any(src, sdt, i));
+}
+
 __global__ __launch_bounds__(EW_THREADS) void cast_kernel(const void* __restrict__ src, int sdt, void* __restrict__ dst,
                                                           int ddt, int64_t n) {
     const int64_t n4 = n / 4;
@@ -32,12 +48,12 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const void* __restr
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int64_t r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < rows && c < cols) ? load1_as_f32(src, sdt, r * cols + c) : 0.f;
+        tile[i][tx] = (r < rows && c < cols) ? ld1_any(src, sdt, r * cols + c) : 0.f;
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
         const int64_t c = c0 + i, r = r0 + tx;
-        if (c < cols && r < rows) store1_from_f32(dst, ddt, c * rows + r, tile[tx][i]);
+        if (c < cols && r < rows) st1_any(dst, ddt, c * rows + r, tile[tx][i]);
     }
 }
 
@@ -334,8 +350,13 @@ __global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p
 extern "C" int me_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ME_CHECK_ARG(src && dst && n >= 0, "me_cast: bad args");
-    ME_CHECK_ARG(me_dtype_ok(src_dtype) && me_dtype_ok(dst_dtype), "me_cast: bad dtype");
+    ME_CHECK_ARG(me_storage_dtype_ok(src_dtype) && me_storage_dtype_ok(dst_dtype), "me_cast: bad dtype");
     if (n == 0) return ME_OK;
+    if (src_dtype == ME_F16 || dst_dtype == ME_F16) {
+        hipLaunchKernelGGL(cast_any_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, src, src_dtype, dst, dst_dtype, n);
+        ME_CHECK_LAUNCH("me_cast");
+        return ME_OK;
+    }
     hipLaunchKernelGGL(cast_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(EW_THREADS), 0, stream, src, src_dtype, dst, dst_dtype, n);
     ME_CHECK_LAUNCH("me_cast");
     return ME_OK;
@@ -345,7 +366,7 @@ extern "C" int me_transpose_cast(const void* src, int src_dtype, void* dst, int 
                                  void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ME_CHECK_ARG(src && dst && rows > 0 && cols > 0, "me_transpose_cast: bad args");
-    ME_CHECK_ARG(me_dtype_ok(src_dtype) && me_dtype_ok(dst_dtype), "me_transpose_cast: bad dtype");
+    ME_CHECK_ARG(me_storage_dtype_ok(src_dtype) && me_storage_dtype_ok(dst_dtype), "me_transpose_cast: bad dtype");
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
     hipLaunchKernelGGL(transpose_cast_kernel, grid, dim3(256), 0, stream, src, src_dtype, dst, dst_dtype, rows, cols);
     ME_CHECK_LAUNCH("me_transpose_cast");

@@ -114,6 +114,9 @@ class _BlockFn(torch.autograd.Function):
         H = blk.attn.num_heads
         hd = C // H
         M = B * N
+        in_dtype = x.dtype
+        if in_dtype == torch.float16:      # fp16 exists at the boundary only: residual stream runs in bf16 (same 16 bits,
+            x = ops.cast(x, torch.bfloat16)    # fp32's range -- no loss scaling needed), converted back on the way out
         rdt = x.dtype                      # residual-stream dtype
         cache: _WeightCache = blk._wcache
         # grad mode is always off inside Function.forward and needs_input_grad ignores torch.no_grad(): the caller
@@ -162,7 +165,8 @@ class _BlockFn(torch.autograd.Function):
                                   n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2, t1, t2, o_att if win is not None else None)
             ctx.blk, ctx.cdt, ctx.dims, ctx.stoch, ctx.win = blk, cdt, (B, N, C, H, hd), stoch, win
             ctx.has_bias = (qkvb is not None, projb is not None, fc1b is not None, fc2b is not None)
-        return y.reshape(B, N, C)
+            ctx.in_dtype = in_dtype
+        return ops.cast(y, in_dtype).reshape(B, N, C)
 
     @staticmethod
     def backward(ctx, dy):
@@ -192,7 +196,8 @@ class _BlockFn(torch.autograd.Function):
                 tgt_b = flat.direct_grad(lin.bias)
             # the fused column sums share C's beta: usable when both accumulate in place or neither does
             fuse_b = need_b and (tgt is None or tgt_b is not None)
-            res = ops.gemm(dout, inp, op=ME_GEMM_TN, out=tgt, out_dtype=w.dtype, beta=1.0 if tgt is not None else 0.0,
+            odt = w.dtype if w.dtype != torch.float16 else torch.float32      # fp16 parameters: fp32 result, cast below
+            res = ops.gemm(dout, inp, op=ME_GEMM_TN, out=tgt, out_dtype=odt, beta=1.0 if tgt is not None else 0.0,
                            want_colsum_a=fuse_b, colsum_out=tgt_b)
             dw, db = res if fuse_b else (res, ops.colsum(dout) if need_b else None)
             if tgt is not None:
@@ -201,6 +206,8 @@ class _BlockFn(torch.autograd.Function):
             if tgt_b is not None:
                 flat.grad_written(lin.bias)
                 db = None
+            if dw is not None and dw.dtype != w.dtype:
+                dw = ops.cast(dw, w.dtype)
             return dw, (db.to(w.dtype) if db is not None else None)
 
         def ln_bwd(dyn, xin, mean, rstd, norm, dres, need_aff):
@@ -258,7 +265,7 @@ class _BlockFn(torch.autograd.Function):
         def aff(g, p):
             return None if g is None else g.to(p.dtype)
 
-        return (dx.reshape(B, N, C) if ng[0] else None,
+        return (ops.cast(dx, ctx.in_dtype).reshape(B, N, C) if ng[0] else None,
                 aff(d_n1w, n1w) if ng[1] else None, aff(d_n1b, n1w) if ng[2] else None,
                 d_qkvw, d_qkvb, d_projw, d_projb,
                 aff(d_n2w, n2w) if ng[7] else None, aff(d_n2b, n2w) if ng[8] else None,
@@ -301,10 +308,11 @@ class Block(nn.Module):
             return self.compute_dtype
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_dtype("cuda")
-            if dt != torch.bfloat16:
+            if dt not in (torch.bfloat16, torch.float16):
                 raise MetaEncError(f"autocast dtype {dt} unsupported: libmetaenc computes in bfloat16 or float32")
-            return dt
-        return self.attn.qkv.weight.dtype
+            return torch.bfloat16           # fp16 autocast (Audio/src/traintest.py, mmcv fp16) runs on the bf16 kernels
+        dt = self.attn.qkv.weight.dtype
+        return torch.bfloat16 if dt == torch.float16 else dt      # .half() checkpoints: bf16 compute, fp16 in / out
 
     def forward(self, x: torch.Tensor, H: Optional[int] = None, W: Optional[int] = None) -> torch.Tensor:
         win = None
@@ -331,7 +339,7 @@ class Block(nn.Module):
                 seed = int(torch.empty((), dtype=torch.int64).random_().item())
                 stoch = (float(self.mlp.drop.p), self.drop_path_prob, seed)
         cdt = self._compute_dtype(x)
-        if x.dtype not in (torch.float32, torch.bfloat16):
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise MetaEncError(f"unsupported token dtype {x.dtype}")
         x = x.contiguous()
         a, m = self.attn, self.mlp

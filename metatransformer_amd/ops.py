@@ -211,7 +211,7 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     lib = _capi.load()
     _req(x, "x")
     y = torch.empty(x.shape, dtype=dtype, device=x.device)
-    check(lib.me_cast(ptr(x), dtype_code(x.dtype), ptr(y), dtype_code(dtype), x.numel(), stream_ptr()), "me_cast")
+    check(lib.me_cast(ptr(x), dtype_code(x.dtype, True), ptr(y), dtype_code(dtype, True), x.numel(), stream_ptr()), "me_cast")
     return y
 
 
@@ -221,7 +221,7 @@ def transpose_cast(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     _req(w, "w")
     rows, cols = w.shape
     y = torch.empty((cols, rows), dtype=dtype, device=w.device)
-    check(lib.me_transpose_cast(ptr(w), dtype_code(w.dtype), ptr(y), dtype_code(dtype), rows, cols, stream_ptr()),
+    check(lib.me_transpose_cast(ptr(w), dtype_code(w.dtype, True), ptr(y), dtype_code(dtype, True), rows, cols, stream_ptr()),
           "me_transpose_cast")
     return y
 

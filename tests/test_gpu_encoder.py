@@ -119,6 +119,32 @@ def test_flat_params_fused_gradient_accumulation(dev):
     assert rel_err(grads[True], grads[False]) < 1e-6
 
 
+@pytest.mark.parametrize("mode", ["autocast_fp16", "half_params"])
+def test_fp16_call_sites_run_on_bf16_kernels(dev, mode):
+    """fp16 autocast (Audio/src/traintest.py:145, mmcv fp16) and `.half()` models: fp16 tensors are converted at the
+    boundary (me_cast), compute is bf16, outputs / gradients come back in the caller's dtype"""
+    c = dict(depth=2, dim=256, heads=4, eps=1e-5, seed=9)
+    sd = bo.make_encoder_state_dict(c["depth"], c["dim"], seed=c["seed"])
+    g = torch.Generator().manual_seed(4)
+    x, go = torch.randn(2, 150, 256, generator=g), torch.randn(2, 150, 256, generator=g)
+    y_ref, dx_ref, dp_ref = bo.encoder_forward_backward(x, sd, c["heads"], go)
+    enc = make_encoder(c, dev).train()
+    if mode == "half_params":
+        enc = enc.half()
+        xr = x.to(dev).half().requires_grad_(True)
+        y = enc(xr)
+        assert y.dtype == torch.float16
+    else:
+        xr = x.to(dev).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = enc(xr)
+    (y.float() * go.to(dev)).sum().backward()
+    assert xr.grad.dtype == xr.dtype
+    assert rel_err(y.float(), y_ref) < 5e-2 and rel_err(xr.grad.float(), dx_ref) < 5e-2
+    for k, p in enc.named_parameters():
+        assert p.grad.dtype == p.dtype and rel_err(p.grad.float(), dp_ref[k]) < 6e-2, k
+
+
 def test_frozen_encoder_passes_input_grad_only(dev):
     """most reference pipelines freeze the encoder but train the tokenizer in front of it."""
     c = dict(depth=1, dim=128, heads=2, eps=1e-5, seed=6)
