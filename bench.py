@@ -108,23 +108,22 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    ops.GEMM_PROFILE = []
+    ops.gemm_profile(True)       # HIP events around every me_gemm launch, recorded by the library on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    prof = ops.gemm_profile_read()
+    ops.gemm_profile(False)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- roofline of the dominant kernel: bf16 NT MFMA GEMM (forward + dgrad launches share one kernel)
-    nt = [(M_, N_, K_, e0.elapsed_time(e1)) for (op, dt, M_, N_, K_, e0, e1) in prof
-          if op == _capi.ME_GEMM_NT and dt == _capi.ME_BF16]
-    tn = [(M_, N_, K_, e0.elapsed_time(e1)) for (op, dt, M_, N_, K_, e0, e1) in prof
-          if op == _capi.ME_GEMM_TN and dt == _capi.ME_BF16]
+    nt = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in prof if op == _capi.ME_GEMM_NT and dt == _capi.ME_BF16]
+    tn = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in prof if op == _capi.ME_GEMM_TN and dt == _capi.ME_BF16]
     roof = None
     if nt:
         flops = sum(2.0 * m * n * k for m, n, k, _ in nt)

@@ -115,6 +115,19 @@ size_t me_gemm_workspace_bytes(const me_gemm_desc* d);
 int me_gemm_fuses_colsum(const me_gemm_desc* d);
 int me_gemm(const me_gemm_desc* d, void* stream);
 
+/* Per-launch timing of me_gemm for roofline accounting (bench.py): while enabled, every me_gemm call -- including those
+ * made from me_block_fwd / me_block_bwd -- is bracketed by HIP events on its stream.  me_gemm_profile_read synchronises
+ * on the recorded events, fills up to `max` records in call order and returns how many there are (and clears them).
+ * Off by default; costs two event records per GEMM when on. */
+typedef struct me_gemm_profile_rec {
+    int32_t op, ab_dtype;
+    int64_t M, N, K;
+    float ms;          /* start of the (first) GEMM kernel to end of its last kernel (split-K fold included) */
+    int32_t reserved;
+} me_gemm_profile_rec;
+int me_gemm_profile_enable(int on);
+int me_gemm_profile_read(me_gemm_profile_rec* out, int max);
+
 /* column sums of a [rows, cols] matrix -> out[cols] fp32 (bias gradients).  accumulate != 0 adds into out.
  * workspace: me_colsum_workspace(cols) bytes. */
 size_t me_colsum_workspace(int64_t cols);
@@ -140,6 +153,49 @@ int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out, int64_t l
                      const void* dout, int64_t ld_dout, const float* lse, float* delta,
                      void* dqkv, int64_t ld_dqkv,
                      int B, int N, int H, int head_dim, float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ One encoder Block, composed on the C side
+ * Block.forward / its autograd (PointCloud/openpoints/models/layers/attention.py:55-58) as ONE call each: the same
+ * kernels as the entry points above, launched back to back on `stream` without returning to the host in between --
+ * the form a non-Python host binds, and what metatransformer_amd.Block uses for the plain (non-stochastic,
+ * non-windowed) path.
+ *   y = x1 + gamma2 * fc2(gelu(fc1(LN2(x1)))),   x1 = x + gamma1 * proj(attn(qkv(LN1(x))))
+ * Weights are in the COMPUTE dtype, checkpoint layout [out, in]; LayerNorm affine, biases and gamma are fp32 (NULL bias /
+ * gamma = absent).  The *_wt pointers are the transposed [in, out] copies backward's dgrad GEMMs read (NULL is fine for
+ * forward-only use).  x / y / dx / dy are [B*N, C] in res_dtype (the residual stream). */
+typedef struct me_block_desc {
+    int32_t dtype;        /* compute dtype: ME_BF16 (bf16 MFMA) or ME_F32 (exact fp32 MFMA) */
+    int32_t res_dtype;    /* dtype of x, y, dx, dy */
+    int32_t B, N, C, heads, hidden;
+    float eps, scale;     /* LayerNorm eps; attention scale (head_dim^-0.5 unless qk_scale was given) */
+    const void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    const void *qkv_wt, *proj_wt, *fc1_wt, *fc2_wt;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+    const float *gamma1, *gamma2;      /* layer-scale (forward only in this entry point) */
+} me_block_desc;
+
+/* Gradient destinations of me_block_bwd; any pointer may be NULL (that gradient is skipped -- frozen encoder).
+ * Weight gradients are [out, in] in w_dtype; bias / LayerNorm gradients fp32.  accumulate != 0 adds into the
+ * destinations (gradient accumulation into a flat buffer) instead of overwriting. */
+typedef struct me_block_grads {
+    void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    int32_t w_dtype;
+    int32_t accumulate;
+} me_block_grads;
+
+/* bytes of the activation stash forward writes for backward (xn1, qkv, o, x1, xn2, fc1 pre-activation, gelu output,
+ * LayerNorm statistics, attention LSE), and of the scratch either call needs (intermediates, split-K slabs) */
+size_t me_block_saved_bytes(const me_block_desc* d);
+size_t me_block_workspace_bytes(const me_block_desc* d, int backward);
+/* saved == NULL: inference (nothing kept; intermediates live in the workspace) */
+int me_block_fwd(const me_block_desc* d, const void* x, void* y, void* saved, void* workspace, size_t workspace_bytes,
+                 void* stream);
+/* dx may be NULL (input does not need a gradient only if nothing upstream does -- rarely useful; kept for symmetry) */
+int me_block_bwd(const me_block_desc* d, const void* x, const void* dy, const void* saved, void* dx,
+                 const me_block_grads* g, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ element-wise helpers */
 /* dst = (dst_dtype) src, n elements */

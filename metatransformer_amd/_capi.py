@@ -50,6 +50,28 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class GemmProfileRec(ctypes.Structure):
+    """Mirror of ``struct me_gemm_profile_rec``."""
+    _fields_ = [("op", c_int32), ("ab_dtype", c_int32), ("M", c_int64), ("N", c_int64), ("K", c_int64), ("ms", c_float),
+                ("reserved", c_int32)]
+
+
+class BlockDesc(ctypes.Structure):
+    """Mirror of ``struct me_block_desc`` (include/metaenc.h)."""
+    _fields_ = ([("dtype", c_int32), ("res_dtype", c_int32), ("B", c_int32), ("N", c_int32), ("C", c_int32),
+                 ("heads", c_int32), ("hidden", c_int32), ("eps", c_float), ("scale", c_float)]
+                + [(n, c_void_p) for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_wt", "proj_wt", "fc1_wt", "fc2_wt",
+                                           "ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_b", "proj_b", "fc1_b", "fc2_b",
+                                           "gamma1", "gamma2")])
+
+
+class BlockGrads(ctypes.Structure):
+    """Mirror of ``struct me_block_grads``."""
+    _fields_ = ([(n, c_void_p) for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b",
+                                         "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+                + [("w_dtype", c_int32), ("accumulate", c_int32)])
+
+
 # name -> (restype, argtypes).  Every symbol include/metaenc.h declares must be listed here
 # (tests/test_boundary.py cross-checks the header against this table and against the built .so).
 SIGNATURES = {
@@ -66,6 +88,8 @@ SIGNATURES = {
     "me_gemm_workspace_bytes": (c_size_t, [POINTER(GemmDesc)]),
     "me_gemm_fuses_colsum": (c_int, [POINTER(GemmDesc)]),
     "me_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "me_gemm_profile_enable": (c_int, [c_int]),
+    "me_gemm_profile_read": (c_int, [POINTER(GemmProfileRec), c_int]),
     "me_colsum_workspace": (c_size_t, [c_int64]),
     "me_colsum": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "me_colsum_mul": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int,
@@ -74,6 +98,11 @@ SIGNATURES = {
                                  c_float, c_int, c_void_p]),
     "me_attention_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "me_block_saved_bytes": (c_size_t, [POINTER(BlockDesc)]),
+    "me_block_workspace_bytes": (c_size_t, [POINTER(BlockDesc), c_int]),
+    "me_block_fwd": (c_int, [POINTER(BlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "me_block_bwd": (c_int, [POINTER(BlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(BlockGrads), c_void_p,
+                             c_size_t, c_void_p]),
     "me_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "me_transpose_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "me_add_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),

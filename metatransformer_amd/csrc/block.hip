@@ -1,0 +1,231 @@
+// block.hip -- one encoder Block (forward / backward) composed on the C side from the library's own entry points.
+// Restates Block.forward, PointCloud/openpoints/models/layers/attention.py:55-58 (and what autograd derives from it):
+// no new arithmetic here, only the launch sequence, the activation stash and the scratch carving, so that a host makes
+// ONE call per block and direction and the GPU never waits for the host between the ~10 (forward) / ~20 (backward) kernels.
+#include "common.h"
+#include <string.h>
+
+namespace {
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Dims {
+    int64_t M;
+    int C, C3, Hd, hd;
+    size_t esz, rsz;
+};
+int get_dims(const me_block_desc* d, Dims& s, const char* fn) {
+    ME_CHECK_ARG(d != nullptr, "%s: null descriptor", fn);
+    ME_CHECK_ARG(me_dtype_ok(d->dtype) && me_dtype_ok(d->res_dtype), "%s: bad dtype", fn);
+    ME_CHECK_ARG(d->B > 0 && d->N > 0 && d->C > 0 && d->heads > 0 && d->hidden > 0 && d->C % d->heads == 0,
+                 "%s: bad shape B=%d N=%d C=%d heads=%d hidden=%d", fn, d->B, d->N, d->C, d->heads, d->hidden);
+    s.M = (int64_t)d->B * d->N;
+    s.C = d->C; s.C3 = 3 * d->C; s.Hd = d->hidden; s.hd = d->C / d->heads;
+    s.esz = me_dtype_size(d->dtype); s.rsz = me_dtype_size(d->res_dtype);
+    return ME_OK;
+}
+
+// ---- activation stash layout
+struct Saved {
+    char *xn1, *qkv, *o, *x1, *xn2, *hpre, *a;
+    float *mean1, *rstd1, *mean2, *rstd2, *lse;
+    size_t bytes;
+};
+Saved carve_saved(const me_block_desc* d, const Dims& s, void* base) {
+    Saved v;
+    size_t off = 0;
+    char* b = reinterpret_cast<char*>(base);
+    auto take = [&](size_t n) { char* p = b + off; off += align256(n); return p; };
+    v.xn1 = take(s.M * s.C * s.esz);
+    v.qkv = take(s.M * s.C3 * s.esz);
+    v.o = take(s.M * s.C * s.esz);
+    v.x1 = take(s.M * s.C * s.rsz);
+    v.xn2 = take(s.M * s.C * s.esz);
+    v.hpre = take(s.M * s.Hd * s.esz);
+    v.a = take(s.M * s.Hd * s.esz);
+    v.mean1 = reinterpret_cast<float*>(take(s.M * 4));
+    v.rstd1 = reinterpret_cast<float*>(take(s.M * 4));
+    v.mean2 = reinterpret_cast<float*>(take(s.M * 4));
+    v.rstd2 = reinterpret_cast<float*>(take(s.M * 4));
+    v.lse = reinterpret_cast<float*>(take((size_t)d->B * d->heads * d->N * 4));
+    v.bytes = off;
+    return v;
+}
+
+void gemm_desc(me_gemm_desc& g, int op, int dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+               int64_t ldb, void* C, int64_t ldc, int cdt) {
+    memset(&g, 0, sizeof(g));
+    g.op = op; g.ab_dtype = dt; g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.c_dtype = cdt;
+    g.alpha = 1.0f;
+}
+
+// the largest GEMM scratch any of the block's GEMMs asks for (tail split forward, split-K wgrad backward)
+size_t gemm_scratch(const me_block_desc* d, const Dims& s, bool backward) {
+    size_t w = 0;
+    me_gemm_desc g;
+    auto probe = [&](int op, int64_t M, int64_t N, int64_t K, int cdt, bool cs) {
+        static char dummy_mem[64] __attribute__((aligned(64)));
+        gemm_desc(g, op, d->dtype, M, N, K, dummy_mem, op == ME_GEMM_NT ? K : M, dummy_mem, op == ME_GEMM_NT ? K : N, dummy_mem, N, cdt);
+        if (cs) g.colsum_a = reinterpret_cast<float*>(dummy_mem);
+        const size_t b = me_gemm_workspace_bytes(&g);
+        if (b > w) w = b;
+    };
+    probe(ME_GEMM_NT, s.M, s.C3, s.C, d->dtype, false);
+    probe(ME_GEMM_NT, s.M, s.C, s.C, d->res_dtype, false);
+    probe(ME_GEMM_NT, s.M, s.Hd, s.C, d->dtype, false);
+    probe(ME_GEMM_NT, s.M, s.C, s.Hd, d->res_dtype, false);
+    if (backward) {
+        probe(ME_GEMM_NT, s.M, s.C, s.C3, d->dtype, false);
+        probe(ME_GEMM_NT, s.M, s.C, s.Hd, d->dtype, false);
+        probe(ME_GEMM_TN, s.C3, s.C, s.M, ME_F32, true);
+        probe(ME_GEMM_TN, s.C, s.C, s.M, ME_F32, true);
+        probe(ME_GEMM_TN, s.Hd, s.C, s.M, ME_F32, true);
+        probe(ME_GEMM_TN, s.C, s.Hd, s.M, ME_F32, true);
+    }
+    return align256(w);
+}
+
+size_t aux_scratch(const Dims& s) {      // LayerNorm-backward and column-sum scratch (used one after the other)
+    size_t a = me_layernorm_bwd_workspace(s.C), b = me_colsum_workspace(s.Hd > s.C3 ? s.Hd : s.C3);
+    return align256(a > b ? a : b);
+}
+
+}  // namespace
+
+extern "C" size_t me_block_saved_bytes(const me_block_desc* d) {
+    Dims s;
+    if (get_dims(d, s, "me_block_saved_bytes") != ME_OK) return 0;
+    return carve_saved(d, s, nullptr).bytes;
+}
+
+extern "C" size_t me_block_workspace_bytes(const me_block_desc* d, int backward) {
+    Dims s;
+    if (get_dims(d, s, "me_block_workspace_bytes") != ME_OK) return 0;
+    size_t w = gemm_scratch(d, s, backward != 0) + aux_scratch(s);
+    if (!backward) return w + carve_saved(d, s, nullptr).bytes;      // inference keeps the intermediates here
+    // dy_c, dh, dxn (shared by dxn2 / dxn1), dx1, dx1_c, do, dqkv, delta
+    w += align256(s.M * s.C * s.esz) * 4 + align256(s.M * s.Hd * s.esz) + align256(s.M * s.C * s.rsz) +
+         align256(s.M * s.C3 * s.esz) + align256((size_t)d->B * d->heads * d->N * 4);
+    return w;
+}
+
+extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void* saved, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+    Dims s;
+    int rc = get_dims(d, s, "me_block_fwd");
+    if (rc) return rc;
+    ME_CHECK_ARG(x && y && workspace, "me_block_fwd: null pointer");
+    ME_CHECK_ARG(d->qkv_w && d->proj_w && d->fc1_w && d->fc2_w && d->ln1_g && d->ln1_b && d->ln2_g && d->ln2_b,
+                 "me_block_fwd: missing parameter");
+    ME_CHECK_ARG(workspace_bytes >= me_block_workspace_bytes(d, 0), "me_block_fwd: workspace too small");
+    char* ws = reinterpret_cast<char*>(workspace);
+    const size_t gsz = gemm_scratch(d, s, false);
+    void* gws = ws;
+    const bool keep = saved != nullptr;
+    Saved v = carve_saved(d, s, keep ? saved : ws + gsz + aux_scratch(s));
+    const int dt = d->dtype, rdt = d->res_dtype;
+    me_gemm_desc g;
+
+    rc = me_layernorm_fwd(x, rdt, d->ln1_g, d->ln1_b, v.xn1, dt, keep ? v.mean1 : nullptr, keep ? v.rstd1 : nullptr, s.M, s.C, d->eps, stream);
+    if (rc) return rc;
+    gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C3, s.C, v.xn1, s.C, d->qkv_w, s.C, v.qkv, s.C3, dt);
+    g.bias = d->qkv_b; g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+    if ((rc = me_gemm(&g, stream))) return rc;
+    rc = me_attention_fwd(v.qkv, s.C3, v.o, s.C, keep ? v.lse : nullptr, d->B, d->N, d->heads, s.hd, d->scale, dt, stream);
+    if (rc) return rc;
+    gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C, s.C, v.o, s.C, d->proj_w, s.C, v.x1, s.C, rdt);
+    g.bias = d->proj_b; g.colscale = d->gamma1; g.residual = x; g.ldres = s.C; g.res_dtype = rdt;
+    g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+    if ((rc = me_gemm(&g, stream))) return rc;
+    rc = me_layernorm_fwd(v.x1, rdt, d->ln2_g, d->ln2_b, v.xn2, dt, keep ? v.mean2 : nullptr, keep ? v.rstd2 : nullptr, s.M, s.C, d->eps, stream);
+    if (rc) return rc;
+    gemm_desc(g, ME_GEMM_NT, dt, s.M, s.Hd, s.C, v.xn2, s.C, d->fc1_w, s.C, v.a, s.Hd, dt);
+    g.bias = d->fc1_b; g.act = ME_ACT_GELU;
+    if (keep) { g.preact = v.hpre; g.ldpre = s.Hd; g.preact_dtype = dt; }
+    g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+    if ((rc = me_gemm(&g, stream))) return rc;
+    gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C, s.Hd, v.a, s.Hd, d->fc2_w, s.Hd, y, s.C, rdt);
+    g.bias = d->fc2_b; g.colscale = d->gamma2; g.residual = v.x1; g.ldres = s.C; g.res_dtype = rdt;
+    g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+    return me_gemm(&g, stream);
+}
+
+extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* dy, const void* saved, void* dx,
+                            const me_block_grads* gr, void* workspace, size_t workspace_bytes, void* stream) {
+    Dims s;
+    int rc = get_dims(d, s, "me_block_bwd");
+    if (rc) return rc;
+    ME_CHECK_ARG(x && dy && saved && dx && gr && workspace, "me_block_bwd: null pointer");
+    ME_CHECK_ARG(d->qkv_wt && d->proj_wt && d->fc1_wt && d->fc2_wt && d->ln1_g && d->ln2_g, "me_block_bwd: missing parameter");
+    ME_CHECK_ARG(!d->gamma1 && !d->gamma2, "me_block_bwd: layer-scale backward is composed by the host (needs the unscaled branch outputs)");
+    ME_CHECK_ARG(me_dtype_ok(gr->w_dtype), "me_block_bwd: bad gradient dtype");
+    ME_CHECK_ARG(workspace_bytes >= me_block_workspace_bytes(d, 1), "me_block_bwd: workspace too small");
+    const Saved v = carve_saved(d, s, const_cast<void*>(saved));
+    const int dt = d->dtype, rdt = d->res_dtype;
+    char* ws = reinterpret_cast<char*>(workspace);
+    size_t off = 0;
+    auto take = [&](size_t n) { char* p = ws + off; off += align256(n); return p; };
+    const size_t gsz = gemm_scratch(d, s, true);
+    void* gws = take(gsz);
+    void* aws = take(aux_scratch(s));
+    char* dy_c = take(s.M * s.C * s.esz);
+    char* dh = take(s.M * s.Hd * s.esz);
+    char* dxn = take(s.M * s.C * s.esz);
+    char* dx1 = take(s.M * s.C * s.rsz);
+    char* dx1_c = take(s.M * s.C * s.esz);
+    char* dout = take(s.M * s.C * s.esz);
+    char* dqkv = take(s.M * s.C3 * s.esz);
+    float* delta = reinterpret_cast<float*>(take((size_t)d->B * d->heads * d->N * 4));
+    const float beta = gr->accumulate ? 1.0f : 0.0f;
+    me_gemm_desc g;
+
+    auto nt = [&](const void* A, int64_t K, const void* Wt, void* C, int64_t N, const void* aux) -> int {
+        gemm_desc(g, ME_GEMM_NT, dt, s.M, N, K, A, K, Wt, K, C, N, dt);
+        if (aux) { g.aux = aux; g.ldaux = N; g.aux_dtype = dt; }
+        g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+        return me_gemm(&g, stream);
+    };
+    // dW[out, in] = dOut^T In (+ the bias gradient from the same kernel when it can fuse it)
+    auto wgrad = [&](const void* dOut, int64_t n_out, const void* In, int64_t n_in, void* dW, float* dB) -> int {
+        if (dW) {
+            gemm_desc(g, ME_GEMM_TN, dt, n_out, n_in, s.M, dOut, n_out, In, n_in, dW, n_in, gr->w_dtype);
+            g.beta = beta; g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+            const bool fuse = dB && me_gemm_fuses_colsum(&g);
+            if (fuse) g.colsum_a = dB;
+            int r = me_gemm(&g, stream);
+            if (r) return r;
+            if (fuse) return ME_OK;
+        }
+        if (dB) return me_colsum(dOut, dt, n_out, s.M, n_out, dB, gr->accumulate, aws, stream);
+        return ME_OK;
+    };
+
+    // ---- MLP branch: y = x1 + fc2(gelu(fc1(LN2(x1))))
+    const void* dyc = dy;
+    if (rdt != dt) {
+        if ((rc = me_cast(dy, rdt, dy_c, dt, s.M * s.C, stream))) return rc;
+        dyc = dy_c;
+    }
+    if ((rc = nt(dyc, s.C, d->fc2_wt, dh, s.Hd, v.hpre))) return rc;                  // dA * gelu'(h)
+    if ((rc = wgrad(dyc, s.C, v.a, s.Hd, gr->fc2_w, gr->fc2_b))) return rc;
+    if ((rc = nt(dh, s.Hd, d->fc1_wt, dxn, s.C, nullptr))) return rc;
+    if ((rc = wgrad(dh, s.Hd, v.xn2, s.C, gr->fc1_w, gr->fc1_b))) return rc;
+    rc = me_layernorm_bwd(dxn, dt, v.x1, rdt, v.mean2, v.rstd2, d->ln2_g, dy, rdt, dx1, rdt, gr->ln2_g, gr->ln2_b,
+                          gr->accumulate, s.M, s.C, aws, stream);
+    if (rc) return rc;
+    // ---- attention branch: x1 = x + proj(attn(qkv(LN1(x))))
+    const void* dx1c = dx1;
+    if (rdt != dt) {
+        if ((rc = me_cast(dx1, rdt, dx1_c, dt, s.M * s.C, stream))) return rc;
+        dx1c = dx1_c;
+    }
+    if ((rc = nt(dx1c, s.C, d->proj_wt, dout, s.C, nullptr))) return rc;
+    if ((rc = wgrad(dx1c, s.C, v.o, s.C, gr->proj_w, gr->proj_b))) return rc;
+    rc = me_attention_bwd(v.qkv, s.C3, v.o, s.C, dout, s.C, v.lse, delta, dqkv, s.C3, d->B, d->N, d->heads, s.hd, d->scale, dt, stream);
+    if (rc) return rc;
+    if ((rc = nt(dqkv, s.C3, d->qkv_wt, dxn, s.C, nullptr))) return rc;
+    if ((rc = wgrad(dqkv, s.C3, v.xn1, s.C, gr->qkv_w, gr->qkv_b))) return rc;
+    return me_layernorm_bwd(dxn, dt, x, rdt, v.mean1, v.rstd1, d->ln1_g, dx1, rdt, dx, rdt, gr->ln1_g, gr->ln1_b, gr->accumulate,
+                            s.M, s.C, aws, stream);
+}

@@ -123,6 +123,17 @@ class _BlockFn(torch.autograd.Function):
         # samples torch.is_grad_enabled() and passes it in, so inference saves nothing (no stats / LSE / pre-activation)
         need_grad = grad_mode and any(ctx.needs_input_grad)
         x2 = x.reshape(M, C)
+        ctx.fast = False
+        if stoch is None and win is None and blk.c_side and not (need_grad and g1 is not None):
+            # plain path: the whole block is ONE library call (me_block_fwd), the launch sequence lives on the C side
+            d, keep = _BlockFn._desc(blk, cache, cdt, rdt, B, N, C, H, (n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb,
+                                                                        fc1w, fc1b, fc2w, fc2b, g1, g2), False)
+            y, saved = ops.block_fwd(d, x2, keep=need_grad)
+            del keep
+            if need_grad:
+                ctx.save_for_backward(x2, saved, n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb, fc1w, fc1b, fc2w, fc2b)
+                ctx.blk, ctx.cdt, ctx.dims, ctx.in_dtype, ctx.fast = blk, cdt, (B, N, C, H, hd), in_dtype, True
+            return ops.cast(y, in_dtype).reshape(B, N, C)
 
         xn1, mean1, rstd1 = ops.layernorm_fwd(x2, n1w, n1b, blk.eps, cdt, save_stats=need_grad)
         qkv = ops.gemm(xn1, cache.fwd("qkv", qkvw, cdt), bias=qkvb)
@@ -169,7 +180,73 @@ class _BlockFn(torch.autograd.Function):
         return ops.cast(y, in_dtype).reshape(B, N, C)
 
     @staticmethod
+    def _desc(blk, cache, cdt, rdt, B, N, C, H, params, transposed):
+        """me_block_desc for this block + the list of tensors that must stay alive while the call is in flight"""
+        (n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb, fc1w, fc1b, fc2w, fc2b, g1, g2) = params
+        ws = {"qkv": qkvw, "proj": projw, "fc1": fc1w, "fc2": fc2w}
+        w = {k: cache.fwd(k, t, cdt) for k, t in ws.items()}
+        wt = {k: cache.transposed(k, t, cdt) for k, t in ws.items()} if transposed else None
+        f = lambda t: None if t is None else ops._f32(t).contiguous()      # noqa: E731
+        vec = dict(ln1_g=f(n1w), ln1_b=f(n1b), ln2_g=f(n2w), ln2_b=f(n2b), qkv_b=f(qkvb), proj_b=f(projb), fc1_b=f(fc1b),
+                   fc2_b=f(fc2b), gamma1=f(g1), gamma2=f(g2))
+        d = ops.block_desc(B, N, C, H, fc1w.shape[0], blk.eps, blk.attn.scale, cdt, rdt, w, wt, vec)
+        return d, (w, wt, vec)
+
+    @staticmethod
+    def _backward_c(ctx, dy):
+        (x2, saved, n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb, fc1w, fc1b, fc2w, fc2b) = ctx.saved_tensors
+        blk, cdt = ctx.blk, ctx.cdt
+        B, N, C, H, hd = ctx.dims
+        rdt = x2.dtype
+        ng = ctx.needs_input_grad
+        dy2 = dy.contiguous().reshape(B * N, C)
+        if dy2.dtype != rdt:
+            dy2 = ops.cast(dy2, rdt)
+        d, keep = _BlockFn._desc(blk, blk._wcache, cdt, rdt, B, N, C, H, (n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb,
+                                                                          fc1w, fc1b, fc2w, fc2b, None, None), True)
+        # gradient destinations: (name in me_block_grads, parameter, index into needs_input_grad)
+        slots = [("ln1_g", blk.norm1.weight, 1), ("ln1_b", blk.norm1.bias, 2), ("qkv_w", blk.attn.qkv.weight, 3),
+                 ("qkv_b", blk.attn.qkv.bias, 4), ("proj_w", blk.attn.proj.weight, 5), ("proj_b", blk.attn.proj.bias, 6),
+                 ("ln2_g", blk.norm2.weight, 7), ("ln2_b", blk.norm2.bias, 8), ("fc1_w", blk.mlp.fc1.weight, 9),
+                 ("fc1_b", blk.mlp.fc1.bias, 10), ("fc2_w", blk.mlp.fc2.weight, 11), ("fc2_b", blk.mlp.fc2.bias, 12)]
+        slots = [(n, p, i) for n, p, i in slots if p is not None and ng[i]]
+        # in place into a FlatParams buffer (accumulating) when EVERY wanted gradient lives there, else fresh tensors
+        flat = getattr(blk.attn.qkv.weight, "_me_flat", None)
+        direct = None
+        if flat is not None and slots and all(p.dtype == torch.float32 and getattr(p, "_me_flat", None) is flat for _, p, _ in slots):
+            direct = [flat.direct_grad(p) for _, p, _ in slots]
+            if any(t is None for t in direct):
+                direct = None
+        g = _capi.BlockGrads()
+        wdt = blk.attn.qkv.weight.dtype
+        g.w_dtype = _capi.dtype_code(wdt if wdt != torch.float16 else torch.float32)
+        g.accumulate = 1 if direct is not None else 0
+        outs = {}
+        for j, (n, p, i) in enumerate(slots):
+            if direct is not None:
+                t = direct[j]
+            elif n.endswith("_w"):
+                t = torch.empty(p.shape, dtype=wdt if wdt != torch.float16 else torch.float32, device=p.device)
+            else:
+                t = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+            outs[i] = t
+            setattr(g, n, ops.ptr(t))
+        dx = ops.block_bwd(d, x2, dy2, saved, g)
+        del keep
+        res = [None] * 20
+        res[0] = ops.cast(dx, ctx.in_dtype).reshape(B, N, C) if ng[0] else None
+        for n, p, i in slots:
+            if direct is not None:
+                flat.grad_written(p)
+            else:
+                t = outs[i]
+                res[i] = t if t.dtype == p.dtype else (ops.cast(t, p.dtype) if t.dim() == 2 else t.to(p.dtype))
+        return tuple(res)
+
+    @staticmethod
     def backward(ctx, dy):
+        if ctx.fast:
+            return _BlockFn._backward_c(ctx, dy)
         (x2, mean1, rstd1, xn1, qkv, lse, o, x1, mean2, rstd2, xn2, hpre, a,
          n1w, qkvw, projw, n2w, fc1w, fc2w, g1, g2, t1, t2, o_att) = ctx.saved_tensors
         blk, cdt = ctx.blk, ctx.cdt
@@ -301,6 +378,7 @@ class Block(nn.Module):
             self.gamma1 = nn.Parameter(torch.ones(dim))
             self.gamma2 = nn.Parameter(torch.ones(dim))
         self.compute_dtype: Optional[torch.dtype] = None     # override; None = infer (autocast / param dtype)
+        self.c_side = True          # plain blocks run as one me_block_fwd / me_block_bwd call; False = op-by-op composition
         self._wcache = _WeightCache()
 
     def _compute_dtype(self, x: torch.Tensor) -> torch.dtype:

@@ -19,7 +19,17 @@ WEIGHT_EPOCH = 0
 
 # bench.py sets this to a list to bracket every me_gemm launch with events on the launch stream:
 # entries are (op, ab_dtype_code, M, N, K, start_event, end_event).
-GEMM_PROFILE = None
+def gemm_profile(on: bool) -> None:
+    """Start (and reset) / stop the library's per-launch HIP-event timing of me_gemm (also inside me_block_fwd/bwd)."""
+    check(_capi.load().me_gemm_profile_enable(1 if on else 0), "me_gemm_profile_enable")
+
+
+def gemm_profile_read(max_records: int = 1 << 16):
+    """-> [(op, ab_dtype, M, N, K, ms)] in call order since gemm_profile(True); waits for the recorded events"""
+    lib = _capi.load()
+    buf = (_capi.GemmProfileRec * max_records)()
+    n = lib.me_gemm_profile_read(buf, max_records)
+    return [(r.op, r.ab_dtype, r.M, r.N, r.K, r.ms) for r in buf[:min(n, max_records)]]
 
 
 def _req(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -150,14 +160,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
     if ws_bytes:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device); keep.append(ws)
         d.workspace, d.workspace_bytes = ptr(ws), ws_bytes
-    if GEMM_PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib.me_gemm(ctypes.byref(d), stream_ptr()), "me_gemm")
-        e1.record()
-        GEMM_PROFILE.append((op, d.ab_dtype, M, N, K, e0, e1))
-    else:
-        check(lib.me_gemm(ctypes.byref(d), stream_ptr()), "me_gemm")
+    check(lib.me_gemm(ctypes.byref(d), stream_ptr()), "me_gemm")
     if want_colsum_a:
         if cs is None:      # not fusable for this problem: separate pass over a
             cs = colsum(a2, out=colsum_out, accumulate=beta != 0.0)
@@ -176,6 +179,44 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
     check(lib.me_colsum(ptr(x2), dtype_code(x.dtype), x2.stride(0), rows, cols, ptr(out), 1 if accumulate else 0, ptr(ws),
                         stream_ptr()), "me_colsum")
     return out
+
+
+# ----------------------------------------------------------------------------- whole block (C-side composition)
+
+def block_desc(B, N, C, heads, hidden, eps, scale, cdt, rdt, w, wt, vec) -> "_capi.BlockDesc":
+    """w / wt: dicts name -> tensor (compute dtype) for qkv, proj, fc1, fc2 (wt may be None); vec: dict of fp32 vectors
+    ln1_g, ln1_b, ln2_g, ln2_b, qkv_b, proj_b, fc1_b, fc2_b, gamma1, gamma2 (None = absent).  The caller keeps the
+    tensors alive for the duration of the call."""
+    d = _capi.BlockDesc()
+    d.dtype, d.res_dtype = dtype_code(cdt), dtype_code(rdt)
+    d.B, d.N, d.C, d.heads, d.hidden, d.eps, d.scale = B, N, C, heads, hidden, eps, scale
+    for k in ("qkv", "proj", "fc1", "fc2"):
+        setattr(d, k + "_w", ptr(w[k]))
+        setattr(d, k + "_wt", ptr(wt[k]) if wt is not None else None)
+    for k, t in vec.items():
+        setattr(d, k, ptr(t))
+    return d
+
+
+def block_fwd(d, x2: torch.Tensor, keep: bool):
+    """-> (y, saved or None)"""
+    lib = _capi.load()
+    y = torch.empty_like(x2)
+    saved = torch.empty(lib.me_block_saved_bytes(ctypes.byref(d)), dtype=torch.uint8, device=x2.device) if keep else None
+    wsb = lib.me_block_workspace_bytes(ctypes.byref(d), 0)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x2.device)
+    check(lib.me_block_fwd(ctypes.byref(d), ptr(x2), ptr(y), ptr(saved), ptr(ws), wsb, stream_ptr()), "me_block_fwd")
+    return y, saved
+
+
+def block_bwd(d, x2: torch.Tensor, dy2: torch.Tensor, saved: torch.Tensor, grads: "_capi.BlockGrads") -> torch.Tensor:
+    lib = _capi.load()
+    dx = torch.empty_like(x2)
+    wsb = lib.me_block_workspace_bytes(ctypes.byref(d), 1)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x2.device)
+    check(lib.me_block_bwd(ctypes.byref(d), ptr(x2), ptr(dy2), ptr(saved), ptr(dx), ctypes.byref(grads), ptr(ws), wsb,
+                           stream_ptr()), "me_block_bwd")
+    return dx
 
 
 # ----------------------------------------------------------------------------- attention

@@ -43,17 +43,14 @@ def test_header_symbols_all_bound_and_exported(lib):
     assert lib.me_build_arch() == b"gfx950"
 
 
-def test_gemm_desc_layout_matches_c():
-    code = r'''
-#include <stdio.h>
-#include <stddef.h>
-#include "metaenc.h"
-#define P(f) printf(#f " %zu\n", offsetof(me_gemm_desc, f))
-int main(void){ printf("size %zu\n", sizeof(me_gemm_desc));
-P(op);P(ab_dtype);P(M);P(N);P(K);P(A);P(lda);P(B);P(ldb);P(C);P(ldc);P(c_dtype);P(act);P(alpha);P(beta);P(bias);
-P(colscale);P(preact);P(ldpre);P(preact_dtype);P(aux_dtype);P(aux);P(ldaux);P(residual);P(ldres);P(res_dtype);
-P(reserved0);P(res_row_mod);P(out_group_rows);P(out_group_stride);P(out_row_offset);P(workspace);P(workspace_bytes);P(colsum_a); return 0; }
-'''
+@pytest.mark.parametrize("cname,pyname", [("me_gemm_desc", "GemmDesc"), ("me_block_desc", "BlockDesc"),
+                                          ("me_block_grads", "BlockGrads"), ("me_gemm_profile_rec", "GemmProfileRec")])
+def test_struct_layouts_match_c(cname, pyname):
+    """every struct that crosses the C ABI: size and field offsets of the ctypes mirror == what gcc lays out from the header"""
+    cls = getattr(_capi, pyname)
+    fields = [n for n, _ in cls._fields_]
+    code = ('#include <stdio.h>\n#include <stddef.h>\n#include "metaenc.h"\nint main(void){ printf("size %zu\\n", sizeof('
+            + cname + '));\n' + "".join(f'printf("{f} %zu\\n", offsetof({cname}, {f}));\n' for f in fields) + "return 0; }\n")
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(code)
@@ -61,9 +58,9 @@ P(reserved0);P(res_row_mod);P(out_group_rows);P(out_group_stride);P(out_row_offs
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
     got = dict(l.split() for l in out if l)
-    assert int(got.pop("size")) == ctypes.sizeof(_capi.GemmDesc)
-    for name, _ in _capi.GemmDesc._fields_:
-        assert int(got[name]) == getattr(_capi.GemmDesc, name).offset, name
+    assert int(got.pop("size")) == ctypes.sizeof(cls)
+    for name in fields:
+        assert int(got[name]) == getattr(cls, name).offset, name
 
 
 def test_product_never_imports_oracle():

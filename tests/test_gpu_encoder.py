@@ -145,6 +145,29 @@ def test_fp16_call_sites_run_on_bf16_kernels(dev, mode):
         assert p.grad.dtype == p.dtype and rel_err(p.grad.float(), dp_ref[k]) < 6e-2, k
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_c_side_block_equals_op_by_op_composition(dev, dt):
+    """me_block_fwd / me_block_bwd (one call per block and direction) launch the same kernels in the same order as the
+    Python op-by-op composition: results must be bit-identical"""
+    c = dict(depth=2, dim=256, heads=4, eps=1e-6, seed=12)
+    g = torch.Generator().manual_seed(8)
+    x, go = torch.randn(3, 197, 256, generator=g).to(dev), torch.randn(3, 197, 256, generator=g).to(dev)
+    res = {}
+    for c_side in (True, False):
+        enc = make_encoder(c, dev).train()
+        for b in enc:
+            b.c_side = c_side
+        xr = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+            y = enc(xr)
+        (y * go).sum().backward()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+            y_inf = enc.eval()(x)
+        res[c_side] = [y.detach(), y_inf, xr.grad] + [p.grad for p in enc.parameters()]
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+
+
 def test_frozen_encoder_passes_input_grad_only(dev):
     """most reference pipelines freeze the encoder but train the tokenizer in front of it."""
     c = dict(depth=1, dim=128, heads=2, eps=1e-5, seed=6)
