@@ -203,6 +203,14 @@ int me_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
 /* dst[c, r] = (dst_dtype) src[r, c]  (weight repack for dgrad: W[out,in] -> W^T[in,out]) */
 int me_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
                       int64_t rows, int64_t cols, void* stream);
+/* The same for up to ME_TC_BATCH matrices in ONE launch (all dgrad copies of the encoder weights after an optimizer step:
+ * 48 launches of ~12 us each otherwise). */
+#define ME_TC_BATCH 48
+typedef struct me_tc_batch {
+    int32_t n, src_dtype, dst_dtype, reserved;
+    struct { const void* src; void* dst; int64_t rows, cols; } item[ME_TC_BATCH];
+} me_tc_batch;
+int me_transpose_cast_batched(const me_tc_batch* b, void* stream);
 /* y = x + pos (pos broadcast over batch: row m uses pos row m % pos_rows); PointCloud re-injects pos before
  * every block (PointCloud/openpoints/models/backbone/metatransformer.py:161-163). */
 int me_add_rows(const void* x, int x_dtype, const void* pos, int pos_dtype, void* y, int y_dtype,
@@ -265,7 +273,9 @@ int me_timeseries_embed(const float* x, const float* conv_w, const int32_t* mark
  * weight decay), grad_scale multiplies the gradient first (1/world_size after an all-reduce sum). */
 int me_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                  float grad_scale, void* stream);
+                  float grad_scale, void* bf16_mirror, void* stream);
+/* bf16_mirror (optional, n bf16 elements, same indexing as param): receives the updated parameters rounded to bf16 --
+ * the forward-layout compute copies of the weights come out of the optimizer pass instead of one cast launch per weight. */
 
 #ifdef __cplusplus
 }

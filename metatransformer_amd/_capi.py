@@ -56,6 +56,19 @@ class GemmProfileRec(ctypes.Structure):
                 ("reserved", c_int32)]
 
 
+ME_TC_BATCH = 48
+
+
+class _TcItem(ctypes.Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", c_int64), ("cols", c_int64)]
+
+
+class TcBatch(ctypes.Structure):
+    """Mirror of ``struct me_tc_batch``."""
+    _fields_ = [("n", c_int32), ("src_dtype", c_int32), ("dst_dtype", c_int32), ("reserved", c_int32),
+                ("item", _TcItem * ME_TC_BATCH)]
+
+
 class BlockDesc(ctypes.Structure):
     """Mirror of ``struct me_block_desc`` (include/metaenc.h)."""
     _fields_ = ([("dtype", c_int32), ("res_dtype", c_int32), ("B", c_int32), ("N", c_int32), ("C", c_int32),
@@ -105,6 +118,7 @@ SIGNATURES = {
                              c_size_t, c_void_p]),
     "me_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "me_transpose_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p]),
+    "me_transpose_cast_batched": (c_int, [POINTER(TcBatch), c_void_p]),
     "me_add_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "me_window_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "me_dropout_add": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_float, c_float,
@@ -114,7 +128,7 @@ SIGNATURES = {
     "me_timeseries_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_void_p), POINTER(c_int32),
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "me_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
-                              c_float, c_int, c_float, c_void_p]),
+                              c_float, c_int, c_float, c_void_p, c_void_p]),
 }
 
 _lib = None

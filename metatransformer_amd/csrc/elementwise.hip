@@ -57,6 +57,35 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const void* __restr
     }
 }
 
+// batched form: the block finds its matrix by walking the (<= 48 entry) tile-count prefix
+__global__ __launch_bounds__(256) void transpose_cast_batched_kernel(const me_tc_batch b) {
+    __shared__ float tile[64][65];
+    int64_t t = blockIdx.x;
+    int k = 0;
+    int64_t tx_tiles = 0;
+    for (; k < b.n; ++k) {
+        tx_tiles = (b.item[k].cols + 63) / 64;
+        const int64_t nt = tx_tiles * ((b.item[k].rows + 63) / 64);
+        if (t < nt) break;
+        t -= nt;
+    }
+    if (k >= b.n) return;
+    const void* src = b.item[k].src;
+    void* dst = b.item[k].dst;
+    const int64_t rows = b.item[k].rows, cols = b.item[k].cols;
+    const int64_t r0 = (t / tx_tiles) * 64, c0 = (t % tx_tiles) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? ld1_any(src, b.src_dtype, r * cols + c) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) st1_any(dst, b.dst_dtype, c * rows + r, tile[tx][i]);
+    }
+}
+
 __global__ __launch_bounds__(EW_THREADS) void add_rows_kernel(const void* __restrict__ x, int xdt,
                                                               const void* __restrict__ pos, int pdt, void* __restrict__ y,
                                                               int ydt, int64_t rows, int64_t pos_rows, int cols) {
@@ -331,7 +360,7 @@ __global__ __launch_bounds__(EW_THREADS) void dropout_add_kernel(const void* __r
 __global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                           float gscale) {
+                                                           float gscale, bf16_t* __restrict__ mirror) {
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
         const float gi = g[i] * gscale;
         float pi = p[i];
@@ -341,7 +370,9 @@ __global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p
         m[i] = mi;
         v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = pi - (lr / bc1) * (mi / denom);
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+        if (mirror) mirror[i] = (bf16_t)pi;
     }
 }
 
@@ -370,6 +401,23 @@ extern "C" int me_transpose_cast(const void* src, int src_dtype, void* dst, int 
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
     hipLaunchKernelGGL(transpose_cast_kernel, grid, dim3(256), 0, stream, src, src_dtype, dst, dst_dtype, rows, cols);
     ME_CHECK_LAUNCH("me_transpose_cast");
+    return ME_OK;
+}
+
+extern "C" int me_transpose_cast_batched(const me_tc_batch* b, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(b && b->n >= 0 && b->n <= ME_TC_BATCH, "me_transpose_cast_batched: bad batch");
+    ME_CHECK_ARG(me_storage_dtype_ok(b->src_dtype) && me_storage_dtype_ok(b->dst_dtype), "me_transpose_cast_batched: bad dtype");
+    int64_t tiles = 0;
+    for (int k = 0; k < b->n; ++k) {
+        ME_CHECK_ARG(b->item[k].src && b->item[k].dst && b->item[k].rows > 0 && b->item[k].cols > 0,
+                     "me_transpose_cast_batched: bad item %d", k);
+        tiles += ((b->item[k].cols + 63) / 64) * ((b->item[k].rows + 63) / 64);
+    }
+    if (tiles == 0) return ME_OK;
+    ME_CHECK_ARG(tiles < (1ll << 31), "me_transpose_cast_batched: too many tiles");
+    hipLaunchKernelGGL(transpose_cast_batched_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, *b);
+    ME_CHECK_LAUNCH("me_transpose_cast_batched");
     return ME_OK;
 }
 
@@ -501,14 +549,14 @@ extern "C" int me_timeseries_embed(const float* x, const float* conv_w, const in
 
 extern "C" int me_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                             void* stream_) {
+                             void* bf16_mirror, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ME_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "me_adamw_step: bad args");
     if (n == 0) return ME_OK;
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, param, grad, exp_avg, exp_avg_sq, n, lr,
-                       beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+                       beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale, reinterpret_cast<bf16_t*>(bf16_mirror));
     ME_CHECK_LAUNCH("me_adamw_step");
     return ME_OK;
 }

@@ -75,11 +75,37 @@ class Attention(nn.Module):
 
 class _WeightCache:
     """Compute-dtype copies of the four weight matrices of a block ([out,in] for forward, transposed
-    [in,out] for dgrad), rebuilt when the parameter changes (optimizer step / load_state_dict / .to())."""
+    [in,out] for dgrad), rebuilt when the parameter changes (optimizer step / load_state_dict / .to()).
+
+    Two shortcuts keep the per-step refresh off the critical path: forward bf16 copies come straight out of the fused
+    optimizer's bf16 mirror when the parameters live in a parallel.FlatParams, and a stale TRANSPOSED copy triggers one
+    batched transpose of every stale weight of every live Block on the device (one launch instead of four per block)."""
+
+    _live = None          # weakref.WeakSet of all caches (set up lazily)
 
     def __init__(self):
+        import weakref
         self._fwd = {}
         self._tr = {}
+        self._owner = None          # weakref to the Block, set by Block.__init__
+        if _WeightCache._live is None:
+            _WeightCache._live = weakref.WeakSet()
+        _WeightCache._live.add(self)
+
+    # a cache is derived state: copies / pickles of a Block start with an empty one (re-bound to the new owner on first use)
+    def __deepcopy__(self, memo):
+        return _WeightCache()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
+    def bind(self, blk) -> None:
+        if self._owner is None or self._owner() is not blk:
+            import weakref
+            self._owner = weakref.ref(blk)
 
     @staticmethod
     def _key(p: torch.Tensor, dtype):
@@ -88,6 +114,12 @@ class _WeightCache:
     def fwd(self, name: str, p: torch.Tensor, dtype) -> torch.Tensor:
         if p.dtype == dtype:
             return p.detach()
+        if dtype == torch.bfloat16:
+            flat = getattr(p, "_me_flat", None)
+            if flat is not None:
+                v = flat.bf16_view(p)
+                if v is not None:
+                    return v
         k = self._key(p, dtype)
         hit = self._fwd.get(name)
         if hit is None or hit[0] != k:
@@ -95,12 +127,31 @@ class _WeightCache:
             self._fwd[name] = hit
         return hit[1]
 
+    def _weights(self):
+        blk = self._owner() if self._owner is not None else None
+        if blk is None:
+            return {}
+        return {"qkv": blk.attn.qkv.weight, "proj": blk.attn.proj.weight, "fc1": blk.mlp.fc1.weight, "fc2": blk.mlp.fc2.weight}
+
     def transposed(self, name: str, p: torch.Tensor, dtype) -> torch.Tensor:
         k = self._key(p, dtype)
         hit = self._tr.get(name)
         if hit is None or hit[0] != k:
-            hit = (k, ops.transpose_cast(p.detach().contiguous(), dtype))
-            self._tr[name] = hit
+            # refresh every stale transposed copy on this device in one go
+            todo = []
+            for c in list(_WeightCache._live):
+                for n, w in c._weights().items():
+                    if w.device == p.device and w.dtype == p.dtype and w.dim() == 2:
+                        kk = _WeightCache._key(w, dtype)
+                        h = c._tr.get(n)
+                        if h is None or h[0] != kk:
+                            todo.append((c, n, kk, w))
+            if not any(c is self and n == name for c, n, _, _ in todo):
+                todo.append((self, name, k, p))
+            outs = ops.transpose_cast_many([w.detach().contiguous() for _, _, _, w in todo], dtype)
+            for (c, n, kk, _), t in zip(todo, outs):
+                c._tr[n] = (kk, t)
+            hit = self._tr[name]
         return hit[1]
 
 
@@ -416,6 +467,7 @@ class Block(nn.Module):
                 # one seed per call from torch's CPU generator (reproducible under torch.manual_seed)
                 seed = int(torch.empty((), dtype=torch.int64).random_().item())
                 stoch = (float(self.mlp.drop.p), self.drop_path_prob, seed)
+        self._wcache.bind(self)
         cdt = self._compute_dtype(x)
         if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise MetaEncError(f"unsupported token dtype {x.dtype}")

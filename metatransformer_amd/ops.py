@@ -267,6 +267,26 @@ def transpose_cast(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return y
 
 
+def transpose_cast_many(ws, dtype: torch.dtype):
+    """[rows, cols] -> [cols, rows] in `dtype` for a list of same-dtype matrices, ME_TC_BATCH per launch"""
+    lib = _capi.load()
+    outs = []
+    for i in range(0, len(ws), _capi.ME_TC_BATCH):
+        chunk = ws[i:i + _capi.ME_TC_BATCH]
+        b = _capi.TcBatch()
+        b.n, b.src_dtype, b.dst_dtype = len(chunk), dtype_code(chunk[0].dtype, True), dtype_code(dtype, True)
+        for k, w in enumerate(chunk):
+            _req(w, "w")
+            if w.dtype != chunk[0].dtype:
+                raise MetaEncError("transpose_cast_many: matrices must share a dtype")
+            rows, cols = w.shape
+            y = torch.empty((cols, rows), dtype=dtype, device=w.device)
+            outs.append(y)
+            b.item[k].src, b.item[k].dst, b.item[k].rows, b.item[k].cols = ptr(w), ptr(y), rows, cols
+        check(lib.me_transpose_cast_batched(ctypes.byref(b), stream_ptr()), "me_transpose_cast_batched")
+    return outs
+
+
 def add_rows(x: torch.Tensor, pos: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """x[B*N, C] + pos[(row % pos_rows), C]"""
     lib = _capi.load()
@@ -359,13 +379,15 @@ def unpatchify_add(dcols: torch.Tensor, x_shape, kt, kh, kw, st, sh, sw) -> torc
 
 def adamw_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
                betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01, step: int = 1,
-               grad_scale: float = 1.0) -> None:
+               grad_scale: float = 1.0, bf16_mirror: Optional[torch.Tensor] = None) -> None:
     lib = _capi.load()
+    if bf16_mirror is not None and (bf16_mirror.dtype != torch.bfloat16 or bf16_mirror.numel() != param.numel()):
+        raise MetaEncError("adamw_step: bf16_mirror must be a bfloat16 tensor of the parameter buffer's size")
     for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _req(t, n)
         if t.dtype != torch.float32:
             raise MetaEncError(f"adamw_step: {n} must be float32")
     check(lib.me_adamw_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, betas[0], betas[1],
-                            eps, weight_decay, step, grad_scale, stream_ptr()), "me_adamw_step")
+                            eps, weight_decay, step, grad_scale, ptr(bf16_mirror), stream_ptr()), "me_adamw_step")
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1

@@ -45,6 +45,9 @@ class FlatParams:
         self.numel = off
         self.flat_param = torch.zeros(off, dtype=dt, device=dev)
         self.flat_grad = torch.zeros(off, dtype=dt, device=dev)
+        self.flat_bf16: Optional[torch.Tensor] = None      # bf16 mirror of flat_param, written by the fused optimizer
+        self._mirror_epoch = -1
+        self._mirror_versions: List[int] = []
         self._index = {}
         self._listeners = []        # callables(param_index): a gradient was written straight into the flat buffer
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
@@ -66,6 +69,17 @@ class FlatParams:
         if p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size() or p.grad.shape != p.shape:
             return None
         return p.grad
+
+    def bf16_view(self, p: torch.nn.Parameter) -> Optional[torch.Tensor]:
+        """bf16 copy of p out of the optimizer's mirror, or None when there is none / it is stale (the parameter was
+        written by anything but the fused optimizer since: load_state_dict, manual edits -> _version moved on)."""
+        i = self._index.get(id(p))
+        if i is None or self.flat_bf16 is None or self._mirror_epoch != ops.WEIGHT_EPOCH or self._mirror_versions[i] != p._version:
+            return None
+        o = self.offsets[i]
+        if p.data_ptr() != self.flat_param.data_ptr() + o * self.flat_param.element_size():
+            return None
+        return self.flat_bf16[o:o + p.numel()].view(p.shape)
 
     def grad_written(self, p: torch.nn.Parameter) -> None:
         i = self._index[id(p)]
@@ -199,15 +213,25 @@ def allreduce_coalesced(tensors: Sequence[torch.Tensor], group=None, bucket_byte
 class FusedAdamW:
     """AdamW over a FlatParams with ONE kernel launch (me_adamw_step); torch.optim.AdamW semantics."""
 
-    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bf16_mirror: bool = True):
+        """bf16_mirror: also emit the updated parameters in bf16 (FlatParams.flat_bf16) from the same kernel; Blocks
+        running in bf16 then take their forward weight copies from it instead of re-casting every weight."""
         if flat.flat_param.dtype != torch.float32:
             raise MetaEncError("FusedAdamW needs fp32 master parameters")
         self.flat, self.lr, self.betas, self.eps, self.wd = flat, lr, betas, eps, weight_decay
+        self.bf16_mirror = bf16_mirror
         self.exp_avg = torch.zeros_like(flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(flat.flat_param)
         self.t = 0
 
     def step(self, grad_scale: float = 1.0) -> None:
         self.t += 1
-        ops.adamw_step(self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, lr=self.lr,
-                       betas=self.betas, eps=self.eps, weight_decay=self.wd, step=self.t, grad_scale=grad_scale)
+        f = self.flat
+        if self.bf16_mirror and f.flat_bf16 is None:
+            f.flat_bf16 = torch.empty(f.numel, dtype=torch.bfloat16, device=f.flat_param.device)
+        ops.adamw_step(f.flat_param, f.flat_grad, self.exp_avg, self.exp_avg_sq, lr=self.lr,
+                       betas=self.betas, eps=self.eps, weight_decay=self.wd, step=self.t, grad_scale=grad_scale,
+                       bf16_mirror=f.flat_bf16 if self.bf16_mirror else None)
+        if self.bf16_mirror:      # valid for this weight epoch as long as nobody else writes the parameters
+            f._mirror_epoch = ops.WEIGHT_EPOCH
+            f._mirror_versions = [p._version for p in f.params]

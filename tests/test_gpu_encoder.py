@@ -168,6 +168,44 @@ def test_c_side_block_equals_op_by_op_composition(dev, dt):
         assert torch.equal(a, b)
 
 
+def test_optimizer_mirror_and_batched_transposes(dev):
+    """FusedAdamW's bf16 mirror feeds the forward weight copies, stale transposed copies of ALL blocks are rebuilt in one
+    batched launch; results equal the per-weight refresh (mirror off), also after load_state_dict and on a deepcopy"""
+    import copy
+    from metatransformer_amd import parallel, ops
+    c = dict(depth=3, dim=128, heads=2, eps=1e-5, seed=13)
+    g = torch.Generator().manual_seed(2)
+    xs = [torch.randn(2, 100, 128, generator=g).to(dev) for _ in range(3)]
+    outs = {}
+    for mirror in (True, False):
+        enc = make_encoder(c, dev).train()
+        flat = parallel.FlatParams(enc.parameters())
+        opt = parallel.FusedAdamW(flat, lr=1e-2, bf16_mirror=mirror)
+        ys = []
+        for x in xs:
+            flat.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = enc(x)
+            y.float().square().mean().backward()
+            opt.step()
+            ys.append(y.detach().clone())
+        if mirror:
+            w = enc[0].attn.qkv.weight
+            assert flat.bf16_view(w) is not None and torch.equal(flat.bf16_view(w), w.detach().bfloat16())
+            tr = enc[1]._wcache.transposed("fc1", enc[1].mlp.fc1.weight, torch.bfloat16)      # refreshes every block at once
+            assert torch.equal(tr, enc[1].mlp.fc1.weight.detach().bfloat16().t())
+            assert all(len(b._wcache._tr) == 4 for b in enc)
+            with torch.no_grad():
+                w.mul_(2.0)                                   # a write the optimizer did not make: the mirror is stale
+            assert flat.bf16_view(w) is None
+            enc2 = copy.deepcopy(enc).eval()                 # caches are not shared with the copy
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                assert torch.equal(enc2(xs[0]), enc.eval()(xs[0]))
+        outs[mirror] = ys
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)
+
+
 def test_frozen_encoder_passes_input_grad_only(dev):
     """most reference pipelines freeze the encoder but train the tokenizer in front of it."""
     c = dict(depth=1, dim=128, heads=2, eps=1e-5, seed=6)
