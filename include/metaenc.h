@@ -146,13 +146,16 @@ int me_colsum_mul(const void* x, int x_dtype, int64_t ldx, const void* y, int y_
  * normally 3C).  out is [B*N, C] head-major.  lse ([B,H,N] fp32, may be NULL) = log-sum-exp of the scaled
  * scores, needed by backward.  scale is applied to the scores in fp32 AFTER QK^T (attention.py:31). */
 int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse,
-                     int B, int N, int H, int head_dim, float scale, int dtype, void* stream);
+                     int B, int N, int H, int head_dim, float scale, int dtype, float p_drop, uint64_t seed, void* stream);
+/* p_drop > 0: attn_drop of attention.py:33 in training mode (the Graph call site, tokengt_graph_encoder.py:191-205, 0.1):
+ * each softmax probability is kept with probability 1 - p_drop and scaled by 1/(1 - p_drop) before P V; the mask is a
+ * counter-based hash of (seed, b, h, q, k), so me_attention_bwd with the same p_drop / seed regenerates it. */
 
 /* Backward of the above.  dqkv has the layout of qkv.  delta ([B,H,N] fp32) is scratch the caller provides. */
 int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out, int64_t ld_out,
                      const void* dout, int64_t ld_dout, const float* lse, float* delta,
                      void* dqkv, int64_t ld_dqkv,
-                     int B, int N, int H, int head_dim, float scale, int dtype, void* stream);
+                     int B, int N, int H, int head_dim, float scale, int dtype, float p_drop, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------ One encoder Block, composed on the C side
  * Block.forward / its autograd (PointCloud/openpoints/models/layers/attention.py:55-58) as ONE call each: the same

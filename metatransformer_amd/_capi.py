@@ -108,9 +108,10 @@ SIGNATURES = {
     "me_colsum_mul": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int,
                               c_void_p, c_void_p]),
     "me_attention_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int,
-                                 c_float, c_int, c_void_p]),
+                                 c_float, c_int, c_float, ctypes.c_uint64, c_void_p]),
     "me_attention_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
-                                 c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+                                 c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, c_float, ctypes.c_uint64,
+                                 c_void_p]),
     "me_block_saved_bytes": (c_size_t, [POINTER(BlockDesc)]),
     "me_block_workspace_bytes": (c_size_t, [POINTER(BlockDesc), c_int]),
     "me_block_fwd": (c_int, [POINTER(BlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

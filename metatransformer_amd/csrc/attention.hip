@@ -207,7 +207,7 @@ template <typename T, int HD>
 __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restrict__ qkv, int64_t ld,
                                                               T* __restrict__ out, int64_t ldo,
                                                               float* __restrict__ lse, int N, int H, int hd,
-                                                              float scale) {
+                                                              float scale, float p_drop, uint64_t seed) {
     typedef Cfg<T, HD> C;
     typedef typename Chunk<T>::type chunk_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -290,6 +290,15 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
             }
         l_run = l_run * alpha + ps;
         m_run = m_new;
+        if (p_drop > 0.f) {      // attn_drop (attention.py:33): mask the NORMALISED probabilities -- the row sum stays unmasked
+            const float keep = 1.0f / (1.0f - p_drop);
+            const uint64_t rowbase = (((uint64_t)b * H + head) * N + (uint64_t)(qbase + l31)) * (uint64_t)N;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    s[u][r] = u01_hash(seed, rowbase + (uint64_t)(kv0 + 32 * u + acc_row(r, h))) >= p_drop ? s[u][r] * keep : 0.f;
+        }
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db) o[db] *= alpha;
 #pragma unroll
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkdv_kernel(const T* __re
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ delta,
                                                                    T* __restrict__ dqkv, int64_t lddq, int N, int H,
-                                                                   int hd, float scale) {
+                                                                   int hd, float scale, float p_drop, uint64_t seed) {
     typedef Cfg<T, HD> C;
     typedef typename Chunk<T>::type chunk_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -476,8 +485,15 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkdv_kernel(const T* __re
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
                     const float p = kv_ok ? __expf(s[u][r] * scale - L[e]) : 0.f;
-                    s[u][r] = p;                                   // P
-                    dp[u][r] = p * (dp[u][r] - D[e]) * scale;      // dS
+                    float pm = p, dpm = dp[u][r];
+                    if (p_drop > 0.f) {      // same mask as forward: dV sees the dropped P, dS the dropped dP
+                        const uint64_t q = (uint64_t)(j * KVT + 32 * u + acc_row(r, h));
+                        const uint64_t idx = (((uint64_t)b * H + head) * N + q) * (uint64_t)N + (uint64_t)(kvbase + l31);
+                        const float k = u01_hash(seed, idx) >= p_drop ? 1.0f / (1.0f - p_drop) : 0.f;
+                        pm *= k; dpm *= k;
+                    }
+                    s[u][r] = pm;                                  // (dropped) P
+                    dp[u][r] = p * (dpm - D[e]) * scale;           // dS
                 }
             }
 #pragma unroll
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
                                                                  const float* __restrict__ lse,
                                                                  const float* __restrict__ delta,
                                                                  T* __restrict__ dqkv, int64_t lddq, int N, int H,
-                                                                 int hd, float scale) {
+                                                                 int hd, float scale, float p_drop, uint64_t seed) {
     typedef Cfg<T, HD> C;
     typedef typename Chunk<T>::type chunk_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -586,7 +602,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
             for (int r = 0; r < 16; ++r) {
                 const int kv = kv0 + 32 * u + acc_row(r, h);
                 const float p = (kv < N) ? __expf(s[u][r] * scale - lse_q) : 0.f;
-                dp[u][r] = p * (dp[u][r] - del_q) * scale;     // dS^T
+                float dpm = dp[u][r];
+                if (p_drop > 0.f) {
+                    const uint64_t idx = (((uint64_t)b * H + head) * N + (uint64_t)(qbase + l31)) * (uint64_t)N + (uint64_t)kv;
+                    dpm = u01_hash(seed, idx) >= p_drop ? dpm * (1.0f / (1.0f - p_drop)) : 0.f;
+                }
+                dp[u][r] = p * (dpm - del_q) * scale;          // dS^T
             }
 #pragma unroll
         for (int c = 0; c < C::NPC; ++c) {
@@ -1106,21 +1127,21 @@ int launch_bwd_small(const void* qkv, int64_t ld, const void* out, int64_t ldo, 
 
 template <typename T, int HD>
 int launch_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
-               hipStream_t stream) {
+               float p_drop, uint64_t seed, hipStream_t stream) {
     typedef Cfg<T, HD> C;
     const size_t smem = C::R_BYTES + (C::T_BYTES > C::R_BYTES ? C::T_BYTES : C::R_BYTES);   // V tile: transposed (fp32) or row-major (bf16)
     static bool once = false;
     if (!once) { set_smem(attn_fwd_kernel<T, HD>, smem); once = true; }
     dim3 grid((N + QPB - 1) / QPB, H, B);
     hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), grid, dim3(AT_THREADS), smem, stream, reinterpret_cast<const T*>(qkv), ld,
-                       reinterpret_cast<T*>(out), ldo, lse, N, H, hd, scale);
+                       reinterpret_cast<T*>(out), ldo, lse, N, H, hd, scale, p_drop, seed);
     ME_CHECK_LAUNCH("me_attention_fwd");
     return ME_OK;
 }
 
 template <typename T, int HD>
 int launch_bwd(const void* qkv, int64_t ld, const void* dout, int64_t lddo, const float* lse, const float* delta, void* dqkv,
-               int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
+               int64_t lddq, int B, int N, int H, int hd, float scale, float p_drop, uint64_t seed, hipStream_t stream) {
     typedef Cfg<T, HD> C;
     const size_t smem1 = 2 * C::R_BYTES + 2 * C::T_BYTES + 2 * KVT * sizeof(float);
     const size_t smem2 = 2 * C::R_BYTES + C::T_BYTES;
@@ -1133,11 +1154,11 @@ int launch_bwd(const void* qkv, int64_t ld, const void* dout, int64_t lddo, cons
     dim3 grid((N + QPB - 1) / QPB, H, B);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, HD>), grid, dim3(AT_THREADS), smem1, stream,
                        reinterpret_cast<const T*>(qkv), ld, reinterpret_cast<const T*>(dout), lddo, lse, delta,
-                       reinterpret_cast<T*>(dqkv), lddq, N, H, hd, scale);
+                       reinterpret_cast<T*>(dqkv), lddq, N, H, hd, scale, p_drop, seed);
     ME_CHECK_LAUNCH("me_attention_bwd(dkdv)");
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), grid, dim3(AT_THREADS), smem2, stream,
                        reinterpret_cast<const T*>(qkv), ld, reinterpret_cast<const T*>(dout), lddo, lse, delta,
-                       reinterpret_cast<T*>(dqkv), lddq, N, H, hd, scale);
+                       reinterpret_cast<T*>(dqkv), lddq, N, H, hd, scale, p_drop, seed);
     ME_CHECK_LAUNCH("me_attention_bwd(dq)");
     return ME_OK;
 }
@@ -1169,29 +1190,32 @@ int check_attn_args(const char* fn, int64_t ld, int B, int N, int H, int hd, int
     } while (0)
 
 extern "C" int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int B, int N,
-                                int H, int head_dim, float scale, int dtype, void* stream_) {
+                                int H, int head_dim, float scale, int dtype, float p_drop, uint64_t seed, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ME_CHECK_ARG(qkv && out, "me_attention_fwd: null pointer");
     int rc = check_attn_args("me_attention_fwd", ld_qkv, B, N, H, head_dim, dtype);
     if (rc) return rc;
     ME_CHECK_ARG(ld_out % 4 == 0, "me_attention_fwd: ld_out must be a multiple of 4");
-    if (dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN && small_path_enabled()) {
+    ME_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "me_attention_fwd: p_drop must be in [0, 1)");
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN && small_path_enabled()) {
         if (head_dim <= 32) return launch_fwd_small<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
         return launch_fwd_small<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
     }
-    ATTN_DISPATCH(launch_fwd, qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+    ATTN_DISPATCH(launch_fwd, qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, p_drop, seed, stream);
 }
 
 extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out, int64_t ld_out, const void* dout,
                                 int64_t ld_dout, const float* lse, float* delta, void* dqkv, int64_t ld_dqkv, int B,
-                                int N, int H, int head_dim, float scale, int dtype, void* stream_) {
+                                int N, int H, int head_dim, float scale, int dtype, float p_drop, uint64_t seed,
+                                void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ME_CHECK_ARG(qkv && out && dout && lse && delta && dqkv, "me_attention_bwd: null pointer");
     int rc = check_attn_args("me_attention_bwd", ld_qkv, B, N, H, head_dim, dtype);
     if (rc) return rc;
     const int E = dtype == ME_BF16 ? 8 : 4;
     ME_CHECK_ARG(ld_dout % E == 0 && ld_dqkv % 4 == 0, "me_attention_bwd: bad strides");
-    if (dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN && ld_out % 8 == 0 && small_path_enabled()) {
+    ME_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "me_attention_bwd: p_drop must be in [0, 1)");
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN && ld_out % 8 == 0 && small_path_enabled()) {
         if (head_dim <= 32)
             return launch_bwd_small<32>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim,
                                         scale, stream);
@@ -1209,5 +1233,5 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, stream, out, ld_out, dout, ld_dout,
                            dtype, delta, N, H, head_dim, rows);
     ME_CHECK_LAUNCH("me_attention_bwd(delta)");
-    ATTN_DISPATCH(launch_bwd, qkv, ld_qkv, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale, stream);
+    ATTN_DISPATCH(launch_bwd, qkv, ld_qkv, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale, p_drop, seed, stream);
 }

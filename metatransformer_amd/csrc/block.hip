@@ -132,7 +132,7 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C3, s.C, v.xn1, s.C, d->qkv_w, s.C, v.qkv, s.C3, dt);
     g.bias = d->qkv_b; g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
     if ((rc = me_gemm(&g, stream))) return rc;
-    rc = me_attention_fwd(v.qkv, s.C3, v.o, s.C, keep ? v.lse : nullptr, d->B, d->N, d->heads, s.hd, d->scale, dt, stream);
+    rc = me_attention_fwd(v.qkv, s.C3, v.o, s.C, keep ? v.lse : nullptr, d->B, d->N, d->heads, s.hd, d->scale, dt, 0.f, 0, stream);
     if (rc) return rc;
     gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C, s.C, v.o, s.C, d->proj_w, s.C, v.x1, s.C, rdt);
     g.bias = d->proj_b; g.colscale = d->gamma1; g.residual = x; g.ldres = s.C; g.res_dtype = rdt;
@@ -222,7 +222,7 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
     }
     if ((rc = nt(dx1c, s.C, d->proj_wt, dout, s.C, nullptr))) return rc;
     if ((rc = wgrad(dx1c, s.C, v.o, s.C, gr->proj_w, gr->proj_b))) return rc;
-    rc = me_attention_bwd(v.qkv, s.C3, v.o, s.C, dout, s.C, v.lse, delta, dqkv, s.C3, d->B, d->N, d->heads, s.hd, d->scale, dt, stream);
+    rc = me_attention_bwd(v.qkv, s.C3, v.o, s.C, dout, s.C, v.lse, delta, dqkv, s.C3, d->B, d->N, d->heads, s.hd, d->scale, dt, 0.f, 0, stream);
     if (rc) return rc;
     if ((rc = nt(dqkv, s.C3, d->qkv_wt, dxn, s.C, nullptr))) return rc;
     if ((rc = wgrad(dqkv, s.C3, v.xn1, s.C, gr->qkv_w, gr->qkv_b))) return rc;

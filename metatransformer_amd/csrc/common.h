@@ -84,6 +84,16 @@ __device__ __forceinline__ void store1_from_f32(void* base, int dt, int64_t idx,
     else reinterpret_cast<float*>(base)[idx] = v;
 }
 
+// counter-based RNG for the stochastic ops (dropout / drop-path / attention dropout): splitmix64 of (seed, element index)
+// -> uniform [0, 1).  The same (seed, index) regenerates the same mask in backward; nothing is stored.
+__device__ __forceinline__ float u01_hash(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);      // 24 random bits -> [0, 1)
+}
+
 // exact-erf GELU and its derivative (nn.GELU(approximate='none')).
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, branch-free) instead of libm's erff, which costs several times
 // more VALU in the GEMM epilogues.  Written on 4-wide vectors so hipcc emits packed fp32 math (v_pk_fma_f32 /

@@ -320,13 +320,6 @@ __global__ __launch_bounds__(EW_THREADS) void ts_embed_kernel(const float* __res
 
 // ---- dropout / drop-path with residual add.  Counter-based RNG (splitmix64 of seed + element index): the same
 // (seed, index) regenerates the same mask in backward, nothing is stored.
-__device__ __forceinline__ float u01_hash(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);      // 24 random bits -> [0, 1)
-}
 __global__ __launch_bounds__(EW_THREADS) void dropout_add_kernel(const void* __restrict__ v, int vdt,
                                                                  const void* __restrict__ res, int rdt,
                                                                  void* __restrict__ out, int odt, int64_t rows, int cols,

@@ -188,8 +188,10 @@ class _BlockFn(torch.autograd.Function):
 
         xn1, mean1, rstd1 = ops.layernorm_fwd(x2, n1w, n1b, blk.eps, cdt, save_stats=need_grad)
         qkv = ops.gemm(xn1, cache.fwd("qkv", qkvw, cdt), bias=qkvb)
+        p_attn = stoch[3] if stoch is not None else 0.0      # training-mode attn_drop (attention.py:33)
         if win is None:
-            o, lse = ops.attention_fwd(qkv, B, N, H, hd, blk.attn.scale, need_lse=need_grad)
+            o, lse = ops.attention_fwd(qkv, B, N, H, hd, blk.attn.scale, need_lse=need_grad, p_drop=p_attn,
+                                       seed=stoch[2] + 4 if stoch is not None else 0)
             o_att = o
         else:
             # windowed attention (Image/detection/.../base/vit.py:160-190): qkv rows regrouped into ws x ws windows
@@ -197,12 +199,13 @@ class _BlockFn(torch.autograd.Function):
             gh_, gw_, ws = win
             nwin = -(-gh_ // ws) * -(-gw_ // ws)
             qkv = ops.window_rows(qkv, B, gh_, gw_, ws, merge=False)
-            o_att, lse = ops.attention_fwd(qkv, B * nwin, ws * ws, H, hd, blk.attn.scale, need_lse=need_grad)
+            o_att, lse = ops.attention_fwd(qkv, B * nwin, ws * ws, H, hd, blk.attn.scale, need_lse=need_grad, p_drop=p_attn,
+                                           seed=stoch[2] + 4 if stoch is not None else 0)
             o = ops.window_rows(o_att, B, gh_, gw_, ws, merge=True)
         # layer-scale with gradients: d gamma = colsum(dy * UNSCALED branch output), so the branch output is kept and
         # gamma is applied by the residual kernel instead of the GEMM epilogue
         ls_grad = need_grad and g1 is not None
-        p_drop, p_path, seed = stoch if stoch is not None else (0.0, 0.0, 0)
+        p_drop, p_path, seed = stoch[:3] if stoch is not None else (0.0, 0.0, 0)
         t1 = t2 = None
         if stoch is None and not ls_grad:
             x1 = ops.gemm(o, cache.fwd("proj", projw, cdt), bias=projb, residual=x2, out_dtype=rdt, colscale=g1)
@@ -353,7 +356,8 @@ class _BlockFn(torch.autograd.Function):
             return dxo, dg, db
 
         stoch = ctx.stoch
-        p_drop, p_path, seed = stoch if stoch is not None else (0.0, 0.0, 0)
+        p_drop, p_path, seed = stoch[:3] if stoch is not None else (0.0, 0.0, 0)
+        p_attn = stoch[3] if stoch is not None else 0.0
 
         def branch_grad(dout, t, g, sd):
             """gradient entering a residual branch y = x + drop_path(gamma * dropout(t)): (d t in compute dtype, d gamma).
@@ -379,12 +383,13 @@ class _BlockFn(torch.autograd.Function):
         do = ops.gemm(dx1_c, cache.transposed("proj", projw, cdt))
         d_projw, d_projb = wgrad(dx1_c, o, blk.attn.proj, ng[5], ng[6] and ctx.has_bias[1])
         if ctx.win is None:
-            dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, hd, blk.attn.scale)
+            dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, hd, blk.attn.scale, p_drop=p_attn, seed=seed + 4)
         else:                 # the same regrouping on the gradient; padded rows are constants (no gradient leaves them)
             gh_, gw_, ws = ctx.win
             nwin = -(-gh_ // ws) * -(-gw_ // ws)
             do_w = ops.window_rows(do, B, gh_, gw_, ws, merge=False)
-            dqkv_w = ops.attention_bwd(qkv, o_att, do_w, lse, B * nwin, ws * ws, H, hd, blk.attn.scale)
+            dqkv_w = ops.attention_bwd(qkv, o_att, do_w, lse, B * nwin, ws * ws, H, hd, blk.attn.scale, p_drop=p_attn,
+                                       seed=seed + 4)
             dqkv = ops.window_rows(dqkv_w, B, gh_, gw_, ws, merge=True)
         dxn1 = ops.gemm(dqkv, cache.transposed("qkv", qkvw, cdt))
         d_qkvw, d_qkvb = wgrad(dqkv, xn1, blk.attn.qkv, ng[3], ng[4] and ctx.has_bias[0])
@@ -457,16 +462,12 @@ class Block(nn.Module):
                                "no CPU fallback (use oracle/ for CPU reference numbers)")
         stoch = None
         if self.training:
-            if self.attn.attn_drop.p > 0:
-                raise MetaEncError("attn_drop > 0 in training mode (dropout on the attention probabilities, used only by "
-                                   "the Graph call site) is not implemented in the fused attention kernel; use .eval() "
-                                   "or attn_drop=0")
             if self.attn.proj_drop.p != self.mlp.drop.p:
                 raise MetaEncError("proj_drop and mlp drop must be equal (timm's Block passes one `drop` to both)")
-            if self.mlp.drop.p > 0 or self.drop_path_prob > 0:
+            if self.mlp.drop.p > 0 or self.drop_path_prob > 0 or self.attn.attn_drop.p > 0:
                 # one seed per call from torch's CPU generator (reproducible under torch.manual_seed)
                 seed = int(torch.empty((), dtype=torch.int64).random_().item())
-                stoch = (float(self.mlp.drop.p), self.drop_path_prob, seed)
+                stoch = (float(self.mlp.drop.p), self.drop_path_prob, seed, float(self.attn.attn_drop.p))
         self._wcache.bind(self)
         cdt = self._compute_dtype(x)
         if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):

@@ -221,26 +221,29 @@ def block_bwd(d, x2: torch.Tensor, dy2: torch.Tensor, saved: torch.Tensor, grads
 
 # ----------------------------------------------------------------------------- attention
 
-def attention_fwd(qkv: torch.Tensor, B: int, N: int, H: int, hd: int, scale: float, need_lse: bool):
+def attention_fwd(qkv: torch.Tensor, B: int, N: int, H: int, hd: int, scale: float, need_lse: bool,
+                  p_drop: float = 0.0, seed: int = 0):
+    """p_drop > 0: dropout on the attention probabilities (training-mode attn_drop); same p_drop / seed in attention_bwd"""
     lib = _capi.load()
     _req(qkv, "qkv")
     C = H * hd
     out = torch.empty((B * N, C), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if need_lse else None
     check(lib.me_attention_fwd(ptr(qkv), 3 * C, ptr(out), C, ptr(lse), B, N, H, hd, float(scale),
-                               dtype_code(qkv.dtype), stream_ptr()), "me_attention_fwd")
+                               dtype_code(qkv.dtype), float(p_drop), seed & 0xFFFFFFFFFFFFFFFF, stream_ptr()), "me_attention_fwd")
     return out, lse
 
 
 def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor,
-                  B: int, N: int, H: int, hd: int, scale: float) -> torch.Tensor:
+                  B: int, N: int, H: int, hd: int, scale: float, p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
     lib = _capi.load()
     _req(qkv, "qkv"); _req(out, "out"); _req(dout, "dout")
     C = H * hd
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     check(lib.me_attention_bwd(ptr(qkv), 3 * C, ptr(out), C, ptr(dout), C, ptr(lse), ptr(delta), ptr(dqkv), 3 * C,
-                               B, N, H, hd, float(scale), dtype_code(qkv.dtype), stream_ptr()), "me_attention_bwd")
+                               B, N, H, hd, float(scale), dtype_code(qkv.dtype), float(p_drop), seed & 0xFFFFFFFFFFFFFFFF,
+                               stream_ptr()), "me_attention_bwd")
     return dqkv
 
 

@@ -295,8 +295,15 @@ def test_stochastic_training_ops(dev):
     for b, d in enumerate(dropped):
         if d:
             assert torch.equal(ga[b], g1[b]), "a sample whose branches are dropped passes its gradient through unchanged"
-    with pytest.raises(M.MetaEncError):
-        M.Block(128, 2, attn_drop=0.1).to(dev).train()(x)
+    # attn_drop (the Graph call site trains with 0.1, tokengt_graph_encoder.py:191-205): runs, is seeded, is off in eval
+    ga_blk = M.Block(128, 2, qkv_bias=True, attn_drop=0.1).to(dev)
+    torch.manual_seed(3); y1 = ga_blk.train()(x)
+    torch.manual_seed(3); y2 = ga_blk(x)
+    torch.manual_seed(4); y3 = ga_blk(x)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    ref_blk = M.Block(128, 2, qkv_bias=True).to(dev)
+    ref_blk.load_state_dict(ga_blk.state_dict())
+    assert torch.equal(ga_blk.eval()(x), ref_blk.eval()(x))
 
 
 def test_layer_scale_variant(dev):

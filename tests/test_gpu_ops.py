@@ -212,6 +212,35 @@ def test_attention_bwd(dev, B, N, H, hd, dt):
     assert rel_err(dqkv.float(), qr.grad) < (5e-5 if dt == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("B,N,H,hd", [(4, 130, 8, 32), (2, 40, 32, 24), (1, 300, 2, 64)])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_dropout(dev, B, N, H, hd, dt):
+    """training-mode attn_drop: masks are a hash of (seed, b, h, q, k) -- reproducible, unbiased, and the backward uses
+    the SAME masks (checked as a directional derivative of the seeded forward, fp32)"""
+    p, seed = 0.25, 1234567
+    scale = hd ** -0.5
+    qkv = (0.5 * rnd(B * N, 3 * H * hd, seed=21)).to(dt).to(dev)
+    o0, _ = ops.attention_fwd(qkv, B, N, H, hd, scale, False)
+    o1, lse = ops.attention_fwd(qkv, B, N, H, hd, scale, True, p_drop=p, seed=seed)
+    o2, _ = ops.attention_fwd(qkv, B, N, H, hd, scale, False, p_drop=p, seed=seed)
+    o3, _ = ops.attention_fwd(qkv, B, N, H, hd, scale, False, p_drop=p, seed=seed + 1)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    # unbiased: E[dropout(P)] = P, so the mean over many (query, head) rows of (o_drop - o) is ~0 relative to its spread
+    d = (o1.float() - o0.float())
+    assert d.abs().max() > 0 and abs(d.mean().item()) < 6 * d.std().item() / (d.numel() ** 0.5) + 1e-4
+    if dt == torch.float32:
+        g = torch.Generator().manual_seed(5)
+        do = torch.randn(B * N, H * hd, generator=g).to(dev)
+        dirn = torch.randn(B * N, 3 * H * hd, generator=g).to(dev)
+        dqkv = ops.attention_bwd(qkv, o1, do, lse, B, N, H, hd, scale, p_drop=p, seed=seed)
+        eps = 1e-2
+        fp, _ = ops.attention_fwd(qkv + eps * dirn, B, N, H, hd, scale, False, p_drop=p, seed=seed)
+        fm, _ = ops.attention_fwd(qkv - eps * dirn, B, N, H, hd, scale, False, p_drop=p, seed=seed)
+        num = ((fp.double() - fm.double()) * do.double()).sum() / (2 * eps)
+        ana = (dqkv.double() * dirn.double()).sum()
+        assert abs(num - ana) < 2e-3 * max(1.0, abs(ana)), (num.item(), ana.item())
+
+
 # ----------------------------------------------------------------------------- tokenizer kernels
 
 @pytest.mark.parametrize("geom", [((2, 3, 64, 48), (1, 16, 16, 1, 16, 16)), ((2, 1, 40, 57), (1, 16, 16, 1, 10, 10)),

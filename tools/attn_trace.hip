@@ -22,8 +22,8 @@ int main(int argc, char** argv) {
     std::vector<long long> tr(nslots * 16);
     for (int pass = 0; pass < 2; ++pass) {
         for (int rep = 0; rep < 3; ++rep) {
-            int rc = pass == 0 ? me_attention_fwd(qkv, 3 * C, out, C, lse, B, N, H, hd, 0.125f, ME_BF16, nullptr)
-                               : me_attention_bwd(qkv, 3 * C, out, C, dout, C, lse, delta, dqkv, 3 * C, B, N, H, hd, 0.125f, ME_BF16, nullptr);
+            int rc = pass == 0 ? me_attention_fwd(qkv, 3 * C, out, C, lse, B, N, H, hd, 0.125f, ME_BF16, 0.f, 0, nullptr)
+                               : me_attention_bwd(qkv, 3 * C, out, C, dout, C, lse, delta, dqkv, 3 * C, B, N, H, hd, 0.125f, ME_BF16, 0.f, 0, nullptr);
             if (rc) { printf("error: %s\n", me_last_error()); return 1; }
             hipDeviceSynchronize();
         }
