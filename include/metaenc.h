@@ -271,6 +271,11 @@ int me_timeseries_embed(const float* x, const float* conv_w, const int32_t* mark
                         void* out, int out_dtype, int B, int L, int cin, int C, int32_t* err_flag,
                         void* stream);
 
+/* Backward helper of the circular Conv1d(k=3) token embedding (Data2Seq/Time_Series.py:29-42): the unfolded input
+ *   out[(b,l), i*3 + k] = x[b, (l + k - 1) mod L, i]      ([B*L, ncols] fp32, ncols >= 3*cin, extra columns zero)
+ * so that the weight gradient is one me_gemm (TN): dW[C, 3*cin] = dY[B*L, C]^T out.  Integer index arithmetic. */
+int me_timeseries_unfold(const float* x, float* out, int B, int L, int cin, int ncols, void* stream);
+
 /* ------------------------------------------------------------------ optimizer (fine-tune paths)
  * Fused AdamW step on a flat fp32 parameter / gradient bucket (torch.optim.AdamW semantics, decoupled
  * weight decay), grad_scale multiplies the gradient first (1/world_size after an all-reduce sum). */

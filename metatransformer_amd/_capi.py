@@ -128,6 +128,7 @@ SIGNATURES = {
     "me_unpatchify_add": (c_int, [c_void_p, c_int, c_void_p] + [c_int] * 11 + [c_void_p]),
     "me_timeseries_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_void_p), POINTER(c_int32),
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "me_timeseries_unfold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "me_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                               c_float, c_int, c_float, c_void_p, c_void_p]),
 }

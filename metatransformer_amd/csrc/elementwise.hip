@@ -519,6 +519,35 @@ extern "C" int me_unpatchify_add(const void* dcols, int dcols_dtype, float* dx, 
     return ME_OK;
 }
 
+// circular unfold for the Conv1d weight gradient: out[(b,l), i*3 + k] = x[b, (l + k - 1) mod L, i], zero in the pad columns
+__global__ __launch_bounds__(EW_THREADS) void ts_unfold_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int L,
+                                                               int cin, int ncols) {
+    const int64_t total = (int64_t)B * L * ncols;
+    for (int64_t t = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; t < total; t += (int64_t)gridDim.x * EW_THREADS) {
+        const int col = (int)(t % ncols);
+        const int64_t row = t / ncols;
+        float v = 0.f;
+        if (col < 3 * cin) {
+            const int i = col / 3, k = col % 3;
+            const int l = (int)(row % L);
+            const int64_t b = row / L;
+            int ls = l + k - 1;
+            ls = ls < 0 ? ls + L : (ls >= L ? ls - L : ls);
+            v = x[(b * L + ls) * cin + i];
+        }
+        out[t] = v;
+    }
+}
+
+extern "C" int me_timeseries_unfold(const float* x, float* out, int B, int L, int cin, int ncols, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(x && out && B > 0 && L > 0 && cin > 0 && ncols >= 3 * cin, "me_timeseries_unfold: bad args");
+    hipLaunchKernelGGL(ts_unfold_kernel, dim3(ew_blocks((int64_t)B * L * ncols)), dim3(EW_THREADS), 0, stream, x, out, B, L, cin,
+                       ncols);
+    ME_CHECK_LAUNCH("me_timeseries_unfold");
+    return ME_OK;
+}
+
 extern "C" int me_timeseries_embed(const float* x, const float* conv_w, const int32_t* marks, int n_mark,
                                    const float* const* tables, const int32_t* table_rows, const float* pe, void* out,
                                    int out_dtype, int B, int L, int cin, int C, int32_t* err_flag, void* stream_) {

@@ -239,40 +239,73 @@ class DataEmbedding(nn.Module):
     def forward(self, x: torch.Tensor, x_mark: Optional[torch.Tensor] = None) -> torch.Tensor:
         if not x.is_cuda:
             raise MetaEncError("DataEmbedding runs on MI355X only (CPU tensor given; no CPU fallback)")
-        if self.training and self.dropout.p > 0:
-            raise MetaEncError("training-mode dropout inside DataEmbedding is not implemented; call .eval() or p=0")
-        if torch.is_grad_enabled() and self.value_embedding.tokenConv.weight.requires_grad:
-            raise MetaEncError("backward through the time-series tokenizer is not implemented yet: "
-                               "freeze value_embedding or run under torch.no_grad()")
-        lib = _capi.load()
+        if x.requires_grad:
+            raise MetaEncError("DataEmbedding: gradient w.r.t. the input series is not implemented (no reference pipeline "
+                               "needs it); detach the input")
         B, L, cin = x.shape
-        C = self.d_model
-        w = self.value_embedding.tokenConv.weight.detach().float().contiguous()
-        xf = x.detach().float().contiguous()
-        out_dtype = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16) else torch.float32
-        out = torch.empty((B, L, C), dtype=out_dtype, device=x.device)
-        pe = self.position_embedding.pe[0].contiguous()
+        pe = self.position_embedding.pe[0]
         if L > pe.shape[0]:
             raise MetaEncError(f"sequence length {L} exceeds positional table {pe.shape[0]}")
-        err = torch.zeros(1, dtype=torch.int32, device=x.device)
-        n_mark = 0
-        marks = None
-        tab_arr = None
-        rows_arr = None
+        marks, tabs = None, []
         if x_mark is not None:
             tabs = [t.detach().float().contiguous() for t in self.temporal_embedding.tables()]
-            n_mark = len(tabs)
-            if x_mark.shape[-1] < n_mark:
-                raise MetaEncError(f"x_mark has {x_mark.shape[-1]} columns, need {n_mark}")
-            marks = x_mark[..., :n_mark].long().to(torch.int32).contiguous()      # == x.long() (Time_Series.py:83)
+            if x_mark.shape[-1] < len(tabs):
+                raise MetaEncError(f"x_mark has {x_mark.shape[-1]} columns, need {len(tabs)}")
+            marks = x_mark[..., :len(tabs)].long().to(torch.int32).contiguous()      # == x.long() (Time_Series.py:83)
+        out_dtype = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16) else torch.float32
+        p = float(self.dropout.p) if self.training else 0.0
+        seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
+        return _TSEmbedFn.apply(x.detach().float().contiguous(), self.value_embedding.tokenConv.weight, marks, tabs,
+                                pe.contiguous(), out_dtype, p, seed)
+
+
+class _TSEmbedFn(torch.autograd.Function):
+    """DataEmbedding.forward (Data2Seq/Time_Series.py:118-126): value + temporal + positional embedding, Dropout(p).
+    Backward: the only trainable tensor of the default (embed_type='fixed') configuration is the Conv1d weight;
+    dW[C, cin, 3] = dY^T unfold(x) as one TN GEMM on the circularly unfolded input (me_timeseries_unfold)."""
+
+    @staticmethod
+    def forward(ctx, xf, weight, marks, tabs, pe, out_dtype, p, seed):
+        lib = _capi.load()
+        B, L, cin = xf.shape
+        C = weight.shape[0]
+        w = weight.detach().float().contiguous()
+        out = torch.empty((B, L, C), dtype=out_dtype, device=xf.device)
+        err = torch.zeros(1, dtype=torch.int32, device=xf.device)
+        n_mark, tab_arr, rows_arr = len(tabs), None, None
+        if marks is not None:
             tab_arr = (ctypes.c_void_p * n_mark)(*[t.data_ptr() for t in tabs])
             rows_arr = (ctypes.c_int32 * n_mark)(*[t.shape[0] for t in tabs])
-        check(lib.me_timeseries_embed(ptr(xf), ptr(w), ptr(marks), n_mark, tab_arr, rows_arr, ptr(pe), ptr(out),
-                                      dtype_code(out_dtype), B, L, cin, C, ptr(err), stream_ptr()),
+        check(lib.me_timeseries_embed(ptr(xf), ptr(w), ptr(marks), n_mark if marks is not None else 0, tab_arr, rows_arr, ptr(pe),
+                                      ptr(out), dtype_code(out_dtype), B, L, cin, C, ptr(err), stream_ptr()),
               "me_timeseries_embed")
-        if x_mark is not None and int(err.item()) != 0:
+        if marks is not None and int(err.item()) != 0:
             raise IndexError("x_mark holds an index outside its embedding table (nn.Embedding would raise too)")
+        if p > 0:      # nn.Dropout(p) of Time_Series.py:126, training mode
+            out = ops.dropout_add(out, None, L, p, 0.0, seed)
+        ctx.save_for_backward(xf)
+        ctx.meta = (p, seed, weight.dtype, weight.shape)
         return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xf,) = ctx.saved_tensors
+        p, seed, wdt, wshape = ctx.meta
+        if not ctx.needs_input_grad[1]:
+            return (None,) * 8
+        lib = _capi.load()
+        B, L, cin = xf.shape
+        C = wshape[0]
+        dy2 = dy.contiguous()
+        if p > 0:
+            dy2 = ops.dropout_add(dy2, None, L, p, 0.0, seed)
+        dy2 = ops.cast(dy2.reshape(B * L, C), torch.float32)
+        ncols = (3 * cin + 3) // 4 * 4
+        xu = torch.empty((B * L, ncols), dtype=torch.float32, device=xf.device)
+        check(lib.me_timeseries_unfold(ptr(xf), ptr(xu), B, L, cin, ncols, stream_ptr()), "me_timeseries_unfold")
+        dw = ops.gemm(dy2, xu, op=_capi.ME_GEMM_TN, out_dtype=torch.float32)          # [C, ncols]
+        dw = dw[:, :3 * cin].reshape(C, cin, 3).to(wdt)
+        return (None, dw, None, None, None, None, None, None)
 
 
 class Data2Seq(nn.Module):

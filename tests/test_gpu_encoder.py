@@ -495,6 +495,42 @@ def test_time_series_tokenizer_matches_reference_golden(dev):
         ts(x.to(dev), bad.to(dev))
 
 
+@pytest.mark.parametrize("cin,L", [(7, 96), (1, 36), (21, 50)])
+def test_time_series_tokenizer_backward_and_dropout(dev, cin, L):
+    """the Time-Series pipelines train this tokenizer in front of the frozen encoder (Time-Series/run.py): Conv1d weight
+    gradient against autograd through the oracle restatement; training-mode Dropout(0.1) is seeded and unbiased"""
+    torch.manual_seed(1)
+    B, C = 4, 256
+    ts = M.DataEmbedding(c_in=cin, d_model=C).to(dev).eval()
+    x = torch.randn(B, L, cin)
+    mark = torch.stack([torch.randint(0, n, (B, L)) for n in (13, 32, 7, 24)], dim=-1).float()
+    go = torch.randn(B, L, C)
+    w = ts.value_embedding.tokenConv.weight.detach().cpu().double().requires_grad_(True)
+    tabs = [to.sinusoid_table_ts(n, C).double() for n in (13, 32, 7, 24)]
+    ref = to.time_series_embedding(x.double(), w, mark, tabs, to.sinusoid_table_ts(5000, C).double())
+    (ref * go.double()).sum().backward()
+    y = ts(x.to(dev), mark.to(dev))
+    (y * go.to(dev)).sum().backward()
+    assert rel_err(y, ref) < 1e-5
+    assert rel_err(ts.value_embedding.tokenConv.weight.grad, w.grad) < 1e-5
+    # dropout in training mode
+    ts.train()
+    torch.manual_seed(7); y1 = ts(x.to(dev), mark.to(dev))
+    torch.manual_seed(7); y2 = ts(x.to(dev), mark.to(dev))
+    assert torch.equal(y1, y2)
+    kept = (y1 != 0)
+    assert 0.85 < kept.float().mean().item() < 0.95
+    assert torch.allclose(y1[kept], (y.detach() / 0.9)[kept], rtol=1e-5, atol=1e-6)
+    ts.value_embedding.tokenConv.weight.grad = None
+    torch.manual_seed(7); (ts(x.to(dev), mark.to(dev)) * go.to(dev)).sum().backward()
+    g_drop = ts.value_embedding.tokenConv.weight.grad
+    # same masks in backward: dW equals the oracle's gradient for the masked, rescaled upstream gradient
+    w2 = w.detach().clone().requires_grad_(True)
+    ref2 = to.time_series_embedding(x.double(), w2, mark, tabs, to.sinusoid_table_ts(5000, C).double())
+    (ref2 * (go.double() * kept.cpu().double() / 0.9)).sum().backward()
+    assert rel_err(g_drop, w2.grad) < 1e-5
+
+
 def test_multimodal_concat_through_encoder(dev):
     """README.md:118-149 demo: tokens of several modalities concatenated along N, one shared encoder."""
     torch.manual_seed(0)
