@@ -412,6 +412,25 @@ def test_large_config3_slice_vs_oracle(dev):
     assert rel_err(y16, ref) < 5e-2       # 24 bf16 layers
 
 
+def test_large_config5_video_tokens_vs_oracle(dev):
+    """BASELINE config 5 shape: VideoMAE tubelet tokens, N = 1568, Large width (4 of the 24 blocks, batch 1 for the CPU
+    oracle): forward and input gradient through the tiled (N > 256) attention path"""
+    c = dict(depth=4, dim=1024, heads=16, eps=1e-6, seed=23)
+    sd = bo.make_encoder_state_dict(c["depth"], c["dim"], seed=c["seed"])
+    g = torch.Generator().manual_seed(6)
+    x, go = torch.randn(1, 1568, 1024, generator=g), torch.randn(1, 1568, 1024, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = bo.encoder_forward(xr, sd, 16, eps=1e-6)
+    (y_ref * go).sum().backward()
+    enc = make_encoder(c, dev)
+    for dt, tol in ((torch.float32, TOL_F32), (torch.bfloat16, 4e-2)):
+        xd = x.to(dev).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+            y = enc(xd)
+        (y * go.to(dev)).sum().backward()
+        assert rel_err(y, y_ref) < tol and rel_err(xd.grad, xr.grad) < tol
+
+
 # ----------------------------------------------------------------------------- tokenizers
 
 def _tok():
