@@ -391,11 +391,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkdv_kernel(const T* __re
     typedef Cfg<T, HD> C;
     typedef typename Chunk<T>::type chunk_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = TRead<T, HD>::kNeedsTransposedTile ? C::T_BYTES : 0;   // bf16 reads the row tiles transposed (tr)
     char* Qs = smem;                           // [64 q][HD]
     char* dOs = Qs + C::R_BYTES;               // [64 q][HD]
-    char* QTs = dOs + C::R_BYTES;              // [HD][64 q]
-    char* dOTs = QTs + C::T_BYTES;             // [HD][64 q]
-    float* lse_s = reinterpret_cast<float*>(dOTs + C::T_BYTES);   // [64]
+    char* QTs = dOs + C::R_BYTES;              // [HD][64 q]   (fp32 only)
+    char* dOTs = QTs + TB;                     // [HD][64 q]   (fp32 only)
+    float* lse_s = reinterpret_cast<float*>(dOTs + TB);           // [64]
     float* del_s = lse_s + KVT;                                   // [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -1143,8 +1144,9 @@ template <typename T, int HD>
 int launch_bwd(const void* qkv, int64_t ld, const void* dout, int64_t lddo, const float* lse, const float* delta, void* dqkv,
                int64_t lddq, int B, int N, int H, int hd, float scale, float p_drop, uint64_t seed, hipStream_t stream) {
     typedef Cfg<T, HD> C;
-    const size_t smem1 = 2 * C::R_BYTES + 2 * C::T_BYTES + 2 * KVT * sizeof(float);
-    const size_t smem2 = 2 * C::R_BYTES + C::T_BYTES;
+    constexpr size_t TB = TRead<T, HD>::kNeedsTransposedTile ? C::T_BYTES : 0;
+    const size_t smem1 = 2 * C::R_BYTES + 2 * TB + 2 * KVT * sizeof(float);
+    const size_t smem2 = 2 * C::R_BYTES + TB;
     static bool once = false;
     if (!once) {
         set_smem(attn_bwd_dkdv_kernel<T, HD>, smem1);

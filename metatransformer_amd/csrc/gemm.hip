@@ -374,6 +374,19 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
                 pl.ws_bytes = (size_t)pl.tail_split * (size_t)pl.tail_rows * (size_t)d->N * sizeof(float);
             }
         }
+        // Small problems (small-batch inference: M = B * N rows with B = 1..32): fewer tiles than a third of the chip's
+        // workgroup slots means the launch is pure latency -- one workgroup walks the whole reduction while 2/3 of the CUs
+        // idle.  The WHOLE problem then runs split over the reduction (same slabs + fold as the tail split, m_main = 0).
+        if (fam >= 2 && tail_split_enabled() && pl.tail_rows == 0 && tiles * 3 <= SLOTS && nk >= 16) {
+            int s = (int)(SLOTS / tiles);
+            while (s > 1 && nk / s < 8) --s;
+            if (s >= 2) {
+                pl.tail_rows = d->M;
+                pl.tail_ksteps = (nk + s - 1) / s;
+                pl.tail_split = (nk + pl.tail_ksteps - 1) / pl.tail_ksteps;
+                pl.ws_bytes = (size_t)pl.tail_split * (size_t)d->M * (size_t)d->N * sizeof(float);
+            }
+        }
     }
     return pl;
 }
@@ -525,14 +538,16 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
         p.ksteps_per_split = (int)(d->K / pl.kstep);
         if (pl.tail_rows > 0 && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes) {
             const int64_t m1 = d->M - pl.tail_rows;
-            GemmParams pm = p;                       // main part: rows [0, m1), fused epilogue as usual
-            pm.M = m1;
-            pm.tiles_m = (int)(m1 / pl.bm);
-            rc = run(pm);
-            if (rc) return rc;
+            if (m1 > 0) {
+                GemmParams pm = p;                   // main part: rows [0, m1), fused epilogue as usual
+                pm.M = m1;
+                pm.tiles_m = (int)(m1 / pl.bm);
+                rc = run(pm);
+                if (rc) return rc;
+            }
             GemmParams pt = p;                       // tail: rows [m1, M) -- every row-indexed operand moves down by m1
             pt.M = pl.tail_rows;
-            pt.tiles_m = (int)(pl.tail_rows / pl.bm);
+            pt.tiles_m = (int)((pl.tail_rows + pl.bm - 1) / pl.bm);
             pt.A = reinterpret_cast<const char*>(p.A) + (size_t)m1 * p.lda * me_dtype_size(d->ab_dtype);
             pt.C = reinterpret_cast<char*>(p.C) + (size_t)m1 * p.ldc * me_dtype_size(p.c_dtype);
             if (p.preact) pt.preact = reinterpret_cast<char*>(p.preact) + (size_t)m1 * p.ldpre * me_dtype_size(p.preact_dtype);

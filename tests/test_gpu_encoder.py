@@ -382,8 +382,9 @@ def test_windowed_block_vs_oracle(dev, dt, tol, H, W, ws):
 
 def test_base_config2_shape_properties(dev):
     """[256,197,768] bf16 (BASELINE config 2): too big for the CPU oracle in seconds, so check properties that do not
-    depend on size: batch independence (sample b of the big batch == the same sample run alone, bit-exact, because no
-    kernel reduces across samples) and agreement of the first samples with the CPU oracle."""
+    depend on size: batch independence (sample b of the big batch == the same sample run alone: no kernel reduces
+    across samples; equal up to the fp32 summation order of the split-K schedules the GEMM planner picks per problem
+    size, i.e. a few bf16 ulps) and agreement of the first samples with the CPU oracle."""
     c = dict(depth=12, dim=768, heads=12, eps=1e-5, seed=14)
     enc = make_encoder(c, dev, torch.bfloat16)
     g = torch.Generator().manual_seed(0)
@@ -392,7 +393,9 @@ def test_base_config2_shape_properties(dev):
         y = enc(x.to(dev))
         y_sub = enc(x[37:39].to(dev))
     assert torch.isfinite(y.float()).all()
-    assert torch.equal(y[37:39], y_sub), "batch independence must be bit-exact"
+    assert rel_err(y_sub.float(), y[37:39].float()) < TOL_BF16, "batch independence (ulp flips of the bf16 stream only)"
+    with torch.no_grad():      # same problem size -> same schedule -> bit-exact run to run
+        assert torch.equal(enc(x[37:39].to(dev)), y_sub)
     sd = bo.make_encoder_state_dict(12, 768, seed=14)
     ref = bo.encoder_forward(x[:2].float(), sd, 12)
     assert rel_err(y[:2].float(), ref) < TOL_BF16

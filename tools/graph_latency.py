@@ -1,0 +1,31 @@
+import torch, time, sys
+sys.path.insert(0, '/root/repo')
+import metatransformer_amd as M
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+enc = M.build_encoder(12, 768, 12).to(dev).eval()
+for b in enc: b.compute_dtype = torch.bfloat16
+for B in (1, 8, 32):
+    x = torch.randn(B, 197, 768, device=dev).bfloat16()
+    with torch.no_grad():
+        for _ in range(3): y = enc(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50): y = enc(x)
+        torch.cuda.synchronize()
+        eager = (time.perf_counter() - t0) / 50 * 1e3
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3): yg = enc(x)
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            yg = enc(x)
+        g.replay(); torch.cuda.synchronize()
+        ok = torch.equal(yg, y)
+        t0 = time.perf_counter()
+        for _ in range(50): g.replay()
+        torch.cuda.synchronize()
+        graph = (time.perf_counter() - t0) / 50 * 1e3
+    print(f"B={B}: eager {eager:.3f} ms, hipGraph replay {graph:.3f} ms, identical={ok}", flush=True)
