@@ -657,9 +657,9 @@ constexpr int SM_MINN = 64;      // at or below one 64-key tile the tiled kernel
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
-template <int HD, int NARR> struct SmallStage {
+template <int HD, int NARR, int MAXN = SM_MAXN> struct SmallStage {
     static constexpr int CPR = HD / 8;
-    static constexpr int ITEMS = (SM_MAXN * CPR) / SM_THREADS;
+    static constexpr int ITEMS = (MAXN * CPR) / SM_THREADS;
     u32x4 v[NARR][ITEMS];
     // branch-free: out-of-range rows / chunks read a clamped (valid) address and are zeroed afterwards, so every load
     // of every array is in flight before the first use
@@ -1070,6 +1070,230 @@ __global__ __launch_bounds__(SM_THREADS) void attn_bwd_small_kernel(const bf16_t
     TRACE_STAMP(trace_slot, 6);
 }
 
+// =====================================================================================================
+// mid-size sequences (256 < N <= 512: audio spectrogram tokens, 512 x 512 segmentation crops at /32, BASELINE config 3).
+// The tiled kernels re-stream Q/dO (or K/V) once per 128-row block of the other side -- four times at N = 512 -- and pay
+// two barriers per 64-row tile.  Here one 8-wave workgroup still owns a (batch, head), but LDS holds only TWO arrays at a
+// time (2 x 512 rows x 144 B = 147 KB): K/V while a wave walks its (up to two) 32-query groups, then -- backward only --
+// the same space is refilled with Q/dO for the pass in which a wave owns its 32-key groups.  Every array is fetched once
+// into LDS plus once as row fragments; no barrier inside the key / query loops.
+// =====================================================================================================
+constexpr int MD_MAXN = 512;
+
+template <int HD>
+__global__ __launch_bounds__(SM_THREADS) void attn_fwd_mid_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                  bf16_t* __restrict__ out, int64_t ldo,
+                                                                  float* __restrict__ lse, int N, int H, int hd, float scale) {
+    typedef Cfg<bf16_t, HD> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NS = (N + 31) >> 5, NR = NS * 32;
+    char* Ks = smem;
+    char* Vs = smem + NR * C::RROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int Cdim = H * hd;
+    const bf16_t* qptr = qkv + (int64_t)b * N * ld + head * hd;
+    {
+        SmallStage<HD, 2, MD_MAXN> st;
+        const bf16_t* const bases[2] = {qptr + Cdim, qptr + 2 * Cdim};
+        const int64_t ldv[2] = {ld, ld};
+        st.load(bases, ldv, N, hd, tid);
+        char* const tiles[2] = {Ks, Vs};
+        st.store(tiles, NR, tid);
+    }
+    __syncthreads();
+    const float sl = scale * LOG2E;
+    for (int sub = wave; sub < NS; sub += SM_THREADS / 64) {      // wave-uniform
+        const int q = 32 * sub + l31;
+        const int qrow = (q < N) ? q : N - 1;
+        bf16x8 qf[C::NKK];
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            const int d = (2 * kk + h) * 8;
+            const bool ok = d < hd;
+            u32x4 raw = *reinterpret_cast<const u32x4*>(qptr + (int64_t)qrow * ld + (ok ? d : 0));
+            raw = ok ? raw : zero4();
+            qf[kk] = *reinterpret_cast<bf16x8*>(&raw);
+        }
+        f32x16 o[C::NDB];
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+        int t = 0;
+        for (; 32 * (t + 2) <= N; t += 2)
+            fwd_small_step<HD, 2, false>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, 32 * t, N, qf, sl, m_run, l_run, o, lane);
+        if (t + 2 <= NS)
+            fwd_small_step<HD, 2, true>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, 32 * t, N, qf, sl, m_run, l_run, o, lane);
+        else if (t < NS)
+            fwd_small_step<HD, 1, true>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, 32 * t, N, qf, sl, m_run, l_run, o, lane);
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (q < N) {
+            bf16_t* orow = out + ((int64_t)b * N + q) * ldo + head * hd;
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = 32 * db + 8 * g + 4 * h;
+                    if (d < hd)
+                        store_quad<bf16_t>(orow + d, f32x4{o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv,
+                                                           o[db][4 * g + 3] * inv});
+                }
+            if (lse && h == 0) lse[((int64_t)b * H + head) * N + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(SM_THREADS) void attn_bwd_mid_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                  const bf16_t* __restrict__ out, int64_t ldo,
+                                                                  const bf16_t* __restrict__ dout, int64_t lddo,
+                                                                  const float* __restrict__ lse, float* __restrict__ delta,
+                                                                  bf16_t* __restrict__ dqkv, int64_t lddq, int N, int H,
+                                                                  int hd, float scale) {
+    typedef Cfg<bf16_t, HD> C;
+    constexpr int NWAVE = SM_THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NS = (N + 31) >> 5, NR = NS * 32;
+    char* T0 = smem;                        // K, later Q
+    char* T1 = smem + NR * C::RROW;         // V, later dO
+    float* lse_s = reinterpret_cast<float*>(T1 + NR * C::RROW);   // [MD_MAXN]  lse * log2(e), +inf on padded rows
+    float* del_s = lse_s + MD_MAXN;                               // [MD_MAXN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int Cdim = H * hd;
+    const bf16_t* qptr = qkv + (int64_t)b * N * ld + head * hd;
+    const bf16_t* doptr = dout + (int64_t)b * N * lddo + head * hd;
+    const bf16_t* optr = out + (int64_t)b * N * ldo + head * hd;
+    const int64_t bh = ((int64_t)b * H + head) * N;
+    const float sl = scale * LOG2E;
+    {
+        SmallStage<HD, 2, MD_MAXN> st;
+        const bf16_t* const bases[2] = {qptr + Cdim, qptr + 2 * Cdim};
+        const int64_t ldv[2] = {ld, ld};
+        st.load(bases, ldv, N, hd, tid);
+        char* const tiles[2] = {T0, T1};
+        st.store(tiles, NR, tid);
+    }
+    if (tid < MD_MAXN) lse_s[tid] = tid < N ? lse[bh + tid] * LOG2E : INFINITY;
+    __syncthreads();
+
+    // ---- pass A (K / V resident): delta and dQ, a wave walks its 32-query groups; row fragments come straight from HBM
+    for (int sub = wave; sub < NS; sub += NWAVE) {
+        const int row = 32 * sub + l31;
+        const bool row_ok = row < N;
+        const int rowc = row_ok ? row : N - 1;
+        bf16x8 qf[C::NKK], dof[C::NKK];
+        float del = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            const int d = (2 * kk + h) * 8;
+            const bool ok = d < hd;
+            const int dc = ok ? d : 0;
+            u32x4 rq = *reinterpret_cast<const u32x4*>(qptr + (int64_t)rowc * ld + dc);
+            u32x4 rd = *reinterpret_cast<const u32x4*>(doptr + (int64_t)rowc * lddo + dc);
+            u32x4 ro = *reinterpret_cast<const u32x4*>(optr + (int64_t)rowc * ldo + dc);
+            const bool keep = ok && row_ok;      // padded queries: zero fragments (P = 0 through lse = +inf as well)
+            rq = keep ? rq : zero4(); rd = keep ? rd : zero4(); ro = keep ? ro : zero4();
+            qf[kk] = *reinterpret_cast<bf16x8*>(&rq);
+            dof[kk] = *reinterpret_cast<bf16x8*>(&rd);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                del += __uint_as_float(ro[e] << 16) * __uint_as_float(rd[e] << 16) +
+                       __uint_as_float(ro[e] & 0xffff0000u) * __uint_as_float(rd[e] & 0xffff0000u);
+        }
+        del += __shfl_xor(del, 32, 64);
+        if (h == 0) {
+            del_s[row] = del;
+            if (row_ok && delta) delta[bh + row] = del;
+        }
+        const float lse2 = lse_s[row];
+        f32x16 dq[C::NDB];
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+        int t = 0;
+        for (; 32 * (t + 2) <= N; t += 2)
+            bwd_small_q_step<HD, 2, false>(T0 + 32 * t * C::RROW, T1 + 32 * t * C::RROW, 32 * t, N, qf, dof, sl, lse2, del, dq, lane);
+        if (t + 2 <= NS)
+            bwd_small_q_step<HD, 2, true>(T0 + 32 * t * C::RROW, T1 + 32 * t * C::RROW, 32 * t, N, qf, dof, sl, lse2, del, dq, lane);
+        else if (t < NS)
+            bwd_small_q_step<HD, 1, true>(T0 + 32 * t * C::RROW, T1 + 32 * t * C::RROW, 32 * t, N, qf, dof, sl, lse2, del, dq, lane);
+        if (row_ok) {
+            bf16_t* dqrow = dqkv + ((int64_t)b * N + row) * lddq + head * hd;
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = 32 * db + 8 * g + 4 * h;
+                    if (d < hd)
+                        store_quad<bf16_t>(dqrow + d, f32x4{dq[db][4 * g] * scale, dq[db][4 * g + 1] * scale,
+                                                            dq[db][4 * g + 2] * scale, dq[db][4 * g + 3] * scale});
+                }
+        }
+    }
+    // ---- hand-over: lift the K / V row fragments of my key groups, then refill the two tiles with Q / dO
+    constexpr int MAXG = MD_MAXN / 32 / NWAVE;      // 2
+    bf16x8 kf[MAXG][C::NKK], vf[MAXG][C::NKK];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        int row = 32 * (wave + NWAVE * g) + l31;
+        row = row < NR ? row : NR - 1;
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            kf[g][kk] = rtile_chunk<bf16_t, HD>(T0, row, 2 * kk + h);
+            vf[g][kk] = rtile_chunk<bf16_t, HD>(T1, row, 2 * kk + h);
+        }
+    }
+    __syncthreads();      // everyone is done with K / V (pass A loops and the lifts above); del_s is complete
+    {
+        SmallStage<HD, 2, MD_MAXN> st;
+        const bf16_t* const bases[2] = {qptr, doptr};
+        const int64_t ldv[2] = {ld, lddo};
+        st.load(bases, ldv, N, hd, tid);
+        char* const tiles[2] = {T0, T1};
+        st.store(tiles, NR, tid);
+    }
+    __syncthreads();
+    // ---- pass B (Q / dO resident): dK, dV, a wave walks its 32-key groups
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int sub = wave + NWAVE * g;
+        if (sub >= NS) break;      // wave-uniform
+        const int row = 32 * sub + l31;
+        f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+        int t = 0;
+        for (; t + 2 <= NS; t += 2)
+            bwd_small_kv_step<HD, 2>(T0 + 32 * t * C::RROW, T1 + 32 * t * C::RROW, lse_s + 32 * t, del_s + 32 * t, kf[g], vf[g], sl, dk, dv, lane);
+        if (t < NS)
+            bwd_small_kv_step<HD, 1>(T0 + 32 * t * C::RROW, T1 + 32 * t * C::RROW, lse_s + 32 * t, del_s + 32 * t, kf[g], vf[g], sl, dk, dv, lane);
+        if (row < N) {
+            bf16_t* dkrow = dqkv + ((int64_t)b * N + row) * lddq + Cdim + head * hd;
+            bf16_t* dvrow = dkrow + Cdim;
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int d = 32 * db + 8 * gq + 4 * h;
+                    if (d < hd) {
+                        store_quad<bf16_t>(dkrow + d, f32x4{dk[db][4 * gq] * scale, dk[db][4 * gq + 1] * scale,
+                                                            dk[db][4 * gq + 2] * scale, dk[db][4 * gq + 3] * scale});
+                        store_quad<bf16_t>(dvrow + d, f32x4{dv[db][4 * gq], dv[db][4 * gq + 1], dv[db][4 * gq + 2], dv[db][4 * gq + 3]});
+                    }
+                }
+        }
+    }
+}
+
 template <typename K> void set_smem(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -1123,6 +1347,33 @@ int launch_bwd_small(const void* qkv, int64_t ld, const void* out, int64_t ldo, 
                        reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd,
                        scale);
     ME_CHECK_LAUNCH("me_attention_bwd(small)");
+    return ME_OK;
+}
+
+template <int HD>
+int launch_fwd_mid(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
+                   hipStream_t stream) {
+    typedef Cfg<bf16_t, HD> C;
+    const size_t smem = (size_t)2 * ((N + 31) / 32 * 32) * C::RROW;
+    static bool once = false;
+    if (!once) { set_smem(attn_fwd_mid_kernel<HD>, (size_t)2 * MD_MAXN * C::RROW); once = true; }
+    hipLaunchKernelGGL((attn_fwd_mid_kernel<HD>), dim3(H, B), dim3(SM_THREADS), smem, stream,
+                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale);
+    ME_CHECK_LAUNCH("me_attention_fwd(mid)");
+    return ME_OK;
+}
+template <int HD>
+int launch_bwd_mid(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                   float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
+    typedef Cfg<bf16_t, HD> C;
+    const size_t smem = (size_t)2 * ((N + 31) / 32 * 32) * C::RROW + 2 * MD_MAXN * sizeof(float);
+    static bool once = false;
+    if (!once) { set_smem(attn_bwd_mid_kernel<HD>, (size_t)2 * MD_MAXN * C::RROW + 2 * MD_MAXN * sizeof(float)); once = true; }
+    hipLaunchKernelGGL((attn_bwd_mid_kernel<HD>), dim3(H, B), dim3(SM_THREADS), smem, stream,
+                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<const bf16_t*>(out), ldo,
+                       reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd,
+                       scale);
+    ME_CHECK_LAUNCH("me_attention_bwd(mid)");
     return ME_OK;
 }
 
@@ -1203,6 +1454,10 @@ extern "C" int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int6
         if (head_dim <= 32) return launch_fwd_small<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
         return launch_fwd_small<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
     }
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MAXN && N <= MD_MAXN && small_path_enabled()) {
+        if (head_dim <= 32) return launch_fwd_mid<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+        return launch_fwd_mid<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+    }
     ATTN_DISPATCH(launch_fwd, qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, p_drop, seed, stream);
 }
 
@@ -1223,6 +1478,13 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
                                         scale, stream);
         return launch_bwd_small<64>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale,
                                     stream);
+    }
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MAXN && N <= MD_MAXN && ld_out % 8 == 0 && small_path_enabled()) {
+        if (head_dim <= 32)
+            return launch_bwd_mid<32>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale,
+                                      stream);
+        return launch_bwd_mid<64>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale,
+                                  stream);
     }
     const int64_t rows = (int64_t)B * N;
     const int64_t nw = rows * H;
