@@ -657,16 +657,16 @@ constexpr int SM_MINN = 64;      // at or below one 64-key tile the tiled kernel
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
-template <int HD, int NARR, int MAXN = SM_MAXN> struct SmallStage {
+template <int HD, int NARR, int MAXN = SM_MAXN, int NTHR = SM_THREADS> struct SmallStage {
     static constexpr int CPR = HD / 8;
-    static constexpr int ITEMS = (MAXN * CPR) / SM_THREADS;
+    static constexpr int ITEMS = (MAXN * CPR) / NTHR;
     u32x4 v[NARR][ITEMS];
     // branch-free: out-of-range rows / chunks read a clamped (valid) address and are zeroed afterwards, so every load
     // of every array is in flight before the first use
     __device__ __forceinline__ void load(const bf16_t* const (&base)[NARR], const int64_t (&ld)[NARR], int N, int hd, int tid) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            const int it = tid + SM_THREADS * i;
+            const int it = tid + NTHR * i;
             const int chunk = it % CPR, row = it / CPR;
             const bool ok = (row < N) && (chunk * 8 < hd);
             const int rc = ok ? row : 0, cc = ok ? chunk : 0;
@@ -679,7 +679,7 @@ template <int HD, int NARR, int MAXN = SM_MAXN> struct SmallStage {
     __device__ __forceinline__ void store(char* const (&lds)[NARR], int NR, int tid) const {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            const int it = tid + SM_THREADS * i;
+            const int it = tid + NTHR * i;
             const int chunk = it % CPR, row = it / CPR;
             if (row < NR) {
 #pragma unroll
@@ -1076,12 +1076,13 @@ __global__ __launch_bounds__(SM_THREADS) void attn_bwd_small_kernel(const bf16_t
 // two barriers per 64-row tile.  Here one 8-wave workgroup still owns a (batch, head), but LDS holds only TWO arrays at a
 // time (2 x 512 rows x 144 B = 147 KB): K/V while a wave walks its (up to two) 32-query groups, then -- backward only --
 // the same space is refilled with Q/dO for the pass in which a wave owns its 32-key groups.  Every array is fetched once
-// into LDS plus once as row fragments; no barrier inside the key / query loops.
+// into LDS plus once as row fragments; no barrier inside the key / query loops.  (The same scheme with 4-wave workgroups,
+// two per CU, was measured for N <= 256 against the all-four-arrays-resident kernels above: 15-40 % slower there.)
 // =====================================================================================================
 constexpr int MD_MAXN = 512;
 
-template <int HD>
-__global__ __launch_bounds__(SM_THREADS) void attn_fwd_mid_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+template <int HD, int NTHR, int MAXN>
+__global__ __launch_bounds__(NTHR) void attn_fwd_mid_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                                   bf16_t* __restrict__ out, int64_t ldo,
                                                                   float* __restrict__ lse, int N, int H, int hd, float scale) {
     typedef Cfg<bf16_t, HD> C;
@@ -1095,7 +1096,7 @@ __global__ __launch_bounds__(SM_THREADS) void attn_fwd_mid_kernel(const bf16_t* 
     const int Cdim = H * hd;
     const bf16_t* qptr = qkv + (int64_t)b * N * ld + head * hd;
     {
-        SmallStage<HD, 2, MD_MAXN> st;
+        SmallStage<HD, 2, MAXN, NTHR> st;
         const bf16_t* const bases[2] = {qptr + Cdim, qptr + 2 * Cdim};
         const int64_t ldv[2] = {ld, ld};
         st.load(bases, ldv, N, hd, tid);
@@ -1104,7 +1105,7 @@ __global__ __launch_bounds__(SM_THREADS) void attn_fwd_mid_kernel(const bf16_t* 
     }
     __syncthreads();
     const float sl = scale * LOG2E;
-    for (int sub = wave; sub < NS; sub += SM_THREADS / 64) {      // wave-uniform
+    for (int sub = wave; sub < NS; sub += NTHR / 64) {      // wave-uniform
         const int q = 32 * sub + l31;
         const int qrow = (q < N) ? q : N - 1;
         bf16x8 qf[C::NKK];
@@ -1147,21 +1148,21 @@ __global__ __launch_bounds__(SM_THREADS) void attn_fwd_mid_kernel(const bf16_t* 
     }
 }
 
-template <int HD>
-__global__ __launch_bounds__(SM_THREADS) void attn_bwd_mid_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+template <int HD, int NTHR, int MAXN>
+__global__ __launch_bounds__(NTHR) void attn_bwd_mid_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                                   const bf16_t* __restrict__ out, int64_t ldo,
                                                                   const bf16_t* __restrict__ dout, int64_t lddo,
                                                                   const float* __restrict__ lse, float* __restrict__ delta,
                                                                   bf16_t* __restrict__ dqkv, int64_t lddq, int N, int H,
                                                                   int hd, float scale) {
     typedef Cfg<bf16_t, HD> C;
-    constexpr int NWAVE = SM_THREADS / 64;
+    constexpr int NWAVE = NTHR / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NS = (N + 31) >> 5, NR = NS * 32;
     char* T0 = smem;                        // K, later Q
     char* T1 = smem + NR * C::RROW;         // V, later dO
     float* lse_s = reinterpret_cast<float*>(T1 + NR * C::RROW);   // [MD_MAXN]  lse * log2(e), +inf on padded rows
-    float* del_s = lse_s + MD_MAXN;                               // [MD_MAXN]
+    float* del_s = lse_s + MAXN;                                  // [MAXN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int head = blockIdx.x, b = blockIdx.y;
@@ -1172,14 +1173,14 @@ __global__ __launch_bounds__(SM_THREADS) void attn_bwd_mid_kernel(const bf16_t* 
     const int64_t bh = ((int64_t)b * H + head) * N;
     const float sl = scale * LOG2E;
     {
-        SmallStage<HD, 2, MD_MAXN> st;
+        SmallStage<HD, 2, MAXN, NTHR> st;
         const bf16_t* const bases[2] = {qptr + Cdim, qptr + 2 * Cdim};
         const int64_t ldv[2] = {ld, ld};
         st.load(bases, ldv, N, hd, tid);
         char* const tiles[2] = {T0, T1};
         st.store(tiles, NR, tid);
     }
-    if (tid < MD_MAXN) lse_s[tid] = tid < N ? lse[bh + tid] * LOG2E : INFINITY;
+    for (int i = tid; i < MAXN; i += NTHR) lse_s[i] = i < N ? lse[bh + i] * LOG2E : INFINITY;
     __syncthreads();
 
     // ---- pass A (K / V resident): delta and dQ, a wave walks its 32-query groups; row fragments come straight from HBM
@@ -1238,7 +1239,7 @@ __global__ __launch_bounds__(SM_THREADS) void attn_bwd_mid_kernel(const bf16_t* 
         }
     }
     // ---- hand-over: lift the K / V row fragments of my key groups, then refill the two tiles with Q / dO
-    constexpr int MAXG = MD_MAXN / 32 / NWAVE;      // 2
+    constexpr int MAXG = MAXN / 32 / NWAVE;      // 2
     bf16x8 kf[MAXG][C::NKK], vf[MAXG][C::NKK];
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) {
@@ -1252,7 +1253,7 @@ __global__ __launch_bounds__(SM_THREADS) void attn_bwd_mid_kernel(const bf16_t* 
     }
     __syncthreads();      // everyone is done with K / V (pass A loops and the lifts above); del_s is complete
     {
-        SmallStage<HD, 2, MD_MAXN> st;
+        SmallStage<HD, 2, MAXN, NTHR> st;
         const bf16_t* const bases[2] = {qptr, doptr};
         const int64_t ldv[2] = {ld, lddo};
         st.load(bases, ldv, N, hd, tid);
@@ -1350,26 +1351,26 @@ int launch_bwd_small(const void* qkv, int64_t ld, const void* out, int64_t ldo, 
     return ME_OK;
 }
 
-template <int HD>
+template <int HD, int NTHR, int MAXN>
 int launch_fwd_mid(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
                    hipStream_t stream) {
     typedef Cfg<bf16_t, HD> C;
     const size_t smem = (size_t)2 * ((N + 31) / 32 * 32) * C::RROW;
     static bool once = false;
-    if (!once) { set_smem(attn_fwd_mid_kernel<HD>, (size_t)2 * MD_MAXN * C::RROW); once = true; }
-    hipLaunchKernelGGL((attn_fwd_mid_kernel<HD>), dim3(H, B), dim3(SM_THREADS), smem, stream,
+    if (!once) { set_smem(attn_fwd_mid_kernel<HD, NTHR, MAXN>, (size_t)2 * MAXN * C::RROW); once = true; }
+    hipLaunchKernelGGL((attn_fwd_mid_kernel<HD, NTHR, MAXN>), dim3(H, B), dim3(NTHR), smem, stream,
                        reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale);
     ME_CHECK_LAUNCH("me_attention_fwd(mid)");
     return ME_OK;
 }
-template <int HD>
+template <int HD, int NTHR, int MAXN>
 int launch_bwd_mid(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
                    float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
     typedef Cfg<bf16_t, HD> C;
-    const size_t smem = (size_t)2 * ((N + 31) / 32 * 32) * C::RROW + 2 * MD_MAXN * sizeof(float);
+    const size_t smem = (size_t)2 * ((N + 31) / 32 * 32) * C::RROW + 2 * MAXN * sizeof(float);
     static bool once = false;
-    if (!once) { set_smem(attn_bwd_mid_kernel<HD>, (size_t)2 * MD_MAXN * C::RROW + 2 * MD_MAXN * sizeof(float)); once = true; }
-    hipLaunchKernelGGL((attn_bwd_mid_kernel<HD>), dim3(H, B), dim3(SM_THREADS), smem, stream,
+    if (!once) { set_smem(attn_bwd_mid_kernel<HD, NTHR, MAXN>, (size_t)2 * MAXN * C::RROW + 2 * MAXN * sizeof(float)); once = true; }
+    hipLaunchKernelGGL((attn_bwd_mid_kernel<HD, NTHR, MAXN>), dim3(H, B), dim3(NTHR), smem, stream,
                        reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<const bf16_t*>(out), ldo,
                        reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd,
                        scale);
@@ -1455,8 +1456,8 @@ extern "C" int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int6
         return launch_fwd_small<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
     }
     if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MAXN && N <= MD_MAXN && small_path_enabled()) {
-        if (head_dim <= 32) return launch_fwd_mid<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
-        return launch_fwd_mid<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+        if (head_dim <= 32) return launch_fwd_mid<32, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+        return launch_fwd_mid<64, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
     }
     ATTN_DISPATCH(launch_fwd, qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, p_drop, seed, stream);
 }
@@ -1481,10 +1482,10 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
     }
     if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MAXN && N <= MD_MAXN && ld_out % 8 == 0 && small_path_enabled()) {
         if (head_dim <= 32)
-            return launch_bwd_mid<32>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale,
-                                      stream);
-        return launch_bwd_mid<64>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale,
-                                  stream);
+            return launch_bwd_mid<32, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H,
+                                                    head_dim, scale, stream);
+        return launch_bwd_mid<64, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H,
+                                                head_dim, scale, stream);
     }
     const int64_t rows = (int64_t)B * N;
     const int64_t nw = rows * H;
