@@ -1295,6 +1295,260 @@ __global__ __launch_bounds__(NTHR) void attn_bwd_mid_kernel(const bf16_t* __rest
     }
 }
 
+// =====================================================================================================
+// long sequences (N > 512: video tubelets N = 1568, dense-prediction grids), bf16, head_dim <= 64: the same 8-wave
+// building blocks, but the other side of the attention matrix streams through LDS in CHUNKS of 256 rows (74 KB) instead
+// of 64-row tiles: two barriers per 256 rows instead of per 64, a workgroup owns 256 rows (so the streamed side is
+// re-read N/256 times, not N/128), and inside a chunk the per-wave loops run barrier-free on the step functions above.
+//   forward : workgroup = 256 queries, K/V chunks stream (online softmax across chunks)
+//   backward: (1) dQ + delta: workgroup = 256 queries, K/V chunks stream; (2) dK/dV: workgroup = 256 keys, Q/dO chunks
+//             (+ their lse / delta) stream.  Deterministic, no atomics.
+// =====================================================================================================
+constexpr int CH_ROWS = 256;
+
+template <int HD>
+__global__ __launch_bounds__(SM_THREADS) void attn_fwd_chunk_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                    bf16_t* __restrict__ out, int64_t ldo,
+                                                                    float* __restrict__ lse, int N, int H, int hd, float scale) {
+    typedef Cfg<bf16_t, HD> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + CH_ROWS * C::RROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int Cdim = H * hd;
+    const bf16_t* qptr = qkv + (int64_t)b * N * ld + head * hd;
+    const int q = blockIdx.x * CH_ROWS + 32 * wave + l31;
+    const bool active = blockIdx.x * CH_ROWS + 32 * wave < N;      // wave-uniform
+    const int qrow = (q < N) ? q : N - 1;
+    bf16x8 qf[C::NKK];
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk) {
+        const int d = (2 * kk + h) * 8;
+        const bool ok = d < hd;
+        u32x4 raw = *reinterpret_cast<const u32x4*>(qptr + (int64_t)qrow * ld + (ok ? d : 0));
+        raw = ok ? raw : zero4();
+        qf[kk] = *reinterpret_cast<bf16x8*>(&raw);
+    }
+    f32x16 o[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl = scale * LOG2E;
+    for (int kv0 = 0; kv0 < N; kv0 += CH_ROWS) {
+        const int rows = N - kv0 < CH_ROWS ? N - kv0 : CH_ROWS;
+        const int NSc = (rows + 31) >> 5;
+        __syncthreads();      // the previous chunk is consumed
+        {
+            SmallStage<HD, 2> st;
+            const bf16_t* const bases[2] = {qptr + Cdim + (int64_t)kv0 * ld, qptr + 2 * Cdim + (int64_t)kv0 * ld};
+            const int64_t ldv[2] = {ld, ld};
+            st.load(bases, ldv, rows, hd, tid);
+            char* const tiles[2] = {Ks, Vs};
+            st.store(tiles, NSc * 32, tid);
+        }
+        __syncthreads();
+        if (!active) continue;
+        int t = 0;
+        for (; 32 * (t + 2) <= rows; t += 2)
+            fwd_small_step<HD, 2, false>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, kv0 + 32 * t, N, qf, sl, m_run, l_run, o, lane);
+        if (t + 2 <= NSc)
+            fwd_small_step<HD, 2, true>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, kv0 + 32 * t, N, qf, sl, m_run, l_run, o, lane);
+        else if (t < NSc)
+            fwd_small_step<HD, 1, true>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, kv0 + 32 * t, N, qf, sl, m_run, l_run, o, lane);
+    }
+    if (!active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q < N) {
+        bf16_t* orow = out + ((int64_t)b * N + q) * ldo + head * hd;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * db + 8 * g + 4 * h;
+                if (d < hd)
+                    store_quad<bf16_t>(orow + d, f32x4{o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv,
+                                                       o[db][4 * g + 3] * inv});
+            }
+        if (lse && h == 0) lse[((int64_t)b * H + head) * N + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
+    }
+}
+
+// backward pass 1: delta and dQ for 256 queries; K/V stream in chunks
+template <int HD>
+__global__ __launch_bounds__(SM_THREADS) void attn_bwd_dq_chunk_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                       const bf16_t* __restrict__ out, int64_t ldo,
+                                                                       const bf16_t* __restrict__ dout, int64_t lddo,
+                                                                       const float* __restrict__ lse, float* __restrict__ delta,
+                                                                       bf16_t* __restrict__ dqkv, int64_t lddq, int N, int H,
+                                                                       int hd, float scale) {
+    typedef Cfg<bf16_t, HD> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + CH_ROWS * C::RROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int Cdim = H * hd;
+    const bf16_t* qptr = qkv + (int64_t)b * N * ld + head * hd;
+    const bf16_t* doptr = dout + (int64_t)b * N * lddo + head * hd;
+    const bf16_t* optr = out + (int64_t)b * N * ldo + head * hd;
+    const int64_t bh = ((int64_t)b * H + head) * N;
+    const int row = blockIdx.x * CH_ROWS + 32 * wave + l31;
+    const bool active = blockIdx.x * CH_ROWS + 32 * wave < N;      // wave-uniform
+    const bool row_ok = row < N;
+    const int rowc = row_ok ? row : N - 1;
+    bf16x8 qf[C::NKK], dof[C::NKK];
+    float del = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk) {
+        const int d = (2 * kk + h) * 8;
+        const bool ok = d < hd;
+        const int dc = ok ? d : 0;
+        u32x4 rq = *reinterpret_cast<const u32x4*>(qptr + (int64_t)rowc * ld + dc);
+        u32x4 rd = *reinterpret_cast<const u32x4*>(doptr + (int64_t)rowc * lddo + dc);
+        u32x4 ro = *reinterpret_cast<const u32x4*>(optr + (int64_t)rowc * ldo + dc);
+        const bool keep = ok && row_ok;
+        rq = keep ? rq : zero4(); rd = keep ? rd : zero4(); ro = keep ? ro : zero4();
+        qf[kk] = *reinterpret_cast<bf16x8*>(&rq);
+        dof[kk] = *reinterpret_cast<bf16x8*>(&rd);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            del += __uint_as_float(ro[e] << 16) * __uint_as_float(rd[e] << 16) +
+                   __uint_as_float(ro[e] & 0xffff0000u) * __uint_as_float(rd[e] & 0xffff0000u);
+    }
+    del += __shfl_xor(del, 32, 64);
+    if (h == 0 && row_ok) delta[bh + row] = del;
+    const float lse2 = row_ok ? lse[bh + row] * LOG2E : INFINITY;      // padded queries: P = 0
+    const float sl = scale * LOG2E;
+    f32x16 dq[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+    for (int kv0 = 0; kv0 < N; kv0 += CH_ROWS) {
+        const int rows = N - kv0 < CH_ROWS ? N - kv0 : CH_ROWS;
+        const int NSc = (rows + 31) >> 5;
+        __syncthreads();
+        {
+            SmallStage<HD, 2> st;
+            const bf16_t* const bases[2] = {qptr + Cdim + (int64_t)kv0 * ld, qptr + 2 * Cdim + (int64_t)kv0 * ld};
+            const int64_t ldv[2] = {ld, ld};
+            st.load(bases, ldv, rows, hd, tid);
+            char* const tiles[2] = {Ks, Vs};
+            st.store(tiles, NSc * 32, tid);
+        }
+        __syncthreads();
+        if (!active) continue;
+        int t = 0;
+        for (; 32 * (t + 2) <= rows; t += 2)
+            bwd_small_q_step<HD, 2, false>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, kv0 + 32 * t, N, qf, dof, sl, lse2, del, dq, lane);
+        if (t + 2 <= NSc)
+            bwd_small_q_step<HD, 2, true>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, kv0 + 32 * t, N, qf, dof, sl, lse2, del, dq, lane);
+        else if (t < NSc)
+            bwd_small_q_step<HD, 1, true>(Ks + 32 * t * C::RROW, Vs + 32 * t * C::RROW, kv0 + 32 * t, N, qf, dof, sl, lse2, del, dq, lane);
+    }
+    if (!active || !row_ok) return;
+    bf16_t* dqrow = dqkv + ((int64_t)b * N + row) * lddq + head * hd;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 32 * db + 8 * g + 4 * h;
+            if (d < hd)
+                store_quad<bf16_t>(dqrow + d, f32x4{dq[db][4 * g] * scale, dq[db][4 * g + 1] * scale, dq[db][4 * g + 2] * scale,
+                                                    dq[db][4 * g + 3] * scale});
+        }
+}
+
+// backward pass 2: dK and dV for 256 keys; Q / dO (and their lse / delta) stream in chunks
+template <int HD>
+__global__ __launch_bounds__(SM_THREADS) void attn_bwd_dkdv_chunk_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                         const bf16_t* __restrict__ dout, int64_t lddo,
+                                                                         const float* __restrict__ lse,
+                                                                         const float* __restrict__ delta,
+                                                                         bf16_t* __restrict__ dqkv, int64_t lddq, int N, int H,
+                                                                         int hd, float scale) {
+    typedef Cfg<bf16_t, HD> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* dOs = smem + CH_ROWS * C::RROW;
+    float* lse_s = reinterpret_cast<float*>(dOs + CH_ROWS * C::RROW);   // [CH_ROWS]
+    float* del_s = lse_s + CH_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int Cdim = H * hd;
+    const bf16_t* qptr = qkv + (int64_t)b * N * ld + head * hd;
+    const bf16_t* doptr = dout + (int64_t)b * N * lddo + head * hd;
+    const int64_t bh = ((int64_t)b * H + head) * N;
+    const int row = blockIdx.x * CH_ROWS + 32 * wave + l31;
+    const bool active = blockIdx.x * CH_ROWS + 32 * wave < N;      // wave-uniform
+    const bool row_ok = row < N;
+    const int rowc = row_ok ? row : N - 1;
+    bf16x8 kf[C::NKK], vf[C::NKK];
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk) {
+        const int d = (2 * kk + h) * 8;
+        const bool ok = d < hd;
+        const int dc = ok ? d : 0;
+        u32x4 rk = *reinterpret_cast<const u32x4*>(qptr + Cdim + (int64_t)rowc * ld + dc);
+        u32x4 rv = *reinterpret_cast<const u32x4*>(qptr + 2 * Cdim + (int64_t)rowc * ld + dc);
+        rk = ok ? rk : zero4(); rv = ok ? rv : zero4();
+        kf[kk] = *reinterpret_cast<bf16x8*>(&rk);
+        vf[kk] = *reinterpret_cast<bf16x8*>(&rv);
+    }
+    const float sl = scale * LOG2E;
+    f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    for (int q0 = 0; q0 < N; q0 += CH_ROWS) {
+        const int rows = N - q0 < CH_ROWS ? N - q0 : CH_ROWS;
+        const int NSc = (rows + 31) >> 5;
+        __syncthreads();
+        {
+            SmallStage<HD, 2> st;
+            const bf16_t* const bases[2] = {qptr + (int64_t)q0 * ld, doptr + (int64_t)q0 * lddo};
+            const int64_t ldv[2] = {ld, lddo};
+            st.load(bases, ldv, rows, hd, tid);
+            char* const tiles[2] = {Qs, dOs};
+            st.store(tiles, NSc * 32, tid);
+        }
+        if (tid < CH_ROWS) {
+            const bool ok = tid < rows;
+            lse_s[tid] = ok ? lse[bh + q0 + tid] * LOG2E : INFINITY;      // padded queries: P = 0
+            del_s[tid] = ok ? delta[bh + q0 + tid] : 0.f;
+        }
+        __syncthreads();
+        if (!active) continue;
+        int t = 0;
+        for (; t + 2 <= NSc; t += 2)
+            bwd_small_kv_step<HD, 2>(Qs + 32 * t * C::RROW, dOs + 32 * t * C::RROW, lse_s + 32 * t, del_s + 32 * t, kf, vf, sl, dk, dv, lane);
+        if (t < NSc)
+            bwd_small_kv_step<HD, 1>(Qs + 32 * t * C::RROW, dOs + 32 * t * C::RROW, lse_s + 32 * t, del_s + 32 * t, kf, vf, sl, dk, dv, lane);
+    }
+    if (!active || !row_ok) return;
+    bf16_t* dkrow = dqkv + ((int64_t)b * N + row) * lddq + Cdim + head * hd;
+    bf16_t* dvrow = dkrow + Cdim;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 32 * db + 8 * g + 4 * h;
+            if (d < hd) {
+                store_quad<bf16_t>(dkrow + d, f32x4{dk[db][4 * g] * scale, dk[db][4 * g + 1] * scale, dk[db][4 * g + 2] * scale,
+                                                    dk[db][4 * g + 3] * scale});
+                store_quad<bf16_t>(dvrow + d, f32x4{dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]});
+            }
+        }
+}
+
 template <typename K> void set_smem(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -1375,6 +1629,41 @@ int launch_bwd_mid(const void* qkv, int64_t ld, const void* out, int64_t ldo, co
                        reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd,
                        scale);
     ME_CHECK_LAUNCH("me_attention_bwd(mid)");
+    return ME_OK;
+}
+
+template <int HD>
+int launch_fwd_chunk(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
+                     hipStream_t stream) {
+    typedef Cfg<bf16_t, HD> C;
+    const size_t smem = (size_t)2 * CH_ROWS * C::RROW;
+    static bool once = false;
+    if (!once) { set_smem(attn_fwd_chunk_kernel<HD>, smem); once = true; }
+    hipLaunchKernelGGL((attn_fwd_chunk_kernel<HD>), dim3((N + CH_ROWS - 1) / CH_ROWS, H, B), dim3(SM_THREADS), smem, stream,
+                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale);
+    ME_CHECK_LAUNCH("me_attention_fwd(chunk)");
+    return ME_OK;
+}
+template <int HD>
+int launch_bwd_chunk(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                     float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
+    typedef Cfg<bf16_t, HD> C;
+    const size_t smem1 = (size_t)2 * CH_ROWS * C::RROW, smem2 = smem1 + 2 * CH_ROWS * sizeof(float);
+    static bool once = false;
+    if (!once) {
+        set_smem(attn_bwd_dq_chunk_kernel<HD>, smem1);
+        set_smem(attn_bwd_dkdv_chunk_kernel<HD>, smem2);
+        once = true;
+    }
+    dim3 grid((N + CH_ROWS - 1) / CH_ROWS, H, B);
+    hipLaunchKernelGGL((attn_bwd_dq_chunk_kernel<HD>), grid, dim3(SM_THREADS), smem1, stream, reinterpret_cast<const bf16_t*>(qkv),
+                       ld, reinterpret_cast<const bf16_t*>(out), ldo, reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta,
+                       reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd, scale);
+    ME_CHECK_LAUNCH("me_attention_bwd(dq chunk)");
+    hipLaunchKernelGGL((attn_bwd_dkdv_chunk_kernel<HD>), grid, dim3(SM_THREADS), smem2, stream, reinterpret_cast<const bf16_t*>(qkv),
+                       ld, reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd,
+                       scale);
+    ME_CHECK_LAUNCH("me_attention_bwd(dkdv chunk)");
     return ME_OK;
 }
 
@@ -1459,6 +1748,10 @@ extern "C" int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int6
         if (head_dim <= 32) return launch_fwd_mid<32, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
         return launch_fwd_mid<64, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
     }
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > MD_MAXN && B <= 65535 && small_path_enabled()) {
+        if (head_dim <= 32) return launch_fwd_chunk<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+        return launch_fwd_chunk<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+    }
     ATTN_DISPATCH(launch_fwd, qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, p_drop, seed, stream);
 }
 
@@ -1486,6 +1779,13 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
                                                     head_dim, scale, stream);
         return launch_bwd_mid<64, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H,
                                                 head_dim, scale, stream);
+    }
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > MD_MAXN && ld_out % 8 == 0 && small_path_enabled()) {
+        if (head_dim <= 32)
+            return launch_bwd_chunk<32>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale,
+                                        stream);
+        return launch_bwd_chunk<64>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale,
+                                    stream);
     }
     const int64_t rows = (int64_t)B * N;
     const int64_t nw = rows * H;
