@@ -11,24 +11,43 @@ namespace {
 constexpr int LN_THREADS = 256;           // 4 rows per block
 constexpr int LN_MAX_VEC = 16;            // supports C up to 4*64*16 = 4096 on the vector path
 
-// VPL = number of 4-element vectors per lane (C = 256 * VPL on the fast path)
-template <int VPL>
-__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const void* __restrict__ x, int x_dt,
-                                                            const float* __restrict__ gamma,
+// compile-time typed 4-element accesses: a runtime dtype switch around every load makes hipcc place a full
+// s_waitcnt vmcnt(0) at each branch join, which serialises the 18 loads a wave has in flight per iteration.
+template <typename T> __device__ __forceinline__ f32x4 ld4(const void* base, int64_t idx);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const void* base, int64_t idx) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+}
+template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const void* base, int64_t idx) {
+    const u32x2 raw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+    return f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u), __uint_as_float(raw[1] << 16),
+                 __uint_as_float(raw[1] & 0xffff0000u)};
+}
+template <typename T> __device__ __forceinline__ void st4(void* base, int64_t idx, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(void* base, int64_t idx, f32x4 v) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(void* base, int64_t idx, f32x4 v) {
+    bf16x4 o;
+    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(base) + idx) = o;
+}
+
+// VPL = number of 4-element vectors per lane (C = 256 * VPL on the fast path); dtypes are template parameters for the
+// reason given above (a runtime switch around the row loads would serialise them)
+template <int VPL, typename TX, typename TY>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, void* __restrict__ y,
-                                                            int y_dt, float* __restrict__ mean_out,
-                                                            float* __restrict__ rstd_out, int64_t rows, int C,
-                                                            float eps) {
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;
     f32x4 v[VPL];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        v[i] = load4_as_f32(x, x_dt, row * C + (int64_t)(lane + 64 * i) * 4);
-        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    }
+    for (int i = 0; i < VPL; ++i) v[i] = ld4<TX>(x, row * C + (int64_t)(lane + 64 * i) * 4);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
@@ -52,7 +71,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const void* __restri
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-        store4_from_f32(y, y_dt, row * C + c, o);
+        st4<TY>(y, row * C + c, o);
     }
 }
 
@@ -90,26 +109,6 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_generic_kernel(const void* 
 // Each wave walks rows with a grid stride; a lane always owns the same columns, so the affine partial sums
 // live in registers and are written once per wave to the workspace [n_waves, 2, C]; a second kernel folds
 // them (deterministic, no atomics).
-// compile-time typed 4-element accesses: a runtime dtype switch around every load makes hipcc place a full
-// s_waitcnt vmcnt(0) at each branch join, which serialises the 18 loads a wave has in flight per iteration.
-template <typename T> __device__ __forceinline__ f32x4 ld4(const void* base, int64_t idx);
-template <> __device__ __forceinline__ f32x4 ld4<float>(const void* base, int64_t idx) {
-    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
-}
-template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const void* base, int64_t idx) {
-    const u32x2 raw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(base) + idx);
-    return f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u), __uint_as_float(raw[1] << 16),
-                 __uint_as_float(raw[1] & 0xffff0000u)};
-}
-template <typename T> __device__ __forceinline__ void st4(void* base, int64_t idx, f32x4 v);
-template <> __device__ __forceinline__ void st4<float>(void* base, int64_t idx, f32x4 v) {
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
-}
-template <> __device__ __forceinline__ void st4<bf16_t>(void* base, int64_t idx, f32x4 v) {
-    bf16x4 o;
-    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-    *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(base) + idx) = o;
-}
 
 constexpr int LNB_BLOCKS = 1024;
 constexpr int LNB_WAVES = LNB_BLOCKS * (LN_THREADS / 64);
@@ -320,10 +319,15 @@ extern "C" int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     ME_CHECK_ARG(rows >= 0 && cols > 0, "me_layernorm_fwd: bad shape");
     if (rows == 0) return ME_OK;
     const unsigned nblk = (unsigned)((rows + 3) / 4);
+#define LN_FWD_LAUNCH(V, TX, TY)                                                                               \
+    hipLaunchKernelGGL((ln_fwd_kernel<V, TX, TY>), dim3(nblk), dim3(LN_THREADS), 0, stream, x, gamma, beta, y, mean, rstd,  \
+                       rows, cols, eps)
 #define LN_FWD_CASE(V)                                                                                         \
     case V:                                                                                                    \
-        hipLaunchKernelGGL((ln_fwd_kernel<V>), dim3(nblk), dim3(LN_THREADS), 0, stream, x, x_dtype, gamma,      \
-                           beta, y, y_dtype, mean, rstd, rows, cols, eps);                                     \
+        if (x_dtype == ME_BF16 && y_dtype == ME_BF16) LN_FWD_LAUNCH(V, bf16_t, bf16_t);                        \
+        else if (x_dtype == ME_BF16) LN_FWD_LAUNCH(V, bf16_t, float);                                          \
+        else if (y_dtype == ME_BF16) LN_FWD_LAUNCH(V, float, bf16_t);                                          \
+        else LN_FWD_LAUNCH(V, float, float);                                                                   \
         break;
     if (cols % 256 == 0 && cols / 256 <= LN_MAX_VEC) {
         switch (cols / 256) {
@@ -336,6 +340,7 @@ extern "C" int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
                            y, y_dtype, mean, rstd, rows, cols, eps);
     }
 #undef LN_FWD_CASE
+#undef LN_FWD_LAUNCH
     ME_CHECK_LAUNCH("me_layernorm_fwd");
     return ME_OK;
 }
