@@ -138,11 +138,16 @@ def main():
         # tools/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md correction); counters cannot be read live
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_{args.mode}.json")))
-            ks = [(v["launches"], v["hbm_traffic_MB"]) for k, v in pmc.items()
-                  if k.startswith("gemm_g2_kernel") and ", false," in k and "hbm_traffic_MB" in v]
-            if ks:
-                roof["traffic"] = round(1e6 * sum(n * t for n, t in ks) / sum(n for n, _ in ks))
-                roof["traffic_unit"] = "HBM bytes per launch (PMC pass in profiles/, not live)"
+            pmc_steps = pmc.get("_meta", {}).get("bench_steps_in_pass", 2)
+            # every kernel an NT me_gemm call launches: the main kernel, its tail-split part (EPI 5) and that part's fold
+            n_tail = sum(v["launches"] for k, v in pmc.items() if k.startswith("gemm_g2_kernel") and ", false, 5>" in k)
+            tot_mb = sum(v["launches"] * v["hbm_traffic_MB"] for k, v in pmc.items()
+                         if k.startswith("gemm_g2_kernel") and ", false," in k and "hbm_traffic_MB" in v)
+            if "splitk_reduce_kernel" in pmc and n_tail:
+                tot_mb += n_tail * pmc["splitk_reduce_kernel"]["hbm_traffic_MB"]
+            if tot_mb > 0:
+                roof["traffic"] = round(1e6 * tot_mb / (pmc_steps * (len(nt) // args.steps)))
+                roof["traffic_unit"] = "HBM bytes per me_gemm(NT) call (PMC pass in profiles/, not live)"
                 roof["algorithmic_bytes_per_launch"] = round(sum(2.0 * (m * k + n * k + m * n) for m, n, k, _ in nt) / len(nt))
         except Exception:      # noqa: BLE001 -- profile file absent: traffic stays null
             pass
