@@ -352,11 +352,11 @@ __global__ __launch_bounds__(NTH) void gemm_g256_kernel(const GemmParams p) {
             v1 = v1 * p.alpha + bias1;
             if (p.preact) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
             if (p.act == ME_ACT_GELU) {
-v0 = gelu_erf4(v0);
+                v0 = gelu_erf4(v0);
                 v1 = gelu_erf4(v1);
             }
             if (p.aux) {
-v0 *= gelu_erf_grad4(cur.v[i][0]);
+                v0 *= gelu_erf_grad4(cur.v[i][0]);
                 v1 *= gelu_erf_grad4(cur.v[i][1]);
             }
             v0 *= cs0; v1 *= cs1;

@@ -24,12 +24,10 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, in
     v *= p.alpha;
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.preact) store4_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v);
-    if (p.act == ME_ACT_GELU) {
-v = gelu_erf4(v);
-    }
+    if (p.act == ME_ACT_GELU) v = gelu_erf4(v);
     if (p.aux) {
         const f32x4 a = load4_as_f32(p.aux, p.aux_dtype, m * p.ldaux + n);
-v *= gelu_erf_grad4(a);
+        v *= gelu_erf_grad4(a);
     }
     if (p.colscale) v *= *reinterpret_cast<const f32x4*>(p.colscale + n);
     if (p.residual) {
@@ -77,13 +75,13 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
     }
     if (p.preact) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
     if (p.act == ME_ACT_GELU) {
-v0 = gelu_erf4(v0);
-                v1 = gelu_erf4(v1);
+        v0 = gelu_erf4(v0);
+        v1 = gelu_erf4(v1);
     }
     if (p.aux) {
         f32x4 a0, a1;
         load8_as_f32(p.aux, p.aux_dtype, m * p.ldaux + n, a0, a1);
-v0 *= gelu_erf_grad4(a0);
+        v0 *= gelu_erf_grad4(a0);
         v1 *= gelu_erf_grad4(a1);
     }
     if (p.colscale) {
