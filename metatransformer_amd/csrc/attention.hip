@@ -1577,8 +1577,8 @@ int launch_fwd_small(const void* qkv, int64_t ld, void* out, int64_t ldo, float*
                      hipStream_t stream) {
     typedef Cfg<bf16_t, HD> C;
     const size_t smem = (size_t)(2 * ((N + 31) / 32 * 32) + SM_THREADS / 2) * C::RROW;      // {K, V} + per-wave [32][HD] scratch
-    static bool once = false;
-    if (!once) { set_smem(attn_fwd_small_kernel<HD>, (size_t)(2 * SM_MAXN + SM_THREADS / 2) * C::RROW); once = true; }
+    static OncePerDevice once;
+    if (once.need()) { set_smem(attn_fwd_small_kernel<HD>, (size_t)(2 * SM_MAXN + SM_THREADS / 2) * C::RROW); }
     const int64_t items = (int64_t)B * H;
     int per_cu = (int)(LDS_PER_CU / smem);
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
@@ -1595,8 +1595,8 @@ int launch_bwd_small(const void* qkv, int64_t ld, const void* out, int64_t ldo, 
                      float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
     typedef Cfg<bf16_t, HD> C;
     const size_t smem = (size_t)4 * ((N + 31) / 32 * 32) * C::RROW + 2 * SM_MAXN * sizeof(float);
-    static bool once = false;
-    if (!once) { set_smem(attn_bwd_small_kernel<HD>, (size_t)4 * SM_MAXN * C::RROW + 2 * SM_MAXN * sizeof(float)); once = true; }
+    static OncePerDevice once;
+    if (once.need()) { set_smem(attn_bwd_small_kernel<HD>, (size_t)4 * SM_MAXN * C::RROW + 2 * SM_MAXN * sizeof(float)); }
     hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), dim3(H, B), dim3(SM_THREADS), smem, stream,
                        reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<const bf16_t*>(out), ldo,
                        reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd,
@@ -1610,8 +1610,8 @@ int launch_fwd_mid(const void* qkv, int64_t ld, void* out, int64_t ldo, float* l
                    hipStream_t stream) {
     typedef Cfg<bf16_t, HD> C;
     const size_t smem = (size_t)2 * ((N + 31) / 32 * 32) * C::RROW;
-    static bool once = false;
-    if (!once) { set_smem(attn_fwd_mid_kernel<HD, NTHR, MAXN>, (size_t)2 * MAXN * C::RROW); once = true; }
+    static OncePerDevice once;
+    if (once.need()) { set_smem(attn_fwd_mid_kernel<HD, NTHR, MAXN>, (size_t)2 * MAXN * C::RROW); }
     hipLaunchKernelGGL((attn_fwd_mid_kernel<HD, NTHR, MAXN>), dim3(H, B), dim3(NTHR), smem, stream,
                        reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale);
     ME_CHECK_LAUNCH("me_attention_fwd(mid)");
@@ -1622,8 +1622,8 @@ int launch_bwd_mid(const void* qkv, int64_t ld, const void* out, int64_t ldo, co
                    float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
     typedef Cfg<bf16_t, HD> C;
     const size_t smem = (size_t)2 * ((N + 31) / 32 * 32) * C::RROW + 2 * MAXN * sizeof(float);
-    static bool once = false;
-    if (!once) { set_smem(attn_bwd_mid_kernel<HD, NTHR, MAXN>, (size_t)2 * MAXN * C::RROW + 2 * MAXN * sizeof(float)); once = true; }
+    static OncePerDevice once;
+    if (once.need()) { set_smem(attn_bwd_mid_kernel<HD, NTHR, MAXN>, (size_t)2 * MAXN * C::RROW + 2 * MAXN * sizeof(float)); }
     hipLaunchKernelGGL((attn_bwd_mid_kernel<HD, NTHR, MAXN>), dim3(H, B), dim3(NTHR), smem, stream,
                        reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<const bf16_t*>(out), ldo,
                        reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd,
@@ -1637,8 +1637,8 @@ int launch_fwd_chunk(const void* qkv, int64_t ld, void* out, int64_t ldo, float*
                      hipStream_t stream) {
     typedef Cfg<bf16_t, HD> C;
     const size_t smem = (size_t)2 * CH_ROWS * C::RROW;
-    static bool once = false;
-    if (!once) { set_smem(attn_fwd_chunk_kernel<HD>, smem); once = true; }
+    static OncePerDevice once;
+    if (once.need()) { set_smem(attn_fwd_chunk_kernel<HD>, smem); }
     hipLaunchKernelGGL((attn_fwd_chunk_kernel<HD>), dim3((N + CH_ROWS - 1) / CH_ROWS, H, B), dim3(SM_THREADS), smem, stream,
                        reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale);
     ME_CHECK_LAUNCH("me_attention_fwd(chunk)");
@@ -1649,11 +1649,10 @@ int launch_bwd_chunk(const void* qkv, int64_t ld, const void* out, int64_t ldo, 
                      float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
     typedef Cfg<bf16_t, HD> C;
     const size_t smem1 = (size_t)2 * CH_ROWS * C::RROW, smem2 = smem1 + 2 * CH_ROWS * sizeof(float);
-    static bool once = false;
-    if (!once) {
+    static OncePerDevice once;
+    if (once.need()) {
         set_smem(attn_bwd_dq_chunk_kernel<HD>, smem1);
         set_smem(attn_bwd_dkdv_chunk_kernel<HD>, smem2);
-        once = true;
     }
     dim3 grid((N + CH_ROWS - 1) / CH_ROWS, H, B);
     hipLaunchKernelGGL((attn_bwd_dq_chunk_kernel<HD>), grid, dim3(SM_THREADS), smem1, stream, reinterpret_cast<const bf16_t*>(qkv),
@@ -1672,8 +1671,8 @@ int launch_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, 
                float p_drop, uint64_t seed, hipStream_t stream) {
     typedef Cfg<T, HD> C;
     const size_t smem = C::R_BYTES + (C::T_BYTES > C::R_BYTES ? C::T_BYTES : C::R_BYTES);   // V tile: transposed (fp32) or row-major (bf16)
-    static bool once = false;
-    if (!once) { set_smem(attn_fwd_kernel<T, HD>, smem); once = true; }
+    static OncePerDevice once;
+    if (once.need()) { set_smem(attn_fwd_kernel<T, HD>, smem); }
     dim3 grid((N + QPB - 1) / QPB, H, B);
     hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), grid, dim3(AT_THREADS), smem, stream, reinterpret_cast<const T*>(qkv), ld,
                        reinterpret_cast<T*>(out), ldo, lse, N, H, hd, scale, p_drop, seed);
@@ -1688,11 +1687,10 @@ int launch_bwd(const void* qkv, int64_t ld, const void* dout, int64_t lddo, cons
     constexpr size_t TB = TRead<T, HD>::kNeedsTransposedTile ? C::T_BYTES : 0;
     const size_t smem1 = 2 * C::R_BYTES + 2 * TB + 2 * KVT * sizeof(float);
     const size_t smem2 = 2 * C::R_BYTES + TB;
-    static bool once = false;
-    if (!once) {
+    static OncePerDevice once;
+    if (once.need()) {
         set_smem(attn_bwd_dkdv_kernel<T, HD>, smem1);
         set_smem(attn_bwd_dq_kernel<T, HD>, smem2);
-        once = true;
     }
     dim3 grid((N + QPB - 1) / QPB, H, B);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, HD>), grid, dim3(AT_THREADS), smem1, stream,

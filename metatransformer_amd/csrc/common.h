@@ -35,6 +35,19 @@ void me_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// hipFuncSetAttribute (dynamic LDS size) is per DEVICE: a per-kernel `static bool` would leave the second GPU of a
+// single-process multi-GPU host (nn.DataParallel, Audio/src/traintest.py) without it.  Benign if two threads race.
+struct OncePerDevice {
+    bool done[64] = {};
+    bool need() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 static inline size_t me_dtype_size(int dt) { return dt == ME_F32 ? 4 : 2; }
 static inline bool me_dtype_ok(int dt) { return dt == ME_F32 || dt == ME_BF16; }                    // compute dtypes
 static inline bool me_storage_dtype_ok(int dt) { return me_dtype_ok(dt) || dt == ME_F16; }          // me_cast only

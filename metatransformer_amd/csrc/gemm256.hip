@@ -374,11 +374,10 @@ template <int BN, bool TN, int VARIANT>
 int launch(const GemmParams& p, hipStream_t stream) {
     typedef G256<BN, TN> G;
     const size_t lds = 2 * G::STAGE;
-    static bool once = false;
-    if (!once) {
+    static OncePerDevice once;
+    if (once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g256_kernel<BN, TN, VARIANT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once = true;
     }
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(p.split_k > 1 ? p.split_k : 1));
     hipLaunchKernelGGL((gemm_g256_kernel<BN, TN, VARIANT>), grid, dim3(NTH), lds, stream, p);

@@ -375,11 +375,10 @@ template <int BM, int BN, bool TN, int EPI>
 int launch2e(const GemmParams& p, hipStream_t stream) {
     typedef G2<BM, BN> G;
     const size_t lds = G::NSTAGE * G::STAGE;
-    static bool once = false;
-    if (!once) {
+    static OncePerDevice once;
+    if (once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g2_kernel<BM, BN, TN, EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once = true;
     }
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(p.split_k > 1 ? p.split_k : 1));
     hipLaunchKernelGGL((gemm_g2_kernel<BM, BN, TN, EPI>), grid, dim3(G::NTH), lds, stream, p);
