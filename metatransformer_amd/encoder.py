@@ -109,7 +109,10 @@ class _WeightCache:
 
     @staticmethod
     def _key(p: torch.Tensor, dtype):
-        return (p.data_ptr(), p._version, ops.WEIGHT_EPOCH, p.dtype, dtype, p.device)
+        # WEIGHT_EPOCH covers the fused optimizer, which writes parameters through raw pointers (no _version bump); it
+        # only ever touches parameters that live in a parallel.FlatParams, so other (e.g. frozen) encoders keep their copies
+        epoch = ops.WEIGHT_EPOCH if hasattr(p, "_me_flat") else 0
+        return (p.data_ptr(), p._version, epoch, p.dtype, dtype, p.device)
 
     def fwd(self, name: str, p: torch.Tensor, dtype) -> torch.Tensor:
         if p.dtype == dtype:
