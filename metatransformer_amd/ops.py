@@ -383,6 +383,10 @@ def unpatchify_add(dcols: torch.Tensor, x_shape, kt, kh, kw, st, sh, sw) -> torc
 def adamw_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
                betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01, step: int = 1,
                grad_scale: float = 1.0, bf16_mirror: Optional[torch.Tensor] = None) -> None:
+    """Raw fused AdamW on flat fp32 buffers (me_adamw_step).  The kernel writes `param` through its raw pointer, so
+    torch's tensor version counters do not move; Block weight-copy caches notice the update through WEIGHT_EPOCH, which
+    they consult for parameters registered in a parallel.FlatParams -- use parallel.FusedAdamW rather than this call
+    unless you manage cache invalidation yourself."""
     lib = _capi.load()
     if bf16_mirror is not None and (bf16_mirror.dtype != torch.bfloat16 or bf16_mirror.numel() != param.numel()):
         raise MetaEncError("adamw_step: bf16_mirror must be a bfloat16 tensor of the parameter buffer's size")
