@@ -24,14 +24,13 @@ Compute dtype: bf16 when the parameters are bf16 or when called under ``torch.au
 """
 from __future__ import annotations
 
-import math
 from typing import Optional
 
 import torch
 import torch.nn as nn
 
 from . import _capi, ops
-from ._capi import ME_ACT_GELU, ME_GEMM_NT, ME_GEMM_TN, MetaEncError
+from ._capi import ME_ACT_GELU, ME_GEMM_TN, MetaEncError
 
 
 def _resolve_eps(norm_layer) -> float:

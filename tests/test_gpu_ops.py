@@ -1,6 +1,5 @@
 """GPU: per-kernel parity of the HIP path (called through the C ABI wrappers in metatransformer_amd.ops) against the
 CPU oracle restatements, on seeded inputs.  fp32 tolerance 1e-3 relative (north star), bf16 stated per test."""
-import math
 
 import pytest
 import torch
