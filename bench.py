@@ -28,6 +28,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_HBM_TBPS = 8.0             # HBM3E (same guide)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -158,6 +159,30 @@ def main():
                                     "unit": "TFLOP/s", "avg_launch_us": round(1e3 * ms2 / len(tn), 2),
                                     "share_of_step_time": round(ms2 * 1e-3 / elapsed, 4)}
 
+    # ---- the other kernel classes of the step, from the same event records: HBM-bound LayerNorm against the 8 TB/s
+    # peak (algorithmic bytes: SURVEY 8d), attention against both peaks
+    def _class(code, work_fn, bytes_fn):
+        recs = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in prof if op == code]
+        if not recs:
+            return None
+        ms = sum(t for *_, t in recs)
+        by = sum(bytes_fn(m, n, k) for m, n, k, _ in recs)
+        out_ = {"launches_per_step": len(recs) // args.steps, "avg_launch_us": round(1e3 * ms / len(recs), 2),
+                "hbm_TBps": round(by / (ms * 1e-3) / 1e12, 3), "hbm_frac": round(by / (ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
+                "share_of_step_time": round(ms * 1e-3 / elapsed, 4)}
+        if work_fn is not None:
+            fl = sum(work_fn(m, n, k) for m, n, k, _ in recs)
+            out_["TFLOPs"] = round(fl / (ms * 1e-3) / 1e12, 1)
+        return out_
+    es = 2      # bf16 token stream
+    other = {
+        "layernorm_fwd": _class(_capi.ME_PROF_LN_FWD, None, lambda m, n, k: 2.0 * m * n * es),
+        "layernorm_bwd": _class(_capi.ME_PROF_LN_BWD, None, lambda m, n, k: 4.0 * m * n * es),
+        "attention_fwd": _class(_capi.ME_PROF_ATTN_FWD, lambda m, n, k: 4.0 * m * n * n * k, lambda m, n, k: 4.0 * m * n * k * es),
+        "attention_bwd": _class(_capi.ME_PROF_ATTN_BWD, lambda m, n, k: 10.0 * m * n * n * k, lambda m, n, k: 8.0 * m * n * k * es),
+    }
+    other = {k: v for k, v in other.items() if v is not None}
+
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -184,6 +209,7 @@ def main():
         "model_tflops_per_s": round(value * model_flops / 1e12, 2),
         "mfma_frac_end_to_end": round(value * model_flops / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "roofline": roof,
+        "other_kernels": other,
     }
     if not args.no_cpu_baseline and world == 1:
         # the CPU oracle runs in its own process (fresh OpenMP pool, hard timeout) so it can never stall the bench

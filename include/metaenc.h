@@ -115,10 +115,13 @@ size_t me_gemm_workspace_bytes(const me_gemm_desc* d);
 int me_gemm_fuses_colsum(const me_gemm_desc* d);
 int me_gemm(const me_gemm_desc* d, void* stream);
 
-/* Per-launch timing of me_gemm for roofline accounting (bench.py): while enabled, every me_gemm call -- including those
- * made from me_block_fwd / me_block_bwd -- is bracketed by HIP events on its stream.  me_gemm_profile_read synchronises
+/* Per-launch timing for roofline accounting (bench.py): while enabled, every me_gemm call -- including those made from
+ * me_block_fwd / me_block_bwd -- and every LayerNorm / attention call is bracketed by HIP events on its stream.  Records
+ * carry op = ME_GEMM_NT / ME_GEMM_TN with (M, N, K), or one of the codes below with (M, N, K) = (rows, cols, 0) for
+ * LayerNorm and (B * heads, N, head_dim) for attention.  me_gemm_profile_read synchronises
  * on the recorded events, fills up to `max` records in call order and returns how many there are (and clears them).
  * Off by default; costs two event records per GEMM when on. */
+enum { ME_PROF_LN_FWD = 16, ME_PROF_LN_BWD = 17, ME_PROF_ATTN_FWD = 18, ME_PROF_ATTN_BWD = 19 };
 typedef struct me_gemm_profile_rec {
     int32_t op, ab_dtype;
     int64_t M, N, K;

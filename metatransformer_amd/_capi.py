@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libmetaenc.so")
 ME_F32, ME_BF16, ME_F16 = 0, 1, 2      # ME_F16: storage dtype of me_cast / me_transpose_cast only
 ME_GEMM_NT, ME_GEMM_TN = 0, 1
 ME_ACT_NONE, ME_ACT_GELU = 0, 1
+ME_PROF_LN_FWD, ME_PROF_LN_BWD, ME_PROF_ATTN_FWD, ME_PROF_ATTN_BWD = 16, 17, 18, 19      # me_gemm_profile_rec.op codes
 
 
 class MetaEncError(RuntimeError):

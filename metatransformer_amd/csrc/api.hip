@@ -2,6 +2,8 @@
 #include "common.h"
 #include <stdarg.h>
 #include <string.h>
+#include <mutex>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -30,4 +32,50 @@ extern "C" int me_device_info(int dev, int* num_cus, int* lds_bytes, int* clock_
         snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
     }
     return ME_OK;
+}
+
+// ---- optional per-launch timing
+namespace {
+struct ProfEntry { int op, dt; int64_t M, N, K; hipEvent_t e0, e1; };
+std::mutex g_prof_mu;
+std::vector<ProfEntry> g_prof;
+bool g_prof_on = false;
+}  // namespace
+
+ProfScope::ProfScope(int op_, int dt_, int64_t M_, int64_t N_, int64_t K_, hipStream_t s) : stream(s), op(op_), dt(dt_), M(M_), N(N_), K(K_) {
+    if (!g_prof_on) return;
+    if (hipEventCreate(&e0) != hipSuccess) { e0 = nullptr; return; }
+    (void)hipEventRecord(e0, stream);
+}
+ProfScope::~ProfScope() {
+    if (!e0) return;
+    hipEvent_t e1 = nullptr;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; }
+    (void)hipEventRecord(e1, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(ProfEntry{op, dt, M, N, K, e0, e1});
+}
+
+extern "C" int me_gemm_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& e : g_prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return ME_OK;
+}
+
+extern "C" int me_gemm_profile_read(me_gemm_profile_rec* out, int max) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto& e : g_prof) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(e.e1);
+        (void)hipEventElapsedTime(&ms, e.e0, e.e1);
+        if (out && n < max) out[n] = me_gemm_profile_rec{e.op, e.dt, e.M, e.N, e.K, ms, 0};
+        ++n;
+        (void)hipEventDestroy(e.e0);
+        (void)hipEventDestroy(e.e1);
+    }
+    g_prof.clear();
+    return n;
 }

@@ -1733,6 +1733,7 @@ int check_attn_args(const char* fn, int64_t ld, int B, int N, int H, int hd, int
 extern "C" int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int B, int N,
                                 int H, int head_dim, float scale, int dtype, float p_drop, uint64_t seed, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ProfScope prof(ME_PROF_ATTN_FWD, dtype, (int64_t)B * H, N, head_dim, stream);
     ME_CHECK_ARG(qkv && out, "me_attention_fwd: null pointer");
     int rc = check_attn_args("me_attention_fwd", ld_qkv, B, N, H, head_dim, dtype);
     if (rc) return rc;
@@ -1758,6 +1759,7 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
                                 int N, int H, int head_dim, float scale, int dtype, float p_drop, uint64_t seed,
                                 void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ProfScope prof(ME_PROF_ATTN_BWD, dtype, (int64_t)B * H, N, head_dim, stream);
     ME_CHECK_ARG(qkv && out && dout && lse && delta && dqkv, "me_attention_bwd: null pointer");
     int rc = check_attn_args("me_attention_bwd", ld_qkv, B, N, H, head_dim, dtype);
     if (rc) return rc;

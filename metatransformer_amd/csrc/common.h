@@ -48,6 +48,17 @@ struct OncePerDevice {
     }
 };
 
+// optional per-launch timing (me_gemm_profile_enable / _read, api.hip): brackets the launches an entry point makes with
+// HIP events on its stream while profiling is on; free when off.  op: ME_GEMM_NT / ME_GEMM_TN or an ME_PROF_* code.
+struct ProfScope {
+    hipEvent_t e0 = nullptr;
+    hipStream_t stream;
+    int op, dt;
+    int64_t M, N, K;
+    ProfScope(int op, int dt, int64_t M, int64_t N, int64_t K, hipStream_t stream);
+    ~ProfScope();
+};
+
 static inline size_t me_dtype_size(int dt) { return dt == ME_F32 ? 4 : 2; }
 static inline bool me_dtype_ok(int dt) { return dt == ME_F32 || dt == ME_BF16; }                    // compute dtypes
 static inline bool me_storage_dtype_ok(int dt) { return me_dtype_ok(dt) || dt == ME_F16; }          // me_cast only

@@ -15,8 +15,6 @@
 //   TN: C[M,N] = A[K,M]^T B[K,N]   (wgrad) the loader transposes while staging: pairs of reduction rows are
 //                                  interleaved into dwords so that LDS rows are again reduction-contiguous.
 #include "gemm_common.h"
-#include <mutex>
-#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -451,53 +449,14 @@ extern "C" int me_gemm_fuses_colsum(const me_gemm_desc* d) {
     return pl.family == 2 && pl.split_k > 1;
 }
 
-// ---- optional per-launch timing (me_gemm_profile_*)
 namespace {
-struct ProfEntry { int op, dt; int64_t M, N, K; hipEvent_t e0, e1; };
-std::mutex g_prof_mu;
-std::vector<ProfEntry> g_prof;
-bool g_prof_on = false;
 int gemm_impl(const me_gemm_desc* d, hipStream_t stream);
-}  // namespace
-
-extern "C" int me_gemm_profile_enable(int on) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto& e : g_prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
-    g_prof.clear();
-    g_prof_on = on != 0;
-    return ME_OK;
-}
-
-extern "C" int me_gemm_profile_read(me_gemm_profile_rec* out, int max) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    int n = 0;
-    for (auto& e : g_prof) {
-        float ms = 0.f;
-        (void)hipEventSynchronize(e.e1);
-        (void)hipEventElapsedTime(&ms, e.e0, e.e1);
-        if (out && n < max) out[n] = me_gemm_profile_rec{e.op, e.dt, e.M, e.N, e.K, ms, 0};
-        ++n;
-        (void)hipEventDestroy(e.e0);
-        (void)hipEventDestroy(e.e1);
-    }
-    g_prof.clear();
-    return n;
 }
 
 extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (!g_prof_on) return gemm_impl(d, stream);
-    ProfEntry e{d ? d->op : 0, d ? d->ab_dtype : 0, d ? d->M : 0, d ? d->N : 0, d ? d->K : 0, nullptr, nullptr};
-    if (hipEventCreate(&e.e0) != hipSuccess || hipEventCreate(&e.e1) != hipSuccess) {
-        me_set_error("me_gemm: cannot create profiling events");
-        return ME_ERR_HIP;
-    }
-    (void)hipEventRecord(e.e0, stream);
-    const int rc = gemm_impl(d, stream);
-    (void)hipEventRecord(e.e1, stream);
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.push_back(e);
-    return rc;
+    ProfScope prof(d ? d->op : 0, d ? d->ab_dtype : 0, d ? d->M : 0, d ? d->N : 0, d ? d->K : 0, stream);
+    return gemm_impl(d, stream);
 }
 
 namespace {

@@ -318,6 +318,7 @@ extern "C" int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     ME_CHECK_ARG(me_dtype_ok(x_dtype) && me_dtype_ok(y_dtype), "me_layernorm_fwd: bad dtype");
     ME_CHECK_ARG(rows >= 0 && cols > 0, "me_layernorm_fwd: bad shape");
     if (rows == 0) return ME_OK;
+    ProfScope prof(ME_PROF_LN_FWD, x_dtype, rows, cols, 0, stream);
     const unsigned nblk = (unsigned)((rows + 3) / 4);
 #define LN_FWD_LAUNCH(V, TX, TY)                                                                               \
     hipLaunchKernelGGL((ln_fwd_kernel<V, TX, TY>), dim3(nblk), dim3(LN_THREADS), 0, stream, x, gamma, beta, y, mean, rstd,  \
@@ -354,6 +355,7 @@ extern "C" int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int
                                 int dx_dtype, float* dgamma, float* dbeta, int accumulate_affine, int64_t rows,
                                 int cols, void* workspace, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ProfScope prof(ME_PROF_LN_BWD, x_dtype, rows, cols, 0, stream);
     ME_CHECK_ARG(dy && x && mean && rstd && gamma && dx, "me_layernorm_bwd: null pointer");
     ME_CHECK_ARG(me_dtype_ok(dy_dtype) && me_dtype_ok(x_dtype) && me_dtype_ok(dx_dtype), "me_layernorm_bwd: bad dtype");
     ME_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "me_layernorm_bwd: dgamma/dbeta must both be given or both NULL");
