@@ -203,6 +203,12 @@ int me_block_fwd(const me_block_desc* d, const void* x, void* y, void* saved, vo
 int me_block_bwd(const me_block_desc* d, const void* x, const void* dy, const void* saved, void* dx,
                  const me_block_grads* g, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The whole encoder, inference: y = Block_{n-1}(... Block_0(x)) -- nn.Sequential(*[Block] * L)(x) of README.md:124-149 as
+ * one call for serving hosts.  All blocks share B, N, C and dtypes.  `pingpong` is one token buffer [B*N, C] in res_dtype
+ * (unused when n_blocks == 1; x itself is never written); workspace >= me_block_workspace_bytes(&blocks[i], 0) for every i. */
+int me_encoder_fwd(const me_block_desc* blocks, int n_blocks, const void* x, void* y, void* pingpong, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ element-wise helpers */
 /* dst = (dst_dtype) src, n elements */
 int me_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);

@@ -5,9 +5,10 @@ feed it (see encoder.py / data2seq.py); all compute runs in libmetaenc.so (hand-
 behind the C ABI of include/metaenc.h.
 """
 from ._capi import MetaEncError, load as load_library  # noqa: F401
-from .encoder import Attention, Block, Mlp, build_encoder, encoder_flops_per_sample  # noqa: F401
+from .encoder import (Attention, Block, Mlp, build_encoder, encoder_flops_per_sample,  # noqa: F401
+                      encoder_forward_inference)
 from .data2seq import (AcousticPatchEmbed, Data2Seq, DataEmbedding, PatchEmbed, VideoPatchEmbed,  # noqa: F401
                        sinusoid_table, video_sinusoid_table)
 
-__all__ = ["Block", "Attention", "Mlp", "build_encoder", "encoder_flops_per_sample", "Data2Seq", "PatchEmbed",
+__all__ = ["Block", "Attention", "Mlp", "build_encoder", "encoder_flops_per_sample", "encoder_forward_inference", "Data2Seq", "PatchEmbed",
            "AcousticPatchEmbed", "VideoPatchEmbed", "DataEmbedding", "MetaEncError", "load_library"]

@@ -116,6 +116,7 @@ SIGNATURES = {
     "me_block_saved_bytes": (c_size_t, [POINTER(BlockDesc)]),
     "me_block_workspace_bytes": (c_size_t, [POINTER(BlockDesc), c_int]),
     "me_block_fwd": (c_int, [POINTER(BlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "me_encoder_fwd": (c_int, [POINTER(BlockDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "me_block_bwd": (c_int, [POINTER(BlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(BlockGrads), c_void_p,
                              c_size_t, c_void_p]),
     "me_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),

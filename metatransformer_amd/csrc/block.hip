@@ -229,3 +229,19 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
     return me_layernorm_bwd(dxn, dt, x, rdt, v.mean1, v.rstd1, d->ln1_g, dx1, rdt, dx, rdt, gr->ln1_g, gr->ln1_b, gr->accumulate,
                             s.M, s.C, aws, stream);
 }
+
+extern "C" int me_encoder_fwd(const me_block_desc* blocks, int n_blocks, const void* x, void* y, void* pingpong, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    ME_CHECK_ARG(blocks && n_blocks > 0 && x && y && workspace, "me_encoder_fwd: bad args");
+    ME_CHECK_ARG(n_blocks == 1 || pingpong, "me_encoder_fwd: more than one block needs the ping-pong token buffer");
+    // block i writes y when (n_blocks - 1 - i) is even, the ping-pong buffer otherwise: the last block lands in y and no
+    // block reads the buffer it writes
+    const void* in = x;
+    for (int i = 0; i < n_blocks; ++i) {
+        void* out = ((n_blocks - 1 - i) % 2 == 0) ? y : pingpong;
+        int rc = me_block_fwd(&blocks[i], in, out, nullptr, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        in = out;
+    }
+    return ME_OK;
+}

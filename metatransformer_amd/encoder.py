@@ -492,6 +492,34 @@ def build_encoder(depth: int = 12, dim: int = 768, num_heads: int = 12, mlp_rati
                                  norm_layer=norm_layer, act_layer=nn.GELU, **kw) for _ in range(depth)])
 
 
+@torch.no_grad()
+def encoder_forward_inference(encoder: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """``encoder(x)`` for a plain stack of Blocks in eval mode as ONE library call (me_encoder_fwd): what a serving host that
+    is not Python would do.  Falls back to nothing: raises if a block is not a plain Block."""
+    blocks = list(encoder)
+    if not blocks or any(not isinstance(b, Block) or b.windowed for b in blocks):
+        raise MetaEncError("encoder_forward_inference: a non-empty nn.Sequential of plain (non-windowed) Blocks is required")
+    if x.dim() != 3 or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
+        raise MetaEncError("encoder_forward_inference: [B, N, C] fp32 / bf16 CUDA tokens required")
+    B, N, C = x.shape
+    x2 = x.contiguous().reshape(B * N, C)
+    descs, keep = [], []
+    for b in blocks:
+        b._wcache.bind(b)
+        cdt = b._compute_dtype(x)
+        a, m = b.attn, b.mlp
+        g1 = b.gamma1 if b.layer_scale else None
+        g2 = b.gamma2 if b.layer_scale else None
+        d, k = _BlockFn._desc(b, b._wcache, cdt, x.dtype, B, N, C, a.num_heads,
+                              (b.norm1.weight, b.norm1.bias, b.norm2.weight, b.norm2.bias, a.qkv.weight, a.qkv.bias,
+                               a.proj.weight, a.proj.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, g1, g2), False)
+        descs.append(d)
+        keep.append(k)
+    y = ops.encoder_fwd(descs, x2)
+    del keep
+    return y.reshape(B, N, C)
+
+
 def encoder_flops_per_sample(N: int, C: int, L: int) -> float:
     """F(N,C,L) = L * (24 N C^2 + 4 N^2 C)  -- the work model of BASELINE.md section 3 (forward)."""
     return float(L) * (24.0 * N * C * C + 4.0 * N * N * C)

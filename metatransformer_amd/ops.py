@@ -209,6 +209,19 @@ def block_fwd(d, x2: torch.Tensor, keep: bool):
     return y, saved
 
 
+def encoder_fwd(descs, x2: torch.Tensor) -> torch.Tensor:
+    """inference through a list of block descriptors in ONE library call (me_encoder_fwd)"""
+    lib = _capi.load()
+    n = len(descs)
+    arr = (_capi.BlockDesc * n)(*descs)
+    y = torch.empty_like(x2)
+    pp = torch.empty_like(x2) if n > 1 else None
+    wsb = max(lib.me_block_workspace_bytes(ctypes.byref(d), 0) for d in descs)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x2.device)
+    check(lib.me_encoder_fwd(arr, n, ptr(x2), ptr(y), ptr(pp), ptr(ws), wsb, stream_ptr()), "me_encoder_fwd")
+    return y
+
+
 def block_bwd(d, x2: torch.Tensor, dy2: torch.Tensor, saved: torch.Tensor, grads: "_capi.BlockGrads") -> torch.Tensor:
     lib = _capi.load()
     dx = torch.empty_like(x2)

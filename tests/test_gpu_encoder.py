@@ -206,6 +206,18 @@ def test_optimizer_mirror_and_batched_transposes(dev):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("depth", [1, 2, 5])
+def test_encoder_forward_single_call(dev, dt, depth):
+    """me_encoder_fwd (the whole stack in one C call, for serving hosts) == encoder(x), bit for bit"""
+    c = dict(depth=depth, dim=256, heads=4, eps=1e-5, seed=31)
+    enc = make_encoder(c, dev, dt)
+    x = torch.randn(3, 77, 256, generator=torch.Generator().manual_seed(1)).to(dev).to(dt)
+    with torch.no_grad():
+        ref = enc(x)
+    assert torch.equal(M.encoder_forward_inference(enc, x), ref)
+
+
 def test_frozen_encoder_passes_input_grad_only(dev):
     """most reference pipelines freeze the encoder but train the tokenizer in front of it."""
     c = dict(depth=1, dim=128, heads=2, eps=1e-5, seed=6)
