@@ -218,6 +218,31 @@ def test_encoder_forward_single_call(dev, dt, depth):
     assert torch.equal(M.encoder_forward_inference(enc, x), ref)
 
 
+def test_training_steps_match_torch_adamw_on_the_oracle(dev):
+    """row f1 end to end: three optimizer steps of the fused training path (C-side block calls, gradients accumulated in
+    place into FlatParams, one-kernel AdamW) against torch.optim.AdamW driving autograd through the CPU oracle"""
+    from metatransformer_amd import parallel
+    c = dict(depth=2, dim=128, heads=2, eps=1e-5, seed=17)
+    sd = bo.make_encoder_state_dict(c["depth"], c["dim"], seed=c["seed"])
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(2, 80, 128, generator=g) for _ in range(3)]
+    tgt = [torch.randn(2, 80, 128, generator=g) for _ in range(3)]
+    ref = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    opt_ref = torch.optim.AdamW(list(ref.values()), lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    enc = make_encoder(c, dev).train()
+    flat = parallel.FlatParams(enc.parameters())
+    opt = parallel.FusedAdamW(flat, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    for x, t in zip(xs, tgt):
+        opt_ref.zero_grad()
+        ((bo.encoder_forward(x.double(), ref, c["heads"]) - t.double()) ** 2).mean().backward()
+        opt_ref.step()
+        flat.zero_grad()
+        ((enc(x.to(dev)) - t.to(dev)) ** 2).mean().backward()
+        opt.step()
+    for k, p in enc.named_parameters():
+        assert rel_err(p.detach(), ref[k].detach()) < 2e-4, k
+
+
 def test_frozen_encoder_passes_input_grad_only(dev):
     """most reference pipelines freeze the encoder but train the tokenizer in front of it."""
     c = dict(depth=1, dim=128, heads=2, eps=1e-5, seed=6)
