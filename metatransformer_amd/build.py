@@ -1,9 +1,13 @@
 """Build libmetaenc.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m metatransformer_amd.build [--force]
+    python -m metatransformer_amd.build [--force] [--dev]
 
 Sources: metatransformer_amd/csrc/*.hip  ->  metatransformer_amd/libmetaenc.so
 (the .so is git-ignored but travels to the GPU box with the snapshot).
+
+--dev builds a second library, tools/_build/libmetaenc_dev.so, from the same sources with -DME_DEV: it additionally
+exports me_dev_set() (kernel-family / debug switches for the A/B runs of tools/gemm_dev) and tools/_build/gemm_dev,
+the torch-free bench driver.  The shipped library has no such switches.
 """
 from __future__ import annotations
 
@@ -41,21 +45,28 @@ def needs_build() -> bool:
     return any(os.path.getmtime(f) > t for f in _deps())
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
+DEV_DIR = os.path.join(os.path.dirname(HERE), "tools", "_build")
+DEV_OUT = os.path.join(DEV_DIR, "libmetaenc_dev.so")
+
+
+def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
+    out = DEV_OUT if dev else OUT
+    obj_dir = os.path.join(DEV_DIR, "_obj") if dev else OBJ_DIR
+    flags = FLAGS + (["-DME_DEV"] if dev else [])
+    if not dev and not force and not needs_build():
         return OUT
     hipcc = _hipcc()
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     headers = [f for f in _deps() if f.endswith(".h")]
     hdr_t = max(os.path.getmtime(h) for h in headers)
 
     def compile_one(src: str) -> str:
-        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         if (not force and os.path.isfile(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and os.path.getmtime(obj) > hdr_t):
             return obj
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
         if verbose:
             print("[metaenc build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -63,13 +74,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT + ".tmp"] + objs
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out + ".tmp"] + objs
     if verbose:
         print("[metaenc build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    if dev:
+        exe = os.path.join(DEV_DIR, "gemm_dev")
+        cmd = [hipcc, "-O2", "-std=c++17", f"--offload-arch={ARCH}", os.path.join(os.path.dirname(HERE), "tools", "gemm_dev.hip"),
+               "-o", exe, "-L" + DEV_DIR, "-lmetaenc_dev", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print("[metaenc build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv))

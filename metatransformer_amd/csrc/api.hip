@@ -79,3 +79,18 @@ extern "C" int me_gemm_profile_read(me_gemm_profile_rec* out, int max) {
     g_prof.clear();
     return n;
 }
+
+// ---- dev build only: kernel-family / debug switches for A/B runs (tools/gemm_dev).  Not part of the C ABI: the symbol
+// does not exist in the shipped library.
+#ifdef ME_DEV
+#include "gemm_common.h"
+GemmDev g_gemm_dev = {-1, 0, 0, 1};
+extern "C" int me_dev_set(const char* key, int value) {
+    if (!strcmp(key, "family")) g_gemm_dev.family = value;
+    else if (!strcmp(key, "bn")) g_gemm_dev.bn = value;
+    else if (!strcmp(key, "debug")) g_gemm_dev.debug = value;
+    else if (!strcmp(key, "tail_split")) g_gemm_dev.tail_split = value;
+    else return ME_ERR_ARG;
+    return ME_OK;
+}
+#endif

@@ -1553,14 +1553,6 @@ template <typename K> void set_smem(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-bool small_path_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("ME_ATTN_SMALL");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
 int device_cus() {
     static int n = 0;
     if (!n) {
@@ -1739,15 +1731,15 @@ extern "C" int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int6
     if (rc) return rc;
     ME_CHECK_ARG(ld_out % 4 == 0, "me_attention_fwd: ld_out must be a multiple of 4");
     ME_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "me_attention_fwd: p_drop must be in [0, 1)");
-    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN && small_path_enabled()) {
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN) {
         if (head_dim <= 32) return launch_fwd_small<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
         return launch_fwd_small<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
     }
-    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MAXN && N <= MD_MAXN && small_path_enabled()) {
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MAXN && N <= MD_MAXN) {
         if (head_dim <= 32) return launch_fwd_mid<32, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
         return launch_fwd_mid<64, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
     }
-    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > MD_MAXN && B <= 65535 && small_path_enabled()) {
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > MD_MAXN && B <= 65535) {
         if (head_dim <= 32) return launch_fwd_chunk<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
         return launch_fwd_chunk<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
     }
@@ -1766,21 +1758,21 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
     const int E = dtype == ME_BF16 ? 8 : 4;
     ME_CHECK_ARG(ld_dout % E == 0 && ld_dqkv % 4 == 0, "me_attention_bwd: bad strides");
     ME_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "me_attention_bwd: p_drop must be in [0, 1)");
-    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN && ld_out % 8 == 0 && small_path_enabled()) {
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN && ld_out % 8 == 0) {
         if (head_dim <= 32)
             return launch_bwd_small<32>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim,
                                         scale, stream);
         return launch_bwd_small<64>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale,
                                     stream);
     }
-    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MAXN && N <= MD_MAXN && ld_out % 8 == 0 && small_path_enabled()) {
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MAXN && N <= MD_MAXN && ld_out % 8 == 0) {
         if (head_dim <= 32)
             return launch_bwd_mid<32, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H,
                                                     head_dim, scale, stream);
         return launch_bwd_mid<64, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H,
                                                 head_dim, scale, stream);
     }
-    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > MD_MAXN && ld_out % 8 == 0 && small_path_enabled()) {
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > MD_MAXN && ld_out % 8 == 0) {
         if (head_dim <= 32)
             return launch_bwd_chunk<32>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale,
                                         stream);

@@ -15,7 +15,6 @@
 //   TN: C[M,N] = A[K,M]^T B[K,N]   (wgrad) the loader transposes while staging: pairs of reduction rows are
 //                                  interleaved into dwords so that LDS rows are again reduction-contiguous.
 #include "gemm_common.h"
-#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -219,11 +218,10 @@ __global__ __launch_bounds__(NT) void gemm_g128_kernel(const GemmParams p) {
 template <typename T, bool TN>
 int launch_g128(const GemmParams& p, hipStream_t stream) {
     const size_t lds = 4 * TILE_BYTES;   // 64 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice once;
+    if (once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g128_kernel<T, TN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const int64_t nblk = (int64_t)p.tiles_m * p.tiles_n;
     hipLaunchKernelGGL((gemm_g128_kernel<T, TN>), dim3((unsigned)nblk), dim3(NT), lds, stream, p);
@@ -272,10 +270,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 }
 
 struct GemmPlan {
-    int family;      // 0 = g128, 1 = g256 (one 8-wave workgroup / CU), 2 = g2b (two 4-wave workgroups / CU)
+    int family;      // 0 = g128, 2 = g2b (two 4-wave workgroups / CU), 3 = g2w (8 waves, K-step 32), 4 = g3 (8 waves, K-tile 64)
     int bn;          // 256 / 128
-    int bm;          // 256 (g256) / 128 (g2b)
-    int kstep;       // 64 / 32
+    int bm;          // 256 / 128
+    int kstep;       // reduction elements per pipeline step (32; g3: 64)
     int split_k;     // >= 1
     int ksteps_per_split;
     size_t ws_bytes;
@@ -284,45 +282,21 @@ struct GemmPlan {
     int tail_split, tail_ksteps;
 };
 
-bool tail_split_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ME_GEMM_TAILSPLIT"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
-}
-
-// ME_GEMM_KERNEL = g128 | g256_256 | g256_128 | g2b_256 | g2b_128   (dev A/B switch)
-void forced_family(int& fam, int& bn) {
-    static int f = -2, b = 0;
-    if (f == -2) {
-        const char* e = getenv("ME_GEMM_KERNEL");
-        f = -1;
-        if (e) {
-            if (!strcmp(e, "g128")) f = 0;
-            else if (!strcmp(e, "g256_256")) { f = 1; b = 256; }
-            else if (!strcmp(e, "g256_128")) { f = 1; b = 128; }
-            else if (!strcmp(e, "g2b_256")) { f = 2; b = 256; }
-            else if (!strcmp(e, "g2b_128")) { f = 2; b = 128; }
-            else if (!strcmp(e, "g2w")) { f = 3; b = 256; }          // 8 waves, 256x256, K-step 32, 4 stages
-        }
-    }
-    fam = f; bn = b;
-}
-
 GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
     GemmPlan pl{0, 0, 128, 0, 1, 0, 0, 0, 1, 0};
-    int ffam, fbn;
-    forced_family(ffam, fbn);
+    const GemmDev dev = gemm_dev();
+    const int ffam = dev.family, fbn = dev.bn;
     if (d->ab_dtype != ME_BF16 || ffam == 0) return pl;
-    // default (measured on the encoder's shapes, tools/gemm_bench.py): NT -> the staggered 8-wave 256x256 kernel ("g2w",
-    // family 3) except small N x small K where the two-workgroup kernel's overlapped epilogue wins; TN (wgrad) -> g2b.
+    // default (measured on the encoder's shapes, tools/gemm_dev): NT -> the 8-wave 256x256 kernels except small N x
+    // small K, where the two-workgroup kernel's overlapped epilogue wins; TN (wgrad) -> g2b.
     int fam = ffam > 0 ? ffam : 2;
     if (ffam < 0 && d->op == ME_GEMM_NT && d->M >= 256 && d->N >= 256 && !(d->N <= 768 && d->K <= 1024)) fam = 3;
-    const bool ok = fam >= 2 ? g2b_supported(p, d->op) : g256_supported(p, d->op);
-    if (!ok) return pl;
+    if (fam == 4 && !g3_supported(p, d->op)) fam = d->op == ME_GEMM_NT ? 3 : 2;
+    if (!g2b_supported(p, d->op)) return pl;
     if (ffam < 0 && (d->M < 128 || d->N < 128)) return pl;       // tiny problems: g128 is enough
     pl.family = fam;
     pl.bm = fam == 2 ? 128 : 256;
-    pl.kstep = fam >= 2 ? 32 : 64;
+    pl.kstep = 32;
     const int64_t tm = (d->M + pl.bm - 1) / pl.bm;
     const int64_t t256 = tm * ((d->N + 255) / 256), t128 = tm * ((d->N + 127) / 128);
     const int nk = (int)(d->K / pl.kstep);
@@ -342,24 +316,21 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
                 pl.ws_bytes += (size_t)pl.split_k * (size_t)((d->N + pl.bn - 1) / pl.bn) * (size_t)d->M * sizeof(float);
         }
     } else {
-        if (fbn) pl.bn = fbn;
-        else if (fam == 3) pl.bn = 256;
-        else if (fam == 2) pl.bn = d->N > 128 ? 256 : 128;       // measured: g2b_256 beats g2b_128 on every encoder shape
-        else {
-            const double c256 = (double)((t256 + SLOTS - 1) / SLOTS), c128 = 0.55 * (double)((t128 + SLOTS - 1) / SLOTS);
-            pl.bn = c256 <= c128 ? 256 : 128;
-        }
+        if (fam >= 3) pl.bn = 256;
+        else if (fbn) pl.bn = fbn;
+        else pl.bn = d->N > 128 ? 256 : 128;                     // measured: g2b_256 beats g2b_128 on every encoder shape
         pl.ksteps_per_split = nk;
+        if (fam == 4) return pl;
         // Tile quantisation: T tiles on SLOTS co-resident workgroups take ceil(T / SLOTS) rounds; the encoder's N = 768
         // outputs give 591 tiles = 2.31 rounds -> 3 (23 % idle), N = 3072 gives 9.23 -> 10.  When the last round is
         // mostly empty, the rows of that round are carved off as a second problem whose reduction is split over the idle
         // workgroups (fp32 slabs + the deterministic fold that also applies the epilogue): 2 rounds + 1/3 instead of 3.
-        // Measured (tools/gemm_bench.py): +4..5 % on the 256x256 kernel at N = 768 (fc2 forward, fc1 / qkv dgrad); a loss
-        // at N = 3072 (one sparse round in ten is cheap: its workgroups run faster on an emptier chip) and on the
-        // two-workgroup kernel at K = 768 (slices too short) -- hence the fam == 3 / N <= 1024 gate.
+        // Measured: +4..5 % on the 256x256 kernel at N = 768 (fc2 forward, fc1 / qkv dgrad); a loss at N = 3072 (one
+        // sparse round in ten is cheap: its workgroups run faster on an emptier chip) and on the two-workgroup kernel at
+        // K = 768 (slices too short) -- hence the fam == 3 / N <= 1024 gate.
         const int64_t tn_ = (d->N + pl.bn - 1) / pl.bn, tiles = tm * tn_;
         const int64_t R = tiles / SLOTS, rem = tiles - R * SLOTS;
-        if (fam == 3 && d->N <= 1024 && tail_split_enabled() && R >= 1 && rem * 20 >= SLOTS && rem * 10 <= SLOTS * 6 &&
+        if (fam == 3 && d->N <= 1024 && dev.tail_split && R >= 1 && rem * 20 >= SLOTS && rem * 10 <= SLOTS * 6 &&
             d->res_row_mod == 0 && d->out_group_rows == 0 && d->M % pl.bm == 0) {
             const int64_t m_main = (R * SLOTS) / tn_;
             const int64_t tail_tiles = (tm - m_main) * tn_;
@@ -375,7 +346,7 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         // Small problems (small-batch inference: M = B * N rows with B = 1..32): fewer tiles than a third of the chip's
         // workgroup slots means the launch is pure latency -- one workgroup walks the whole reduction while 2/3 of the CUs
         // idle.  The WHOLE problem then runs split over the reduction (same slabs + fold as the tail split, m_main = 0).
-        if (fam >= 2 && tail_split_enabled() && pl.tail_rows == 0 && tiles * 3 <= SLOTS && nk >= 16) {
+        if (dev.tail_split && pl.tail_rows == 0 && tiles * 3 <= SLOTS && nk >= 16) {
             int s = (int)(SLOTS / tiles);
             while (s > 1 && nk / s < 8) --s;
             if (s >= 2) {
@@ -423,11 +394,7 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     p.split_k = 1; p.ksteps_per_split = 0;
     p.colsum_ws = nullptr;
     if (d->colsum_a) ME_CHECK_ARG(d->op == ME_GEMM_TN, "me_gemm: colsum_a is defined for ME_GEMM_TN only");
-    {
-        static int dbg = -1;
-        if (dbg < 0) { const char* e = getenv("ME_G256_DEBUG"); dbg = e ? atoi(e) : 0; }
-        p.debug = dbg;
-    }
+    p.debug = gemm_dev().debug;
     p.tiles_m = (int)((d->M + BM - 1) / BM);
     p.tiles_n = (int)((d->N + BN - 1) / BN);
     ME_CHECK_ARG((int64_t)p.tiles_m * p.tiles_n < (1ll << 31), "me_gemm: too many tiles");
@@ -470,7 +437,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
                      "me_gemm: colsum_a needs the split-K wgrad kernel and its workspace (see me_gemm_fuses_colsum)");
     if (pl.family >= 1) {
         auto run = [&](const GemmParams& q) {
-            return pl.family >= 2 ? launch_g2b(q, d->op, pl.bm, pl.bn, stream) : launch_g256(q, d->op, pl.bn, stream);
+            return pl.family == 4 ? launch_g3(q, pick_epi(q), stream) : launch_g2b(q, d->op, pl.bm, pl.bn, stream);
         };
         p.tiles_m = (int)((d->M + pl.bm - 1) / pl.bm);
         p.tiles_n = (int)((d->N + pl.bn - 1) / pl.bn);

@@ -15,7 +15,6 @@
 //        TN tiles stay [32 t][cols] as in memory, read with ds_read_b64_tr_b16, slot = chunk ^ (4 * (t & 3))
 //   pipeline      : wait(step t landed) -> barrier -> issue DMA(t+2) -> compute(t)      (counted vmcnt, never 0 in-loop)
 #include "gemm_stage.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -47,15 +46,6 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int tm = wgid / p.tiles_n, tn = wgid % p.tiles_n;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
-    if (BM == 128 && (p.debug & (512 | 1024))) {
-        // dev experiment: de-phase the two workgroups that share a CU so that one's epilogue runs under the other's
-        // K-loop (they are dispatched together and otherwise stay in lock-step): first-round workgroups of odd parity
-        // start late by (debug >> 16) x 8128 cycles.  512: parity = slot within the XCD; 1024: parity = slot / 32.
-        const int slot = bid >> 3;
-        const bool odd = (p.debug & 512) ? (slot & 1) : ((slot >> 5) & 1);
-        if (bid < 512 && odd)
-            for (int i = 0; i < (p.debug >> 16); ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
     const int nk_total = (int)(p.K / KS2);
@@ -151,7 +141,6 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
     int cs_turn = do_cs ? (tn - ks_begin % p.tiles_n + p.tiles_n) % p.tiles_n : -1;      // steps until my next turn
-    const bool prio_mma = (p.debug & 256) != 0;
     auto mma_step = [&](const Frags& f) {
         if (do_cs) {
             if (cs_turn == 0) {
@@ -168,7 +157,6 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
             --cs_turn;
         }
-        if (prio_mma) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -176,7 +164,6 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int ni = 0; ni < G::NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wa[kk][ni], f.xb[kk][mi], acc[mi][ni], 0, 0, 0);
-        if (prio_mma) __builtin_amdgcn_s_setprio(0);
     };
     // fragments of substep 0, then the DMA issue while they fly, then substep 1 (measured best order)
     auto load_and_issue = [&](int t, int stage, int stage_ahead, Frags& f) {
@@ -192,10 +179,10 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // row 0 and one of row 1; after barrier t row 0 reads its fragments / issues DMA while row 1 still executes the
     // MFMAs of step t-1 on fragments it kept in registers, then they swap -- LDS/DMA phases of one wave sit under the
     // MFMA phase of its SIMD partner instead of all eight waves doing the same thing at the same time.
-    const bool trailing = (BM == 256) && wr == 1 && !(p.debug & 64);
+    const bool trailing = (BM == 256) && wr == 1;
     // static priority for the later-dispatched wave row (it loses VALU arbitration to the older row otherwise; measured
     // +2..5 %; per-MFMA-group s_setprio flips measured neutral) -- wave-uniform condition, scalar branch
-    if (trailing && !(p.debug & 128)) __builtin_amdgcn_s_setprio(1);
+    if (trailing) __builtin_amdgcn_s_setprio(1);
     int s_cur = 0, s_ahead = LOOK;
     if (!trailing) {
         for (int t = 0; t < nk; ++t) {
@@ -226,7 +213,8 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int64_t m = m0 + wc * 32 + l31;
         if (m < p.M) p.colsum_ws[((int64_t)blockIdx.y * p.tiles_n + tn) * p.M + m] = cs[0];
     }
-    // ---- epilogue (same scheme as gemm256.hip): accumulators -> per-wave LDS patch -> row-contiguous 16-byte accesses
+    // ---- epilogue: accumulators -> per-wave LDS patch -> row-contiguous 16-byte accesses
+#ifdef ME_DEV
     if (p.debug & 1) {                                    // dev: K-loop only
         float keep = 0.f;
 #pragma unroll
@@ -238,6 +226,7 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (keep == 1.2345e-30f) reinterpret_cast<float*>(p.C)[0] = keep;
         return;
     }
+#endif
     // ---- epilogue.  A lane owns one output ROW and scattered 4-column quads (MFMA layout); stored directly that is
     // 16-byte fragments of 32 different lines per instruction.  Each wave therefore transposes 32-row slabs of its
     // accumulators through its own LDS patch (pitch padded by 16 B: conflict-free 16-byte accesses) and re-reads them
@@ -248,24 +237,6 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // s_waitcnt vmcnt(0) -- which here would drain the previous slab's global stores four times per tile (measured:
     // the epilogue then costs 18 us per tile, more than the K-loop at K = 768).  Hidden from the compiler, the slabs'
     // stores stay in flight; a wave's DS operations execute in order, so write -> read needs no wait in between.
-    if (EPI == 6) {
-        // dev experiment: no LDS transposition, no barrier -- every lane stores its own row's 4-column quads (8 bytes
-        // in bf16); the two half-waves make 16 contiguous bytes per row per instruction
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int64_t m = m0 + wr * 128 + mi * 32 + l31;
-#pragma unroll
-            for (int ni = 0; ni < G::NI; ++ni)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int64_t nn = n0 + wc * (BN / 4) + ni * 32 + 8 * g + 4 * h;
-                    f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-                    if (p.bias) v = v * p.alpha + *reinterpret_cast<const f32x4*>(p.bias + (nn < p.N ? nn : 0));
-                    if (m < p.M && nn < p.N) store4_from_f32(p.C, p.c_dtype, m * p.ldc + nn, v);
-                }
-        }
-        return;
-    }
     constexpr int WCOLS = BN / 4;
     constexpr int PITCH = WCOLS * 4 + 16;
     constexpr int LPR = WCOLS / 8;                        // lanes per row in the read phase: 8 / 4
@@ -386,19 +357,6 @@ int launch2e(const GemmParams& p, hipStream_t stream) {
     return ME_OK;
 }
 
-// which specialised epilogue covers this call (4 = generic)
-int pick_epi(const GemmParams& p) {
-    if (p.split_k > 1) return 5;
-    if (p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return 4;
-    const int nrow = (p.residual ? 1 : 0) + (p.aux ? 1 : 0);
-    if (nrow > 1) return 4;
-    if (p.act == ME_ACT_GELU) return (nrow == 0) ? 1 : 4;
-    if (p.preact) return 4;
-    if (p.residual) return p.res_dtype == ME_BF16 ? 2 : 4;
-    if (p.aux) return p.aux_dtype == ME_BF16 ? 3 : 4;
-    return 0;
-}
-
 template <int BM, int BN, bool TN>
 int launch2(const GemmParams& p, hipStream_t stream) {
     const int epi = pick_epi(p);
@@ -407,7 +365,7 @@ int launch2(const GemmParams& p, hipStream_t stream) {
         return epi == 0 ? launch2e<BM, BN, TN, 0>(p, stream) : launch2e<BM, BN, TN, 4>(p, stream);
     }
     switch (epi) {
-        case 0: return (p.debug & 32) ? launch2e<BM, BN, TN, 6>(p, stream) : launch2e<BM, BN, TN, 0>(p, stream);
+        case 0: return launch2e<BM, BN, TN, 0>(p, stream);
         case 1: return launch2e<BM, BN, TN, 1>(p, stream);
         case 2: return launch2e<BM, BN, TN, 2>(p, stream);
         case 3: return launch2e<BM, BN, TN, 3>(p, stream);

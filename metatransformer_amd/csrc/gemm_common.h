@@ -13,7 +13,7 @@ struct GemmParams {
     const void* residual; int64_t ldres; int res_dtype;
     int64_t res_row_mod, out_group_rows, out_group_stride, out_row_offset;
     int tiles_m, tiles_n;
-    int debug;                              // dev switches (ME_G256_DEBUG): 1 = skip the epilogue
+    int debug;                              // dev builds only (GemmDev::debug, 0 in the shipped library): 1 = skip the epilogue
     int split_k, ksteps_per_split;          // split-K (wgrad): grid.y = split_k, slab z written to C + z*M*ldc
     float* colsum_ws;                       // TN only: partial column sums of A, [split_k * tiles_n][M] (null = off)
 };
@@ -105,8 +105,34 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
     store8_from_f32(p.C, p.c_dtype, orow * p.ldc + n, v0, v1);
 }
 
+// which specialised epilogue covers this call:
+//   0 alpha*acc + bias (* colscale)   1 ... -> (store pre-activation) -> GELU   2 ... + bf16 residual row operand
+//   3 ... * gelu'(bf16 aux row operand)   4 generic (anything include/metaenc.h allows)   5 raw fp32 split-K slab
+static inline int pick_epi(const GemmParams& p) {
+    if (p.split_k > 1) return 5;
+    if (p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return 4;
+    const int nrow = (p.residual ? 1 : 0) + (p.aux ? 1 : 0);
+    if (nrow > 1) return 4;
+    if (p.act == ME_ACT_GELU) return (nrow == 0) ? 1 : 4;
+    if (p.preact) return 4;
+    if (p.residual) return p.res_dtype == ME_BF16 ? 2 : 4;
+    if (p.aux) return p.aux_dtype == ME_BF16 ? 3 : 4;
+    return 0;
+}
+
 // kernel families (each in its own translation unit)
-int launch_g256(const GemmParams& p, int op, int bn, hipStream_t stream);
-bool g256_supported(const GemmParams& p, int op);
 int launch_g2b(const GemmParams& p, int op, int bm, int bn, hipStream_t stream);
 bool g2b_supported(const GemmParams& p, int op);
+int launch_g3(const GemmParams& p, int epi, hipStream_t stream);
+bool g3_supported(const GemmParams& p, int op);
+
+// Dev switches for A/B runs (tools/gemm_dev): they exist only in the dev build of the library (-DME_DEV, built by
+// `python -m metatransformer_amd.build --dev` into tools/_build/); the shipped library has no knobs and reads no
+// environment variables.
+struct GemmDev { int family, bn, debug, tail_split; };
+#ifdef ME_DEV
+extern GemmDev g_gemm_dev;
+static inline GemmDev gemm_dev() { return g_gemm_dev; }
+#else
+static inline GemmDev gemm_dev() { return GemmDev{-1, 0, 0, 1}; }
+#endif

@@ -1,4 +1,4 @@
-// gemm_stage.h -- operand staging shared by the LDS-DMA GEMM families (gemm2b.hip, gemm4w.hip): K-step size, the
+// gemm_stage.h -- operand staging shared by the LDS-DMA GEMM families (gemm2b.hip): K-step size, the
 // global->LDS DMA wrapper, the swizzled NT / TN stagers and the matching fragment reads.
 #pragma once
 #include "gemm_common.h"
@@ -77,7 +77,9 @@ struct TnStager2 {
         for (int j = 0; j < NINS; ++j) glds16(src[j] + t0 * ld, tile + (wave * NINS + j) * 1024);
     }
 };
-// same fragment gather as gemm256.hip's tn_frag (see there for the lane algebra); kk in {0, 1}
+// TN fragment gather; kk in {0, 1}.  The MFMA wants, per lane, 8 reduction-consecutive values of ONE operand column; the tile
+// holds reduction rows.  ds_read_b64_tr_b16 hands lane (g, p) of a 16-lane group column p & 3 .. of a 4 x 16 block
+// transposed, so two reads (r = 0, 1: reduction rows 4r .. 4r+3 of the lane's 8) build the fragment.
 template <int COLS>
 __device__ __forceinline__ bf16x8 tn_frag2(const lds_char* tile, int cb, int kk, int lane) {
     const int g = lane >> 4, p = lane & 15;

@@ -1,0 +1,220 @@
+// gemm_dev -- torch-free A/B bench + full-tensor check of me_gemm kernel families on the encoder's shapes (dev tool).
+//
+//   python -m metatransformer_amd.build --dev      # builds tools/_build/libmetaenc_dev.so and tools/_build/gemm_dev
+//   tools/_build/gemm_dev [--iters N] [--check] case [case ...]
+//   case  = family:M:N:K:epi[:debug]      family in {auto, g128, g2b, g2w, g3}; epi 0 bias, 1 gelu(+preact), 2 residual,
+//           3 gelu'(aux); debug = GemmDev::debug bits (1 = K-loop only)
+//
+// Every case is checked (all M x N outputs) against a straightforward fp32 kernel on the same bf16 operands, then timed
+// over rotating operand / output sets (3 copies: the 256 MiB Infinity Cache must not hold them -- as inside the model).
+// Operands are random full-range values (never zeros: MI355X clocks ~20 % higher on zero-filled operands).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../include/metaenc.h"
+
+extern "C" int me_dev_set(const char* key, int value);
+
+#define CK(x)                                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) {                                                                 \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));   \
+            exit(2);                                                                            \
+        }                                                                                       \
+    } while (0)
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+__global__ void fill_kernel(uint16_t* p, size_t n, uint64_t seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t z = seed + i * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        // sum of two uniforms in [-1, 1): full-range signs and exponents
+        const float a = (float)(uint32_t)(z >> 40) * (1.0f / 8388608.0f) - 1.0f;
+        const float b = (float)(uint32_t)((z >> 16) & 0xffffff) * (1.0f / 8388608.0f) - 1.0f;
+        p[i] = f2bf(scale * (a + b));
+    }
+}
+__global__ void fill_f32_kernel(float* p, size_t n, uint64_t seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t z = seed + i * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 29;
+        p[i] = scale * ((float)(uint32_t)(z >> 40) * (1.0f / 8388608.0f) - 1.0f);
+    }
+}
+
+// reference: one thread per output, fp32 accumulate in k order; the epilogue in exact libm arithmetic
+__global__ void ref_kernel(const uint16_t* A, const uint16_t* B, const float* bias, const uint16_t* rowop, int epi, int64_t M,
+                           int64_t N, int64_t K, float* out, float* out_pre) {
+    const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    const uint16_t* a = A + m * K;
+    const uint16_t* b = B + n * K;
+    float acc = 0.f;
+    for (int64_t k = 0; k < K; ++k) acc = fmaf(bf2f(a[k]), bf2f(b[k]), acc);
+    float v = acc + (bias ? bias[n] : 0.f);
+    if (epi == 1) {
+        out_pre[m * N + n] = v;
+        v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    } else if (epi == 2) {
+        v += bf2f(rowop[m * N + n]);
+    } else if (epi == 3) {
+        const float x = bf2f(rowop[m * N + n]);
+        v *= 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+    }
+    out[m * N + n] = v;
+}
+
+__global__ void cmp_kernel(const uint16_t* got, const float* ref, size_t n, float atol, float rtol, unsigned long long* nbad,
+                           float* maxerr) {
+    float me = 0.f;
+    unsigned long long bad = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = bf2f(got[i]), r = ref[i];
+        const float e = fabsf(g - r);
+        if (!(e <= atol + rtol * fabsf(r))) ++bad;
+        me = fmaxf(me, e / (1.0f + fabsf(r)));
+    }
+    if (bad) atomicAdd(nbad, bad);
+    atomicMax(reinterpret_cast<unsigned int*>(maxerr), __float_as_uint(me));
+}
+
+static int family_code(const std::string& f) {
+    if (f == "auto") return -1;
+    if (f == "g128") return 0;
+    if (f == "g2b") return 2;
+    if (f == "g2w") return 3;
+    if (f == "g3") return 4;
+    fprintf(stderr, "unknown family %s\n", f.c_str());
+    exit(2);
+}
+
+int main(int argc, char** argv) {
+    int iters = 20;
+    bool check = false;
+    std::vector<std::string> cases;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--iters")) iters = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--check")) check = true;
+        else cases.push_back(argv[i]);
+    }
+    constexpr int NSET = 3;
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (const std::string& c : cases) {
+        char fam[32];
+        long long M, N, K;
+        int epi = 0, debug = 0;
+        if (sscanf(c.c_str(), "%31[^:]:%lld:%lld:%lld:%d:%d", fam, &M, &N, &K, &epi, &debug) < 4) {
+            fprintf(stderr, "bad case %s\n", c.c_str());
+            return 2;
+        }
+        me_dev_set("family", family_code(fam));
+        me_dev_set("debug", debug);
+        uint16_t *A[NSET], *C[NSET], *P[NSET], *Bw, *rowop = nullptr;
+        float *bias, *ref = nullptr, *ref_pre = nullptr;
+        for (int s = 0; s < NSET; ++s) {
+            CK(hipMalloc(&A[s], (size_t)M * K * 2));
+            CK(hipMalloc(&C[s], (size_t)M * N * 2));
+            P[s] = nullptr;
+            if (epi == 1) CK(hipMalloc(&P[s], (size_t)M * N * 2));
+            fill_kernel<<<2048, 256, 0, st>>>(A[s], (size_t)M * K, 17, 1.0f);     // same content in every set
+            CK(hipMemsetAsync(C[s], 0xff, (size_t)M * N * 2, st));
+        }
+        CK(hipMalloc(&Bw, (size_t)N * K * 2));
+        CK(hipMalloc(&bias, (size_t)N * 4));
+        fill_kernel<<<2048, 256, 0, st>>>(Bw, (size_t)N * K, 99, 0.05f);
+        fill_f32_kernel<<<64, 256, 0, st>>>(bias, (size_t)N, 5, 0.5f);
+        if (epi == 2 || epi == 3) {
+            CK(hipMalloc(&rowop, (size_t)M * N * 2));
+            fill_kernel<<<2048, 256, 0, st>>>(rowop, (size_t)M * N, 1234, 1.0f);
+        }
+        me_gemm_desc d;
+        memset(&d, 0, sizeof(d));
+        d.op = ME_GEMM_NT; d.ab_dtype = ME_BF16; d.M = M; d.N = N; d.K = K;
+        d.lda = K; d.B = Bw; d.ldb = K; d.ldc = N; d.c_dtype = ME_BF16;
+        d.alpha = 1.0f; d.beta = 0.0f; d.bias = bias;
+        if (epi == 1) { d.act = ME_ACT_GELU; d.ldpre = N; d.preact_dtype = ME_BF16; }
+        if (epi == 2) { d.residual = rowop; d.ldres = N; d.res_dtype = ME_BF16; }
+        if (epi == 3) { d.aux = rowop; d.ldaux = N; d.aux_dtype = ME_BF16; }
+        d.A = A[0]; d.C = C[0]; d.preact = P[0];
+        const size_t wsb = me_gemm_workspace_bytes(&d);
+        void* ws = nullptr;
+        if (wsb) CK(hipMalloc(&ws, wsb));
+        d.workspace = ws; d.workspace_bytes = (int64_t)wsb;
+        auto run = [&](int s) {
+            d.A = A[s]; d.C = C[s]; d.preact = P[s];
+            const int rc = me_gemm(&d, st);
+            if (rc) { fprintf(stderr, "me_gemm failed (%d): %s\n", rc, me_last_error()); exit(3); }
+        };
+        for (int s = 0; s < NSET; ++s) run(s);
+        CK(hipStreamSynchronize(st));
+        std::string verdict = "unchecked";
+        if (check && !(debug & 1)) {
+            CK(hipMalloc(&ref, (size_t)M * N * 4));
+            if (epi == 1) CK(hipMalloc(&ref_pre, (size_t)M * N * 4));
+            ref_kernel<<<dim3((unsigned)((N + 255) / 256), (unsigned)M), 256, 0, st>>>(A[0], Bw, bias, rowop, epi, M, N, K, ref, ref_pre);
+            unsigned long long* nbad;
+            float* maxerr;
+            CK(hipMalloc(&nbad, 8));
+            CK(hipMalloc(&maxerr, 4));
+            char buf[256];
+            verdict.clear();
+            for (int s = 0; s < NSET; s += NSET - 1) {          // first and last set
+                for (int which = 0; which < (epi == 1 ? 2 : 1); ++which) {
+                    CK(hipMemsetAsync(nbad, 0, 8, st));
+                    CK(hipMemsetAsync(maxerr, 0, 4, st));
+                    // bf16 output rounding (2^-9 relative) + accumulation-order noise
+                    cmp_kernel<<<1024, 256, 0, st>>>(which ? P[s] : C[s], which ? ref_pre : ref, (size_t)M * N, 2e-2f, 8e-3f, nbad, maxerr);
+                    unsigned long long hb;
+                    float hm;
+                    CK(hipMemcpyAsync(&hb, nbad, 8, hipMemcpyDeviceToHost, st));
+                    CK(hipMemcpyAsync(&hm, maxerr, 4, hipMemcpyDeviceToHost, st));
+                    CK(hipStreamSynchronize(st));
+                    snprintf(buf, sizeof(buf), "%s[set%d%s bad=%llu maxerr=%.3g]", verdict.empty() ? "" : " ", s, which ? " preact" : "", hb, hm);
+                    verdict += buf;
+                    if (hb) verdict += " MISMATCH";
+                }
+            }
+            CK(hipFree(ref));
+            if (ref_pre) CK(hipFree(ref_pre));
+            CK(hipFree(nbad));
+            CK(hipFree(maxerr));
+        }
+        for (int i = 0; i < 3; ++i) run(i % NSET);
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) run(i % NSET);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = 1e3 * ms / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+        printf("%-34s %8.1f us  %7.1f TF/s  %s\n", c.c_str(), us, tf, verdict.c_str());
+        fflush(stdout);
+        for (int s = 0; s < NSET; ++s) {
+            CK(hipFree(A[s])); CK(hipFree(C[s]));
+            if (P[s]) CK(hipFree(P[s]));
+        }
+        CK(hipFree(Bw)); CK(hipFree(bias));
+        if (rowop) CK(hipFree(rowop));
+        if (ws) CK(hipFree(ws));
+    }
+    return 0;
+}
