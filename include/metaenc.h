@@ -18,7 +18,9 @@
  *   - `stream` is a hipStream_t passed as void* (0 = default stream).  Launches are asynchronous
  *     on that stream; no implicit device synchronisation.
  *   - Return value: 0 = OK, negative = error; message via me_last_error() (thread-local).
- *   - Thread-safe for distinct streams; no hidden global state.
+ *   - Thread-safe for distinct streams.  Process-wide state is limited to: the optional launch-timing records of
+ *     me_gemm_profile_* (mutex-protected, off by default), the lazily resolved RCCL entry points (me_comm_*), and
+ *     explicit handles (me_comm).  The library reads no environment variables.
  */
 #ifndef METAENC_H
 #define METAENC_H
@@ -293,6 +295,31 @@ int me_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float grad_scale, void* bf16_mirror, void* stream);
 /* bf16_mirror (optional, n bf16 elements, same indexing as param): receives the updated parameters rounded to bf16 --
  * the forward-layout compute copies of the weights come out of the optimizer pass instead of one cast launch per weight. */
+
+/* ------------------------------------------------------------------ data-parallel gradient exchange
+ * The ONE exchange step of batch-sharded data parallelism: a sum all-reduce per flat gradient bucket over RCCL (xGMI
+ * inside a node).  Replaces _allreduce_coalesced (Image/segmentation/mmseg_custom/core/utils/dist_utils.py:14-35:
+ * bucket -> flatten -> dist.all_reduce -> div_(world_size) -> copy back) and DistributedDataParallel's bucketed
+ * all-reduce (Video/run_class_finetuning.py:739-742) for the encoder's gradients.  There is no flatten / copy back
+ * here (gradients already live in one flat buffer) and the 1/world factor is me_adamw_step's grad_scale.
+ *
+ * One process per GPU.  Rank 0 calls me_comm_unique_id and hands the ME_COMM_ID_BYTES opaque bytes to the other ranks
+ * by any host channel (torch.distributed store, MPI, a file); every rank then calls me_comm_init.  RCCL is resolved at
+ * run time by these two calls (dlopen: no link-time dependency; ME_ERR_UNSUPPORTED if it is not installed).
+ *
+ * me_allreduce_bucket(comm, buf, count, dtype, producer_stream): in-place sum over all ranks of buf[0..count)
+ * (ME_F32 or ME_BF16), enqueued on the communicator's OWN stream after everything enqueued so far on
+ * producer_stream (the backward stream) -- so the reduction of a finished bucket overlaps the rest of backward.
+ * Asynchronous; every rank must call it with the same (count, dtype) sequence.
+ * me_comm_join(comm, consumer_stream): consumer_stream (the optimizer's) waits for every reduction enqueued so far. */
+#define ME_COMM_ID_BYTES 128
+typedef struct me_comm me_comm;
+int me_comm_unique_id(void* id_out);
+int me_comm_init(me_comm** comm, const void* unique_id, int rank, int world, int device);
+int me_comm_destroy(me_comm* comm);
+int me_comm_info(const me_comm* comm, int* rank, int* world, int64_t* buckets_reduced);
+int me_allreduce_bucket(me_comm* comm, void* buf, int64_t count, int dtype, void* producer_stream);
+int me_comm_join(me_comm* comm, void* consumer_stream);
 
 #ifdef __cplusplus
 }

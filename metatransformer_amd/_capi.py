@@ -21,6 +21,7 @@ ME_F32, ME_BF16, ME_F16 = 0, 1, 2      # ME_F16: storage dtype of me_cast / me_t
 ME_GEMM_NT, ME_GEMM_TN = 0, 1
 ME_ACT_NONE, ME_ACT_GELU = 0, 1
 ME_PROF_LN_FWD, ME_PROF_LN_BWD, ME_PROF_ATTN_FWD, ME_PROF_ATTN_BWD = 16, 17, 18, 19      # me_gemm_profile_rec.op codes
+ME_COMM_ID_BYTES = 128
 
 
 class MetaEncError(RuntimeError):
@@ -133,6 +134,12 @@ SIGNATURES = {
     "me_timeseries_unfold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "me_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                               c_float, c_int, c_float, c_void_p, c_void_p]),
+    "me_comm_unique_id": (c_int, [c_void_p]),
+    "me_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int, c_int]),
+    "me_comm_destroy": (c_int, [c_void_p]),
+    "me_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int64)]),
+    "me_allreduce_bucket": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "me_comm_join": (c_int, [c_void_p, c_void_p]),
 }
 
 _lib = None

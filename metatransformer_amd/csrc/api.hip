@@ -84,12 +84,13 @@ extern "C" int me_gemm_profile_read(me_gemm_profile_rec* out, int max) {
 // does not exist in the shipped library.
 #ifdef ME_DEV
 #include "gemm_common.h"
-GemmDev g_gemm_dev = {-1, 0, 0, 1};
+GemmDev g_gemm_dev = {-1, 0, 0, 1, 0};
 extern "C" int me_dev_set(const char* key, int value) {
     if (!strcmp(key, "family")) g_gemm_dev.family = value;
     else if (!strcmp(key, "bn")) g_gemm_dev.bn = value;
     else if (!strcmp(key, "debug")) g_gemm_dev.debug = value;
     else if (!strcmp(key, "tail_split")) g_gemm_dev.tail_split = value;
+    else if (!strcmp(key, "g3_persistent")) g_gemm_dev.g3_persistent = value;
     else return ME_ERR_ARG;
     return ME_OK;
 }

@@ -287,10 +287,14 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
     const GemmDev dev = gemm_dev();
     const int ffam = dev.family, fbn = dev.bn;
     if (d->ab_dtype != ME_BF16 || ffam == 0) return pl;
-    // default (measured on the encoder's shapes, tools/gemm_dev): NT -> the 8-wave 256x256 kernels except small N x
-    // small K, where the two-workgroup kernel's overlapped epilogue wins; TN (wgrad) -> g2b.
+    // default (measured on the encoder's shapes, tools/gemm_dev): NT with at least half a chip of 256x256 tiles -> g3
+    // (K-tile 64, 4-phase ping-pong: 860-1000 TF on the Base shapes against 500-780 for the K-step-32 kernels); fewer
+    // tiles or K not a multiple of 128 -> the K-step-32 kernels with their split-K forms; TN (wgrad) -> g2b.
     int fam = ffam > 0 ? ffam : 2;
-    if (ffam < 0 && d->op == ME_GEMM_NT && d->M >= 256 && d->N >= 256 && !(d->N <= 768 && d->K <= 1024)) fam = 3;
+    if (ffam < 0 && d->op == ME_GEMM_NT && d->M >= 256 && d->N >= 256) {
+        const int64_t t256 = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+        fam = (t256 >= 128 && g3_supported(p, d->op)) ? 4 : ((d->N <= 768 && d->K <= 1024) ? 2 : 3);
+    }
     if (fam == 4 && !g3_supported(p, d->op)) fam = d->op == ME_GEMM_NT ? 3 : 2;
     if (!g2b_supported(p, d->op)) return pl;
     if (ffam < 0 && (d->M < 128 || d->N < 128)) return pl;       // tiny problems: g128 is enough
@@ -320,7 +324,14 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         else if (fbn) pl.bn = fbn;
         else pl.bn = d->N > 128 ? 256 : 128;                     // measured: g2b_256 beats g2b_128 on every encoder shape
         pl.ksteps_per_split = nk;
-        if (fam == 4) return pl;
+        if (fam == 4) {
+#ifdef ME_DEV
+            // dev build: the persistent stream-K form (its scratch = one fp32 tile per CU)
+            const int64_t tiles = tm * ((d->N + 255) / 256);
+            if (tiles >= 128 && dev.g3_persistent) pl.ws_bytes = g3_workspace_bytes();
+#endif
+            return pl;
+        }
         // Tile quantisation: T tiles on SLOTS co-resident workgroups take ceil(T / SLOTS) rounds; the encoder's N = 768
         // outputs give 591 tiles = 2.31 rounds -> 3 (23 % idle), N = 3072 gives 9.23 -> 10.  When the last round is
         // mostly empty, the rows of that round are carved off as a second problem whose reduction is split over the idle
@@ -436,9 +447,14 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
         ME_CHECK_ARG(pl.family == 2 && pl.split_k > 1 && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes,
                      "me_gemm: colsum_a needs the split-K wgrad kernel and its workspace (see me_gemm_fuses_colsum)");
     if (pl.family >= 1) {
-        auto run = [&](const GemmParams& q) {
-            return pl.family == 4 ? launch_g3(q, pick_epi(q), stream) : launch_g2b(q, d->op, pl.bm, pl.bn, stream);
-        };
+        if (pl.family == 4) {
+            p.tiles_m = (int)((d->M + 255) / 256);
+            p.tiles_n = (int)((d->N + 255) / 256);
+            p.split_k = 1;
+            void* ws = (pl.ws_bytes && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes) ? d->workspace : nullptr;
+            return launch_g3(p, pick_epi(p), ws, stream);
+        }
+        auto run = [&](const GemmParams& q) { return launch_g2b(q, d->op, pl.bm, pl.bn, stream); };
         p.tiles_m = (int)((d->M + pl.bm - 1) / pl.bm);
         p.tiles_n = (int)((d->N + pl.bn - 1) / pl.bn);
         p.ksteps_per_split = pl.ksteps_per_split;

@@ -37,16 +37,12 @@
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void3;
-typedef const __attribute__((address_space(1))) void gbl_void3;
 
 constexpr int G3_BM = 256, G3_BN = 256, G3_BK = 64;
 constexpr int G3_HALF = 128 * 128;              // bytes in a half-tile
 constexpr int G3_BUF = 4 * G3_HALF;             // 64 KiB
 constexpr int G3_LDS = 2 * G3_BUF;              // 128 KiB
-
-__device__ __forceinline__ void g3_dma16(const char* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gbl_void3*)gsrc, (lds_void3*)lds_wave_base, 16, 0, 0);
-}
+constexpr int G3_SLAB_FLOATS = G3_BM * G3_BN;   // one fp32 partial tile per workgroup (stream-K fix-up)
 
 // Everything the K-loop keeps in registers.  All arrays are indexed with compile-time constants only.
 struct G3State {
@@ -54,20 +50,43 @@ struct G3State {
                                 //  lane l holds row (l & 15), cols 4*(l >> 4) .. +3 of the 16 x 16 tile)
     bf16x8 bx[2][2], by[2][2];  // weight fragments [n-tile][k-sub]
     bf16x8 ax[4][2], ay[4][2];  // token fragments  [m-tile][k-sub]
-    uint32_t src[4][2];         // DMA source byte offsets from the tile's A / B row base: [half-tile type][instruction]
-    const char* a_base;         // A + m0 * lda (bytes), wave-uniform
-    const char* b_base;         // B + n0 * ldb
+    uint32_t src[4][2];         // DMA source byte offsets from the tile's first A / B row: [half-tile type][instruction]
     char* smem;
     uint32_t ra[2], rb[2];      // fragment read byte offsets inside a half-tile for k-sub 0 / 1 (wave + lane part)
     int wave;
 };
 
-template <int J> __device__ __forceinline__ void g3_issue(const G3State& s, int buf, int kt) {
-    // half-tile type J of K-tile kt into buffer buf
-    const char* base = ((J & 1) ? s.a_base : s.b_base) + (int64_t)kt * (G3_BK * 2);
+// Wave-uniform source of one output tile's operand rows: buffer descriptors over rows [m0, m0+256) of A and [n0, n0+256)
+// of B (clipped at the matrix edge: rows past the edge read as zeros through the descriptor's bounds check, so edge
+// tiles need no clamping and every lane keeps ONE set of offsets for the whole kernel).
+struct G3Src {
+    __amdgpu_buffer_rsrc_t a, b;
+};
+__device__ __forceinline__ G3Src g3_make_src(const GemmParams& p, int tm, int tn) {
+    const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
+    int64_t ra = p.M - m0, rb = p.N - n0;
+    ra = ra < G3_BM ? ra : G3_BM;
+    rb = rb < G3_BN ? rb : G3_BN;
+    G3Src s;
+    s.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.A)) + m0 * p.lda * 2, 0,
+                                            (int)((ra - 1) * p.lda * 2 + p.K * 2), 0x00020000);
+    s.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.B)) + n0 * p.ldb * 2, 0,
+                                            (int)((rb - 1) * p.ldb * 2 + p.K * 2), 0x00020000);
+    return s;
+}
+__device__ __forceinline__ G3Src g3_null_src(const GemmParams& p) {
+    G3Src s;
+    s.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, 0, 0x00020000);
+    s.b = s.a;
+    return s;
+}
+
+// half-tile type J of the K-tile at byte offset koff (= 128 * kt) into buffer buf
+template <int J> __device__ __forceinline__ void g3_issue(const G3State& s, const G3Src& src, int buf, int koff) {
     char* dst = s.smem + buf * G3_BUF + J * G3_HALF + s.wave * 2048;
-    g3_dma16(base + s.src[J][0], dst);
-    g3_dma16(base + s.src[J][1], dst + 1024);
+    const __amdgpu_buffer_rsrc_t r = (J & 1) ? src.a : src.b;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)dst, 16, (int)s.src[J][0], koff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)(dst + 1024), 16, (int)s.src[J][1], koff, 0, 0);
 }
 
 __device__ __forceinline__ bf16x8 g3_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -76,8 +95,13 @@ __device__ __forceinline__ bf16x8 g3_frag(const char* p) { return *reinterpret_c
     s.acc[MT][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(NT) & 1][0], AF[(MT) & 3][0], s.acc[MT][NT], 0, 0, 0); \
     s.acc[MT][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(NT) & 1][1], AF[(MT) & 3][1], s.acc[MT][NT], 0, 0, 0);
 
-// MODE 0: steady state; 1: second-to-last K-tile (only phase 0 still issues, the wait drains); 2: last K-tile
-template <int BUF, int P, int MODE> __device__ __forceinline__ void g3_phase(G3State& s, int kt) {
+// One phase of K-tile `BUF`.  s0 / k0: where the NEXT K-tile of the stream comes from (phase 0 issues its A-Y);
+// s1 / k1: the K-tile after that (phases 1..3 issue its B-X, A-X, B-Y).  There is ONE code path: past the end of a
+// workgroup's stream the source is a null descriptor (zero records: the DMA writes zeros into a buffer nobody reads any
+// more and touches no memory), so the issue pattern, and with it the counted wait, never changes -- and the 128
+// accumulators never meet a control-flow join inside the K-loop.
+template <int BUF, int P>
+__device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1) {
     const char* buf = s.smem + BUF * G3_BUF;
     if (P == 0) {
 #pragma unroll
@@ -101,16 +125,13 @@ template <int BUF, int P, int MODE> __device__ __forceinline__ void g3_phase(G3S
             for (int k = 0; k < 2; ++k) s.ay[mt][k] = g3_frag(buf + 3 * G3_HALF + mt * 2048 + s.ra[k]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE == 0 || (MODE == 1 && P == 0)) {
-        if (P == 0) g3_issue<3>(s, BUF ^ 1, kt + 1);
-        if (P == 1) g3_issue<0>(s, BUF, kt + 2);
-        if (P == 2) g3_issue<1>(s, BUF, kt + 2);
-        if (P == 3) g3_issue<2>(s, BUF, kt + 2);
-    }
+    if (P == 0) g3_issue<3>(s, s0, BUF ^ 1, k0);
+    if (P == 1) g3_issue<0>(s, s1, BUF, k1);
+    if (P == 2) g3_issue<1>(s, s1, BUF, k1);
+    if (P == 3) g3_issue<2>(s, s1, BUF, k1);
     __builtin_amdgcn_sched_barrier(0);
     if (P == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    if (P == 3 && MODE == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    if (P == 3 && MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (P == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -133,21 +154,360 @@ template <int BUF, int P, int MODE> __device__ __forceinline__ void g3_phase(G3S
     __builtin_amdgcn_s_barrier();
 }
 
-template <int BUF, int MODE> __device__ __forceinline__ void g3_ktile(G3State& s, int kt) {
-    g3_phase<BUF, 0, MODE>(s, kt);
-    g3_phase<BUF, 1, MODE>(s, kt);
-    g3_phase<BUF, 2, MODE>(s, kt);
-    g3_phase<BUF, 3, MODE>(s, kt);
+template <int BUF>
+__device__ __forceinline__ void g3_ktile(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1) {
+    g3_phase<BUF, 0>(s, s0, k0, s1, k1);
+    g3_phase<BUF, 1>(s, s0, k0, s1, k1);
+    g3_phase<BUF, 2>(s, s0, k0, s1, k1);
+    g3_phase<BUF, 3>(s, s0, k0, s1, k1);
 }
 
-// EPI as in gemm2b.hip: 0 bias (* colscale), 1 + GELU (+ pre-activation save), 2 + residual row operand,
-// 3 * gelu'(aux row operand), 4 generic (epilogue_oct), 5 raw fp32 slab (split-K partial sums)
+__device__ __forceinline__ void g3_init_lane(G3State& s, const GemmParams& p, char* smem, int wave, int lane) {
+    s.smem = smem;
+    s.wave = wave;
+    const int wr = wave >> 2, wc = wave & 3;
+    // DMA sources: instruction i of this wave covers local rows 16*wave + 8*i + (lane >> 3) of a half-tile, slot lane & 7
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rl = 16 * wave + 8 * i + (lane >> 3);
+        const int c = (lane & 7) ^ ((rl >> 1) & 7);
+        const int ax_row = (rl >> 6) * 128 + (rl & 63), bx_row = (rl >> 5) * 64 + (rl & 31);
+        s.src[0][i] = (uint32_t)(bx_row * p.ldb * 2 + c * 16);
+        s.src[1][i] = (uint32_t)(ax_row * p.lda * 2 + c * 16);
+        s.src[2][i] = (uint32_t)((bx_row + 32) * p.ldb * 2 + c * 16);
+        s.src[3][i] = (uint32_t)((ax_row + 64) * p.lda * 2 + c * 16);
+    }
+    // fragment reads: local row = (wave part) + 16 * tile + (lane & 15), chunk = 4 * ksub + (lane >> 4)
+    const int l15 = lane & 15;
+    const uint32_t lp = (l15 >> 3) * 1024 + (lane & 7) * 128 + ((((lane >> 4) ^ (l15 >> 1)) & 7) << 4);
+    s.ra[0] = wr * 8192 + lp; s.ra[1] = s.ra[0] ^ 64;
+    s.rb[0] = wc * 4096 + lp; s.rb[1] = s.rb[0] ^ 64;
+}
+__device__ __forceinline__ void g3_zero(G3State& s) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s.acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// ---- epilogue without LDS.  Two neighbouring 16 x 16 accumulator tiles (n-tiles 2q, 2q+1) are re-dealt inside the wave
+// with v_permlane16_swap (rows of 16 lanes: odd rows of the first operand <-> even rows of the second), after which lane
+// (r = l & 15, g = l >> 4) holds EIGHT consecutive output columns of row r: n-tile 2q + (g & 1), columns 8 (g >> 1) ..
+// +7 -- one 16-byte bf16 store / row-operand load per lane, 64 contiguous bytes per row and instruction.  The operand
+// buffers in LDS are not touched, so the DMA stream of the next tile keeps running under the epilogue.
+// EPI: 0 bias, 1 + GELU (+ pre-activation save), 2 + residual row operand, 3 * gelu'(aux row operand), 4 generic
+// (epilogue_oct: colscale, beta, row remaps, fp32 row operands ...)
+template <int EPI>
+__device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int64_t m0, int64_t n0, int lane) {
+    // everything lane-dependent below is derived HERE: an address hoisted out of the persistent loop would sit in
+    // registers across the K-loops (which have none to spare) and come back from scratch
+    asm volatile("" : "+v"(lane));
+    const int wr = s.wave >> 2, wc = s.wave & 3;
+    const int r = lane & 15, g = lane >> 4;
+    const f32x4 alpha4 = {p.alpha, p.alpha, p.alpha, p.alpha};
+    int64_t n[2];
+    bool n_ok[2];
+    f32x4 bias[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        n[q] = n0 + wc * 64 + (2 * q + (g & 1)) * 16 + 8 * (g >> 1);
+        n_ok[q] = n[q] + 8 <= p.N;
+        const int64_t nc = n_ok[q] ? n[q] : 0;
+        bias[q][0] = bias[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI != 4 && p.bias) {
+            bias[q][0] = *reinterpret_cast<const f32x4*>(p.bias + nc);
+            bias[q][1] = *reinterpret_cast<const f32x4*>(p.bias + nc + 4);
+        }
+    }
+    // pin the per-column operands in registers NOW (straight-line code): otherwise hipcc waits for them with vmcnt(0)
+    // inside every guarded store block, which drains the stores of the previous rows each time
+    asm volatile("" ::"v"(bias[0][0]), "v"(bias[0][1]), "v"(bias[1][0]), "v"(bias[1][1]));
+    const uint16_t* rop = reinterpret_cast<const uint16_t*>(EPI == 2 ? p.residual : p.aux);
+    const int64_t rop_ld = EPI == 2 ? p.ldres : p.ldaux;
+    const int64_t mrow = m0 + wr * 128 + r;
+    auto fetch = [&](const int mt, u32x4 (&raw)[2]) {
+        int64_t m = mrow + mt * 16;
+        m = m < p.M ? m : p.M - 1;                       // unconditional loads with clamped coordinates (no wait in a branch)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) raw[q] = *reinterpret_cast<const u32x4*>(rop + m * rop_ld + (n_ok[q] ? n[q] : 0));
+    };
+    auto unpack = [](const u32x4& rw, f32x4& a, f32x4& b) {
+        a[0] = __uint_as_float(rw[0] << 16); a[1] = __uint_as_float(rw[0] & 0xffff0000u);
+        a[2] = __uint_as_float(rw[1] << 16); a[3] = __uint_as_float(rw[1] & 0xffff0000u);
+        b[0] = __uint_as_float(rw[2] << 16); b[1] = __uint_as_float(rw[2] & 0xffff0000u);
+        b[2] = __uint_as_float(rw[3] << 16); b[3] = __uint_as_float(rw[3] & 0xffff0000u);
+    };
+    // row operand (residual / gelu' input): twelve of the tile's sixteen 16-byte loads go out at once, the last four as
+    // soon as the first slabs have freed their registers and BEFORE those slabs' stores (vmcnt retires in order) -- one
+    // memory latency per tile instead of one per 16-row slab (the K-loop's fragment registers are free here)
+    constexpr int AHEAD = 6;
+    u32x4 rowop[8][2];
+    if (EPI == 2 || EPI == 3) {
+#pragma unroll
+        for (int mt = 0; mt < AHEAD; ++mt) fetch(mt, rowop[mt]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        f32x4 ro[2][2];
+        if (EPI == 2 || EPI == 3) {
+            unpack(rowop[mt][0], ro[0][0], ro[0][1]);
+            unpack(rowop[mt][1], ro[1][0], ro[1][1]);
+            if (mt + AHEAD < 8) fetch(mt + AHEAD, rowop[mt + AHEAD]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int64_t m = mrow + mt * 16;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 v0 = s.acc[mt][2 * q], v1 = s.acc[mt][2 * q + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0[e]), __float_as_uint(v1[e]), false, false);
+                v0[e] = __uint_as_float(sw[0]);
+                v1[e] = __uint_as_float(sw[1]);
+            }
+            const bool ok = m < p.M && n_ok[q];
+            if (EPI == 4) {
+                if (ok) epilogue_oct(p, m, n[q], v0, v1);
+                continue;
+            }
+            v0 = v0 * alpha4 + bias[q][0];
+            v1 = v1 * alpha4 + bias[q][1];
+            if (EPI == 1) {
+                if (p.preact && ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n[q], v0, v1);
+                v0 = gelu_erf4(v0);
+                v1 = gelu_erf4(v1);
+            }
+            const f32x4 qa = ro[q][0], qb = ro[q][1];
+            if (EPI == 3) {
+                v0 *= gelu_erf_grad4(qa);
+                v1 *= gelu_erf_grad4(qb);
+            }
+            if (EPI == 2) { v0 += qa; v1 += qb; }
+#ifdef ME_DEV
+            if (p.debug & 4) {                         // dev: epilogue arithmetic without the stores
+                asm volatile("" ::"v"(v0), "v"(v1));
+                continue;
+            }
+#endif
+            if (ok) store8_from_f32(p.C, p.c_dtype, m * p.ldc + n[q], v0, v1);
+        }
+    }
+}
+
+#ifdef ME_DEV
+// (dev build only: correct and tested with tools/gemm_dev, but not faster than one tile per workgroup yet -- see DESIGN.md)
+// ---- persistent kernel: data-parallel rounds + a stream-K remainder.
+// Work unit = a PAIR of K-tiles (buffer 0 / buffer 1).  With G workgroups (one per CU) and T tiles of hk pairs each:
+//   * R = T / G (rounded down, minus one when the rest would be less than a tile per workgroup) rounds are plain
+//     data-parallel: in round j workgroup v owns tile j G + v, so at any time the 32 CUs of an XCD work on 32
+//     neighbouring tiles and share their operand panels through the XCD's L2 (v is the XCD-chunked id);
+//   * the remaining tiles' pairs are dealt out in contiguous ranges [v q + min(v, r), ...), 1 .. 2 tiles' worth each:
+//     every CU gets the same amount of MFMA work whatever T is (N = 768: 591 tiles on 256 CUs used to be 3 rounds for
+//     2.31 rounds of work).  A range generally starts inside a tile; that leading fragment is computed FIRST, then the
+//     data-parallel rounds, then the rest of the range.  The leading fragments have every length between nothing and
+//     a whole tile, so the CUs reach their epilogues at different times for the rest of the launch: the output bursts
+//     (all 256 CUs storing at once, then all computing) become a steady stream that overlaps the other CUs' MFMAs.
+// A tile split between workgroups is finished by the workgroup that holds its FIRST K-tiles (the end of that
+// workgroup's stream); the others (v+1, ...: the very start of theirs) hand over raw fp32 accumulators through `slabs`
+// [G][8 waves][32 regs][64 lanes] x 16 B with the release / acquire protocol of cdna_hip_programming.md, Guideline 16
+// (flags zeroed by a memset node ahead of every launch).  A workgroup writes its only partial before it ever waits, and
+// it waits only for workgroups with a higher id: no cycles.
+struct G3Plan {
+    int hk;          // K-tile pairs per tile
+    int rounds;      // data-parallel rounds R
+    int rem_q, rem_r;// remainder pairs per workgroup: total = G rem_q + rem_r
+};
+
+// Walks one workgroup's stream of (tile, K-tile pair) on the scalar unit.
+struct G3Walk {
+    int stage;       // 0 leading fragment, 1 data-parallel rounds, 2 rest of the remainder range, 3 done
+    int j;           // round (stage 1)
+    int rr;          // position in the remainder pair space (stages 0 / 2): next pair to visit
+    int tile, kp, seg_begin, seg_end;       // current tile, current pair in it, this workgroup's share [seg_begin, seg_end)
+};
+__device__ __forceinline__ void g3_walk_segment(G3Walk& w, const G3Plan& pl, int v, int G, int r1) {
+    // enter the next segment; w.stage / w.j / w.rr say where we are
+    if (w.stage == 1 && w.j < pl.rounds) {
+        w.tile = w.j * G + v; w.kp = 0; w.seg_begin = 0; w.seg_end = pl.hk;
+        ++w.j;
+        return;
+    }
+    if (w.stage <= 1) w.stage = 2;
+    if (w.rr >= r1) { w.stage = 3; w.kp = 0; w.seg_begin = 0; w.seg_end = 0; return; }
+    const int t = __builtin_amdgcn_readfirstlane(w.rr / pl.hk);
+    const int kb = w.rr - t * pl.hk;
+    int ke = kb + (r1 - w.rr);
+    ke = ke < pl.hk ? ke : pl.hk;
+    w.tile = pl.rounds * G + t; w.kp = kb; w.seg_begin = kb; w.seg_end = ke;
+    w.rr += ke - kb;
+}
+__device__ __forceinline__ void g3_walk_init(G3Walk& w, const G3Plan& pl, int v, int G, int r0, int r1, bool lead_first) {
+    w.j = 0; w.rr = r0;
+    const int t = __builtin_amdgcn_readfirstlane(r0 / pl.hk);
+    if (lead_first && r0 < r1 && r0 - t * pl.hk != 0) {           // the range starts inside a tile: that fragment goes first
+        w.stage = 0;
+        g3_walk_segment(w, pl, v, G, r1);
+        w.stage = 0;
+    } else {
+        w.stage = 1;
+        g3_walk_segment(w, pl, v, G, r1);
+    }
+}
+// one pair forward; returns true when that moved to another tile
+__device__ __forceinline__ bool g3_walk_next(G3Walk& w, const G3Plan& pl, int v, int G, int r1) {
+    if (++w.kp < w.seg_end) return false;
+    if (w.stage == 0) w.stage = 1;
+    g3_walk_segment(w, pl, v, G, r1);
+    return true;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_g3p_kernel(const GemmParams p, const G3Plan pl, float* __restrict__ slabs, unsigned* flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2;
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, gq = G >> 3, gr = G & 7;
+    const int v = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (bid >> 3);
+    auto range_begin = [&](int w) { return w * pl.rem_q + (w < pl.rem_r ? w : pl.rem_r); };
+    const int r0 = range_begin(v), r1 = range_begin(v + 1);
+
+    G3State s;
+    g3_init_lane(s, p, smem, wave, lane);
+    g3_zero(s);
+
+    G3Walk wc, wn;                                 // compute cursor / the pair after it (DMA source)
+#ifdef ME_DEV
+    g3_walk_init(wc, pl, v, G, r0, r1, (p.debug & 2) != 0);
+#else
+    g3_walk_init(wc, pl, v, G, r0, r1, false);
+#endif
+    if (wc.stage == 3) return;                     // nothing to do (more workgroups than work)
+    wn = wc;
+    auto src_of = [&](const G3Walk& w) {
+        const int tm = __builtin_amdgcn_readfirstlane(w.tile / p.tiles_n);
+        return g3_make_src(p, tm, w.tile - tm * p.tiles_n);
+    };
+    G3Src cur = src_of(wc);
+    G3Src nxt = cur;
+    auto advance_next = [&]() {
+        if (wn.stage == 3) return;
+        if (g3_walk_next(wn, pl, v, G, r1)) {
+            if (wn.stage == 3) nxt = g3_null_src(p);
+            else nxt = src_of(wn);
+        }
+    };
+    // prologue: half-tiles 0..6 of the stream (first K-tile complete, second without A-Y)
+    {
+        const int k = wc.kp * 256;
+        g3_issue<0>(s, cur, 0, k); g3_issue<1>(s, cur, 0, k); g3_issue<2>(s, cur, 0, k); g3_issue<3>(s, cur, 0, k);
+        g3_issue<0>(s, cur, 1, k + 128); g3_issue<1>(s, cur, 1, k + 128); g3_issue<2>(s, cur, 1, k + 128);
+    }
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();    // wave row 1 runs one barrier behind (wave-uniform scalar branch)
+    advance_next();                               // nxt / wn = the second pair of the stream
+
+    while (wc.stage != 3) {
+        const int kc = wc.kp * 256, kn = wn.kp * 256;
+        g3_ktile<0>(s, cur, kc + 128, nxt, kn);
+        g3_ktile<1>(s, nxt, kn, nxt, kn + 128);
+        if (wc.kp + 1 == wc.seg_end) {
+            // ---- seam: this workgroup's share [seg_begin, seg_end) of tile wc.tile is accumulated
+            const int tm = __builtin_amdgcn_readfirstlane(wc.tile / p.tiles_n), tn = wc.tile - tm * p.tiles_n;
+            const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
+            bool skip = false;
+#ifdef ME_DEV
+            if (p.debug & 1) {                    // dev: K-loops only
+                float keep = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) keep += s.acc[i][j][0] + s.acc[i][j][1] + s.acc[i][j][2] + s.acc[i][j][3];
+                if (keep == 1.2345e-30f) reinterpret_cast<float*>(p.C)[0] = keep;
+                skip = true;
+            }
+#endif
+#ifdef ME_DEV
+            if ((p.debug & 8) && (wc.seg_begin != 0 || wc.seg_end < pl.hk)) skip = true;     // dev: no hand-over at all
+#endif
+            if (skip) {
+            } else if (wc.seg_begin != 0) {
+                // hand my partial sums to the workgroup that owns the tile's first K-tiles
+                int le = lane;
+                asm volatile("" : "+v"(le));      // (derive the address here, not ahead of the loop)
+                // write-through (sc1) 16-byte stores: visible at agent scope once this wave's vmcnt drains, without the
+                // release fence's write-back of the whole L2 (Guideline 16, form R1 / "publish-large")
+                const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc(
+                    slabs + (int64_t)v * G3_SLAB_FLOATS, 0, G3_SLAB_FLOATS * 4, 0x00020000);
+                const int voff = ((wave * 32) * 64 + le) * 16;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s.acc[i][j]), slab, voff + (i * 4 + j) * 1024, 0, /*sc1*/ 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave drains
+                if (wr == 0) __builtin_amdgcn_s_barrier();          // realign the wave rows for a true workgroup barrier
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(flags + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (wr == 1) __builtin_amdgcn_s_barrier();          // and stagger them again
+            } else {
+                if (wc.seg_end < pl.hk) {
+                    // I hold the first K-tiles: collect the partial sums of the workgroups after me that cover the rest
+                    const int tile_end = (wc.tile - pl.rounds * G + 1) * pl.hk;      // in the remainder pair space
+                    int le = lane;
+                    asm volatile("" : "+v"(le));
+                    if (wr == 0) __builtin_amdgcn_s_barrier();
+                    for (int w = v + 1; w < G && range_begin(w) < tile_end; ++w) {
+                        if (range_begin(w) >= range_begin(w + 1)) continue;
+                        if (tid == 0) {
+                            unsigned spins = 0;
+                            while (__hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                                __builtin_amdgcn_s_sleep(8);
+                                if (++spins > (1u << 26)) { flags[G] = 1u + (unsigned)w; break; }   // give up: error word
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        }
+                        __syncthreads();
+                        const f32x4* slab = reinterpret_cast<const f32x4*>(slabs + (int64_t)w * G3_SLAB_FLOATS) + (wave * 32) * 64 + le;
+#pragma unroll
+                        for (int i0 = 0; i0 < 8; i0 += 4) {          // 16 loads in flight
+                            f32x4 t[4][4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) t[i][j] = slab[((i0 + i) * 4 + j) * 64];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) s.acc[i0 + i][j] += t[i][j];
+                        }
+                    }
+                    if (wr == 1) __builtin_amdgcn_s_barrier();
+                }
+                g3_epilogue<EPI>(p, s, m0, n0, lane);
+            }
+            g3_zero(s);
+        }
+        wc = wn;
+        cur = nxt;
+        advance_next();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing null DMAs must land before the LDS is released
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // match wave row 1's final barrier
+}
+#endif  // ME_DEV
+
+// ---- one tile per workgroup
 template <int EPI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g3_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave >> 2;
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -155,55 +515,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tm = wgid / p.tiles_n, tn = wgid % p.tiles_n;
     const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
 
-    G3State s;
-    s.smem = smem;
-    s.wave = wave;
-    s.a_base = reinterpret_cast<const char*>(p.A) + m0 * p.lda * 2;
-    s.b_base = reinterpret_cast<const char*>(p.B) + n0 * p.ldb * 2;
-    {
-        // DMA sources: instruction i of this wave covers local rows 16*wave + 8*i + (lane >> 3), slot lane & 7
-        const int64_t a_last = p.M - 1 - m0, b_last = p.N - 1 - n0;         // clamp: rows past the edge re-read the last row
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rl = 16 * wave + 8 * i + (lane >> 3);
-            const int c = (lane & 7) ^ ((rl >> 1) & 7);
-            int64_t ax_row = (rl >> 6) * 128 + (rl & 63), bx_row = (rl >> 5) * 64 + (rl & 31);
-            int64_t ay_row = ax_row + 64, by_row = bx_row + 32;
-            ax_row = ax_row < a_last ? ax_row : a_last; ay_row = ay_row < a_last ? ay_row : a_last;
-            bx_row = bx_row < b_last ? bx_row : b_last; by_row = by_row < b_last ? by_row : b_last;
-            s.src[0][i] = (uint32_t)(bx_row * p.ldb * 2 + c * 16);
-            s.src[1][i] = (uint32_t)(ax_row * p.lda * 2 + c * 16);
-            s.src[2][i] = (uint32_t)(by_row * p.ldb * 2 + c * 16);
-            s.src[3][i] = (uint32_t)(ay_row * p.lda * 2 + c * 16);
-        }
-        // fragment reads: local row = (wave part) + 16 * tile + (lane & 15), chunk = 4 * ksub + (lane >> 4)
-        const int l15 = lane & 15;
-        const uint32_t lp = (l15 >> 3) * 1024 + (lane & 7) * 128 + ((((lane >> 4) ^ (l15 >> 1)) & 7) << 4);
-        s.ra[0] = wr * 8192 + lp; s.ra[1] = s.ra[0] ^ 64;
-        s.rb[0] = wc * 4096 + lp; s.rb[1] = s.rb[0] ^ 64;
+#ifdef ME_DEV
+    if ((p.debug & 16) && bid < 256) {           // dev experiment: first-round start stagger per M-tile group
+        const int steps = (tm & 7) * (p.debug >> 8);
+        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);      // 16 * 64 cycles ~ 0.5 us each
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s.acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+    G3State s;
+    g3_init_lane(s, p, smem, wave, lane);
+    g3_zero(s);
+    const G3Src src = g3_make_src(p, tm, tn);
 
     const int nkt = (int)(p.K / G3_BK);          // even, >= 2 (g3_supported)
-    // prologue: half-tiles 0..6 of the stream (K-tile 0 complete, K-tile 1 without A-Y)
-    g3_issue<0>(s, 0, 0); g3_issue<1>(s, 0, 0); g3_issue<2>(s, 0, 0); g3_issue<3>(s, 0, 0);
-    g3_issue<0>(s, 1, 1); g3_issue<1>(s, 1, 1); g3_issue<2>(s, 1, 1);
+    g3_issue<0>(s, src, 0, 0); g3_issue<1>(s, src, 0, 0); g3_issue<2>(s, src, 0, 0); g3_issue<3>(s, src, 0, 0);
+    g3_issue<0>(s, src, 1, 128); g3_issue<1>(s, src, 1, 128); g3_issue<2>(s, src, 1, 128);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind (wave-uniform scalar branch)
+    if (wr == 1) __builtin_amdgcn_s_barrier();
 
-    int kt = 0;
-    for (; kt < nkt - 2; kt += 2) {
-        g3_ktile<0, 0>(s, kt);
-        g3_ktile<1, 0>(s, kt + 1);
+    // K-tiles past the end read as zeros through the descriptor's bounds check (offset >= K * 2 in every row -- the last
+    // row is the one that matters: num_records ends with it)
+    const G3Src null = g3_null_src(p);
+    for (int kt = 0; kt < nkt - 2; kt += 2) {
+        g3_ktile<0>(s, src, (kt + 1) * 128, src, (kt + 2) * 128);
+        g3_ktile<1>(s, src, (kt + 2) * 128, src, (kt + 3) * 128);
     }
-    g3_ktile<0, 1>(s, kt);
-    g3_ktile<1, 2>(s, kt + 1);
-    if (wr == 0) __builtin_amdgcn_s_barrier();   // realign the two wave rows: every operand read is complete
-
+    g3_ktile<0>(s, src, (nkt - 1) * 128, null, 0);
+    g3_ktile<1>(s, null, 0, null, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) __builtin_amdgcn_s_barrier();
 #ifdef ME_DEV
     if (p.debug & 1) {                           // dev: K-loop only
         float keep = 0.f;
@@ -215,110 +555,56 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
 #endif
-
-    // ---- epilogue: same scheme as gemm2b.hip.  Each wave transposes 32-row slabs of its accumulators through its own
-    // LDS patch (inline-asm DS ops so hipcc adds no vmcnt(0) that would drain the previous slab's stores) and re-reads
-    // them row-contiguous, 8 columns per lane: whole 128-byte lines per row, 16-byte coalesced loads / stores.
-    constexpr int PITCH = 64 * 4 + 16;
-    constexpr int LPR = 8, RPI = 8, NIT = 4;
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const uint32_t patch = (uint32_t)(uintptr_t)(smem + wave * (32 * PITCH));
-    const uint32_t waddr = patch + l15 * PITCH + 16 * g4;                      // + (16*ml) * PITCH + (16*nt) * 4
-    const uint32_t raddr = patch + (lane / LPR) * PITCH + 32 * (lane % LPR);    // + RPI*i*PITCH (+16)
-    float* slab = p.split_k > 1 ? reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.y * p.M * p.N : nullptr;
-    const int64_t n = n0 + wc * 64 + 8 * (lane % LPR);
-    const bool n_ok = n + 8 <= p.N;
-    const int64_t mrow0 = m0 + wr * 128 + (lane / LPR);
-    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0, cs0 = {1.f, 1.f, 1.f, 1.f}, cs1 = cs0;
-    if (EPI != 4 && EPI != 5 && n_ok) {
-        if (p.bias) { bias0 = *reinterpret_cast<const f32x4*>(p.bias + n); bias1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
-        if (p.colscale) { cs0 = *reinterpret_cast<const f32x4*>(p.colscale + n); cs1 = *reinterpret_cast<const f32x4*>(p.colscale + n + 4); }
-    }
-    asm volatile("" ::"v"(bias0), "v"(bias1), "v"(cs0), "v"(cs1));
-    const uint16_t* rop = reinterpret_cast<const uint16_t*>(EPI == 2 ? p.residual : p.aux);
-    const int64_t rop_ld = EPI == 2 ? p.ldres : p.ldaux;
-    const int64_t n_cl = n_ok ? n : 0;
-    struct RowOp { u32x4 raw[NIT]; };
-    auto fetch = [&](int sl, RowOp& ro) {
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            int64_t m = mrow0 + sl * 32 + RPI * i;
-            m = m < p.M ? m : p.M - 1;
-            ro.raw[i] = *reinterpret_cast<const u32x4*>(rop + m * rop_ld + n_cl);
-        }
-    };
-    auto unpack = [](const u32x4& rw, f32x4& a, f32x4& b) {
-        a[0] = __uint_as_float(rw[0] << 16); a[1] = __uint_as_float(rw[0] & 0xffff0000u);
-        a[2] = __uint_as_float(rw[1] << 16); a[3] = __uint_as_float(rw[1] & 0xffff0000u);
-        b[0] = __uint_as_float(rw[2] << 16); b[1] = __uint_as_float(rw[2] & 0xffff0000u);
-        b[2] = __uint_as_float(rw[3] << 16); b[3] = __uint_as_float(rw[3] & 0xffff0000u);
-    };
-    RowOp cur, nxt;
-    if (EPI == 2 || EPI == 3) fetch(0, cur);
-    auto slab_pass = [&](const int sl, const f32x4 (&a0)[4], const f32x4 (&a1)[4]) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(waddr), "v"(a0[nt]), "i"(nt * 64) : "memory");
-            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(waddr), "v"(a1[nt]), "i"(16 * PITCH + nt * 64) : "memory");
-        }
-        if ((EPI == 2 || EPI == 3) && sl + 1 < 4) fetch(sl + 1, nxt);
-        f32x4 r0[NIT], r1[NIT];
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r0[i]) : "v"(raddr), "i"(RPI * i * PITCH) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r1[i]) : "v"(raddr), "i"(RPI * i * PITCH + 16) : "memory");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            f32x4 v0 = r0[i], v1 = r1[i];
-            const int64_t m = mrow0 + sl * 32 + RPI * i;
-            const bool ok = m < p.M && n_ok;
-            if (EPI == 5) {
-                if (ok) {
-                    *reinterpret_cast<f32x4*>(slab + m * p.N + n) = v0;
-                    *reinterpret_cast<f32x4*>(slab + m * p.N + n + 4) = v1;
-                }
-                continue;
-            }
-            if (EPI == 4) {
-                if (ok) epilogue_oct(p, m, n, v0, v1);
-                continue;
-            }
-            v0 = v0 * p.alpha + bias0;
-            v1 = v1 * p.alpha + bias1;
-            if (EPI == 1) {
-                if (p.preact && ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
-                v0 = gelu_erf4(v0);
-                v1 = gelu_erf4(v1);
-            }
-            f32x4 qa, qb;
-            if (EPI == 2 || EPI == 3) unpack(cur.raw[i], qa, qb);
-            if (EPI == 3) {
-                v0 *= gelu_erf_grad4(qa);
-                v1 *= gelu_erf_grad4(qb);
-            }
-            v0 *= cs0; v1 *= cs1;
-            if (EPI == 2) { v0 += qa; v1 += qb; }
-            if (ok) store8_from_f32(p.C, p.c_dtype, m * p.ldc + n, v0, v1);
-        }
-        if ((EPI == 2 || EPI == 3) && sl + 1 < 4) cur = nxt;
-    };
-    slab_pass(0, s.acc[0], s.acc[1]);
-    slab_pass(1, s.acc[2], s.acc[3]);
-    slab_pass(2, s.acc[4], s.acc[5]);
-    slab_pass(3, s.acc[6], s.acc[7]);
+    g3_epilogue<EPI>(p, s, m0, n0, lane);
 }
 
-template <int EPI> int launch3e(const GemmParams& p, hipStream_t stream) {
+int g3_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t stream) {
     static OncePerDevice once;
     if (once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3_kernel<EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+#ifdef ME_DEV
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3p_kernel<EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+#endif
     }
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1);
-    hipLaunchKernelGGL((gemm_g3_kernel<EPI>), grid, dim3(512), G3_LDS, stream, p);
+    const int tiles = p.tiles_m * p.tiles_n;
+#ifdef ME_DEV
+    if (ws) {
+        G3Plan pl;
+        pl.hk = (int)(p.K / (2 * G3_BK));
+        int G = g3_cus();
+        G = G < tiles ? G : tiles;
+        pl.rounds = tiles / G;
+        // keep at least one tile's worth of remainder per workgroup (that is what de-phases the epilogues) when there
+        // are rounds to take it from
+        if (pl.rounds > 0 && (int64_t)(tiles - pl.rounds * G) * pl.hk < (int64_t)G * pl.hk) --pl.rounds;
+        const int64_t rem_pairs = (int64_t)(tiles - pl.rounds * G) * pl.hk;
+        pl.rem_q = (int)(rem_pairs / G);
+        pl.rem_r = (int)(rem_pairs % G);
+        float* slabs = reinterpret_cast<float*>(ws);
+        unsigned* flags = reinterpret_cast<unsigned*>(slabs + (size_t)G * G3_SLAB_FLOATS);
+        if (hipMemsetAsync(flags, 0, (size_t)(G + 1) * sizeof(unsigned), stream) != hipSuccess) {
+            me_set_error("me_gemm(g3): flag reset failed");
+            return ME_ERR_HIP;
+        }
+        hipLaunchKernelGGL((gemm_g3p_kernel<EPI>), dim3((unsigned)G), dim3(512), G3_LDS, stream, p, pl, slabs, flags);
+        ME_CHECK_LAUNCH("me_gemm(g3p)");
+        return ME_OK;
+    }
+#endif
+    (void)ws;
+    hipLaunchKernelGGL((gemm_g3_kernel<EPI>), dim3((unsigned)tiles), dim3(512), G3_LDS, stream, p);
     ME_CHECK_LAUNCH("me_gemm(g3)");
     return ME_OK;
 }
@@ -328,17 +614,26 @@ template <int EPI> int launch3e(const GemmParams& p, hipStream_t stream) {
 bool g3_supported(const GemmParams& p, int op) {
     if (op != ME_GEMM_NT) return false;
     if (p.K % (2 * G3_BK) != 0 || p.N % 8 != 0) return false;
-    // DMA source offsets are 32-bit from the tile's first row
+    // per-tile buffer descriptors and lane offsets are 32-bit
     if (256 * p.lda * 2 >= (1ll << 31) || 256 * p.ldb * 2 >= (1ll << 31)) return false;
     return true;
 }
 
-int launch_g3(const GemmParams& p, int epi, hipStream_t stream) {
+// scratch of the persistent stream-K form (dev build): one fp32 partial tile per workgroup + the hand-over flags (+ 1
+// error word)
+size_t g3_workspace_bytes() {
+    const size_t G = (size_t)g3_cus();
+    return G * G3_SLAB_FLOATS * sizeof(float) + (G + 1) * sizeof(unsigned);
+}
+
+// one tile per workgroup; in the dev build ws != nullptr (>= g3_workspace_bytes()) selects the persistent stream-K form
+int launch_g3(const GemmParams& p, int epi, void* ws, hipStream_t stream) {
+    if (p.colscale) epi = 4;                       // (the specialised epilogues of this family carry no column scale)
     switch (epi) {
-        case 0: return launch3e<0>(p, stream);
-        case 1: return launch3e<1>(p, stream);
-        case 2: return launch3e<2>(p, stream);
-        case 3: return launch3e<3>(p, stream);
-        default: return launch3e<4>(p, stream);
+        case 0: return launch3e<0>(p, ws, stream);
+        case 1: return launch3e<1>(p, ws, stream);
+        case 2: return launch3e<2>(p, ws, stream);
+        case 3: return launch3e<3>(p, ws, stream);
+        default: return launch3e<4>(p, ws, stream);
     }
 }

@@ -123,16 +123,17 @@ static inline int pick_epi(const GemmParams& p) {
 // kernel families (each in its own translation unit)
 int launch_g2b(const GemmParams& p, int op, int bm, int bn, hipStream_t stream);
 bool g2b_supported(const GemmParams& p, int op);
-int launch_g3(const GemmParams& p, int epi, hipStream_t stream);
+int launch_g3(const GemmParams& p, int epi, void* ws, hipStream_t stream);      // ws = nullptr: one tile per workgroup
 bool g3_supported(const GemmParams& p, int op);
+size_t g3_workspace_bytes();
 
 // Dev switches for A/B runs (tools/gemm_dev): they exist only in the dev build of the library (-DME_DEV, built by
 // `python -m metatransformer_amd.build --dev` into tools/_build/); the shipped library has no knobs and reads no
 // environment variables.
-struct GemmDev { int family, bn, debug, tail_split; };
+struct GemmDev { int family, bn, debug, tail_split, g3_persistent; };
 #ifdef ME_DEV
 extern GemmDev g_gemm_dev;
 static inline GemmDev gemm_dev() { return g_gemm_dev; }
 #else
-static inline GemmDev gemm_dev() { return GemmDev{-1, 0, 0, 1}; }
+static inline GemmDev gemm_dev() { return GemmDev{-1, 0, 0, 1, 1}; }
 #endif

@@ -123,10 +123,11 @@ class _WeightCache:
                 if v is not None:
                     return v
         k = self._key(p, dtype)
-        hit = self._fwd.get(name)
+        slot = (name, p.device)       # nn.DataParallel replicas share this object (shallow __dict__ copy): one slot per device
+        hit = self._fwd.get(slot)
         if hit is None or hit[0] != k:
             hit = (k, ops.cast(p.detach().contiguous(), dtype))
-            self._fwd[name] = hit
+            self._fwd[slot] = hit
         return hit[1]
 
     def _weights(self):
@@ -137,24 +138,28 @@ class _WeightCache:
 
     def transposed(self, name: str, p: torch.Tensor, dtype) -> torch.Tensor:
         k = self._key(p, dtype)
-        hit = self._tr.get(name)
-        if hit is None or hit[0] != k:
-            # refresh every stale transposed copy on this device in one go
-            todo = []
-            for c in list(_WeightCache._live):
-                for n, w in c._weights().items():
-                    if w.device == p.device and w.dtype == p.dtype and w.dim() == 2:
-                        kk = _WeightCache._key(w, dtype)
-                        h = c._tr.get(n)
-                        if h is None or h[0] != kk:
-                            todo.append((c, n, kk, w))
-            if not any(c is self and n == name for c, n, _, _ in todo):
-                todo.append((self, name, k, p))
-            outs = ops.transpose_cast_many([w.detach().contiguous() for _, _, _, w in todo], dtype)
-            for (c, n, kk, _), t in zip(todo, outs):
-                c._tr[n] = (kk, t)
-            hit = self._tr[name]
-        return hit[1]
+        slot = (name, p.device)
+        hit = self._tr.get(slot)
+        if hit is not None and hit[0] == k:
+            return hit[1]
+        # refresh every stale transposed copy on this device in one go
+        todo = []
+        for c in list(_WeightCache._live):
+            for n, w in c._weights().items():
+                if w.device == p.device and w.dtype == p.dtype and w.dim() == 2:
+                    kk = _WeightCache._key(w, dtype)
+                    h = c._tr.get((n, w.device))
+                    if h is None or h[0] != kk:
+                        todo.append((c, n, kk, w))
+        if not any(c is self and n == name and kk == k for c, n, kk, _ in todo):
+            todo.append((self, name, k, p))       # (a DataParallel replica: its parameters are not the owner's)
+        outs = ops.transpose_cast_many([w.detach().contiguous() for _, _, _, w in todo], dtype)
+        mine = None
+        for (c, n, kk, w), t in zip(todo, outs):
+            c._tr[(n, w.device)] = (kk, t)
+            if c is self and n == name and kk == k:
+                mine = t        # returned from this local: the shared dict may be rewritten by another replica's thread
+        return mine
 
 
 class _BlockFn(torch.autograd.Function):
