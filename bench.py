@@ -1,72 +1,113 @@
 #!/usr/bin/env python
 """bench.py -- encoder samples/sec at B=256, N=197, C=768 (Base) on N MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--batch 256] [--no-cpu-baseline]
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--workload base|large512|large1568|mixed]
+                    [--batch B] [--no-cpu-baseline]
+
+--gpus N > 1 launches itself: when no torchrun environment is present the script re-executes under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per GPU; started
+by torchrun directly (the driver's form) it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
 One "step" (mode=train, the default; BASELINE config 2 "Meta-Transformer-Base forward+backward ... [256,197,768], bf16"):
     forward of the 12-layer/768-d encoder on a per-GPU batch of synthetic bf16 tokens, backward (input + all weight
-    gradients), one all-reduce per flat gradient bucket when N > 1, fused AdamW step on the fp32 master weights.
-mode=fwd times the forward only (torch.no_grad), the configuration the north star's "40 % MFMA" target is quoted on.
+    gradients), one RCCL all-reduce per flat gradient bucket when N > 1 (through the C ABI: me_allreduce_bucket on the
+    communicator's own stream, launched from gradient hooks while backward still runs), fused AdamW on the fp32 masters.
+The default run also times the encoder FORWARD alone (torch.no_grad) -- the configuration the north star's "40 % MFMA"
+target is quoted on -- and reports it in the same JSON line under "fwd".
 
-Prints ONE JSON line (rank 0).  `value` = whole-job samples/s with the tokens resident in HBM.  The `roofline` object is
-for the dominant kernel (the bf16 NT MFMA GEMM): algorithmic FLOPs of its launches / their summed duration, measured with
-events on the launch stream inside the timed region.  `cpu_baseline` = the CPU oracle on the host cores (rank 0, N=1).
+Prints ONE JSON line (rank 0).  `value` = whole-job samples/s with the tokens resident in HBM, timed with the library's
+launch-timing hooks OFF.  `roofline` is for the dominant kernel (the bf16 NT MFMA GEMM): algorithmic FLOPs of its launches
+/ their summed duration, from HIP events on the launch stream in a SEPARATE pass of the same steps right after the timed
+region.  `cpu_baseline` = the reference's CPU formulation on the host cores (rank 0, N=1), threads and batch swept.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
-PEAK_HBM_TBPS = 8.0             # HBM3E (same guide)
-PEAK_HBM_GBS = 8000.0
+PEAK_HBM_TBPS = 8.0            # HBM3E (same guide)
+
+WORKLOADS = {       # name: (model, per-GPU batch, tokens)
+    "base": ("base", 256, 197),          # BASELINE config 2 (the metric)
+    "large512": ("large", 128, 512),     # config 3 token shape
+    "large1568": ("large", 32, 1568),    # config 5 token shape
+    "mixed": ("base", 64, 0),            # config 4: Image + Time-Series + Audio tokenizers, sequence-concat (README.md:122)
+}
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["train", "fwd"], default="train")
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--tokens", type=int, default=197)
-    ap.add_argument("--model", choices=["base", "large"], default="base")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="base")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling); 0 = the workload's")
+    ap.add_argument("--tokens", type=int, default=0)
+    ap.add_argument("--model", choices=["base", "large"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--no-fwd-leg", action="store_true")
+    ap.add_argument("--attn-dtype", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8: e4m3 attention forward on the block-scaled MFMA (config 5; head_dim 64)")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def self_launch(args) -> None:
+    """--gpus N > 1 without a torchrun environment: start one rank per GPU and relay rank 0's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("ME_BENCH_FORCE_DIST") == "1"     # (forced: exercises the RCCL path on 1 GPU)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
 
     import metatransformer_amd as M
     from metatransformer_amd import ops, parallel, _capi
 
-    L, C, H = (12, 768, 12) if args.model == "base" else (24, 1024, 16)
-    B, N = args.batch, args.tokens
+    comm = None
+    if use_dist:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # host-side rendezvous only: carries the RCCL id to the ranks and the max-over-ranks of the timings
+            dist.init_process_group("gloo")
+            comm = parallel.Comm.from_torch_distributed()
+        else:
+            comm = parallel.Comm(parallel.Comm.new_unique_id(), 0, 1)
+
+    model, B0, N0 = WORKLOADS[args.workload]
+    model = args.model or model
+    L, C, H = (12, 768, 12) if model == "base" else (24, 1024, 16)
+    B = args.batch or B0
     torch.manual_seed(0)                         # identical weights on every rank
     enc = M.build_encoder(L, C, H).to(dev)
     for p in enc.parameters():                   # N(0, 0.02) weights in the checkpoint layout (no .pth available)
@@ -74,16 +115,35 @@ def main():
             torch.nn.init.normal_(p, std=0.02)
     for blk in enc:
         blk.compute_dtype = torch.bfloat16       # fp32 master weights, bf16 MFMA compute, bf16 token stream
+        blk.attn_fp8 = args.attn_dtype == "fp8"
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)        # per-rank data (Video/run_class_finetuning.py:417)
-    x = torch.randn(B, N, C, generator=g).to(dev).bfloat16()
+    tok_note = None
+    if args.workload == "mixed":
+        # BASELINE config 4: three Data2Seq tokenizers feed one encoder; tokens are concatenated along the sequence
+        # (the only multi-modal usage the reference shows: README.md:118-123)
+        img = M.PatchEmbed(img_size=224, patch_size=16, in_c=3, embed_dim=C).to(dev)
+        ts = M.DataEmbedding(c_in=7, d_model=C).to(dev).eval()
+        aud = M.AcousticPatchEmbed(embed_dim=C).to(dev)
+        with torch.no_grad():
+            xi = img(torch.randn(B, 3, 224, 224, generator=g).to(dev))
+            xt = ts(torch.randn(B, 96, 7, generator=g).to(dev))
+            xa = aud(torch.randn(B, 1, 128, 256, generator=g).to(dev))
+            x = torch.cat([xi, xt, xa], dim=1).bfloat16().contiguous()
+        N = x.shape[1]
+        tok_note = f"Image 224/16 -> {xi.shape[1]} + Time-Series L96/c7 -> {xt.shape[1]} + Audio 128x256 k16/s10 -> {xa.shape[1]} tokens"
+    else:
+        N = args.tokens or N0
+        x = torch.randn(B, N, C, generator=g).to(dev).bfloat16()
     gy = (torch.randn(B, N, C, generator=g) / (B * N)).to(dev).bfloat16()
 
     train = args.mode == "train"
+    flat = opt = reducer = None
     if train:
         enc.train()
-        flat = parallel.FlatParams(enc.parameters())
+        # 1-D parameters and biases carry no weight decay, as in the reference recipes (Video/optim_factory.py:67-73)
+        flat = parallel.FlatParams(enc.named_parameters(), no_decay=parallel.no_decay_rule)
         opt = parallel.FusedAdamW(flat, lr=1e-4, weight_decay=0.05)
-        reducer = parallel.OverlappedGradReducer(flat, force=use_dist) if use_dist else None
+        reducer = parallel.OverlappedGradReducer(flat, comm=comm, force=use_dist) if use_dist else None
         x.requires_grad_(True)                   # the tokenizer in front of the encoder needs dL/dx
 
         def step():
@@ -101,123 +161,150 @@ def main():
             with torch.no_grad():
                 enc(x)
 
+    def fwd_step():
+        with torch.no_grad():
+            enc(x)
+
     def sync():
-        if use_dist:
+        torch.cuda.synchronize()
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    ops.gemm_profile(True)       # HIP events around every me_gemm launch, recorded by the library on the launch stream
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    prof = ops.gemm_profile_read()
-    ops.gemm_profile(False)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
-    # ---- roofline of the dominant kernel: bf16 NT MFMA GEMM (forward + dgrad launches share one kernel)
-    nt = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in prof if op == _capi.ME_GEMM_NT and dt == _capi.ME_BF16]
-    tn = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in prof if op == _capi.ME_GEMM_TN and dt == _capi.ME_BF16]
-    roof = None
-    if nt:
+    def profiled(fn, steps):
+        """the same steps again with the library's launch-timing hooks on (HIP events on the launch stream)"""
+        ops.gemm_profile(True)
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        recs = ops.gemm_profile_read()
+        ops.gemm_profile(False)
+        return recs
+
+    elapsed = timed(step, args.steps, args.warmup)
+    psteps = max(1, min(args.steps, 5))
+    prof = profiled(step, psteps)
+    fwd = None
+    if train and not args.no_fwd_leg:
+        enc.eval()
+        fwd_el = timed(fwd_step, args.steps, min(args.warmup, 2))
+        fwd_prof = profiled(fwd_step, psteps)
+        enc.train()
+        fwd = (fwd_el, fwd_prof)
+
+    def gemm_roofline(recs, wall_s, nsteps, with_wgrad):
+        nt = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_NT and dt == _capi.ME_BF16]
+        tn = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_TN and dt == _capi.ME_BF16]
+        if not nt:
+            return None
         flops = sum(2.0 * m * n * k for m, n, k, _ in nt)
         ms = sum(t for *_, t in nt)
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_g2_kernel<BM,256,NT,EPI> (all bf16 NT MFMA GEMM launches: forward + dgrad)", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "launches_per_step": len(nt) // args.steps, "avg_launch_us": round(1e3 * ms / len(nt), 2),
+        roof = {"bound": "mfma",
+                "kernel": "gemm_g3_kernel<EPI> (bf16 NT MFMA GEMM, 256x256x64 tiles: every forward + dgrad launch)",
+                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "traffic": None,
+                "traffic_note": "HBM bytes per launch are PMC-only (rocprofv3 --pmc, separate passes): see profiles/r02_pmc_*.json",
+                "launches_per_step": len(nt) // nsteps, "avg_launch_us": round(1e3 * ms / len(nt), 2),
                 "avg_launch_gflop": round(flops / len(nt) / 1e9, 2),
-                "share_of_step_time": round(ms * 1e-3 / elapsed, 4)}
-        # HBM bytes per launch of the same kernels from the committed rocprofv3 PMC pass (tools/pmc_bench.sh ->
-        # tools/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md correction); counters cannot be read live
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_{args.mode}.json")))
-            pmc_steps = pmc.get("_meta", {}).get("bench_steps_in_pass", 2)
-            # every kernel an NT me_gemm call launches: the main kernel, its tail-split part (EPI 5) and that part's fold
-            n_tail = sum(v["launches"] for k, v in pmc.items() if k.startswith("gemm_g2_kernel") and ", false, 5>" in k)
-            tot_mb = sum(v["launches"] * v["hbm_traffic_MB"] for k, v in pmc.items()
-                         if k.startswith("gemm_g2_kernel") and ", false," in k and "hbm_traffic_MB" in v)
-            if "splitk_reduce_kernel" in pmc and n_tail:
-                tot_mb += n_tail * pmc["splitk_reduce_kernel"]["hbm_traffic_MB"]
-            if tot_mb > 0:
-                roof["traffic"] = round(1e6 * tot_mb / (pmc_steps * (len(nt) // args.steps)))
-                roof["traffic_unit"] = "HBM bytes per me_gemm(NT) call (PMC pass in profiles/, not live)"
-                roof["algorithmic_bytes_per_launch"] = round(sum(2.0 * (m * k + n * k + m * n) for m, n, k, _ in nt) / len(nt))
-        except Exception:      # noqa: BLE001 -- profile file absent: traffic stays null
-            pass
-        if tn:
+                "algorithmic_bytes_per_launch": round(sum(2.0 * (m * k + n * k + m * n) for m, n, k, _ in nt) / len(nt)),
+                "share_of_step_time": round(ms * 1e-3 / nsteps / wall_s, 4)}
+        if with_wgrad and tn:
             f2 = sum(2.0 * m * n * k for m, n, k, _ in tn)
             ms2 = sum(t for *_, t in tn)
-            roof["wgrad_kernel"] = {"kernel": "gemm_g2_kernel<128,256,TN,5> (wgrad, split-K)", "achieved": round(f2 / (ms2 * 1e-3) / 1e12, 2),
-                                    "unit": "TFLOP/s", "avg_launch_us": round(1e3 * ms2 / len(tn), 2),
-                                    "share_of_step_time": round(ms2 * 1e-3 / elapsed, 4)}
+            roof["wgrad_kernel"] = {"kernel": "gemm_g2_kernel<128,256,TN,5> (wgrad, split-K)",
+                                    "achieved": round(f2 / (ms2 * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                                    "avg_launch_us": round(1e3 * ms2 / len(tn), 2),
+                                    "share_of_step_time": round(ms2 * 1e-3 / nsteps / wall_s, 4)}
+        return roof
 
-    # ---- the other kernel classes of the step, from the same event records: HBM-bound LayerNorm against the 8 TB/s
-    # peak (algorithmic bytes: SURVEY 8d), attention against both peaks
-    def _class(code, work_fn, bytes_fn):
-        recs = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in prof if op == code]
-        if not recs:
-            return None
-        ms = sum(t for *_, t in recs)
-        by = sum(bytes_fn(m, n, k) for m, n, k, _ in recs)
-        out_ = {"launches_per_step": len(recs) // args.steps, "avg_launch_us": round(1e3 * ms / len(recs), 2),
-                "hbm_TBps": round(by / (ms * 1e-3) / 1e12, 3), "hbm_frac": round(by / (ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
-                "share_of_step_time": round(ms * 1e-3 / elapsed, 4)}
-        if work_fn is not None:
-            fl = sum(work_fn(m, n, k) for m, n, k, _ in recs)
-            out_["TFLOPs"] = round(fl / (ms * 1e-3) / 1e12, 1)
-        return out_
-    es = 2      # bf16 token stream
-    other = {
-        "layernorm_fwd": _class(_capi.ME_PROF_LN_FWD, None, lambda m, n, k: 2.0 * m * n * es),
-        "layernorm_bwd": _class(_capi.ME_PROF_LN_BWD, None, lambda m, n, k: 4.0 * m * n * es),
-        "attention_fwd": _class(_capi.ME_PROF_ATTN_FWD, lambda m, n, k: 4.0 * m * n * n * k, lambda m, n, k: 4.0 * m * n * k * es),
-        "attention_bwd": _class(_capi.ME_PROF_ATTN_BWD, lambda m, n, k: 10.0 * m * n * n * k, lambda m, n, k: 8.0 * m * n * k * es),
-    }
-    other = {k: v for k, v in other.items() if v is not None}
+    def other_kernels(recs, wall_s, nsteps):
+        """the other kernel classes of the step, from the same event records: HBM-bound LayerNorm against the 8 TB/s
+        peak (algorithmic bytes: SURVEY 8d), attention against both peaks"""
+        def _class(code, work_fn, bytes_fn):
+            rs = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == code]
+            if not rs:
+                return None
+            ms = sum(t for *_, t in rs)
+            by = sum(bytes_fn(m, n, k) for m, n, k, _ in rs)
+            o = {"launches_per_step": len(rs) // nsteps, "avg_launch_us": round(1e3 * ms / len(rs), 2),
+                 "hbm_TBps": round(by / (ms * 1e-3) / 1e12, 3), "hbm_frac": round(by / (ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
+                 "share_of_step_time": round(ms * 1e-3 / nsteps / wall_s, 4)}
+            if work_fn is not None:
+                o["TFLOPs"] = round(sum(work_fn(m, n, k) for m, n, k, _ in rs) / (ms * 1e-3) / 1e12, 1)
+            return o
+        es = 2      # bf16 token stream
+        d = {"layernorm_fwd": _class(_capi.ME_PROF_LN_FWD, None, lambda m, n, k: 2.0 * m * n * es),
+             "layernorm_bwd": _class(_capi.ME_PROF_LN_BWD, None, lambda m, n, k: 4.0 * m * n * es),
+             "attention_fwd": _class(_capi.ME_PROF_ATTN_FWD, lambda m, n, k: 4.0 * m * n * n * k, lambda m, n, k: 4.0 * m * n * k * es),
+             "attention_bwd": _class(_capi.ME_PROF_ATTN_BWD, lambda m, n, k: 10.0 * m * n * n * k, lambda m, n, k: 8.0 * m * n * k * es)}
+        return {k: v for k, v in d.items() if v is not None}
 
+    comm_info = comm.info() if comm is not None else None
     if rank != 0:
-        if use_dist:
+        if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
-    ms_per_step = 1e3 * elapsed / args.steps
+    step_s = elapsed / args.steps
     value = world * B * args.steps / elapsed
     fwd_flops = M.encoder_flops_per_sample(N, C, L)
     model_flops = (3.0 if train else 1.0) * fwd_flops
+    is_metric = args.workload == "base" and B == 256 and N == 197 and model == "base"
+    what = "forward+backward+AdamW" if train else "encoder forward (no_grad)"
     out = {
-        "metric": "encoder samples/sec at B=256,N=197,C=768 (Base)" if (args.model == "base" and B == 256 and N == 197)
-                  else f"encoder samples/sec at B={B},N={N},C={C}",
-        "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": (("BASELINE config 2: " if (args.model == "base" and B == 256 and N == 197) else "")
-                                + f"Meta-Transformer-{args.model.capitalize()} "
-                                + ("forward+backward+AdamW" if train else "encoder forward (no_grad)"))
-                               + f", tokens [{B},{N},{C}] bf16 per GPU, "
-                               f"{L}L/{C}d/{H}h, fp32 master weights, random init N(0,0.02)",
+        "metric": "encoder samples/sec at B=256,N=197,C=768 (Base)" if is_metric else f"encoder samples/sec at B={B},N={N},C={C}",
+        "value": round(value, 2), "unit": "samples/s", "n_gpus": comm_info["world"] if comm_info else world,
+        "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * step_s, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.attn_dtype == "bf16" else "bf16 (attention forward in fp8 e4m3, fp32 softmax statistics)",
+        "data": "synthetic",
+        "config": {"workload": ("BASELINE config 2: " if is_metric else ("BASELINE config 4 (sequence-concat): " if args.workload == "mixed" else ""))
+                               + f"Meta-Transformer-{model.capitalize()} {what}, tokens [{B},{N},{C}] bf16 per GPU, "
+                               f"{L}L/{C}d/{H}h, fp32 master weights, random init N(0,0.02)" + (f"; {tok_note}" if tok_note else ""),
                    "mode": args.mode, "per_gpu_batch": B, "global_batch": B * world, "tokens": N,
                    "parallelism": f"dp{world}" if world > 1 else "single",
-                   "grad_allreduce": "RCCL all-reduce(sum) per 64 MiB flat fp32 bucket, launched from grad hooks (overlaps backward), 1/world folded into AdamW" if world > 1 else None},
+                   "grad_allreduce": (f"me_allreduce_bucket (RCCL behind the C ABI, own stream, event hand-off): one all-reduce(sum) per "
+                                      f"64 MiB flat fp32 bucket launched from grad hooks, 1/world folded into AdamW; "
+                                      f"{comm_info['buckets_reduced'] // max(1, args.steps + args.warmup + psteps)} buckets/step, "
+                                      f"RCCL world {comm_info['world']}") if (comm_info and train) else None},
         "model_tflops_per_s": round(value * model_flops / 1e12, 2),
         "mfma_frac_end_to_end": round(value * model_flops / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
-        "roofline": roof,
-        "other_kernels": other,
+        "roofline": gemm_roofline(prof, step_s, psteps, train),
+        "other_kernels": other_kernels(prof, step_s, psteps),
     }
+    if fwd is not None:
+        fwd_el, fwd_prof = fwd
+        fs = fwd_el / args.steps
+        fv = world * B * args.steps / fwd_el
+        out["fwd"] = {"what": "encoder forward alone (torch.no_grad), same tokens and weights, same K steps",
+                      "ms_per_step": round(1e3 * fs, 3), "samples_per_s": round(fv, 2),
+                      "model_tflops_per_s": round(fv * fwd_flops / 1e12, 2),
+                      "mfma_frac": round(fv * fwd_flops / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+                      "roofline": gemm_roofline(fwd_prof, fs, psteps, False),
+                      "other_kernels": other_kernels(fwd_prof, fs, psteps)}
     if not args.no_cpu_baseline and world == 1:
-        # the CPU oracle runs in its own process (fresh OpenMP pool, hard timeout) so it can never stall the bench
-        import subprocess
+        # the CPU leg runs in its own process (fresh OpenMP pool, hard timeout) so it can never stall the bench
         cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--depth", str(L), "--dim", str(C), "--heads", str(H),
-               "--tokens", str(N), "--batch", "8", "--budget-s", str(args.cpu_budget_s)] + ([] if train else ["--forward-only"])
+               "--tokens", str(N), "--budget-s", str(args.cpu_budget_s)] + ([] if train else ["--forward-only"])
         try:
-            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=args.cpu_budget_s * 6 + 120)
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=args.cpu_budget_s * 8 + 120)
             cb = json.loads(r.stdout.strip().splitlines()[-1])
             cb["value"] = round(cb["value"], 3)
             out["cpu_baseline"] = cb
@@ -226,8 +313,9 @@ def main():
                                    "sample": f"failed: {type(e).__name__}: {e}"[:300]}
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
-    if use_dist:
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

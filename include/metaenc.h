@@ -162,6 +162,18 @@ int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out, int64_t l
                      void* dqkv, int64_t ld_dqkv,
                      int B, int N, int H, int head_dim, float scale, int dtype, float p_drop, uint64_t seed, void* stream);
 
+/* fp8 (OCP e4m3) forward for long sequences -- BASELINE config 5 (Large video tokens [32, 1568, 1024]).  Same contract as
+ * me_attention_fwd (math of Video/models/modeling_finetune.py:172-195) for bf16 qkv / out and head_dim 64, with Q, K, V and
+ * the softmax probabilities quantised to e4m3 (per-tensor scales from an absmax pre-pass; P scaled by 2^7) and both
+ * products on V_MFMA_SCALE_F32_32X32X64_F8F6F4 with unit block scales (the fp8 matrix instruction that runs at twice the
+ * bf16 rate); running max / sum, the output accumulator and lse are fp32.  The reference has no fp8 path: accuracy is stated
+ * against the fp32 oracle in tests/ (2e-2 of max|out| at N = 1568).  workspace: me_attention_fp8_workspace(...) bytes
+ * (the quantised, re-laid-out Q / K / V^T).  Returns ME_ERR_UNSUPPORTED for head_dim != 64.  Backward: me_attention_bwd on
+ * the bf16 qkv with this call's lse. */
+size_t me_attention_fp8_workspace(int B, int N, int H, int head_dim);
+int me_attention_fwd_fp8(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int B, int N, int H,
+                         int head_dim, float scale, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ One encoder Block, composed on the C side
  * Block.forward / its autograd (PointCloud/openpoints/models/layers/attention.py:55-58) as ONE call each: the same
  * kernels as the entry points above, launched back to back on `stream` without returning to the host in between --
@@ -295,6 +307,40 @@ int me_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float grad_scale, void* bf16_mirror, void* stream);
 /* bf16_mirror (optional, n bf16 elements, same indexing as param): receives the updated parameters rounded to bf16 --
  * the forward-layout compute copies of the weights come out of the optimizer pass instead of one cast launch per weight. */
+
+/* ------------------------------------------------------------------ token pooling for the task heads
+ * [B, N, C] tokens -> [B, C] fp32 features: x.mean(1) ahead of fc_norm / x[:, 0] (Video/models/modeling_finetune.py:445-454),
+ * and the 'max' / 'avg' global features of the PointCloud ClsHead (openpoints/models/classification/cls_base.py:126-133).
+ * ME_POOL_MAX also writes the arg-max token per (b, c) (first index on ties; may be NULL in inference).
+ * me_pool_tokens_bwd scatters dy [B, C] back to dx [B, N, C] (every element written). */
+enum { ME_POOL_MEAN = 0, ME_POOL_MAX = 1, ME_POOL_FIRST = 2 };
+int me_pool_tokens(const void* x, int x_dtype, float* out, int32_t* argmax, int B, int N, int C, int mode, void* stream);
+int me_pool_tokens_bwd(const float* dy, const int32_t* argmax, void* dx, int dx_dtype, int B, int N, int C, int mode,
+                       void* stream);
+
+/* ------------------------------------------------------------------ point-cloud tokenizer front end
+ * The index-producing part of PointPatchEmbed (PointCloud/openpoints/models/layers/group_embed.py:138-172); the per-point
+ * MLP behind it is me_gemm + me_pool_tokens(ME_POOL_MAX).
+ * me_fps: farthest point sampling, restating furthest_point_sampling_kernel
+ *   (PointCloud/openpoints/cpp/pointnet2_batch/src/sampling_gpu.cu:101-210) selection rule and tie-breaking exactly:
+ *   points [B, n, 3] fp32 -> idx [B, m] int32 (idx[:, 0] = 0); temp = [B, n] fp32 scratch.
+ * me_knn: for every query [B, m, 3] the k nearest of support [B, n, 3] (squared distance, ascending, ties -> lower
+ *   index): what KNN.forward's cdist + topk(largest=False) selects (openpoints/models/layers/group.py:12-28). n <= 10240.
+ * me_group_relative: rows[(b, s, j), 0:3] = points[b, idx[b, s, j]] - centers[b, s] (grouping_operation + relative_xyz,
+ *   group.py:310-313), columns 3..cols-1 zero (cols = the GEMM's padded reduction length). */
+int me_fps(const float* points, int32_t* idx, float* temp, int B, int n, int m, void* stream);
+int me_knn(const float* support, const float* query, int32_t* idx, int B, int n, int m, int k, void* stream);
+int me_group_relative(const float* points, const float* centers, const int32_t* idx, float* rows, int B, int n, int m,
+                      int k, int cols, void* stream);
+
+/* ------------------------------------------------------------------ position-embedding table resize
+ * Replaces TIMMVisionTransformer.resize_pos_embed (Image/detection/mmdet_custom/models/backbones/base/vit.py:459-486,
+ * also vit_adapter.py:73-78): the [h*w, cols] grid part of a pos-embed table resampled to [H*W, cols] with
+ * F.interpolate(mode, align_corners=False) semantics, on the token-major layout (rows = grid positions).  The caller keeps
+ * the cls row(s) as the reference does (cat).  fp32 arithmetic; modes: */
+enum { ME_RESIZE_BILINEAR = 0, ME_RESIZE_BICUBIC = 1 };
+int me_resize_rows(const void* src, int src_dtype, void* dst, int dst_dtype, int h, int w, int H, int W, int cols,
+                   int mode, void* stream);
 
 /* ------------------------------------------------------------------ data-parallel gradient exchange
  * The ONE exchange step of batch-sharded data parallelism: a sum all-reduce per flat gradient bucket over RCCL (xGMI

@@ -22,6 +22,8 @@ ME_GEMM_NT, ME_GEMM_TN = 0, 1
 ME_ACT_NONE, ME_ACT_GELU = 0, 1
 ME_PROF_LN_FWD, ME_PROF_LN_BWD, ME_PROF_ATTN_FWD, ME_PROF_ATTN_BWD = 16, 17, 18, 19      # me_gemm_profile_rec.op codes
 ME_COMM_ID_BYTES = 128
+ME_RESIZE_BILINEAR, ME_RESIZE_BICUBIC = 0, 1
+ME_POOL_MEAN, ME_POOL_MAX, ME_POOL_FIRST = 0, 1, 2
 
 
 class MetaEncError(RuntimeError):
@@ -114,6 +116,9 @@ SIGNATURES = {
     "me_attention_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, c_float, ctypes.c_uint64,
                                  c_void_p]),
+    "me_attention_fp8_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "me_attention_fwd_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                     c_void_p, c_size_t, c_void_p]),
     "me_block_saved_bytes": (c_size_t, [POINTER(BlockDesc)]),
     "me_block_workspace_bytes": (c_size_t, [POINTER(BlockDesc), c_int]),
     "me_block_fwd": (c_int, [POINTER(BlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -134,6 +139,12 @@ SIGNATURES = {
     "me_timeseries_unfold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "me_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                               c_float, c_int, c_float, c_void_p, c_void_p]),
+    "me_fps": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "me_knn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "me_group_relative": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "me_pool_tokens": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "me_pool_tokens_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "me_resize_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "me_comm_unique_id": (c_int, [c_void_p]),
     "me_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int, c_int]),
     "me_comm_destroy": (c_int, [c_void_p]),

@@ -1,0 +1,317 @@
+// attention_fp8.hip -- fp8 (OCP e4m3) MFMA attention forward for long sequences (BASELINE config 5: Large video tokens
+// [32, 1568, 1024], where attention is 20 % of the FLOPs).
+//
+// Replaces Attention.forward's core, Video/models/modeling_finetune.py:172-195 (q*scale @ k^T -> softmax -> @ v), same
+// math as me_attention_fwd, with Q, K, V and the softmax probabilities P quantised to e4m3:
+//   * per-tensor scales for Q, K, V (absmax -> 240, well inside e4m3's 448), P scaled by 2^7 (p <= 1 -> 128);
+//   * products on the block-scaled MFMA V_MFMA_SCALE_F32_32X32X64_F8F6F4 with unit block scales -- the only fp8 matrix
+//     instruction that runs at twice the bf16 rate (the plain fp8 MFMAs run at the bf16 rate, MI355X_MICROARCH.md); head
+//     dimension 64 is exactly ONE such instruction per 32 x 32 score tile;
+//   * softmax statistics (running max, sum), the output accumulator and the LSE stay fp32.
+// The reference has no fp8 path: parity is stated against the fp32 oracle with an fp8-sized tolerance (tests).
+//
+// Pre-pass (two elementwise kernels): absmax of the three thirds of qkv, then quantise + re-layout into
+//   Q8  [B*H][Nq][64]            rows of 64 bytes (Nq = N rounded up to 128, zero rows past N)
+//   K8  [B*H][Nk / 64][64][64]   64-key blocks, 16-byte chunks of a row XOR-swizzled with (key >> 2) & 3
+//   Vt8 [B*H][Nk / 64][64][64]   per block: row = head-dim index d, 64 bytes = the block's keys in MFMA order
+//        (byte h*32 + j of row d = V[key = 32*(j>>4) + crow(j & 15, h)][d], crow(r, h) = (r & 3) + 8*(r >> 2) + 4*h)
+// so that a K / V block is one contiguous 4 KiB chunk that LDS-DMA copies verbatim and every MFMA operand is 32
+// contiguous bytes in LDS.  The key permutation of Vt8 is the order in which a lane holds its probabilities after the
+// transposed score MFMA (S^T = K Q^T: lane = query column, registers = keys), so P feeds the second MFMA straight from
+// registers.  Any assignment of reduction indices to operand bytes is valid as long as both operands use the same one.
+//
+// Main kernel: workgroup = 4 waves x 32 queries = 128 queries of one (batch, head); keys stream through LDS in blocks of 64
+// (double-buffered LDS-DMA, one barrier per block); per block and wave 2 score MFMAs + 2 output MFMAs (64 cycles each) and
+// 32 exponentials per lane.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((address_space(3))) void lds_void8;
+typedef const __attribute__((address_space(1))) void gbl_void8;
+
+constexpr int F8_QT = 128;                 // queries per workgroup
+constexpr float F8_MAXV = 240.0f;          // absmax of Q / K / V maps here
+constexpr float F8_PSCALE = 128.0f;        // probabilities are stored as p * 128
+
+__device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- pre-pass 1: absmax of Q, K, V (atomicMax on the float bits: values are non-negative).  One wave per token row,
+// lanes stride over the row's 16-byte chunks third by third -- no index divisions in the loop.
+__global__ __launch_bounds__(256) void f8_absmax_kernel(const bf16_t* __restrict__ qkv, int64_t ld, int64_t rows, int C, float* __restrict__ amax) {
+    float m[3] = {0.f, 0.f, 0.f};
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave0; r < rows; r += nwave) {
+        const bf16_t* row = qkv + r * ld;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            float a = m[t];
+            for (int c = lane * 8; c < C; c += 64 * 8) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + t * C + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = fmaxf(a, fabsf((float)v[e]));
+            }
+            m[t] = a;
+        }
+    }
+    // one atomic per workgroup and third (atomics on one word serialise at ~90 per microsecond: per-wave atomics from a
+    // 2048-block grid took 300 us)
+    __shared__ float red[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const float w = wave_max(m[t]);
+        if (lane == 0) red[t][threadIdx.x >> 6] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float w = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
+        atomicMax(reinterpret_cast<unsigned int*>(amax + threadIdx.x), __float_as_uint(w));
+    }
+}
+
+__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+
+// ---- pre-pass 2a: Q and K -- quantise + re-layout, one thread = 16 output bytes (16 consecutive d of one token)
+__global__ __launch_bounds__(256) void f8_quant_qk_kernel(const bf16_t* __restrict__ qkv, int64_t ld, int B, int N, int H, int C,
+                                                          const float* __restrict__ amax, uint8_t* __restrict__ q8, uint8_t* __restrict__ k8,
+                                                          int Nq, int Nk) {
+    const float sq = F8_MAXV / fmaxf(amax[0], 1e-20f), sk = F8_MAXV / fmaxf(amax[1], 1e-20f);
+    const int64_t nq = (int64_t)B * H * Nq * 4, nk = (int64_t)B * H * Nk * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nq + nk; i += (int64_t)gridDim.x * 256) {
+        u32x4 out = {0u, 0u, 0u, 0u};
+        const bool isq = i < nq;
+        const int64_t j = isq ? i : i - nq;
+        const int Np = isq ? Nq : Nk;
+        const int c = (int)(j & 3);
+        const int n = (int)((j >> 2) % Np);
+        const int64_t bh = (j >> 2) / Np;
+        const int b = (int)(bh / H), h = (int)(bh % H);
+        if (n < N) {
+            const bf16_t* src = qkv + ((int64_t)b * N + n) * ld + (isq ? 0 : C) + h * 64 + c * 16;
+            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(src), v1 = *reinterpret_cast<const bf16x8*>(src + 8);
+            const float s = isq ? sq : sk;
+            out[0] = pack4_fp8((float)v0[0] * s, (float)v0[1] * s, (float)v0[2] * s, (float)v0[3] * s);
+            out[1] = pack4_fp8((float)v0[4] * s, (float)v0[5] * s, (float)v0[6] * s, (float)v0[7] * s);
+            out[2] = pack4_fp8((float)v1[0] * s, (float)v1[1] * s, (float)v1[2] * s, (float)v1[3] * s);
+            out[3] = pack4_fp8((float)v1[4] * s, (float)v1[5] * s, (float)v1[6] * s, (float)v1[7] * s);
+        }
+        if (isq) {
+            *reinterpret_cast<u32x4*>(q8 + (bh * Nq + n) * 64 + c * 16) = out;
+        } else {
+            const int kb = n >> 6, kr = n & 63;
+            const int cs = c ^ ((kr >> 2) & 3);                 // chunk swizzle: conflict-free ds_read_b128 by key rows
+            *reinterpret_cast<u32x4*>(k8 + ((bh * (Nk >> 6) + kb) * 64 + kr) * 64 + cs * 16) = out;
+        }
+    }
+}
+
+// ---- pre-pass 2b: V -- one workgroup per (b, h, 64-key block): coalesced 32-byte reads of [key][16 d], transposition and
+// key permutation through a 4 KiB LDS tile, coalesced 16-byte writes of [d][64 permuted keys]
+__global__ __launch_bounds__(256) void f8_quant_vt_kernel(const bf16_t* __restrict__ qkv, int64_t ld, int N, int H, int C,
+                                                          const float* __restrict__ amax, uint8_t* __restrict__ vt8, int Nk) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[64 * 64];       // [d][position]
+    const float sv = F8_MAXV / fmaxf(amax[2], 1e-20f);
+    const int kb = blockIdx.x, bh = blockIdx.y;
+    const int b = bh / H, h = bh % H;
+    const int tid = threadIdx.x;
+    {
+        const int kr = tid >> 2, c = tid & 3;                            // key row of the block, 16 d
+        const int key = kb * 64 + kr;
+        // position of this key in a Vt row: key = 32*t + crow(r, half) -> byte half*32 + 16*t + r
+        const int t = kr >> 5, w = kr & 31;
+        const int half = (w >> 2) & 1, r = (w & 3) + 4 * (w >> 3);
+        const int pos = half * 32 + 16 * t + r;
+        float f[16];
+        if (key < N) {
+            const bf16_t* src = qkv + ((int64_t)b * N + key) * ld + 2 * C + h * 64 + c * 16;
+            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(src), v1 = *reinterpret_cast<const bf16x8*>(src + 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[e] = (float)v0[e] * sv; f[8 + e] = (float)v1[e] * sv; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) f[e] = 0.f;
+        }
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+            const uint32_t pk = pack4_fp8(f[4 * w4], f[4 * w4 + 1], f[4 * w4 + 2], f[4 * w4 + 3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[(c * 16 + 4 * w4 + e) * 64 + pos] = (uint8_t)(pk >> (8 * e));
+        }
+    }
+    __syncthreads();
+    {
+        const int d = tid >> 2, c = tid & 3;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(tile + d * 64 + c * 16);
+        const int cs = c ^ ((d >> 2) & 3);
+        *reinterpret_cast<u32x4*>(vt8 + (((int64_t)bh * (Nk >> 6) + kb) * 64 + d) * 64 + cs * 16) = v;
+    }
+}
+
+// 32 operand bytes of LDS row `row` (64-byte rows, chunk-swizzled), half h
+__device__ __forceinline__ i32x8 f8_operand(const char* tile, int row, int h) {
+    const int sw = (row >> 2) & 3;
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(tile + row * 64 + (((2 * h) ^ sw) << 4));
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(tile + row * 64 + (((2 * h + 1) ^ sw) << 4));
+    i32x8 r;
+    r[0] = (int)lo[0]; r[1] = (int)lo[1]; r[2] = (int)lo[2]; r[3] = (int)lo[3];
+    r[4] = (int)hi[0]; r[5] = (int)hi[1]; r[6] = (int)hi[2]; r[7] = (int)hi[3];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_fp8_kernel(const uint8_t* __restrict__ q8, const uint8_t* __restrict__ k8,
+                                                           const uint8_t* __restrict__ vt8, const float* __restrict__ amax,
+                                                           bf16_t* __restrict__ out, int64_t ld_out, float* __restrict__ lse, int N, int H,
+                                                           int Nq, int Nk, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 8192];          // {K block, Vt block} x 2
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int qt = blockIdx.x, bh = blockIdx.y;
+    const int b = bh / H, head = bh % H;
+    const int nkb = Nk >> 6;
+    const int q = qt * F8_QT + wave * 32 + l31;                          // this lane's query (column of the score tiles)
+
+    // Q operand: 32 bytes of the lane's query row, half h -- resident for the whole kernel
+    i32x8 qop;
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(q8 + ((int64_t)bh * Nq + q) * 64 + h * 32);
+        const u32x4 lo = src[0], hi = src[1];
+        qop[0] = (int)lo[0]; qop[1] = (int)lo[1]; qop[2] = (int)lo[2]; qop[3] = (int)lo[3];
+        qop[4] = (int)hi[0]; qop[5] = (int)hi[1]; qop[6] = (int)hi[2]; qop[7] = (int)hi[3];
+    }
+    const float aq = fmaxf(amax[0], 1e-20f), ak = fmaxf(amax[1], 1e-20f), av = fmaxf(amax[2], 1e-20f);
+    // scores come out multiplied by (240/aq)(240/ak): fold the de-quantisation, the softmax scale and log2(e) together
+    const float c2 = scale * (aq / F8_MAXV) * (ak / F8_MAXV) * 1.4426950408889634f;
+
+    const uint8_t* kbase = k8 + (int64_t)bh * nkb * 4096;
+    const uint8_t* vbase = vt8 + (int64_t)bh * nkb * 4096;
+    auto issue = [&](int kb, int buf) {                                  // 4 KiB + 4 KiB, 16 bytes per lane
+        char* dst = smem + buf * 8192 + wave * 1024;
+        __builtin_amdgcn_global_load_lds((gbl_void8*)(kbase + (int64_t)kb * 4096 + wave * 1024 + lane * 16), (lds_void8*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void8*)(vbase + (int64_t)kb * 4096 + wave * 1024 + lane * 16), (lds_void8*)(dst + 4096), 16, 0, 0);
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+    float m = -1e30f, lsum = 0.f;
+    const int unit = 0x7f7f7f7f;                                         // E8M0 block scales = 2^0
+
+    issue(0, 0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                    // block kb landed; everyone is done with the other buffer
+        if (kb + 1 < nkb) issue(kb + 1, (kb + 1) & 1);
+        const char* kt = smem + (kb & 1) * 8192;
+        const char* vt = kt + 4096;
+        // scores, transposed: S^T[key][query] -- lane = query column, registers = 16 keys of each 32-key tile
+        f32x16 s0, s1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+        const i32x8 k0 = f8_operand(kt, l31, h), k1 = f8_operand(kt, 32 + l31, h);
+        s0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k0, qop, s0, 0, 0, 0, unit, 0, unit);
+        s1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k1, qop, s1, 0, 0, 0, unit, 0, unit);
+        const i32x8 v0 = f8_operand(vt, l31, h), v1 = f8_operand(vt, 32 + l31, h);
+        // online softmax in the log2 domain.  Raw scores carry the quantisation scales: x = s * c2 is the scaled score in
+        // log2 units; the running max is kept in those units, and p * 2^7 = exp2(fma(s, c2, 7 - m)) costs one FMA + one
+        // exponential per score.  Keys past N exist only in the last block (zero padding): masked there, nowhere else.
+        if (kb == nkb - 1 && (N & 63)) {
+            const int key0 = kb * 64;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (key0 + crow(r, h) >= N) s0[r] = -3.0e38f;
+                if (key0 + 32 + crow(r, h) >= N) s1[r] = -3.0e38f;
+            }
+        }
+        float mx = s0[0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;                     // the other half-wave holds the query's other 32 keys
+        if (__builtin_amdgcn_ballot_w64(mx > m) != 0) {                  // (wave-uniform) some query's maximum moved: rescale
+            const float mn = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            m = mn;
+            lsum *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+        }
+        const float off = 7.0f - m;                                      // 2^7 = F8_PSCALE
+        float ps = 0.f;
+        i32x8 pop;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            float p[4], pb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                p[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[4 * w + e], c2, off));
+                pb[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[4 * w + e], c2, off));
+                ps += p[e] + pb[e];
+            }
+            pop[w] = (int)pack4_fp8(p[0], p[1], p[2], p[3]);
+            pop[4 + w] = (int)pack4_fp8(pb[0], pb[1], pb[2], pb[3]);
+        }
+        lsum += ps;                                                      // (in units of 2^-7, like the stored probabilities)
+        // O^T[d][query] += V^T[d][keys] P^T[keys][query]
+        o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v0, pop, o0, 0, 0, 0, unit, 0, unit);
+        o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v1, pop, o1, 0, 0, 0, unit, 0, unit);
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    if (q < N) {
+        const float inv = (av / F8_MAXV) / ltot;                         // O and ltot both carry the 2^7 of the stored probabilities
+        bf16_t* orow = out + ((int64_t)b * N + q) * ld_out + head * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * h;                                  // crow(4g .. 4g+3, h) = d .. d+3
+            bf16x4 a, c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = (bf16_t)(o0[4 * g + e] * inv); c[e] = (bf16_t)(o1[4 * g + e] * inv); }
+            *reinterpret_cast<bf16x4*>(orow + d) = a;
+            *reinterpret_cast<bf16x4*>(orow + 32 + d) = c;
+        }
+        if (lse && h == 0) lse[(int64_t)bh * N + q] = (m - 7.0f + __builtin_amdgcn_logf(ltot)) * 0.6931471805599453f;
+    }
+}
+
+int f8_pad(int n, int to) { return (n + to - 1) / to * to; }
+
+}  // namespace
+
+extern "C" size_t me_attention_fp8_workspace(int B, int N, int H, int head_dim) {
+    if (B <= 0 || N <= 0 || H <= 0 || head_dim != 64) return 0;
+    const size_t Nq = (size_t)f8_pad(N, F8_QT), Nk = (size_t)f8_pad(N, 64);
+    return 256 + (size_t)B * H * 64 * (Nq + 2 * Nk);
+}
+
+extern "C" int me_attention_fwd_fp8(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int B, int N, int H,
+                                    int head_dim, float scale, void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(qkv && out && workspace && B > 0 && N > 0 && H > 0, "me_attention_fwd_fp8: bad args");
+    if (head_dim != 64) {
+        me_set_error("me_attention_fwd_fp8: head_dim %d (64 is implemented: one 32x32x64 MFMA per score tile)", head_dim);
+        return ME_ERR_UNSUPPORTED;
+    }
+    const int C = H * 64;
+    ME_CHECK_ARG(ld_qkv % 8 == 0 && ld_out % 4 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 8 == 0, "me_attention_fwd_fp8: alignment");
+    ME_CHECK_ARG(workspace_bytes >= me_attention_fp8_workspace(B, N, H, head_dim), "me_attention_fwd_fp8: workspace too small");
+    const int Nq = f8_pad(N, F8_QT), Nk = f8_pad(N, 64);
+    float* amax = reinterpret_cast<float*>(workspace);
+    uint8_t* q8 = reinterpret_cast<uint8_t*>(workspace) + 256;
+    uint8_t* k8 = q8 + (size_t)B * H * Nq * 64;
+    uint8_t* vt8 = k8 + (size_t)B * H * Nk * 64;
+    if (hipMemsetAsync(amax, 0, 16, stream) != hipSuccess) { me_set_error("me_attention_fwd_fp8: memset failed"); return ME_ERR_HIP; }
+    const bf16_t* x = reinterpret_cast<const bf16_t*>(qkv);
+    hipLaunchKernelGGL(f8_absmax_kernel, dim3(1024), dim3(256), 0, stream, x, ld_qkv, (int64_t)B * N, C, amax);
+    hipLaunchKernelGGL(f8_quant_qk_kernel, dim3(4096), dim3(256), 0, stream, x, ld_qkv, B, N, H, C, amax, q8, k8, Nq, Nk);
+    hipLaunchKernelGGL(f8_quant_vt_kernel, dim3((unsigned)(Nk / 64), (unsigned)(B * H)), dim3(256), 0, stream, x, ld_qkv, N, H, C, amax, vt8, Nk);
+    hipLaunchKernelGGL(attn_fwd_fp8_kernel, dim3((unsigned)(Nq / F8_QT), (unsigned)(B * H)), dim3(256), 0, stream, q8, k8, vt8, amax,
+                       reinterpret_cast<bf16_t*>(out), ld_out, lse, N, H, Nq, Nk, scale);
+    ME_CHECK_LAUNCH("me_attention_fwd_fp8");
+    return ME_OK;
+}

@@ -369,6 +369,222 @@ __global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p
     }
 }
 
+// ---- position-embedding table resize (cls/pos-embed glue).
+// Replaces TIMMVisionTransformer.resize_pos_embed (Image/detection/mmdet_custom/models/backbones/base/vit.py:459-486:
+// reshape the [h*w, C] table to [1, C, h, w], F.interpolate(size=(H, W), mode, align_corners=False), flatten back) on the
+// token-major layout directly: rows are grid positions, channels contiguous -- no permutes.  The sampling arithmetic is
+// ATen's upsample_bicubic2d / upsample_bilinear2d restated: source coordinate s = (in/out) * (d + 0.5) - 0.5 (bilinear
+// clamps it at 0, bicubic does not), cubic-convolution weights with A = -0.75, taps clamped to the table edge, fp32.
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__global__ __launch_bounds__(EW_THREADS) void resize_rows_kernel(const void* __restrict__ src, int src_dtype, void* __restrict__ dst,
+                                                                 int dst_dtype, int h, int w, int H, int W, int C, int mode) {
+    const int cq = C / 4;
+    const int64_t total = (int64_t)H * W * cq;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % cq) * 4;
+        const int ox = (int)((i / cq) % W), oy = (int)(i / ((int64_t)cq * W));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (mode == 1) {                 // bicubic
+            const float fy = sy * ((float)oy + 0.5f) - 0.5f, fx = sx * ((float)ox + 0.5f) - 0.5f;
+            const float fly = floorf(fy), flx = floorf(fx);
+            const int iy = (int)fly, ix = (int)flx;
+            const float ty = fy - fly, tx = fx - flx;
+            const float A = -0.75f;
+            const float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+            const float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                int yy = iy - 1 + a;
+                yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+                f32x4 row = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    int xx = ix - 1 + b;
+                    xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+                    row += wx[b] * load4_as_f32(src, src_dtype, ((int64_t)yy * w + xx) * C + c);
+                }
+                acc += wy[a] * row;
+            }
+        } else {                         // bilinear
+            float fy = sy * ((float)oy + 0.5f) - 0.5f, fx = sx * ((float)ox + 0.5f) - 0.5f;
+            fy = fy < 0.f ? 0.f : fy;
+            fx = fx < 0.f ? 0.f : fx;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 < h - 1 ? y0 + 1 : y0, x1 = x0 < w - 1 ? x0 + 1 : x0;
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            const f32x4 v00 = load4_as_f32(src, src_dtype, ((int64_t)y0 * w + x0) * C + c);
+            const f32x4 v01 = load4_as_f32(src, src_dtype, ((int64_t)y0 * w + x1) * C + c);
+            const f32x4 v10 = load4_as_f32(src, src_dtype, ((int64_t)y1 * w + x0) * C + c);
+            const f32x4 v11 = load4_as_f32(src, src_dtype, ((int64_t)y1 * w + x1) * C + c);
+            acc = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        }
+        store4_from_f32(dst, dst_dtype, ((int64_t)oy * W + ox) * C + c, acc);
+    }
+}
+
+// ---- token pooling in front of the task heads: [B, N, C] tokens -> [B, C] features.
+// Replaces x.mean(1) ahead of fc_norm (Video/models/modeling_finetune.py:445-454), x[:, 0] (cls token, same lines) and
+// the 'max' / 'avg' global features of the PointCloud ClsHead (openpoints/models/classification/cls_base.py:126-133).
+// One pass over the tokens, 4 channels per thread (coalesced along C), fp32 accumulation; max also records the arg-max
+// token per channel (first index on ties, as torch.max) for the backward.
+__global__ __launch_bounds__(EW_THREADS) void pool_tokens_kernel(const void* __restrict__ x, int x_dtype, float* __restrict__ out,
+                                                                 int32_t* __restrict__ arg, int B, int N, int C, int mode) {
+    const int cq = C / 4;
+    const int64_t total = (int64_t)B * cq;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % cq) * 4, b = (int)(i / cq);
+        const int64_t base = (int64_t)b * N * C + c;
+        f32x4 acc = load4_as_f32(x, x_dtype, base);
+        if (mode == ME_POOL_MEAN) {
+            for (int n = 1; n < N; ++n) acc += load4_as_f32(x, x_dtype, base + (int64_t)n * C);
+            acc *= 1.0f / (float)N;
+        } else if (mode == ME_POOL_MAX) {
+            int a[4] = {0, 0, 0, 0};
+            for (int n = 1; n < N; ++n) {
+                const f32x4 v = load4_as_f32(x, x_dtype, base + (int64_t)n * C);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > acc[e]) { acc[e] = v[e]; a[e] = n; }
+            }
+            if (arg) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) arg[(int64_t)b * C + c + e] = a[e];
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + (int64_t)b * C + c) = acc;
+    }
+}
+__global__ __launch_bounds__(EW_THREADS) void pool_tokens_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg,
+                                                                     void* __restrict__ dx, int dx_dtype, int B, int N, int C, int mode) {
+    const int cq = C / 4;
+    const int64_t total = (int64_t)B * N * cq;
+    const float inv = 1.0f / (float)N;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % cq) * 4;
+        const int n = (int)((i / cq) % N), b = (int)(i / ((int64_t)cq * N));
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (int64_t)b * C + c);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (mode == ME_POOL_MEAN) v = g * inv;
+        else if (mode == ME_POOL_MAX) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = arg[(int64_t)b * C + c + e] == n ? g[e] : 0.f;
+        } else if (n == 0) v = g;
+        store4_from_f32(dx, dx_dtype, ((int64_t)b * N + n) * C + c, v);
+    }
+}
+
+// ---- point-cloud tokenizer front end: farthest point sampling, k nearest neighbours, neighbourhood gather.
+// Replaces, for PointPatchEmbed (PointCloud/openpoints/models/layers/group_embed.py:138-172):
+//   furthest_point_sample  -> furthest_point_sampling_kernel (openpoints/cpp/pointnet2_batch/src/sampling_gpu.cu:101-210)
+//   KNNGroup / KNN         -> torch.cdist + topk(largest=False) (openpoints/models/layers/group.py:12-28, 297-320)
+//   grouping_operation + "relative_xyz"  (group.py:310-313)
+// Index arithmetic is integer; the sampled / neighbour INDICES are what the parity tests compare bit-exactly.
+//
+// FPS restates the reference kernel's selection rule exactly, ties included: start at point 0; every round each of T
+// threads walks its points k = t, t+T, ... keeping the FIRST strict maximum of min(d, temp[k]); the per-thread winners
+// are folded by the same binary tree (partner t + s for s = T/2 .. 1, the higher-indexed side wins only when strictly
+// larger).  T = the largest power of two <= n, capped at 1024, as opt_n_threads() picks it.  The distance is evaluated as
+// fma(dz, dz, fma(dy, dy, dx*dx)) -- nvcc's default contraction of the reference's expression.
+template <int T>
+__global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ pts, float* __restrict__ temp, int32_t* __restrict__ idxs, int n, int m) {
+    __shared__ float dists[T];
+    __shared__ int dists_i[T];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    pts += (int64_t)b * n * 3;
+    temp += (int64_t)b * n;
+    idxs += (int64_t)b * m;
+    for (int k = tid; k < n; k += T) temp[k] = 1e10f;
+    int old = 0;
+    if (tid == 0) idxs[0] = 0;
+    __syncthreads();
+    for (int j = 1; j < m; ++j) {
+        int besti = 0;
+        float best = -1.f;
+        const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+        for (int k = tid; k < n; k += T) {
+            const float dx = pts[k * 3 + 0] - x1, dy = pts[k * 3 + 1] - y1, dz = pts[k * 3 + 2] - z1;
+            const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const float d2 = fminf(d, temp[k]);
+            temp[k] = d2;
+            besti = d2 > best ? k : besti;
+            best = d2 > best ? d2 : best;
+        }
+        dists[tid] = best;
+        dists_i[tid] = besti;
+        __syncthreads();
+#pragma unroll
+        for (int s = T / 2; s >= 1; s >>= 1) {
+            if (tid < s) {
+                const float v1 = dists[tid], v2 = dists[tid + s];
+                const int i1 = dists_i[tid], i2 = dists_i[tid + s];
+                dists[tid] = fmaxf(v1, v2);
+                dists_i[tid] = v2 > v1 ? i2 : i1;
+            }
+            __syncthreads();
+        }
+        old = dists_i[0];
+        if (tid == 0) idxs[j] = old;
+        __syncthreads();
+    }
+}
+
+// k nearest support points of every query, ascending by squared distance, ties by lower index: one wave per query.
+// Each lane scans its strided share keeping a sorted private top-k list is too register-hungry for k = 32; instead the
+// wave selects the k winners one at a time (k rounds of a wave-wide arg-min over the distances held in LDS).
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ support, const float* __restrict__ query,
+                                                  int32_t* __restrict__ idx, int n, int m, int k) {
+    extern __shared__ __attribute__((aligned(16))) char knn_smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* dist = reinterpret_cast<float*>(knn_smem) + (int64_t)wave * n;      // this wave's [n] distances
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= m) return;                                                         // (whole wave)
+    support += (int64_t)b * n * 3;
+    const float qx = query[((int64_t)b * m + q) * 3 + 0], qy = query[((int64_t)b * m + q) * 3 + 1], qz = query[((int64_t)b * m + q) * 3 + 2];
+    for (int i = lane; i < n; i += 64) {
+        const float dx = support[i * 3 + 0] - qx, dy = support[i * 3 + 1] - qy, dz = support[i * 3 + 2] - qz;
+        dist[i] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    }
+    __builtin_amdgcn_wave_barrier();
+    int32_t* out = idx + ((int64_t)b * m + q) * k;
+    for (int r = 0; r < k; ++r) {
+        float best = 3.0e38f;
+        int besti = 0x7fffffff;
+        for (int i = lane; i < n; i += 64) {
+            const float d = dist[i];
+            if (d < best) { best = d; besti = i; }                              // first (lowest index) of equal values per lane
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(besti, o, 64);
+            if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (lane == 0) { out[r] = besti; dist[besti] = 3.0e38f; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// rows[(b, s, j), 0..2] = pts[b, idx[b, s, j]] - centers[b, s] (relative_xyz), columns 3 .. cols-1 zero: the first MLP layer's
+// GEMM operand (reduction dimension padded to the GEMM's 16-byte granule).
+__global__ __launch_bounds__(EW_THREADS) void group_rel_kernel(const float* __restrict__ pts, const float* __restrict__ centers,
+                                                               const int32_t* __restrict__ idx, float* __restrict__ rows, int B, int n,
+                                                               int m, int k, int cols) {
+    const int64_t total = (int64_t)B * m * k;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t bs = i / k;
+        const int b = (int)(bs / m);
+        const int id = idx[i];
+        const float* p = pts + ((int64_t)b * n + id) * 3;
+        const float* c = centers + bs * 3;
+        float* r = rows + i * cols;
+        r[0] = p[0] - c[0]; r[1] = p[1] - c[1]; r[2] = p[2] - c[2];
+        for (int j = 3; j < cols; ++j) r[j] = 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" int me_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream_) {
@@ -422,6 +638,79 @@ extern "C" int me_add_rows(const void* x, int x_dtype, const void* pos, int pos_
     hipLaunchKernelGGL(add_rows_kernel, dim3(ew_blocks(rows * (cols / 4))), dim3(EW_THREADS), 0, stream, x, x_dtype, pos,
                        pos_dtype, y, y_dtype, rows, pos_rows, cols);
     ME_CHECK_LAUNCH("me_add_rows");
+    return ME_OK;
+}
+
+extern "C" int me_resize_rows(const void* src, int src_dtype, void* dst, int dst_dtype, int h, int w, int H, int W, int cols,
+                              int mode, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(src && dst && h > 0 && w > 0 && H > 0 && W > 0 && cols > 0 && cols % 4 == 0, "me_resize_rows: bad args");
+    ME_CHECK_ARG(me_dtype_ok(src_dtype) && me_dtype_ok(dst_dtype), "me_resize_rows: bad dtype");
+    ME_CHECK_ARG(mode == ME_RESIZE_BILINEAR || mode == ME_RESIZE_BICUBIC, "me_resize_rows: mode %d (bilinear / bicubic only)", mode);
+    hipLaunchKernelGGL(resize_rows_kernel, dim3(ew_blocks((int64_t)H * W * (cols / 4))), dim3(EW_THREADS), 0, stream, src,
+                       src_dtype, dst, dst_dtype, h, w, H, W, cols, mode);
+    ME_CHECK_LAUNCH("me_resize_rows");
+    return ME_OK;
+}
+
+extern "C" int me_pool_tokens(const void* x, int x_dtype, float* out, int32_t* argmax, int B, int N, int C, int mode, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(x && out && B > 0 && N > 0 && C > 0 && C % 4 == 0, "me_pool_tokens: bad args");
+    ME_CHECK_ARG(me_dtype_ok(x_dtype), "me_pool_tokens: bad dtype");
+    ME_CHECK_ARG(mode == ME_POOL_MEAN || mode == ME_POOL_MAX || mode == ME_POOL_FIRST, "me_pool_tokens: bad mode %d", mode);
+    hipLaunchKernelGGL(pool_tokens_kernel, dim3(ew_blocks((int64_t)B * (C / 4))), dim3(EW_THREADS), 0, stream, x, x_dtype, out,
+                       argmax, B, N, C, mode);
+    ME_CHECK_LAUNCH("me_pool_tokens");
+    return ME_OK;
+}
+
+extern "C" int me_pool_tokens_bwd(const float* dy, const int32_t* argmax, void* dx, int dx_dtype, int B, int N, int C, int mode,
+                                  void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(dy && dx && B > 0 && N > 0 && C > 0 && C % 4 == 0, "me_pool_tokens_bwd: bad args");
+    ME_CHECK_ARG(me_dtype_ok(dx_dtype), "me_pool_tokens_bwd: bad dtype");
+    ME_CHECK_ARG(mode == ME_POOL_MEAN || mode == ME_POOL_FIRST || (mode == ME_POOL_MAX && argmax),
+                 "me_pool_tokens_bwd: bad mode %d (max needs the forward's argmax)", mode);
+    hipLaunchKernelGGL(pool_tokens_bwd_kernel, dim3(ew_blocks((int64_t)B * N * (C / 4))), dim3(EW_THREADS), 0, stream, dy, argmax, dx,
+                       dx_dtype, B, N, C, mode);
+    ME_CHECK_LAUNCH("me_pool_tokens_bwd");
+    return ME_OK;
+}
+
+extern "C" int me_fps(const float* points, int32_t* idx, float* temp, int B, int n, int m, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(points && idx && temp && B > 0 && n > 0 && m > 0 && m <= n, "me_fps: bad args (B=%d n=%d m=%d)", B, n, m);
+    int T = 1;
+    while (T * 2 <= n && T < 1024) T *= 2;          // opt_n_threads(n) of the reference launcher
+#define ME_FPS_CASE(TT) case TT: hipLaunchKernelGGL(fps_kernel<TT>, dim3((unsigned)B), dim3(TT), 0, stream, points, temp, idx, n, m); break;
+    switch (T) {
+        ME_FPS_CASE(1024) ME_FPS_CASE(512) ME_FPS_CASE(256) ME_FPS_CASE(128) ME_FPS_CASE(64) ME_FPS_CASE(32) ME_FPS_CASE(16)
+        ME_FPS_CASE(8) ME_FPS_CASE(4) ME_FPS_CASE(2) default: ME_FPS_CASE(1)
+    }
+#undef ME_FPS_CASE
+    ME_CHECK_LAUNCH("me_fps");
+    return ME_OK;
+}
+
+extern "C" int me_knn(const float* support, const float* query, int32_t* idx, int B, int n, int m, int k, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(support && query && idx && B > 0 && n > 0 && m > 0 && k > 0 && k <= n, "me_knn: bad args");
+    const size_t lds = (size_t)4 * n * sizeof(float);
+    ME_CHECK_ARG(lds <= 160 * 1024, "me_knn: %d support points exceed the LDS-resident form (max 10240)", n);
+    static OncePerDevice once;
+    if (once.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(knn_kernel, dim3((unsigned)((m + 3) / 4), (unsigned)B), dim3(256), lds, stream, support, query, idx, n, m, k);
+    ME_CHECK_LAUNCH("me_knn");
+    return ME_OK;
+}
+
+extern "C" int me_group_relative(const float* points, const float* centers, const int32_t* idx, float* rows, int B, int n, int m,
+                                 int k, int cols, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(points && centers && idx && rows && B > 0 && n > 0 && m > 0 && k > 0 && cols >= 3, "me_group_relative: bad args");
+    hipLaunchKernelGGL(group_rel_kernel, dim3(ew_blocks((int64_t)B * m * k)), dim3(EW_THREADS), 0, stream, points, centers, idx,
+                       rows, B, n, m, k, cols);
+    ME_CHECK_LAUNCH("me_group_relative");
     return ME_OK;
 }
 

@@ -325,10 +325,34 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         else pl.bn = d->N > 128 ? 256 : 128;                     // measured: g2b_256 beats g2b_128 on every encoder shape
         pl.ksteps_per_split = nk;
         if (fam == 4) {
+            // Tile quantisation (see gemm3.hip): when the last round is mostly empty its tiles run as `tail_split` parts each
+            // inside the same launch (fp32 slabs + the deterministic fold, which also applies the epilogue).  Gated to narrow
+            // outputs with a long reduction (N <= 1024, K >= 2048: fc2, the qkv / fc1 dgrads -- measured +2..6 %); at
+            // K = 768 the fold's extra pass costs more than the idle third round (-15 %), and at N = 3072 one sparse round
+            // in ten is cheap.
+            const int64_t tn_ = (d->N + 255) / 256, tiles4 = tm * tn_;
+            const int SL = 256;
+            const int64_t R4 = tiles4 / SL, rem4 = tiles4 - R4 * SL;
+            const int nkt = (int)(d->K / 64);
+            if (d->N <= 1024 && d->K >= 2048 && dev.tail_split && R4 >= 1 && rem4 * 20 >= SL && rem4 * 10 <= SL * 6 && d->res_row_mod == 0 &&
+                d->out_group_rows == 0) {
+                const int64_t m_main = (R4 * SL) / tn_;
+                const int64_t tail_tiles = (tm - m_main) * tn_;
+                int s = (int)(SL / tail_tiles);
+                int ktp = (nkt + s - 1) / s;
+                ktp += ktp & 1;                                   // whole K-tile pairs
+                if (s >= 2 && m_main >= 1 && ktp >= 2) {
+                    pl.tail_rows = d->M - m_main * 256;
+                    pl.tail_ksteps = ktp;
+                    pl.tail_split = (nkt + ktp - 1) / ktp;
+                    if (pl.tail_split >= 2) pl.ws_bytes = (size_t)pl.tail_split * (size_t)pl.tail_rows * (size_t)d->N * sizeof(float);
+                    else pl.tail_rows = 0;
+                }
+            }
 #ifdef ME_DEV
             // dev build: the persistent stream-K form (its scratch = one fp32 tile per CU)
             const int64_t tiles = tm * ((d->N + 255) / 256);
-            if (tiles >= 128 && dev.g3_persistent) pl.ws_bytes = g3_workspace_bytes();
+            if (tiles >= 128 && dev.g3_persistent) { pl.ws_bytes = g3_workspace_bytes(); pl.tail_rows = 0; }
 #endif
             return pl;
         }
@@ -404,6 +428,7 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     p.out_group_stride = d->out_group_stride; p.out_row_offset = d->out_row_offset;
     p.split_k = 1; p.ksteps_per_split = 0;
     p.colsum_ws = nullptr;
+    p.g3_full_tiles = 0; p.g3_split = 0; p.g3_ktp = 0; p.g3_slabs = nullptr;
     if (d->colsum_a) ME_CHECK_ARG(d->op == ME_GEMM_TN, "me_gemm: colsum_a is defined for ME_GEMM_TN only");
     p.debug = gemm_dev().debug;
     p.tiles_m = (int)((d->M + BM - 1) / BM);
@@ -451,7 +476,37 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
             p.tiles_m = (int)((d->M + 255) / 256);
             p.tiles_n = (int)((d->N + 255) / 256);
             p.split_k = 1;
-            void* ws = (pl.ws_bytes && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes) ? d->workspace : nullptr;
+            const bool have_ws = pl.ws_bytes && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes;
+            p.g3_full_tiles = p.tiles_m * p.tiles_n; p.g3_split = 1; p.g3_ktp = 0; p.g3_slabs = nullptr;
+            if (pl.tail_rows > 0 && have_ws) {
+                const int64_t m1 = d->M - pl.tail_rows;          // rows covered by whole tiles (a multiple of 256)
+                p.g3_full_tiles = (int)(m1 / 256) * p.tiles_n;
+                p.g3_split = pl.tail_split;
+                p.g3_ktp = pl.tail_ksteps;
+                p.g3_slabs = reinterpret_cast<float*>(d->workspace);
+                rc = launch_g3(p, pick_epi(p), nullptr, stream);
+                if (rc) return rc;
+                GemmParams pt = p;                               // the fold sees the tail rows as its own problem
+                pt.M = pl.tail_rows;
+                pt.split_k = 1;
+                pt.A = nullptr;
+                pt.C = reinterpret_cast<char*>(p.C) + (size_t)m1 * p.ldc * me_dtype_size(p.c_dtype);
+                if (p.preact) pt.preact = reinterpret_cast<char*>(p.preact) + (size_t)m1 * p.ldpre * me_dtype_size(p.preact_dtype);
+                if (p.aux) pt.aux = reinterpret_cast<const char*>(p.aux) + (size_t)m1 * p.ldaux * me_dtype_size(p.aux_dtype);
+                if (p.residual) pt.residual = reinterpret_cast<const char*>(p.residual) + (size_t)m1 * p.ldres * me_dtype_size(p.res_dtype);
+                const int64_t quads = pt.M * (d->N / 4);
+                int64_t nb = (quads + 255) / 256;
+                if (nb > 2048) nb = 2048;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, pt,
+                                   reinterpret_cast<const float*>(d->workspace), pl.tail_split, nullptr, 0, nullptr);
+                ME_CHECK_LAUNCH("me_gemm(g3 tail fold)");
+                return ME_OK;
+            }
+#ifdef ME_DEV
+            void* ws = (pl.tail_rows == 0 && have_ws) ? d->workspace : nullptr;
+#else
+            void* ws = nullptr;
+#endif
             return launch_g3(p, pick_epi(p), ws, stream);
         }
         auto run = [&](const GemmParams& q) { return launch_g2b(q, d->op, pl.bm, pl.bn, stream); };

@@ -197,8 +197,10 @@ __device__ __forceinline__ void g3_zero(G3State& s) {
 // buffers in LDS are not touched, so the DMA stream of the next tile keeps running under the epilogue.
 // EPI: 0 bias, 1 + GELU (+ pre-activation save), 2 + residual row operand, 3 * gelu'(aux row operand), 4 generic
 // (epilogue_oct: colscale, beta, row remaps, fp32 row operands ...)
+// EPI 5: raw fp32 partial sums into a split-K slab (row-major [rows][N], first row = slab_row0)
 template <int EPI>
-__device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int64_t m0, int64_t n0, int lane) {
+__device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int64_t m0, int64_t n0, int lane,
+                                            float* slab = nullptr, int64_t slab_row0 = 0) {
     // everything lane-dependent below is derived HERE: an address hoisted out of the persistent loop would sit in
     // registers across the K-loops (which have none to spare) and come back from scratch
     asm volatile("" : "+v"(lane));
@@ -214,7 +216,7 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
         n_ok[q] = n[q] + 8 <= p.N;
         const int64_t nc = n_ok[q] ? n[q] : 0;
         bias[q][0] = bias[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EPI != 4 && p.bias) {
+        if (EPI != 4 && EPI != 5 && p.bias) {
             bias[q][0] = *reinterpret_cast<const f32x4*>(p.bias + nc);
             bias[q][1] = *reinterpret_cast<const f32x4*>(p.bias + nc + 4);
         }
@@ -266,6 +268,14 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
                 v1[e] = __uint_as_float(sw[1]);
             }
             const bool ok = m < p.M && n_ok[q];
+            if (EPI == 5) {
+                if (ok) {
+                    float* d = slab + (m - slab_row0) * p.N + n[q];
+                    *reinterpret_cast<f32x4*>(d) = v0;
+                    *reinterpret_cast<f32x4*>(d + 4) = v1;
+                }
+                continue;
+            }
             if (EPI == 4) {
                 if (ok) epilogue_oct(p, m, n[q], v0, v1);
                 continue;
@@ -509,38 +519,56 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2;
 
+    // Work ids: F = p.g3_full_tiles whole tiles, then the tiles of the last, mostly empty round as S = p.g3_split parts
+    // each (tile quantisation: the encoder's N = 768 outputs are 591 tiles = 2.31 rounds on 256 CUs; as whole tiles that is
+    // 3 rounds of time, as 510 tiles + 81 x 3 thirds it is 2.31).  Block b runs on XCD b % 8: every XCD gets a contiguous
+    // range of the whole tiles (neighbours share operand panels through its L2) AND its share of the parts, so all XCDs
+    // carry the same amount of work.
     const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tm = wgid / p.tiles_n, tn = wgid % p.tiles_n;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int F = p.g3_full_tiles;
+    const int nf = (F >> 3) + (xcd < (F & 7) ? 1 : 0);
+    const int base_f = xcd * (F >> 3) + (xcd < (F & 7) ? xcd : (F & 7));
+    int tile, part = -1;
+    if (slot < nf) {
+        tile = base_f + slot;
+    } else {
+        const int base_all = xcd * (nwg >> 3) + (xcd < (nwg & 7) ? xcd : (nwg & 7));
+        const int tid_ = base_all - base_f + (slot - nf);                 // index among the parts
+        const int tq = __builtin_amdgcn_readfirstlane(tid_ / p.g3_split);
+        tile = F + tq;
+        part = tid_ - tq * p.g3_split;
+    }
+    const int tm = __builtin_amdgcn_readfirstlane(tile / p.tiles_n), tn = tile - tm * p.tiles_n;
     const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
 
-#ifdef ME_DEV
-    if ((p.debug & 16) && bid < 256) {           // dev experiment: first-round start stagger per M-tile group
-        const int steps = (tm & 7) * (p.debug >> 8);
-        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);      // 16 * 64 cycles ~ 0.5 us each
-    }
-#endif
     G3State s;
     g3_init_lane(s, p, smem, wave, lane);
     g3_zero(s);
     const G3Src src = g3_make_src(p, tm, tn);
 
     const int nkt = (int)(p.K / G3_BK);          // even, >= 2 (g3_supported)
-    g3_issue<0>(s, src, 0, 0); g3_issue<1>(s, src, 0, 0); g3_issue<2>(s, src, 0, 0); g3_issue<3>(s, src, 0, 0);
-    g3_issue<0>(s, src, 1, 128); g3_issue<1>(s, src, 1, 128); g3_issue<2>(s, src, 1, 128);
+    int kt0 = 0, kt1 = nkt;
+    if (part >= 0) {
+        kt0 = part * p.g3_ktp;
+        kt1 = kt0 + p.g3_ktp < nkt ? kt0 + p.g3_ktp : nkt;
+    }
+    {
+        const int k = kt0 * 128;
+        g3_issue<0>(s, src, 0, k); g3_issue<1>(s, src, 0, k); g3_issue<2>(s, src, 0, k); g3_issue<3>(s, src, 0, k);
+        g3_issue<0>(s, src, 1, k + 128); g3_issue<1>(s, src, 1, k + 128); g3_issue<2>(s, src, 1, k + 128);
+    }
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
 
-    // K-tiles past the end read as zeros through the descriptor's bounds check (offset >= K * 2 in every row -- the last
-    // row is the one that matters: num_records ends with it)
+    // past the end of the K-range the source is a null descriptor (see g3_phase)
     const G3Src null = g3_null_src(p);
-    for (int kt = 0; kt < nkt - 2; kt += 2) {
+    for (int kt = kt0; kt < kt1 - 2; kt += 2) {
         g3_ktile<0>(s, src, (kt + 1) * 128, src, (kt + 2) * 128);
         g3_ktile<1>(s, src, (kt + 2) * 128, src, (kt + 3) * 128);
     }
-    g3_ktile<0>(s, src, (nkt - 1) * 128, null, 0);
+    g3_ktile<0>(s, src, (kt1 - 1) * 128, null, 0);
     g3_ktile<1>(s, null, 0, null, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wr == 0) __builtin_amdgcn_s_barrier();
@@ -555,6 +583,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
 #endif
+    if (part >= 0) {
+        // a part of a split tile: raw partial sums; the fold that follows the launch applies the real epilogue
+        const int64_t row0 = (int64_t)(F / p.tiles_n) * G3_BM;
+        g3_epilogue<5>(p, s, m0, n0, lane, p.g3_slabs + (int64_t)part * (p.M - row0) * p.N, row0);
+        return;
+    }
     g3_epilogue<EPI>(p, s, m0, n0, lane);
 }
 
@@ -604,7 +638,10 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
     }
 #endif
     (void)ws;
-    hipLaunchKernelGGL((gemm_g3_kernel<EPI>), dim3((unsigned)tiles), dim3(512), G3_LDS, stream, p);
+    GemmParams q = p;
+    if (q.g3_split <= 1 || q.g3_slabs == nullptr) { q.g3_full_tiles = tiles; q.g3_split = 1; q.g3_ktp = 0; q.g3_slabs = nullptr; }
+    const int nwg = q.g3_full_tiles + (tiles - q.g3_full_tiles) * q.g3_split;
+    hipLaunchKernelGGL((gemm_g3_kernel<EPI>), dim3((unsigned)nwg), dim3(512), G3_LDS, stream, q);
     ME_CHECK_LAUNCH("me_gemm(g3)");
     return ME_OK;
 }

@@ -16,6 +16,10 @@ struct GemmParams {
     int debug;                              // dev builds only (GemmDev::debug, 0 in the shipped library): 1 = skip the epilogue
     int split_k, ksteps_per_split;          // split-K (wgrad): grid.y = split_k, slab z written to C + z*M*ldc
     float* colsum_ws;                       // TN only: partial column sums of A, [split_k * tiles_n][M] (null = off)
+    // g3 tail split (gemm3.hip): tiles [g3_full_tiles, tiles) run as g3_split workgroups each, g3_ktp K-tiles (of 64) per
+    // part, raw fp32 partial sums into g3_slabs [g3_split][rows past the full tiles][N]; 0 = every tile is a full tile
+    int g3_full_tiles, g3_split, g3_ktp;
+    float* g3_slabs;
 };
 
 

@@ -182,7 +182,8 @@ class _BlockFn(torch.autograd.Function):
         need_grad = grad_mode and any(ctx.needs_input_grad)
         x2 = x.reshape(M, C)
         ctx.fast = False
-        if stoch is None and win is None and blk.c_side and not (need_grad and g1 is not None):
+        fp8 = bool(getattr(blk, "attn_fp8", False)) and win is None and cdt == torch.bfloat16 and hd == 64 and stoch is None
+        if stoch is None and win is None and blk.c_side and not fp8 and not (need_grad and g1 is not None):
             # plain path: the whole block is ONE library call (me_block_fwd), the launch sequence lives on the C side
             d, keep = _BlockFn._desc(blk, cache, cdt, rdt, B, N, C, H, (n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb,
                                                                         fc1w, fc1b, fc2w, fc2b, g1, g2), False)
@@ -197,7 +198,7 @@ class _BlockFn(torch.autograd.Function):
         qkv = ops.gemm(xn1, cache.fwd("qkv", qkvw, cdt), bias=qkvb)
         p_attn = stoch[3] if stoch is not None else 0.0      # training-mode attn_drop (attention.py:33)
         if win is None:
-            o, lse = ops.attention_fwd(qkv, B, N, H, hd, blk.attn.scale, need_lse=need_grad, p_drop=p_attn,
+            o, lse = ops.attention_fwd(qkv, B, N, H, hd, blk.attn.scale, need_lse=need_grad, p_drop=p_attn, fp8=fp8,
                                        seed=stoch[2] + 4 if stoch is not None else 0)
             o_att = o
         else:
@@ -442,6 +443,7 @@ class Block(nn.Module):
             self.gamma2 = nn.Parameter(torch.ones(dim))
         self.compute_dtype: Optional[torch.dtype] = None     # override; None = infer (autocast / param dtype)
         self.c_side = True          # plain blocks run as one me_block_fwd / me_block_bwd call; False = op-by-op composition
+        self.attn_fp8 = False       # True: e4m3 attention forward (me_attention_fwd_fp8; bf16 compute, head_dim 64) -- config 5
         self._wcache = _WeightCache()
 
     def _compute_dtype(self, x: torch.Tensor) -> torch.dtype:
@@ -486,6 +488,59 @@ class Block(nn.Module):
         return _BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
                               a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
                               m.fc2.weight, m.fc2.bias, g1, g2, self, cdt, stoch, torch.is_grad_enabled(), win)
+
+
+def resize_pos_embed(pos_embed: torch.Tensor, input_shape, pos_shape, mode: str = "bicubic") -> torch.Tensor:
+    """TIMMVisionTransformer.resize_pos_embed (Image/detection/mmdet_custom/models/backbones/base/vit.py:459-486), same
+    signature: pos_embed [1, L, C] whose LAST pos_h * pos_w rows are the grid table and whose row 0 is the cls entry ->
+    [1, 1 + H * W, C] with the grid resampled (align_corners=False) on the GPU."""
+    if pos_embed.dim() != 3 or pos_embed.shape[0] != 1:
+        raise MetaEncError("shape of pos_embed must be [1, L, C]")
+    if not pos_embed.is_cuda:
+        raise MetaEncError("resize_pos_embed runs on MI355X only (no CPU fallback)")
+    ph, pw = pos_shape
+    grid = pos_embed[0, -ph * pw:].contiguous()
+    new = ops.resize_rows(grid, (ph, pw), tuple(input_shape), mode)
+    return torch.cat([pos_embed[:, :1], new.unsqueeze(0)], dim=1)
+
+
+def convert_video_state_dict(sd) -> "dict":
+    """Key set of the Video pipeline's blocks (Video/models/modeling_finetune.py) -> this package's Block keys:
+        attn.q_bias, attn.v_bias (:160-166; K has no bias, :172-178)  ->  attn.qkv.bias = cat(q_bias, 0, v_bias)
+        gamma_1, gamma_2 (:245-259)                                   ->  gamma1, gamma2   (Block(layer_scale=True))
+    Works on one block's dict or on a whole `blocks.{i}.`-prefixed checkpoint; other keys pass through.  The zero K third
+    stays without effect in training too: a bias on K shifts every score of a softmax row by the same amount."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("attn.v_bias"):
+            continue
+        if k.endswith("attn.q_bias"):
+            vb = sd[k[:-len("q_bias")] + "v_bias"]
+            out[k[:-len("q_bias")] + "qkv.bias"] = torch.cat([v, torch.zeros_like(vb), vb])
+        elif k.endswith("gamma_1"):
+            out[k[:-len("gamma_1")] + "gamma1"] = v
+        elif k.endswith("gamma_2"):
+            out[k[:-len("gamma_2")] + "gamma2"] = v
+        else:
+            out[k] = v
+    return out
+
+
+def to_video_state_dict(sd) -> "dict":
+    """Inverse of convert_video_state_dict (also maps gradients keyed like a state dict)."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("attn.qkv.bias"):
+            C = v.shape[0] // 3
+            out[k[:-len("qkv.bias")] + "q_bias"] = v[:C].clone()
+            out[k[:-len("qkv.bias")] + "v_bias"] = v[2 * C:].clone()
+        elif k.endswith("gamma1"):
+            out[k[:-1] + "_1"] = v
+        elif k.endswith("gamma2"):
+            out[k[:-1] + "_2"] = v
+        else:
+            out[k] = v
+    return out
 
 
 def build_encoder(depth: int = 12, dim: int = 768, num_heads: int = 12, mlp_ratio: float = 4., qkv_bias: bool = True,

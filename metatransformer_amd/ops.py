@@ -234,14 +234,30 @@ def block_bwd(d, x2: torch.Tensor, dy2: torch.Tensor, saved: torch.Tensor, grads
 
 # ----------------------------------------------------------------------------- attention
 
+_FP8_WS = {}        # (device, bytes) -> scratch for the quantised Q / K / V^T of the fp8 attention forward
+
+
 def attention_fwd(qkv: torch.Tensor, B: int, N: int, H: int, hd: int, scale: float, need_lse: bool,
-                  p_drop: float = 0.0, seed: int = 0):
-    """p_drop > 0: dropout on the attention probabilities (training-mode attn_drop); same p_drop / seed in attention_bwd"""
+                  p_drop: float = 0.0, seed: int = 0, fp8: bool = False):
+    """p_drop > 0: dropout on the attention probabilities (training-mode attn_drop); same p_drop / seed in attention_bwd.
+    fp8: e4m3 Q / K / V / P on the block-scaled MFMA (me_attention_fwd_fp8: bf16 qkv, head_dim 64, no dropout)."""
     lib = _capi.load()
     _req(qkv, "qkv")
     C = H * hd
     out = torch.empty((B * N, C), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if need_lse else None
+    if fp8:
+        if qkv.dtype != torch.bfloat16 or hd != 64 or p_drop > 0:
+            raise MetaEncError("fp8 attention: bf16 qkv, head_dim 64 and no attention dropout are required")
+        nbytes = lib.me_attention_fp8_workspace(B, N, H, hd)
+        key = (qkv.device, nbytes)
+        ws = _FP8_WS.get(key)
+        if ws is None:
+            _FP8_WS.clear()
+            ws = _FP8_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+        check(lib.me_attention_fwd_fp8(ptr(qkv), 3 * C, ptr(out), C, ptr(lse), B, N, H, hd, float(scale), ptr(ws), nbytes,
+                                       stream_ptr()), "me_attention_fwd_fp8")
+        return out, lse
     check(lib.me_attention_fwd(ptr(qkv), 3 * C, ptr(out), C, ptr(lse), B, N, H, hd, float(scale),
                                dtype_code(qkv.dtype), float(p_drop), seed & 0xFFFFFFFFFFFFFFFF, stream_ptr()), "me_attention_fwd")
     return out, lse
@@ -314,6 +330,23 @@ def add_rows(x: torch.Tensor, pos: torch.Tensor, out_dtype: Optional[torch.dtype
     check(lib.me_add_rows(ptr(x), dtype_code(x.dtype), ptr(pos), dtype_code(pos.dtype), ptr(y), dtype_code(y.dtype),
                           rows, pos_rows, C, stream_ptr()), "me_add_rows")
     return y
+
+
+def resize_rows(table: torch.Tensor, hw, HW, mode: str = "bicubic") -> torch.Tensor:
+    """[h*w, C] grid table -> [H*W, C], F.interpolate(mode, align_corners=False) semantics (me_resize_rows)."""
+    lib = _capi.load()
+    _req(table, "table")
+    (h, w), (H, W) = hw, HW
+    C = table.shape[-1]
+    if table.numel() != h * w * C:
+        raise MetaEncError(f"resize_rows: table has {table.numel() // C} rows, expected {h}x{w}")
+    if mode not in ("bicubic", "bilinear"):
+        raise MetaEncError(f"resize_rows: mode {mode!r} (bicubic / bilinear are implemented)")
+    out = torch.empty((H * W, C), dtype=table.dtype, device=table.device)
+    check(lib.me_resize_rows(ptr(table), dtype_code(table.dtype), ptr(out), dtype_code(out.dtype), h, w, H, W, C,
+                             _capi.ME_RESIZE_BICUBIC if mode == "bicubic" else _capi.ME_RESIZE_BILINEAR, stream_ptr()),
+          "me_resize_rows")
+    return out
 
 
 def dropout_add(v: torch.Tensor, res: Optional[torch.Tensor], rows_per_sample: int, p_drop: float, p_path: float,

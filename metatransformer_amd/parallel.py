@@ -1,5 +1,7 @@
 """Batch-sharded data parallelism for the encoder: one process per GPU, flat gradient buckets, one RCCL all-reduce
-per bucket over xGMI (torch.distributed backend "nccl" IS RCCL on ROCm; "gloo" on CPU for tests).
+per bucket over xGMI.  On GPUs the all-reduce goes through the C ABI (`Comm` = me_comm_init / me_allreduce_bucket /
+me_comm_join: RCCL on a communication stream of its own, event hand-off from the backward stream); torch.distributed
+is the host-side rendezvous only (it carries the 128-byte RCCL id) -- and the reduction path of the CPU tests (gloo).
 
 Semantics follow the reference's explicit helper, Image/segmentation/mmseg_custom/core/utils/dist_utils.py:14-55
 (`_allreduce_coalesced`): take tensors in buckets -> flatten -> all_reduce(sum) -> divide by world size ->
@@ -23,14 +25,103 @@ from . import ops
 from ._capi import MetaEncError
 
 
-class FlatParams:
-    """Re-homes parameters (and their gradients) into flat fp32 buffers; `p.data` / `p.grad` become views."""
+class Comm:
+    """RCCL communicator behind the C ABI (include/metaenc.h: me_comm_*).  One per process / GPU."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], fused_accumulate: bool = True):
-        """fused_accumulate: let the Block backward accumulate weight gradients straight into the flat buffer (see
-        direct_grad).  Turn it off if you call torch.autograd.grad() on encoder weights (they would come back None)."""
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: Optional[int] = None):
+        import ctypes
+        from . import _capi
+        self._lib = _capi.load()
+        if len(unique_id) != _capi.ME_COMM_ID_BYTES:
+            raise MetaEncError(f"Comm: the RCCL id must be {_capi.ME_COMM_ID_BYTES} bytes")
+        dev = torch.cuda.current_device() if device is None else device
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), _capi.ME_COMM_ID_BYTES)
+        _capi.check(self._lib.me_comm_init(ctypes.byref(h), buf, rank, world, dev), "me_comm_init")
+        self._h, self.rank, self.world = h, rank, world
+        try:        # RCCL prints a version banner through C stdio at init: push it out now, not after the caller's own output
+            ctypes.CDLL(None).fflush(None)
+        except Exception:       # noqa: BLE001
+            pass
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        import ctypes
+        from . import _capi
+        buf = ctypes.create_string_buffer(_capi.ME_COMM_ID_BYTES)
+        _capi.check(_capi.load().me_comm_unique_id(buf), "me_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_torch_distributed(cls, group=None, device: Optional[int] = None) -> "Comm":
+        """Rank 0 draws the id, torch.distributed (any backend) carries it to the other ranks."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(box[0], rank, world, device)
+
+    def allreduce(self, t: torch.Tensor, producer_stream: Optional[int] = None) -> None:
+        """In-place sum over ranks, enqueued on the communicator's stream behind everything already enqueued on the
+        producer stream (default: torch's current stream)."""
+        from . import _capi
+        if not t.is_cuda or not t.is_contiguous():
+            raise MetaEncError("Comm.allreduce: contiguous CUDA tensors only")
+        ps = torch.cuda.current_stream().cuda_stream if producer_stream is None else producer_stream
+        _capi.check(self._lib.me_allreduce_bucket(self._h, t.data_ptr(), t.numel(), _capi.dtype_code(t.dtype), ps),
+                    "me_allreduce_bucket")
+
+    def join(self, consumer_stream: Optional[int] = None) -> None:
+        from . import _capi
+        cs = torch.cuda.current_stream().cuda_stream if consumer_stream is None else consumer_stream
+        _capi.check(self._lib.me_comm_join(self._h, cs), "me_comm_join")
+
+    def info(self):
+        import ctypes
+        r, w, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        from . import _capi
+        _capi.check(self._lib.me_comm_info(self._h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(n)), "me_comm_info")
+        return {"rank": r.value, "world": w.value, "buckets_reduced": n.value}
+
+    def destroy(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.me_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def no_decay_rule(name: str, p: torch.nn.Parameter) -> bool:
+    """The reference fine-tuning recipes exempt 1-D parameters and biases from weight decay
+    (Video/optim_factory.py:67-73: `len(param.shape) == 1 or name.endswith(".bias")`)."""
+    return p.dim() == 1 or name.endswith(".bias")
+
+
+class FlatParams:
+    """Re-homes parameters (and their gradients) into flat fp32 buffers; `p.data` / `p.grad` become views.
+
+    Use `flat.zero_grad()` (NOT model.zero_grad() / a torch optimizer's zero_grad(), which set .grad to None): the fused
+    optimizer reads the flat gradient buffer.  `FusedAdamW.step()` verifies that every p.data / p.grad still aliases the
+    flat buffers and repairs or rejects what does not."""
+
+    def __init__(self, params: Iterable, fused_accumulate: bool = True, no_decay=None):
+        """params: parameters, or (name, parameter) pairs (model.named_parameters()).
+        fused_accumulate: let the Block backward accumulate weight gradients straight into the flat buffer (see
+        direct_grad).  Turn it off if you call torch.autograd.grad() on encoder weights (they would come back None).
+        no_decay: optional predicate (name, parameter) -> bool; those parameters are laid out FIRST in the flat buffers,
+        [0, no_decay_numel), so that FusedAdamW applies weight decay to the rest only (two launches)."""
         self.fused_accumulate = fused_accumulate
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        named = [(q if isinstance(q, tuple) else ("", q)) for q in params]
+        named = [(n, p) for n, p in named if p.requires_grad]
+        if no_decay is not None:
+            head = [(n, p) for n, p in named if no_decay(n, p)]
+            tail = [(n, p) for n, p in named if not no_decay(n, p)]
+            named = head + tail
+        self.params: List[torch.nn.Parameter] = [p for _, p in named]
         if not self.params:
             raise MetaEncError("FlatParams: no trainable parameters")
         dev = self.params[0].device
@@ -39,9 +130,12 @@ class FlatParams:
             raise MetaEncError("FlatParams: parameters must share dtype and device")
         # 64-element alignment keeps every view 256-byte aligned for the vectorised kernels
         self.offsets, off = [], 0
-        for p in self.params:
+        self.no_decay_numel = 0
+        for n, p in named:
             self.offsets.append(off)
             off += (p.numel() + 63) // 64 * 64
+            if no_decay is not None and no_decay(n, p):
+                self.no_decay_numel = off
         self.numel = off
         self.flat_param = torch.zeros(off, dtype=dt, device=dev)
         self.flat_grad = torch.zeros(off, dtype=dt, device=dev)
@@ -92,6 +186,27 @@ class FlatParams:
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
 
+    def check(self) -> None:
+        """Called by FusedAdamW.step(): every p.data / p.grad must still alias the flat buffers.
+        * p.grad replaced by a fresh tensor (autograd allocates one after `model.zero_grad()` set it to None): its values
+          are copied into the flat slice and the view is re-attached -- the step then sees the right gradient;
+        * p.grad is None at step time, or p.data was re-homed (.to() / .cuda() / load into a new storage): MetaEncError --
+          stepping would silently apply stale gradients or update a buffer the model no longer reads."""
+        es = self.flat_grad.element_size()
+        gbase, pbase = self.flat_grad.data_ptr(), self.flat_param.data_ptr()
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if p.data_ptr() != pbase + o * es:
+                raise MetaEncError(f"FlatParams: parameter #{i} {tuple(p.shape)} no longer lives in the flat buffer "
+                                   "(moved by .to()/.cuda()/assignment after FlatParams was built); rebuild FlatParams")
+            g = p.grad
+            if g is None:
+                raise MetaEncError(f"FlatParams: parameter #{i} {tuple(p.shape)} has .grad = None at step time -- use "
+                                   "flat.zero_grad() instead of model.zero_grad() / optimizer.zero_grad(set_to_none=True)")
+            if g.data_ptr() != gbase + o * es or g.shape != p.shape:
+                view = self.flat_grad[o:o + p.numel()].view(p.shape)
+                view.copy_(g)
+                p.grad = view
+
     def buckets(self, bucket_bytes: int) -> List[torch.Tensor]:
         """Slices of the flat gradient, split at parameter boundaries, in REVERSE parameter order (the order
         backward finishes them: last layer first)."""
@@ -107,9 +222,18 @@ class FlatParams:
 
 
 def allreduce_gradients(flat: FlatParams, group=None, bucket_bytes: int = 64 << 20, average: bool = False,
-                        force: bool = False) -> None:
+                        force: bool = False, comm: Optional[Comm] = None) -> None:
     """One all_reduce(sum) per flat bucket.  `average=True` divides by the world size afterwards (reference
     semantics, dist_utils.py:31-32); the bench leaves it False and folds 1/world into the optimizer."""
+    if comm is not None:
+        if comm.world == 1 and not force:
+            return
+        for b in flat.buckets(bucket_bytes):
+            comm.allreduce(b)
+        comm.join()
+        if average:
+            flat.flat_grad.div_(comm.world)
+        return
     if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in flat.buckets(bucket_bytes)]
@@ -127,8 +251,14 @@ class OverlappedGradReducer:
     Every parameter gets a post-accumulate-grad hook; a bucket launches ``all_reduce(async_op=True)`` when its last
     parameter has fired.  ``finish()`` waits for the handles (call it before the optimizer step)."""
 
-    def __init__(self, flat: FlatParams, group=None, bucket_bytes: int = 64 << 20, force: bool = False):
-        self.flat, self.group, self.force = flat, group, force
+    def __init__(self, flat: FlatParams, group=None, bucket_bytes: int = 64 << 20, force: bool = False,
+                 comm: Optional[Comm] = None):
+        """comm: a `Comm` (RCCL behind the C ABI) -- the GPU path; without one the buckets go through torch.distributed
+        (`group`), which is what the CPU tests use with gloo.
+        One backward per step is assumed; for gradient accumulation wrap the extra backwards in `no_sync()` (every
+        reduction is then deferred to the backward that runs outside it, as DDP.no_sync does)."""
+        self.flat, self.group, self.force, self.comm = flat, group, force, comm
+        self._defer = False
         es = flat.flat_grad.element_size()
         # same partition as FlatParams.buckets(): walk parameters in reverse order
         self.bucket_of, self.bucket_slices, self.bucket_left = {}, [], []
@@ -144,19 +274,58 @@ class OverlappedGradReducer:
                 cur_end, members = flat.offsets[i], []
         self._initial = list(self.bucket_left)
         self.handles = []
+        # Two notification routes per parameter: autograd's post-accumulate hook, and FlatParams.grad_written for gradients
+        # the fused backward accumulated in place (it hands autograd None for those).  torch still runs the hook for a
+        # None gradient, so a parameter is usually announced TWICE per backward -- it is counted once, on the first
+        # announcement (both come after the kernel that writes the gradient was enqueued); the same ROUTE announcing a
+        # parameter twice means a second backward.
+        self._seen = [0] * len(flat.params)             # bit 0: hook, bit 1: direct
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(flat.params)]
-        self._direct = lambda i: self._fire(i)          # gradients the fused backward wrote in place (FlatParams.direct_grad)
+        self._direct = lambda i: self._fire(i, 2)       # gradients the fused backward wrote in place (FlatParams.direct_grad)
         flat._listeners.append(self._direct)
 
     def _active(self) -> bool:
+        if self.comm is not None:
+            return self.comm.world > 1 or self.force
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
 
-    def _fire(self, idx) -> None:
+    def _reduce(self, b: int, blocking: bool = False) -> None:
+        if self.comm is not None:
+            self.comm.allreduce(self.bucket_slices[b])          # asynchronous on the communicator's stream
+        elif blocking:
+            dist.all_reduce(self.bucket_slices[b], op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self.handles.append(dist.all_reduce(self.bucket_slices[b], op=dist.ReduceOp.SUM, group=self.group,
+                                                async_op=True))
+
+    def no_sync(self):
+        """Context manager for gradient accumulation: backwards inside it only accumulate locally."""
+        reducer = self
+
+        class _NoSync:
+            def __enter__(self_):
+                reducer._defer = True
+
+            def __exit__(self_, *exc):
+                reducer._defer = False
+                reducer.bucket_left = list(reducer._initial)
+                reducer._seen = [0] * len(reducer._seen)
+        return _NoSync()
+
+    def _fire(self, idx, route: int = 1) -> None:
+        if self._defer:
+            return
+        seen = self._seen[idx]
+        if seen & route:
+            raise MetaEncError("OverlappedGradReducer: a parameter received a second gradient before finish() -- one "
+                               "backward per step is assumed; wrap accumulation backwards in reducer.no_sync()")
+        self._seen[idx] = seen | route
+        if seen:
+            return                      # already counted through the other route
         b = self.bucket_of[idx]
         self.bucket_left[b] -= 1
         if self.bucket_left[b] == 0 and self._active():
-            self.handles.append(dist.all_reduce(self.bucket_slices[b], op=dist.ReduceOp.SUM, group=self.group,
-                                                async_op=True))
+            self._reduce(b)
 
     def _make_hook(self, idx):
         def hook(param):
@@ -171,8 +340,11 @@ class OverlappedGradReducer:
             # a parameter received no gradient this step (unused / frozen late): reduce what was not launched
             for b, left in enumerate(self.bucket_left):
                 if left != 0:
-                    dist.all_reduce(self.bucket_slices[b], op=dist.ReduceOp.SUM, group=self.group)
+                    self._reduce(b, blocking=True)
+        if self.comm is not None and self._active():
+            self.comm.join()            # the current (optimizer) stream waits for every bucket reduction
         self.bucket_left = list(self._initial)
+        self._seen = [0] * len(self._seen)
 
     def remove(self) -> None:
         for h in self._hooks:
@@ -227,11 +399,15 @@ class FusedAdamW:
     def step(self, grad_scale: float = 1.0) -> None:
         self.t += 1
         f = self.flat
+        f.check()
         if self.bf16_mirror and f.flat_bf16 is None:
             f.flat_bf16 = torch.empty(f.numel, dtype=torch.bfloat16, device=f.flat_param.device)
-        ops.adamw_step(f.flat_param, f.flat_grad, self.exp_avg, self.exp_avg_sq, lr=self.lr,
-                       betas=self.betas, eps=self.eps, weight_decay=self.wd, step=self.t, grad_scale=grad_scale,
-                       bf16_mirror=f.flat_bf16 if self.bf16_mirror else None)
+        # parameters exempt from weight decay (FlatParams(no_decay=...)) sit in [0, no_decay_numel): two launches
+        for lo, hi, wd in ((0, f.no_decay_numel, 0.0), (f.no_decay_numel, f.numel, self.wd)):
+            if hi > lo:
+                ops.adamw_step(f.flat_param[lo:hi], f.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], lr=self.lr,
+                               betas=self.betas, eps=self.eps, weight_decay=wd, step=self.t, grad_scale=grad_scale,
+                               bf16_mirror=f.flat_bf16[lo:hi] if self.bf16_mirror else None)
         if self.bf16_mirror:      # valid for this weight epoch as long as nobody else writes the parameters
             f._mirror_epoch = ops.WEIGHT_EPOCH
             f._mirror_versions = [p._version for p in f.params]

@@ -176,6 +176,16 @@ def block_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], num_heads: int, e
     return x
 
 
+def video_block_params(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Video/models/modeling_finetune.py key set -> the names block_forward() reads.  The Video Attention has a bias-free
+    qkv Linear plus q_bias / v_bias and builds `cat(q_bias, zeros_like(v_bias), v_bias)` at run time (:172-178): the K
+    third of the bias is identically zero.  gamma_1 / gamma_2 (:245-259) are the layer-scale vectors."""
+    p = {k: v for k, v in sd.items() if k not in ("attn.q_bias", "attn.v_bias", "gamma_1", "gamma_2")}
+    p["attn.qkv.bias"] = torch.cat([sd["attn.q_bias"], torch.zeros_like(sd["attn.v_bias"]), sd["attn.v_bias"]])
+    p["gamma1"], p["gamma2"] = sd["gamma_1"], sd["gamma_2"]
+    return p
+
+
 def split_state_dict(sd: Dict[str, torch.Tensor]) -> "list[Dict[str, torch.Tensor]]":
     """'{i}.name' -> per-block dicts, in block order (nn.Sequential key layout, README.md:125-135)."""
     blocks: Dict[int, Dict[str, torch.Tensor]] = {}

@@ -145,6 +145,7 @@ def gen_tokenizers(check):
     # Time series: Data2Seq/Time_Series.py DataEmbedding(c_in=7, d_model=768, 'fixed', freq 'h')
     g = torch.Generator().manual_seed(2004)
     TS = ref_loader.reference_time_series_embedding()
+    torch.manual_seed(2004)                                    # the reference ctor draws its kaiming init from the global RNG
     ts = TS(c_in=7, d_model=768, embed_type="fixed", freq="h", dropout=0.1).eval()
     w = ts.value_embedding.tokenConv.weight.data.clone()       # kaiming init from the reference ctor
     out["ts/conv_weight"] = w.numpy()
@@ -169,6 +170,128 @@ def gen_tokenizers(check):
     print("wrote tokenizers")
 
 
+def _randomize(module, g, skip=()):
+    """seeded N(0, .) values for every parameter, so that the fixture is sensitive to each of them"""
+    for k, p in module.named_parameters():
+        if k in skip:
+            continue
+        if k.startswith("gamma"):
+            p.data.copy_(0.5 + 0.5 * torch.rand(p.shape, generator=g))
+        elif p.dim() == 1 and "norm" in k and k.endswith("weight"):
+            p.data.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+        elif p.dim() == 1:
+            p.data.copy_(0.05 * torch.randn(p.shape, generator=g))
+        else:
+            p.data.copy_(0.05 * torch.randn(p.shape, generator=g))
+
+
+def _run_block(blk, x, go, *fwd_args):
+    xr = x.clone().requires_grad_(True)
+    y = blk(xr, *fwd_args)
+    (y * go).sum().backward()
+    grads = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    for p in blk.parameters():
+        p.grad = None
+    return y.detach(), xr.grad.detach(), grads
+
+
+def _store_grads(out, tag, grads):
+    """parameter gradients: (sum, abs-sum) + the first 256 flat values per tensor (1-D tensors in full)"""
+    for k, v in grads.items():
+        out[f"{tag}/dw_stats/" + k] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+        out[f"{tag}/dw_head/" + k] = v.flatten()[:256].numpy() if v.dim() > 1 else v.numpy()
+
+
+def gen_variants(check):
+    """Block variants of the big pipelines and the pos-embed table resize (a16), from the reference's
+    own classes: Video/models/modeling_finetune.py Block (q/v-only bias :160-166, q pre-scaled :183-184, gamma_1/gamma_2
+    :245-259) and Image/detection/.../base/vit.py Block (WindowedAttention :148-192, gamma1/gamma2 :298-320,
+    resize_pos_embed :459-486)."""
+    from functools import partial
+    import torch.nn as nn
+    out = {}
+    # ---- Video block: dim 128, 2 heads (hd 64), eps 1e-6 as vit_base_patch16_224 builds it
+    VM = ref_loader.reference_video_module()
+    g = torch.Generator().manual_seed(3001)
+    vb = VM.Block(128, 2, qkv_bias=True, init_values=0.1, norm_layer=partial(nn.LayerNorm, eps=1e-6)).eval()
+    _randomize(vb, g)
+    x, go = torch.randn(2, 40, 128, generator=g), torch.randn(2, 40, 128, generator=g)
+    y, dx, grads = _run_block(vb, x, go)
+    out.update({"video/x": x.numpy(), "video/go": go.numpy(), "video/y": y.numpy(), "video/dx": dx.numpy()})
+    for k, v in vb.state_dict().items():
+        out["video/w/" + k] = v.numpy()
+    _store_grads(out, "video", grads)
+    if check:
+        p = bo.video_block_params(vb.state_dict())
+        yo = bo.block_forward(x, p, 2, 1e-6, gamma1=p["gamma1"], gamma2=p["gamma2"], pre_scale_q=True)
+        err = ((yo - y).abs().max() / y.abs().max()).item()
+        assert err < 2e-6, err
+        print("  video block oracle rel", err)
+
+    # ---- detection blocks: windowed + layer-scale on a ragged 9 x 11 grid with 4 x 4 windows; full attention + layer-scale
+    DV = ref_loader.reference_detection_vit_module()
+    for tag, kw, hw in (("det_win", dict(windowed=True, window_size=4, layer_scale=True), (9, 11)),
+                        ("det_full", dict(windowed=False, layer_scale=True), (5, 7))):
+        g = torch.Generator().manual_seed(3002 if tag == "det_win" else 3003)
+        db = DV.Block(128, 2, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kw).eval()
+        _randomize(db, g)
+        H, W = hw
+        x, go = torch.randn(2, H * W, 128, generator=g), torch.randn(2, H * W, 128, generator=g)
+        y, dx, grads = _run_block(db, x, go, H, W)
+        out.update({f"{tag}/x": x.numpy(), f"{tag}/go": go.numpy(), f"{tag}/y": y.numpy(), f"{tag}/dx": dx.numpy(),
+                    f"{tag}/hw": np.array([H, W, kw.get("window_size", 0)])})
+        for k, v in db.state_dict().items():
+            out[f"{tag}/w/" + k] = v.numpy()
+        _store_grads(out, tag, grads)
+        if check:
+            p = dict(db.state_dict())
+            yo = bo.block_forward(x, p, 2, 1e-6, gamma1=p["gamma1"], gamma2=p["gamma2"],
+                                  window=(H, W, kw["window_size"]) if kw["windowed"] else None)
+            err = ((yo - y).abs().max() / y.abs().max()).item()
+            assert err < 2e-6, (tag, err)
+            print(f"  {tag} oracle rel", err)
+    # Base-sized windowed block: 768-d, 12 heads, 14 x 14 windows on a 20 x 30 grid (forward only, subsampled)
+    g = torch.Generator().manual_seed(3004)
+    db = DV.Block(768, 12, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), windowed=True, window_size=14, layer_scale=True).eval()
+    sd = bo.make_encoder_state_dict(1, 768, seed=3004)
+    db.load_state_dict({**{k[2:]: v for k, v in sd.items()}, "gamma1": db.gamma1.data, "gamma2": db.gamma2.data}, strict=True)
+    db.gamma1.data.copy_(0.5 + 0.5 * torch.rand(768, generator=g)); db.gamma2.data.copy_(0.5 + 0.5 * torch.rand(768, generator=g))
+    x = torch.randn(1, 600, 768, generator=g)
+    with torch.no_grad():
+        y = db(x, 20, 30)
+    out.update({"det_win_base/y": y[:, ::5, ::3].numpy(), "det_win_base/gamma1": db.gamma1.data.numpy(),
+                "det_win_base/gamma2": db.gamma2.data.numpy(), "det_win_base/weights_checksum": np.float64(bo.state_dict_checksum(sd))})
+
+    # ---- pos-embed table resize (bicubic, align_corners=False), cls row kept: 14 x 14 -> 20 x 24 and -> 10 x 7
+    g = torch.Generator().manual_seed(3005)
+    pos = torch.randn(1, 1 + 14 * 14, 96, generator=g)
+    out["resize/pos"] = pos.numpy()
+    for tag, shp in (("up", (20, 24)), ("down", (10, 7))):
+        out[f"resize/{tag}"] = DV.TIMMVisionTransformer.resize_pos_embed(pos, shp, (14, 14), "bicubic").numpy()
+    out["resize/bilinear_up"] = DV.TIMMVisionTransformer.resize_pos_embed(pos, (20, 24), (14, 14), "bilinear").numpy()
+    # ---- classification tail of the Video model (modeling_finetune.py:395, 445-454): fc_norm(x.mean(1)) -> head, and the
+    # cls-token form norm(x)[:, 0] -> head, on the reference's own modules (174 classes: not a multiple of 8)
+    g = torch.Generator().manual_seed(3006)
+    for tag, mean_pool in (("head_mean", True), ("head_cls", False)):
+        vt = VM.VisionTransformer(img_size=32, patch_size=16, in_chans=3, num_classes=174, embed_dim=64, depth=1, num_heads=2,
+                                  mlp_ratio=4, qkv_bias=True, init_values=0.0, all_frames=4, tubelet_size=2,
+                                  use_mean_pooling=mean_pool, init_scale=1.0).eval()
+        ln = vt.fc_norm if mean_pool else vt.norm
+        ln.weight.data.copy_(1.0 + 0.1 * torch.randn(64, generator=g)); ln.bias.data.copy_(0.05 * torch.randn(64, generator=g))
+        vt.head.weight.data.copy_(0.1 * torch.randn(174, 64, generator=g)); vt.head.bias.data.copy_(0.05 * torch.randn(174, generator=g))
+        x = torch.randn(3, 9, 64, generator=g, requires_grad=True)
+        go = torch.randn(3, 174, generator=g)
+        feat = vt.fc_norm(x.mean(1)) if mean_pool else vt.norm(x)[:, 0]        # the tail of forward_features (:445-454)
+        y = vt.head(vt.head_dropout(feat))                                     # forward (:456-460)
+        (y * go).sum().backward()
+        out.update({f"{tag}/x": x.detach().numpy(), f"{tag}/go": go.numpy(), f"{tag}/y": y.detach().numpy(), f"{tag}/dx": x.grad.numpy(),
+                    f"{tag}/ln_w": ln.weight.data.numpy(), f"{tag}/ln_b": ln.bias.data.numpy(), f"{tag}/head_w": vt.head.weight.data.numpy(),
+                    f"{tag}/head_b": vt.head.bias.data.numpy(), f"{tag}/dhead_w": vt.head.weight.grad.numpy(),
+                    f"{tag}/dhead_b": vt.head.bias.grad.numpy(), f"{tag}/dln_w": ln.weight.grad.numpy(), f"{tag}/dln_b": ln.bias.grad.numpy()})
+    np.savez(os.path.join(GOLDEN_DIR, "variants.npz"), **out)
+    print("wrote variants", sum(v.nbytes for v in out.values()) // 1024, "KiB")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -180,6 +303,7 @@ def main():
     for name, c in ENCODER_CASES.items():
         gen_encoder_case(name, c, args.check)
     gen_tokenizers(args.check)
+    gen_variants(args.check)
 
 
 if __name__ == "__main__":

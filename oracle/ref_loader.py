@@ -123,7 +123,7 @@ def _timm_stub():
     layers = types.ModuleType("timm.models.layers")
     registry = types.ModuleType("timm.models.registry")
     layers.to_2tuple = to_2tuple
-    layers.trunc_normal_ = lambda t, std=.02, **kw: t.normal_(0, std)
+    layers.trunc_normal_ = lambda t, std=.02, **kw: t.data.normal_(0, std)
     layers.drop_path = lambda x, p=0., training=False: x
     registry.register_model = lambda f: f
     timm.models, models.layers, models.registry = models, layers, registry
@@ -145,3 +145,45 @@ def reference_acoustic_patch_embed():
 
 def reference_video_module():
     return _load_file("_ref_video_ft", "Video/models/modeling_finetune.py", _timm_stub())
+
+
+def reference_detection_vit_module():
+    """Image/detection/mmdet_custom/models/backbones/base/vit.py, unmodified: WindowedAttention (pad / unfold / attend /
+    fold / crop, :148-192), Block with layer_scale gamma1 / gamma2 (:276-335) and TIMMVisionTransformer.resize_pos_embed
+    (:459-486).  The file imports mmcv / mmcv_custom / mmdet / mmengine / timm at module level, none installed here and
+    none arithmetic on this path: BaseModule -> nn.Module, loggers / checkpoint loaders / initialisers -> no-ops.  The
+    two timm layers it USES, Mlp and DropPath, are served from the reference's own in-tree twin of timm
+    (PointCloud/openpoints/models/layers/{mlp,drop}.py) behind timm's 0.4.12 constructor signature."""
+    import torch.nn as nn
+    att = load_reference_layers()
+    pkg = sys.modules[_PKG]
+
+    class Mlp(pkg.Mlp):
+        def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+            assert act_layer is nn.GELU
+            super().__init__(in_features, hidden_features, out_features, act_args={"act": "gelu"}, drop=drop)
+
+    stubs = dict(_timm_stub())
+    # (an earlier loader call may already have installed the timm stub: _load_file keeps the first one)
+    lay = sys.modules.get("timm.models.layers", stubs["timm.models.layers"])
+    lay.Mlp = Mlp
+    lay.DropPath = pkg.DropPath
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+    noop = lambda *a, **k: None          # noqa: E731
+    stubs.update({
+        "mmcv": mod("mmcv"), "mmcv.runner": mod("mmcv.runner", BaseModule=nn.Module),
+        "mmcv_custom": mod("mmcv_custom", my_load_checkpoint=noop),
+        "mmdet": mod("mmdet"), "mmdet.utils": mod("mmdet.utils", get_root_logger=noop),
+        "mmengine": mod("mmengine"), "mmengine.logging": mod("mmengine.logging", print_log=noop),
+        "mmengine.model": mod("mmengine.model", BaseModule=nn.Module, ModuleList=nn.ModuleList),
+        "mmengine.model.weight_init": mod("mmengine.model.weight_init", constant_init=noop, kaiming_init=noop, trunc_normal_=noop),
+        "mmengine.runner": mod("mmengine.runner"),
+        "mmengine.runner.checkpoint": mod("mmengine.runner.checkpoint", CheckpointLoader=object, load_state_dict=noop),
+    })
+    del att
+    return _load_file("_ref_det_vit", "Image/detection/mmdet_custom/models/backbones/base/vit.py", stubs)

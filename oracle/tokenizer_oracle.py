@@ -132,3 +132,107 @@ def time_series_embedding(x: torch.Tensor, conv_weight: torch.Tensor,
     if pe is not None:
         out = out + pe[:L].unsqueeze(0)
     return out
+
+
+def _cubic_weights(t: torch.Tensor, A: float = -0.75):
+    """ATen's cubic-convolution coefficients (UpSample.h get_cubic_upsample_coefficients)."""
+    def c1(x): return ((A + 2.0) * x - (A + 3.0)) * x * x + 1.0
+    def c2(x): return ((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A
+    return [c2(t + 1.0), c1(t), c1(1.0 - t), c2(2.0 - t)]
+
+
+def _resize_axis_taps(n_in: int, n_out: int, mode: str):
+    """per output index: (tap indices [n_out, T], tap weights [n_out, T]); align_corners=False"""
+    scale = n_in / n_out
+    d = torch.arange(n_out, dtype=torch.float32)
+    s = scale * (d + 0.5) - 0.5
+    if mode == "bicubic":
+        fl = torch.floor(s)
+        t = s - fl
+        idx = torch.stack([fl.long() + k for k in (-1, 0, 1, 2)], dim=1).clamp(0, n_in - 1)
+        return idx, torch.stack(_cubic_weights(t), dim=1)
+    s = s.clamp_min(0.0)
+    i0 = s.long()
+    i1 = torch.where(i0 < n_in - 1, i0 + 1, i0)
+    lam = s - i0.float()
+    return torch.stack([i0, i1], dim=1), torch.stack([1.0 - lam, lam], dim=1)
+
+
+def resize_pos_embed(pos_embed: torch.Tensor, input_shape, pos_shape, mode: str = "bicubic") -> torch.Tensor:
+    """TIMMVisionTransformer.resize_pos_embed, Image/detection/mmdet_custom/models/backbones/base/vit.py:459-486: keep row 0
+    (cls), resample the last pos_h * pos_w rows as a [pos_h, pos_w] grid to input_shape with F.interpolate(mode,
+    align_corners=False) (:478-479), restated as explicit separable taps (x first, then y, as ATen evaluates it)."""
+    ph, pw = pos_shape
+    H, W = input_shape
+    C = pos_embed.shape[2]
+    grid = pos_embed[0, -ph * pw:].reshape(ph, pw, C)
+    ix, wx = _resize_axis_taps(pw, W, mode)
+    iy, wy = _resize_axis_taps(ph, H, mode)
+    rows = (grid[:, ix] * wx[None, :, :, None]).sum(dim=2)          # [ph, W, C]
+    out = (rows[iy] * wy[:, :, None, None]).sum(dim=1)              # [H, W, C]
+    return torch.cat([pos_embed[:, :1], out.reshape(1, H * W, C)], dim=1)
+
+
+# ---- point-cloud tokenizer front end (numpy / torch-CPU restatements)
+
+def fps_reference(points, m: int):
+    """furthest_point_sampling_kernel, PointCloud/openpoints/cpp/pointnet2_batch/src/sampling_gpu.cu:101-210, with its
+    thread-strided scan and binary-tree fold restated literally (T = largest power of two <= n, capped at 1024:
+    opt_n_threads): start at index 0; temp = 1e10 (the caller's fill); each round every thread keeps the first strict
+    maximum of min(d, temp[k]) over its points, partners (t, t + s) fold with `v2 > v1 ? i2 : i1`."""
+    import numpy as np
+    pts = np.asarray(points, dtype=np.float32)
+    B, n, _ = pts.shape
+    T = 1
+    while T * 2 <= n and T < 1024:
+        T *= 2
+    out = np.zeros((B, m), dtype=np.int32)
+    for b in range(B):
+        P = pts[b]
+        temp = np.full(n, 1e10, dtype=np.float32)
+        old = 0
+        for j in range(1, m):
+            d = P - P[old]
+            # fma(dz, dz, fma(dy, dy, dx*dx)) evaluated in double and rounded after each step (products of floats are exact there)
+            t0 = (d[:, 0].astype(np.float64) * d[:, 0]).astype(np.float32)
+            t1 = (d[:, 1].astype(np.float64) * d[:, 1] + t0).astype(np.float32)
+            dist = (d[:, 2].astype(np.float64) * d[:, 2] + t1).astype(np.float32)
+            temp = np.minimum(dist, temp)
+            best = np.full(T, -1.0, dtype=np.float32)
+            besti = np.zeros(T, dtype=np.int64)
+            for t in range(min(T, n)):
+                sub = temp[t::T]
+                a = int(np.argmax(sub))                      # first maximum of the strided walk
+                if sub[a] > -1.0:
+                    best[t], besti[t] = sub[a], t + a * T
+            s = T // 2
+            while s >= 1:
+                v1, v2 = best[:s].copy(), best[s:2 * s].copy()
+                i1, i2 = besti[:s].copy(), besti[s:2 * s].copy()
+                best[:s] = np.maximum(v1, v2)
+                besti[:s] = np.where(v2 > v1, i2, i1)
+                s //= 2
+            old = int(besti[0])
+            out[b, j] = old
+    return out
+
+
+def knn_reference(support: torch.Tensor, query: torch.Tensor, k: int):
+    """KNN.forward, PointCloud/openpoints/models/layers/group.py:17-28: cdist + topk(largest=False); returns [B, m, k]."""
+    dist = torch.cdist(support, query)
+    return dist.topk(k=k, dim=1, largest=False).indices.transpose(1, 2).contiguous().int()
+
+
+def point_patch_embed_reference(p: torch.Tensor, mod, fps_idx=None):
+    """PointPatchEmbed.forward (group_embed.py:138-172) for feature_type 'dp', knn grouping, max reduction, on the module's own
+    conv1 / conv2 (eval mode): returns out_f [B, C, S]."""
+    B, n, _ = p.shape
+    S, k = int(n * mod.sample_ratio), mod.group_size
+    idx = torch.from_numpy(fps_reference(p.numpy(), S)).long() if fps_idx is None else fps_idx.long()
+    center = torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+    nbr = knn_reference(p, center, k).long()                                   # [B, S, k]
+    grouped = torch.gather(p.unsqueeze(1).expand(-1, S, -1, -1), 2, nbr.unsqueeze(-1).expand(-1, -1, -1, 3))   # [B, S, k, 3]
+    dp = (grouped - center.unsqueeze(2)).permute(0, 3, 1, 2)                   # [B, 3, S, k]  (relative_xyz, group.py:312-313)
+    fj = mod.conv1(dp)
+    fj = torch.cat([fj.max(dim=-1, keepdim=True)[0].expand(-1, -1, -1, k), fj], dim=1)
+    return mod.conv2(fj).max(dim=-1)[0], idx, nbr

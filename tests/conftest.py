@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of host CPU work for the oracle (full-size parity); still part of -m gpu")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -36,8 +37,37 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-# tolerances, stated once:
-#   fp32 path  : 1e-3 relative (north star); in practice ~1e-6
-#   bf16 path  : operands rounded to 8 mantissa bits, fp32 accumulation/statistics -> 3e-2 of max-abs per block stack
+# tolerances, stated once (max-abs error / max-abs of the reference unless said otherwise):
+#   fp32 path      : 1e-3 relative (north star); in practice ~1e-6
+#   bf16 path      : operands and the residual stream carry 8 mantissa bits, accumulation / statistics are fp32.
+#                    Measured on MI355X (round 2), fp32 residual stream (autocast): forward of a block stack 1.5e-3,
+#                    dL/dx 2.3e-3, weight gradients 4.5e-3 -> bounds at ~3x measured: forward 5e-3, gradients 1.5e-2,
+#                    single ops 8e-3.  With a bf16 RESIDUAL STREAM (bf16 parameters / bf16 tokens: every residual add rounds
+#                    to 8 bits) the measured forward error is 5.8e-3 for one Base block, 1.3e-2 .. 2.1e-2 for twelve
+#                    -> bounds 1e-2 per block, 3e-2 for the 12-layer stack (TOL_BF16_STREAM12).
 TOL_F32 = 1e-3
-TOL_BF16 = 3e-2
+TOL_BF16_FWD = 5e-3
+TOL_BF16_GRAD = 1.5e-2
+TOL_BF16_OP = 8e-3
+TOL_BF16_STREAM1 = 1e-2
+TOL_BF16_STREAM12 = 3e-2
+TOL_BF16 = TOL_BF16_FWD
+
+
+def check_close(a: torch.Tensor, ref: torch.Tensor, tol: float, what: str = "") -> None:
+    """Parity check with a per-element part: (1) max-abs error <= tol * max|ref|, and (2) EVERY element within
+    4 tol |ref| + tol/2 max|ref| -- for elements below max/8 that is tighter than (1), so an error confined to small
+    outputs (a dropped bias on a few columns, a wrong tail tile of near-zero values) cannot hide under the global scale."""
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert a.shape == ref.shape, (what, tuple(a.shape), tuple(ref.shape))
+    scale = float(ref.abs().max().clamp_min(1e-30))
+    err = (a - ref).abs()
+    worst = float(err.max()) / scale
+    assert worst <= tol, f"{what}: max-abs error {worst:.3e} of max|ref| exceeds {tol:.1e}"
+    bound = 4.0 * tol * ref.abs() + 0.5 * tol * scale
+    bad = err > bound
+    if bool(bad.any()):
+        i = int(torch.argmax((err / bound).flatten()))
+        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.numel()} elements outside 4*tol*|ref| + tol/2*max|ref| "
+                             f"(tol {tol:.1e}); worst: got {float(a.flatten()[i]):.6g}, want {float(ref.flatten()[i]):.6g}")

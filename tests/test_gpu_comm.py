@@ -1,0 +1,90 @@
+"""GPU: the data-parallel exchange step through the C ABI (me_comm_* / me_allreduce_bucket = RCCL on its own stream).
+One MI355X is available to the tests, so the communicator has world size 1 -- which still exercises RCCL's
+ncclCommInitRank / ncclAllReduce, the stream hand-off and the reducer integration; world-2 semantics are covered on CPU
+(gloo) in tests/test_parallel_cpu.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_comm_world1_allreduce_and_stream_order():
+    from metatransformer_amd import parallel
+    comm = parallel.Comm(parallel.Comm.new_unique_id(), 0, 1)
+    assert comm.info() == {"rank": 0, "world": 1, "buckets_reduced": 0}
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream()
+    n = 8 << 20
+    for dtype in (torch.float32, torch.bfloat16):
+        buf = torch.zeros(n, dtype=dtype, device=dev)
+        with torch.cuda.stream(side):
+            # a long producer on a side stream: the reduction must wait for it (event hand-off), and the consumer
+            # stream must wait for the reduction (me_comm_join)
+            for _ in range(20):
+                buf.add_(1.0)
+            comm.allreduce(buf)                       # producer stream = torch's current stream = side
+        comm.join()                                   # consumer = the default stream
+        out = buf.clone()                             # enqueued on the default stream behind the join
+        torch.cuda.synchronize()
+        assert torch.equal(out, torch.full_like(out, 20.0)), dtype      # world 1: sum over ranks == identity
+    assert comm.info()["buckets_reduced"] == 2
+    comm.destroy()
+
+
+def test_reducer_uses_the_c_abi_comm():
+    import metatransformer_amd as M
+    from metatransformer_amd import parallel
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    enc = M.build_encoder(2, 128, 4).to(dev)
+    flat = parallel.FlatParams(enc.named_parameters(), no_decay=parallel.no_decay_rule)
+    comm = parallel.Comm(parallel.Comm.new_unique_id(), 0, 1)
+    red = parallel.OverlappedGradReducer(flat, comm=comm, force=True, bucket_bytes=256 << 10)
+    opt = parallel.FusedAdamW(flat, lr=1e-3, weight_decay=0.1)
+    x = torch.randn(4, 33, 128, device=dev, requires_grad=True)
+    ref = None
+    for it in range(2):
+        flat.zero_grad()
+        enc(x).square().mean().backward()
+        red.finish()
+        g = flat.flat_grad.clone()
+        if ref is None:
+            # same step without any reducer
+            enc2 = M.build_encoder(2, 128, 4).to(dev)
+            enc2.load_state_dict(enc.state_dict())
+            enc2(x).square().mean().backward()
+            for (n1, p1), (n2, p2) in zip(enc.named_parameters(), enc2.named_parameters()):
+                assert torch.allclose(p1.grad, p2.grad, atol=1e-6, rtol=1e-5), n1
+            ref = g
+        opt.step()
+    n_buckets = len(red.bucket_slices)
+    assert n_buckets >= 2 and comm.info()["buckets_reduced"] == 2 * n_buckets
+    # weight decay skipped the 1-D parameters: with zero gradient a decayed weight shrinks, a bias does not
+    flat.zero_grad()
+    before = flat.flat_param.clone()
+    opt.exp_avg.zero_(); opt.exp_avg_sq.zero_()
+    opt.step()
+    torch.cuda.synchronize()
+    nd = flat.no_decay_numel
+    assert torch.equal(flat.flat_param[:nd], before[:nd])
+    assert (flat.flat_param[nd:] - before[nd:]).abs().max() > 0
+    red.remove()
+    comm.destroy()
+
+
+def test_bench_forced_dist_on_one_gpu():
+    """ME_BENCH_FORCE_DIST=1 python bench.py --gpus 1: the whole step with the RCCL-behind-the-C-ABI exchange in it."""
+    env = dict(os.environ, ME_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--batch", "16", "--no-cpu-baseline", "--no-fwd-leg"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and "me_allreduce_bucket" in line["config"]["grad_allreduce"]
+    assert line["roofline"]["achieved"] > 0 and line["value"] > 0

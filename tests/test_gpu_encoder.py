@@ -8,7 +8,8 @@ import pytest
 import torch
 import torch.nn as nn
 
-from conftest import GOLDEN, TOL_BF16, TOL_F32, rel_err
+from conftest import (GOLDEN, TOL_BF16, TOL_BF16_FWD, TOL_BF16_GRAD, TOL_BF16_STREAM1, TOL_BF16_STREAM12, TOL_F32, check_close,
+                      rel_err)
 import metatransformer_amd as M
 from oracle import block_oracle as bo
 from oracle import tokenizer_oracle as to
@@ -43,7 +44,7 @@ def test_forward_fp32_matches_reference_golden(dev, name):
 @pytest.mark.parametrize("name", ["small_hd64", "base_1blk", "base_12blk", "large_2blk", "graph_hd24"])
 @pytest.mark.parametrize("mode", ["autocast", "bf16_params"])
 def test_forward_bf16_matches_reference_golden(dev, name, mode):
-    """bf16 MFMA path vs the fp32 reference output: tolerance 3e-2 of max-abs (operands carry 8 mantissa bits)."""
+    """bf16 MFMA path vs the fp32 reference output: TOL_BF16_FWD of max-abs plus the per-element bound of check_close."""
     z, c = golden(name)
     x, _ = _inputs(c)
     with torch.no_grad():
@@ -56,7 +57,11 @@ def test_forward_bf16_matches_reference_golden(dev, name, mode):
             enc = make_encoder(c, dev, torch.bfloat16)
             y = enc(x.to(dev).bfloat16())
             assert y.dtype == torch.bfloat16
-    assert rel_err(y[:, ::c["tok_stride"]].float(), torch.from_numpy(z["y"])) < TOL_BF16
+    if mode == "autocast":          # fp32 residual stream
+        tol = TOL_BF16_FWD * (2.0 if c["depth"] > 2 else 1.0)
+    else:                           # bf16 parameters AND a bf16 residual stream
+        tol = TOL_BF16_STREAM12 if c["depth"] > 2 else TOL_BF16_STREAM1
+    check_close(y[:, ::c["tok_stride"]].float(), torch.from_numpy(z["y"]), tol, name)
 
 
 @pytest.mark.parametrize("name", [n for n, c in ENCODER_CASES.items() if c["backward"]])
@@ -84,7 +89,7 @@ def test_backward_full_parity_vs_oracle(dev):
     g = torch.Generator().manual_seed(42)
     x, go = torch.randn(3, 70, 256, generator=g), torch.randn(3, 70, 256, generator=g)
     y_ref, dx_ref, dp_ref = bo.encoder_forward_backward(x, sd, c["heads"], go)
-    for dt, t in ((torch.float32, TOL_F32), (torch.bfloat16, 5e-2)):
+    for dt, t in ((torch.float32, TOL_F32), (torch.bfloat16, TOL_BF16_GRAD)):
         enc = make_encoder(c, dev).train()
         xr = x.to(dev).requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
@@ -140,7 +145,7 @@ def test_fp16_call_sites_run_on_bf16_kernels(dev, mode):
             y = enc(xr)
     (y.float() * go.to(dev)).sum().backward()
     assert xr.grad.dtype == xr.dtype
-    assert rel_err(y.float(), y_ref) < 5e-2 and rel_err(xr.grad.float(), dx_ref) < 5e-2
+    assert rel_err(y.float(), y_ref) < 2 * TOL_BF16_FWD and rel_err(xr.grad.float(), dx_ref) < TOL_BF16_GRAD
     for k, p in enc.named_parameters():
         assert p.grad.dtype == p.dtype and rel_err(p.grad.float(), dp_ref[k]) < 6e-2, k
 
@@ -353,7 +358,7 @@ def test_layer_scale_variant(dev):
         assert rel_err(blk(x), ref) < TOL_F32
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_F32), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_F32), (torch.bfloat16, TOL_BF16_GRAD)])
 def test_layer_scale_backward_vs_oracle(dev, dt, tol):
     """gamma1/gamma2 of the Image pipelines (vit.py:313-316): every gradient incl. d gamma against autograd through the
     oracle's restatement"""
@@ -391,7 +396,7 @@ def test_window_rows_bit_exact(dev, B, H, W, ws, C, dt):
     assert torch.equal(back.cpu(), x)
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_F32), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, TOL_F32), (torch.bfloat16, TOL_BF16_GRAD)])
 @pytest.mark.parametrize("H,W,ws", [(20, 31, 14), (28, 28, 14), (9, 5, 4)])
 def test_windowed_block_vs_oracle(dev, dt, tol, H, W, ws):
     """row f3: WindowedAttention blocks of the detection backbone (vit.py:148-192, 284-287) -- forward, dL/dx and every
@@ -430,12 +435,12 @@ def test_base_config2_shape_properties(dev):
         y = enc(x.to(dev))
         y_sub = enc(x[37:39].to(dev))
     assert torch.isfinite(y.float()).all()
-    assert rel_err(y_sub.float(), y[37:39].float()) < TOL_BF16, "batch independence (ulp flips of the bf16 stream only)"
+    assert rel_err(y_sub.float(), y[37:39].float()) < TOL_BF16_STREAM12, "batch independence (ulp flips of the bf16 stream only)"
     with torch.no_grad():      # same problem size -> same schedule -> bit-exact run to run
         assert torch.equal(enc(x[37:39].to(dev)), y_sub)
     sd = bo.make_encoder_state_dict(12, 768, seed=14)
     ref = bo.encoder_forward(x[:2].float(), sd, 12)
-    assert rel_err(y[:2].float(), ref) < TOL_BF16
+    check_close(y[:2].float(), ref, TOL_BF16_STREAM12, 'config 2, 12 bf16 layers, bf16 stream')
 
 
 def test_large_config3_slice_vs_oracle(dev):
@@ -449,7 +454,7 @@ def test_large_config3_slice_vs_oracle(dev):
             y16 = enc(x.to(dev))
     ref = bo.encoder_forward(x, bo.make_encoder_state_dict(24, 1024, seed=21), 16)
     assert rel_err(y32, ref) < TOL_F32
-    assert rel_err(y16, ref) < 5e-2       # 24 bf16 layers
+    assert rel_err(y16, ref) < 1.5e-2       # 24 bf16 layers
 
 
 def test_large_config5_video_tokens_vs_oracle(dev):
@@ -463,7 +468,7 @@ def test_large_config5_video_tokens_vs_oracle(dev):
     y_ref = bo.encoder_forward(xr, sd, 16, eps=1e-6)
     (y_ref * go).sum().backward()
     enc = make_encoder(c, dev)
-    for dt, tol in ((torch.float32, TOL_F32), (torch.bfloat16, 4e-2)):
+    for dt, tol in ((torch.float32, TOL_F32), (torch.bfloat16, TOL_BF16_GRAD)):
         xd = x.to(dev).requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
             y = enc(xd)
@@ -605,3 +610,198 @@ def test_multimodal_concat_through_encoder(dev):
         y = enc(feats)
         ref = bo.encoder_forward(feats.cpu(), bo.make_encoder_state_dict(2, 768, seed=4), 12)
     assert rel_err(y, ref) < TOL_F32
+
+
+# ---------------------------------------------------------------- Block variants pinned to the reference's own classes
+# (tests/golden/variants.npz: outputs of Video/models/modeling_finetune.py Block and Image/detection/.../base/vit.py Block,
+#  generated by oracle/make_golden.py in the build container)
+def _variants():
+    return np.load(os.path.join(GOLDEN, "variants.npz"))
+
+
+def _variant_sd(z, tag):
+    pre = f"{tag}/w/"
+    return {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+
+
+def _check_param_grads(z, tag, grads, tol_rel):
+    for k, g in grads.items():
+        st = z[f"{tag}/dw_stats/{k}"]
+        gd = g.detach().double().cpu()
+        assert abs(gd.abs().sum().item() - st[1]) <= tol_rel * st[1], (k, gd.abs().sum().item(), st[1])
+        head = torch.from_numpy(z[f"{tag}/dw_head/{k}"])
+        assert rel_err(g.detach().flatten()[:head.numel()].reshape(head.shape).float(), head) < 10 * tol_rel, k
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_video_block_matches_reference_golden(dev, dt):
+    """VideoMAE-style block: q/v-only bias, q pre-scaled, gamma_1 / gamma_2 -- through the state-dict adapter."""
+    from functools import partial
+    z = _variants()
+    ref_sd = _variant_sd(z, "video")
+    blk = M.Block(128, 2, qkv_bias=True, layer_scale=True, norm_layer=partial(nn.LayerNorm, eps=1e-6))
+    blk.load_state_dict(M.convert_video_state_dict(ref_sd), strict=True)
+    assert set(M.to_video_state_dict(blk.state_dict())) == set(ref_sd)          # the adapter round-trips the key set
+    blk = blk.to(dev).train()
+    x = torch.from_numpy(z["video/x"]).to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+        y = blk(x)
+    (y * torch.from_numpy(z["video/go"]).to(dev)).sum().backward()
+    tf, tg = (TOL_F32, TOL_F32) if dt == torch.float32 else (TOL_BF16_FWD, TOL_BF16_GRAD)
+    check_close(y.float(), torch.from_numpy(z["video/y"]), tf, "video block y")
+    check_close(x.grad.float(), torch.from_numpy(z["video/dx"]), tg, "video block dx")
+    grads = M.to_video_state_dict({k: p.grad for k, p in blk.named_parameters()})
+    _check_param_grads(z, "video", grads, 2e-3 if dt == torch.float32 else 2e-2)
+    kb = blk.attn.qkv.bias.grad[128:256]                                       # no K bias in the reference: its gradient is ~0
+    assert kb.abs().max() < 1e-3 * blk.attn.qkv.bias.grad.abs().max()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag", ["det_win", "det_full"])
+def test_detection_blocks_match_reference_golden(dev, tag, dt):
+    """layer-scale block with WindowedAttention (4 x 4 windows on a ragged 9 x 11 grid) / global attention, loaded
+    strict=True from the reference's own key set and called the reference's way: blk(x, H, W)."""
+    from functools import partial
+    z = _variants()
+    H, W, ws = (int(v) for v in z[f"{tag}/hw"])
+    blk = M.Block(128, 2, qkv_bias=True, layer_scale=True, windowed=ws > 0, window_size=ws or 14,
+                  norm_layer=partial(nn.LayerNorm, eps=1e-6))
+    blk.load_state_dict(_variant_sd(z, tag), strict=True)
+    blk = blk.to(dev).train()
+    x = torch.from_numpy(z[f"{tag}/x"]).to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+        y = blk(x, H, W)
+    (y * torch.from_numpy(z[f"{tag}/go"]).to(dev)).sum().backward()
+    tf, tg = (TOL_F32, TOL_F32) if dt == torch.float32 else (TOL_BF16_FWD, TOL_BF16_GRAD)
+    check_close(y.float(), torch.from_numpy(z[f"{tag}/y"]), tf, tag + " y")
+    check_close(x.grad.float(), torch.from_numpy(z[f"{tag}/dx"]), tg, tag + " dx")
+    _check_param_grads(z, tag, {k: p.grad for k, p in blk.named_parameters()}, 2e-3 if dt == torch.float32 else 2e-2)
+
+
+def test_windowed_base_block_matches_reference_golden(dev):
+    """Base width, 14 x 14 windows on a 20 x 30 grid (the detection backbone's shape class), fp32 and bf16 forward."""
+    from functools import partial
+    z = _variants()
+    sd = bo.make_encoder_state_dict(1, 768, seed=3004)
+    assert abs(bo.state_dict_checksum(sd) - float(z["det_win_base/weights_checksum"])) < 1e-6
+    blk = M.Block(768, 12, qkv_bias=True, layer_scale=True, windowed=True, window_size=14, norm_layer=partial(nn.LayerNorm, eps=1e-6))
+    blk.load_state_dict({**{k[2:]: v for k, v in sd.items()}, "gamma1": torch.from_numpy(z["det_win_base/gamma1"]),
+                         "gamma2": torch.from_numpy(z["det_win_base/gamma2"])}, strict=True)
+    blk = blk.to(dev).eval()
+    g = torch.Generator().manual_seed(3004)
+    torch.rand(768, generator=g); torch.rand(768, generator=g)                 # (the two gamma draws of the generator script)
+    x = torch.randn(1, 600, 768, generator=g).to(dev)
+    ref = torch.from_numpy(z["det_win_base/y"])
+    with torch.no_grad():
+        y = blk(x, 20, 30)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y16 = blk(x, 20, 30)
+    check_close(y[:, ::5, ::3], ref, TOL_F32, "windowed base fp32")
+    check_close(y16[:, ::5, ::3].float(), ref, TOL_BF16_FWD, "windowed base bf16")
+
+
+def test_resize_pos_embed_matches_reference_golden(dev):
+    """a16: TIMMVisionTransformer.resize_pos_embed (vit.py:459-486) -- cls row kept bit-exactly, grid resampled."""
+    z = _variants()
+    pos = torch.from_numpy(z["resize/pos"]).to(dev)
+    for tag, shp, mode in (("up", (20, 24), "bicubic"), ("down", (10, 7), "bicubic"), ("bilinear_up", (20, 24), "bilinear")):
+        out = M.resize_pos_embed(pos, shp, (14, 14), mode)
+        ref = torch.from_numpy(z[f"resize/{tag}"])
+        assert out.shape == ref.shape and torch.equal(out[:, 0].cpu(), ref[:, 0])
+        assert rel_err(out, ref) < 1e-5, tag
+    # identity resize returns the table itself (up to fp32 rounding of weights that are exactly 0 / 1)
+    same = M.resize_pos_embed(pos, (14, 14), (14, 14), "bicubic")
+    assert rel_err(same, pos) < 1e-6
+    with pytest.raises(M.MetaEncError):
+        M.resize_pos_embed(pos.cpu(), (20, 24), (14, 14))
+
+
+# ---------------------------------------------------------------- full-size backward parity (VERDICT r1 weak #3)
+@pytest.mark.slow
+def test_base_config2_full_batch_backward_vs_oracle(dev):
+    """BASELINE config 2 at FULL size: B = 256, N = 197, 12 x 768 -- dL/dx of every sample and all 144 parameter gradients
+    (weight gradients reduce over 50 432 rows: split-K inside the Block path, bias-colsum fusion, in-place flat accumulation)
+    against the CPU oracle's autograd.  The oracle runs the batch in chunks of 32 samples and sums the parameter gradients
+    (the loss is a sum over samples, so that is exact)."""
+    from metatransformer_amd import parallel
+    L, C, Hh, B, N = 12, 768, 12, 256, 197
+    sd = bo.make_encoder_state_dict(L, C, seed=77)
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(B, N, C, generator=g)
+    go = torch.randn(B, N, C, generator=g) / (B * N) ** 0.5
+    enc = M.build_encoder(L, C, Hh)
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(dev).train()
+    for blk in enc:
+        blk.compute_dtype = torch.bfloat16
+    flat = parallel.FlatParams(enc.named_parameters(), no_decay=parallel.no_decay_rule)       # the bench's configuration
+    xd = x.to(dev).bfloat16().requires_grad_(True)
+    flat.zero_grad()
+    y = enc(xd)
+    y.backward(go.to(dev).bfloat16())
+    torch.cuda.synchronize()
+    # oracle on the SAME bf16-rounded inputs, fp32 arithmetic
+    xr, gor = x.bfloat16().float(), go.bfloat16().float()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    dx_ref = torch.empty_like(xr)
+    y_ref = torch.empty_like(xr)
+    torch.set_num_threads(max(1, min(64, len(os.sched_getaffinity(0)))))
+    for i in range(0, B, 32):
+        xs = xr[i:i + 32].clone().requires_grad_(True)
+        ys = bo.encoder_forward(xs, params, Hh)
+        (ys * gor[i:i + 32]).sum().backward()
+        dx_ref[i:i + 32] = xs.grad
+        y_ref[i:i + 32] = ys.detach()
+    check_close(y.float(), y_ref, TOL_BF16_STREAM12, "config 2 y (12 bf16 layers, bf16 stream)")
+    assert rel_err(xd.grad.float(), dx_ref) < TOL_BF16_STREAM12         # dL/dx through 12 layers of bf16 stream (measured 1.7e-2)
+    worst = {}
+    for k, p in enc.named_parameters():
+        e = rel_err(p.grad, params[k].grad)
+        worst[k.split(".", 1)[1]] = max(worst.get(k.split(".", 1)[1], 0.0), e)
+    print("config-2 full-batch gradient errors (worst over layers):", {k: f"{v:.1e}" for k, v in worst.items()})
+    for k, e in worst.items():
+        assert e < TOL_BF16_STREAM12, (k, e)
+
+
+def test_large_config3_backward_vs_oracle(dev):
+    """config 3 shape class (Large, N = 512): dL/dx and every parameter gradient of a 2-block slice, batch 3."""
+    sd = bo.make_encoder_state_dict(2, 1024, seed=31)
+    g = torch.Generator().manual_seed(32)
+    x, go = torch.randn(3, 512, 1024, generator=g), torch.randn(3, 512, 1024, generator=g)
+    y_ref, dx_ref, dp_ref = bo.encoder_forward_backward(x, sd, 16, go)
+    for dt, tf, tg in ((torch.float32, TOL_F32, TOL_F32), (torch.bfloat16, TOL_BF16_FWD, TOL_BF16_GRAD)):
+        enc = M.build_encoder(2, 1024, 16)
+        enc.load_state_dict(sd, strict=True)
+        enc = enc.to(dev).train()
+        xr = x.to(dev).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+            y = enc(xr)
+        (y * go.to(dev)).sum().backward()
+        check_close(y.float(), y_ref, tf, f"config 3 y {dt}")
+        check_close(xr.grad.float(), dx_ref, tg, f"config 3 dx {dt}")
+        for k, p in enc.named_parameters():
+            assert rel_err(p.grad, dp_ref[k]) < tg, (k, dt)
+
+
+def test_block_with_fp8_attention_config5_shape(dev):
+    """BASELINE config 5's block (Large: 1024-d, 16 heads) on video-length sequences with attn_fp8: forward against the fp32
+    oracle, backward (bf16 kernels on the saved bf16 qkv with the fp8 forward's LSE) against the oracle's gradients."""
+    sd = bo.make_encoder_state_dict(1, 1024, seed=55)
+    g = torch.Generator().manual_seed(56)
+    x, go = torch.randn(2, 1568, 1024, generator=g), torch.randn(2, 1568, 1024, generator=g)
+    y_ref, dx_ref, dp_ref = bo.encoder_forward_backward(x, sd, 16, go)
+    enc = M.build_encoder(1, 1024, 16)
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(dev).train()
+    enc[0].attn_fp8 = True
+    xr = x.to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = enc(xr)
+    (y * go.to(dev)).sum().backward()
+    assert rel_err(y, y_ref) < 1e-2 and rel_err(xr.grad, dx_ref) < 3e-2
+    for k, p in enc.named_parameters():
+        assert rel_err(p.grad, dp_ref[k]) < 3e-2, k
+    enc[0].attn_fp8 = False
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y16 = enc(x.to(dev))
+    assert rel_err(y16, y_ref) < TOL_BF16_FWD          # the bf16 attention on the same block, for scale

@@ -94,3 +94,85 @@ def test_flatparams_single_process_semantics():
     flat.zero_grad()
     assert flat.flat_grad.abs().sum() == 0 and all(p.grad is not None for p in m.parameters())
     parallel.allreduce_gradients(flat)          # no process group: a no-op, not an error
+
+
+def test_flatparams_check_repairs_or_rejects():
+    """model.zero_grad() sets .grad to None, autograd then allocates fresh tensors, and a fused optimizer that
+    only looks at the flat buffer would step on stale gradients.  check() (called by FusedAdamW.step) must notice."""
+    from metatransformer_amd import MetaEncError
+    m = _model()
+    flat = parallel.FlatParams(m.parameters())
+    x = torch.randn(4, 40)
+    m(x).sum().backward()
+    flat.check()                                            # everything aliases: fine
+    want = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad(set_to_none=True)                           # the torch-2.x default
+    with pytest.raises(MetaEncError, match="zero_grad"):
+        flat.check()
+    m(x).sum().backward()                                   # autograd allocates stray .grad tensors
+    assert all(p.grad.data_ptr() != flat.flat_grad.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
+    flat.flat_grad.fill_(123.0)                             # stale content the optimizer must NOT see
+    flat.check()                                            # copies the stray gradients in and re-attaches the views
+    for p, o, w in zip(flat.params, flat.offsets, want):
+        assert p.grad.data_ptr() == flat.flat_grad.data_ptr() + 4 * o
+        assert torch.equal(p.grad, w)
+    p0 = flat.params[0]
+    p0.data = p0.data.clone()                               # re-homed parameter: the flat master no longer feeds the model
+    with pytest.raises(MetaEncError, match="no longer lives"):
+        flat.check()
+
+
+def test_flatparams_no_decay_layout():
+    m = _model()
+    flat = parallel.FlatParams(m.named_parameters(), no_decay=parallel.no_decay_rule)
+    names = {id(p): n for n, p in m.named_parameters()}
+    order = [names[id(p)] for p in flat.params]
+    head = [n for n in order if n.endswith(".bias") or n == "1.weight"]       # 1 = the LayerNorm
+    assert order[:len(head)] == head and all(n.endswith(".weight") and n != "1.weight" for n in order[len(head):])
+    assert flat.no_decay_numel == flat.offsets[len(head)] and 0 < flat.no_decay_numel < flat.numel
+    m(torch.randn(4, 40)).sum().backward()                  # views still work in the permuted layout
+    assert all(p.grad.data_ptr() == flat.flat_grad.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
+
+
+def test_reducer_accumulation_needs_no_sync():
+    from metatransformer_amd import MetaEncError
+    m = _model()
+    flat = parallel.FlatParams(m.parameters())
+    red = parallel.OverlappedGradReducer(flat, bucket_bytes=4096)
+    x = torch.randn(4, 40)
+    flat.zero_grad()
+    with red.no_sync():
+        m(x).sum().backward()                               # accumulation micro-step: nothing is counted
+    m(x).sum().backward()
+    red.finish()
+    m(x).sum().backward()
+    with pytest.raises(MetaEncError, match="no_sync"):      # a second backward before finish(): caught, not mis-reduced
+        m(x).sum().backward()
+    red.remove()
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without a torchrun environment re-executes itself under torch.distributed.run."""
+    import importlib.util
+    import sys
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

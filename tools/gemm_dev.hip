@@ -2,7 +2,7 @@
 //
 //   python -m metatransformer_amd.build --dev      # builds tools/_build/libmetaenc_dev.so and tools/_build/gemm_dev
 //   tools/_build/gemm_dev [--iters N] [--check] case [case ...]
-//   case  = family:M:N:K:epi[:debug]      family in {auto, g128, g2b, g2w, g3, g3t}; epi 0 bias, 1 gelu(+preact), 2 residual,
+//   case  = family:M:N:K:epi[:debug]      family in {auto, g128, g2b, g2w, g3, g3x, g3p}; epi 0 bias, 1 gelu(+preact), 2 residual,
 //           3 gelu'(aux); debug = GemmDev::debug bits (1 = K-loop only)
 //
 // Every case is checked (all M x N outputs) against a straightforward fp32 kernel on the same bf16 operands, then timed
@@ -98,7 +98,7 @@ static int family_code(const std::string& f) {
     if (f == "g128") return 0;
     if (f == "g2b") return 2;
     if (f == "g2w") return 3;
-    if (f == "g3" || f == "g3t") return 4;      // g3: persistent stream-K; g3t: one tile per workgroup
+    if (f == "g3" || f == "g3x" || f == "g3p") return 4;      // g3: shipped form; g3x: without the tail split; g3p: persistent stream-K
     fprintf(stderr, "unknown family %s\n", f.c_str());
     exit(2);
 }
@@ -127,7 +127,8 @@ int main(int argc, char** argv) {
             return 2;
         }
         me_dev_set("family", family_code(fam));
-        me_dev_set("g3_persistent", strcmp(fam, "g3t") != 0);
+        me_dev_set("g3_persistent", strcmp(fam, "g3p") == 0);
+        me_dev_set("tail_split", strcmp(fam, "g3x") != 0);
         me_dev_set("debug", debug);
         uint16_t *A[NSET], *C[NSET], *P[NSET], *Bw, *rowop = nullptr;
         float *bias, *ref = nullptr, *ref_pre = nullptr;
