@@ -291,11 +291,13 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
     // (K-tile 64, 4-phase ping-pong: 860-1000 TF on the Base shapes against 500-780 for the K-step-32 kernels); fewer
     // tiles or K not a multiple of 128 -> the K-step-32 kernels with their split-K forms; TN (wgrad) -> g2b.
     int fam = ffam > 0 ? ffam : 2;
+    if (ffam < 0 && d->op == ME_GEMM_TN && d->M >= 256 && d->N >= 256 && d->K >= 4096) fam = 4;      // wgrad: g3 (950 vs 640 TF)
     if (ffam < 0 && d->op == ME_GEMM_NT && d->M >= 256 && d->N >= 256) {
         const int64_t t256 = ((d->M + 255) / 256) * ((d->N + 255) / 256);
         fam = (t256 >= 128 && g3_supported(p, d->op)) ? 4 : ((d->N <= 768 && d->K <= 1024) ? 2 : 3);
     }
-    if (fam == 4 && !g3_supported(p, d->op)) fam = d->op == ME_GEMM_NT ? 3 : 2;
+    if (fam == 4 && d->op == ME_GEMM_NT && !g3_supported(p, d->op)) fam = 3;
+    if (fam == 4 && d->op == ME_GEMM_TN && (!g3_tn_supported(p) || d->M < 256 || d->N < 256)) fam = 2;
     if (!g2b_supported(p, d->op)) return pl;
     if (ffam < 0 && (d->M < 128 || d->N < 128)) return pl;       // tiny problems: g128 is enough
     pl.family = fam;
@@ -305,7 +307,23 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
     const int64_t t256 = tm * ((d->N + 255) / 256), t128 = tm * ((d->N + 127) / 128);
     const int nk = (int)(d->K / pl.kstep);
     const int SLOTS = fam == 2 ? 512 : 256;                      // co-resident workgroups on the chip
-    if (d->op == ME_GEMM_TN) {
+    if (d->op == ME_GEMM_TN && fam == 4) {
+        // wgrad on the g3 skeleton (gemm3.hip): 256 x 256 output tiles, the reduction split over the CUs in K-tile pairs
+        if (!g3_tn_supported(p)) return GemmPlan{0, 0, 128, 0, 1, 0, 0, 0, 1, 0};
+        pl.bn = 256; pl.bm = 256; pl.kstep = 64;
+        const int64_t tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+        const int nkt = (int)((d->K + 63) / 64);
+        int s = (int)(256 / tiles);
+        if (s < 1) s = 1;
+        int ktp = (nkt + s - 1) / s;
+        ktp += ktp & 1;
+        if (ktp < 2) ktp = 2;
+        pl.ksteps_per_split = ktp;
+        pl.split_k = (nkt + ktp - 1) / ktp;
+        pl.ws_bytes = (size_t)pl.split_k * (size_t)d->M * (size_t)d->N * sizeof(float);
+        if (d->colsum_a)                  // partial column sums of A: one [M] row per (split, N-tile)
+            pl.ws_bytes += (size_t)pl.split_k * (size_t)((d->N + 255) / 256) * (size_t)d->M * sizeof(float);
+    } else if (d->op == ME_GEMM_TN) {
         pl.bn = fbn ? fbn : ((d->N % 256 == 0 || d->N > 512) ? 256 : 128);
         const int64_t tiles = pl.bn == 256 ? t256 : t128;
         int s = (int)(SLOTS / tiles);
@@ -449,7 +467,7 @@ extern "C" int me_gemm_fuses_colsum(const me_gemm_desc* d) {
     GemmParams p;
     if (!d || d->op != ME_GEMM_TN || fill_params(d, p) != ME_OK) return 0;
     const GemmPlan pl = plan_gemm(d, p);
-    return pl.family == 2 && pl.split_k > 1;
+    return (pl.family == 2 && pl.split_k > 1) || pl.family == 4;
 }
 
 namespace {
@@ -469,9 +487,32 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
     if (rc) return rc;
     GemmPlan pl = plan_gemm(d, p);
     if (d->colsum_a)
-        ME_CHECK_ARG(pl.family == 2 && pl.split_k > 1 && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes,
+        ME_CHECK_ARG(((pl.family == 2 && pl.split_k > 1) || pl.family == 4) && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes,
                      "me_gemm: colsum_a needs the split-K wgrad kernel and its workspace (see me_gemm_fuses_colsum)");
     if (pl.family >= 1) {
+        if (pl.family == 4 && d->op == ME_GEMM_TN) {
+            ME_CHECK_ARG(d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes,
+                         "me_gemm(TN, g3): workspace of me_gemm_workspace_bytes() required");
+            p.tiles_m = (int)((d->M + 255) / 256);
+            p.tiles_n = (int)((d->N + 255) / 256);
+            GemmParams ps = p;
+            ps.C = d->workspace;
+            ps.split_k = pl.split_k;
+            ps.ksteps_per_split = pl.ksteps_per_split;
+            if (d->colsum_a)
+                ps.colsum_ws = reinterpret_cast<float*>(d->workspace) + (size_t)pl.split_k * (size_t)d->M * (size_t)d->N;
+            rc = launch_g3_tn(ps, stream);
+            if (rc) return rc;
+            p.split_k = 1;
+            const int64_t quads = d->M * (d->N / 4);
+            int64_t nb = (quads + 255) / 256;
+            if (nb > 2048) nb = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p,
+                               reinterpret_cast<const float*>(d->workspace), pl.split_k, ps.colsum_ws, pl.split_k * p.tiles_n,
+                               d->colsum_a);
+            ME_CHECK_LAUNCH("me_gemm(g3 tn fold)");
+            return ME_OK;
+        }
         if (pl.family == 4) {
             p.tiles_m = (int)((d->M + 255) / 256);
             p.tiles_n = (int)((d->N + 255) / 256);

@@ -52,7 +52,10 @@ struct G3State {
     bf16x8 ax[4][2], ay[4][2];  // token fragments  [m-tile][k-sub]
     uint32_t src[4][2];         // DMA source byte offsets from the tile's first A / B row: [half-tile type][instruction]
     char* smem;
-    uint32_t ra[2], rb[2];      // fragment read byte offsets inside a half-tile for k-sub 0 / 1 (wave + lane part)
+    uint32_t ra[2], rb[2];      // NT: fragment read byte offsets inside a half-tile for k-sub 0 / 1 (wave + lane part)
+    uint32_t ta[4], tb[2];      // TN: transposing-read byte offsets per m-tile / n-tile of a quadrant (wave + lane part)
+    int kstep_a, kstep_b;       // source bytes per K-tile: NT 128 (along the row); TN 64 rows = 128 * ld
+    float cs[2];                // TN: running column sums of A (the bias gradient) for m-tiles wc and 4 + wc of this wave row
     int wave;
 };
 
@@ -81,16 +84,47 @@ __device__ __forceinline__ G3Src g3_null_src(const GemmParams& p) {
     return s;
 }
 
-// half-tile type J of the K-tile at byte offset koff (= 128 * kt) into buffer buf
-template <int J> __device__ __forceinline__ void g3_issue(const G3State& s, const G3Src& src, int buf, int koff) {
+// half-tile type J of K-tile kt (of the source's own numbering) into buffer buf
+template <int J> __device__ __forceinline__ void g3_issue(const G3State& s, const G3Src& src, int buf, int kt) {
     char* dst = s.smem + buf * G3_BUF + J * G3_HALF + s.wave * 2048;
     const __amdgpu_buffer_rsrc_t r = (J & 1) ? src.a : src.b;
+    const int koff = kt * ((J & 1) ? s.kstep_a : s.kstep_b);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)dst, 16, (int)s.src[J][0], koff, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)(dst + 1024), 16, (int)s.src[J][1], koff, 0, 0);
 }
 
 __device__ __forceinline__ bf16x8 g3_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
+// TN operand tiles lie in LDS as in memory, [64 k][128 columns] (256-byte rows); the MFMA wants 8 consecutive k of ONE
+// column per lane.  ds_read_b64_tr_b16 transposes a 4 (k) x 16 (columns) block per 16-lane group: lane (g = l >> 4,
+// p = l & 15) ADDRESSES 4 columns (4 (p & 3)..) of k-row (p >> 2) and RECEIVES column p's four k-values; two reads
+// (k-rows 4r + 0..3, r = 0, 1) make the fragment of k-group g.  `base` carries everything lane- and tile-dependent
+// (ta / tb); the k-sub (x 32 rows) and r (x 4 rows) parts are immediates.
+// The reads are inline asm: with LDS-DMA in flight hipcc guards every compiler-visible transposing read with
+// s_waitcnt vmcnt(0) (it cannot prove the intrinsic does not alias the DMA's destination), which would drain the stream
+// four times per K-tile.  Their results are consumed only behind the phase's own `s_waitcnt lgkmcnt(0)` + sched_barrier.
+template <int OFF> __device__ __forceinline__ bf16x8 g3_frag_tn(uint32_t addr) {
+    u32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "i"(OFF) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "i"(OFF + 1024) : "memory");
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// sum of a fragment's eight bf16 values (one column of A, eight consecutive k) in fp32
+__device__ __forceinline__ float g3_frag_sum(bf16x8 f) {
+    // v_dot2_f32_bf16 with a vector of ones: two elements per instruction, fp32 accumulation
+    const bf16x2 one = {(bf16_t)1.0f, (bf16_t)1.0f};
+    float a = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{f[2 * e], f[2 * e + 1]}, one, a, false);
+    return a;
+}
+// bias gradient on the side (wgrad): the column sums of A over this workgroup's K-range come from the A fragments the
+// wave already holds -- a few VALU additions in the LOAD part of a phase, no extra pass over dY and no extra MFMA.  The
+// four wave columns of a wave row hold the same A fragments: wave column wc takes m-tiles wc (A-X) and 4 + wc (A-Y).
+// The index is wave-uniform; a scalar if-chain on the state's own arrays keeps every fragment index static (an array
+// passed by reference, or indexed at run time, is demoted to scratch).
 #define G3_MMA(MT, NT, AF, BF)                                                                                   \
     s.acc[MT][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(NT) & 1][0], AF[(MT) & 3][0], s.acc[MT][NT], 0, 0, 0); \
     s.acc[MT][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(NT) & 1][1], AF[(MT) & 3][1], s.acc[MT][NT], 0, 0, 0);
@@ -100,37 +134,41 @@ __device__ __forceinline__ bf16x8 g3_frag(const char* p) { return *reinterpret_c
 // workgroup's stream the source is a null descriptor (zero records: the DMA writes zeros into a buffer nobody reads any
 // more and touches no memory), so the issue pattern, and with it the counted wait, never changes -- and the 128
 // accumulators never meet a control-flow join inside the K-loop.
-template <int BUF, int P>
-__device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1) {
+template <int BUF, int P, bool TN = false>
+__device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1, bool cs_on = false) {
     const char* buf = s.smem + BUF * G3_BUF;
-    if (P == 0) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) s.bx[nt][k] = g3_frag(buf + 0 * G3_HALF + nt * 2048 + s.rb[k]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) s.ax[mt][k] = g3_frag(buf + 1 * G3_HALF + mt * 2048 + s.ra[k]);
-    } else if (P == 1) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) s.by[nt][k] = g3_frag(buf + 2 * G3_HALF + nt * 2048 + s.rb[k]);
-    } else if (P == 2) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) s.ay[mt][k] = g3_frag(buf + 3 * G3_HALF + mt * 2048 + s.ra[k]);
+    if (TN && (P == 1 || P == 3) && cs_on) {      // (wave-uniform) fragments read one / two phases ago, waited for in that phase
+        const int wcol = s.wave & 3;
+        if (wcol == 0) s.cs[P >> 1] += g3_frag_sum((P == 1 ? s.ax : s.ay)[0][0]) + g3_frag_sum((P == 1 ? s.ax : s.ay)[0][1]);
+        else if (wcol == 1) s.cs[P >> 1] += g3_frag_sum((P == 1 ? s.ax : s.ay)[1][0]) + g3_frag_sum((P == 1 ? s.ax : s.ay)[1][1]);
+        else if (wcol == 2) s.cs[P >> 1] += g3_frag_sum((P == 1 ? s.ax : s.ay)[2][0]) + g3_frag_sum((P == 1 ? s.ax : s.ay)[2][1]);
+        else s.cs[P >> 1] += g3_frag_sum((P == 1 ? s.ax : s.ay)[3][0]) + g3_frag_sum((P == 1 ? s.ax : s.ay)[3][1]);
     }
+    // fragment (tile t, k-sub k) of half-tile slot SL: NT one 16-byte read, TN two transposing 8-byte reads
+    const uint32_t lbuf = (uint32_t)(uintptr_t)s.smem + BUF * G3_BUF;      // (TN) 32-bit LDS address of this buffer
+#define G3_RD_B(SL, t, k) (TN ? g3_frag_tn<(SL) * G3_HALF + (k) * 8192>(lbuf + s.tb[t]) : g3_frag(buf + (SL) * G3_HALF + (t) * 2048 + s.rb[k]))
+#define G3_RD_A(SL, t, k) (TN ? g3_frag_tn<(SL) * G3_HALF + (k) * 8192>(lbuf + s.ta[t]) : g3_frag(buf + (SL) * G3_HALF + (t) * 2048 + s.ra[k]))
+    if (P == 0) {
+        s.bx[0][0] = G3_RD_B(0, 0, 0); s.bx[0][1] = G3_RD_B(0, 0, 1); s.bx[1][0] = G3_RD_B(0, 1, 0); s.bx[1][1] = G3_RD_B(0, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        s.ax[0][0] = G3_RD_A(1, 0, 0); s.ax[0][1] = G3_RD_A(1, 0, 1); s.ax[1][0] = G3_RD_A(1, 1, 0); s.ax[1][1] = G3_RD_A(1, 1, 1);
+        s.ax[2][0] = G3_RD_A(1, 2, 0); s.ax[2][1] = G3_RD_A(1, 2, 1); s.ax[3][0] = G3_RD_A(1, 3, 0); s.ax[3][1] = G3_RD_A(1, 3, 1);
+    } else if (P == 1) {
+        s.by[0][0] = G3_RD_B(2, 0, 0); s.by[0][1] = G3_RD_B(2, 0, 1); s.by[1][0] = G3_RD_B(2, 1, 0); s.by[1][1] = G3_RD_B(2, 1, 1);
+    } else if (P == 2) {
+        s.ay[0][0] = G3_RD_A(3, 0, 0); s.ay[0][1] = G3_RD_A(3, 0, 1); s.ay[1][0] = G3_RD_A(3, 1, 0); s.ay[1][1] = G3_RD_A(3, 1, 1);
+        s.ay[2][0] = G3_RD_A(3, 2, 0); s.ay[2][1] = G3_RD_A(3, 2, 1); s.ay[3][0] = G3_RD_A(3, 3, 0); s.ay[3][1] = G3_RD_A(3, 3, 1);
+    }
+#undef G3_RD_A
+#undef G3_RD_B
     __builtin_amdgcn_sched_barrier(0);
     if (P == 0) g3_issue<3>(s, s0, BUF ^ 1, k0);
     if (P == 1) g3_issue<0>(s, s1, BUF, k1);
     if (P == 2) g3_issue<1>(s, s1, BUF, k1);
     if (P == 3) g3_issue<2>(s, s1, BUF, k1);
     __builtin_amdgcn_sched_barrier(0);
-    if (P == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    // (the B-X reads are issued first: NT 4 of 12, TN 8 of 24 DS operations -- retire exactly those before the barrier)
+    if (P == 0) { if (TN) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); }
     if (P == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -154,12 +192,12 @@ __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, co
     __builtin_amdgcn_s_barrier();
 }
 
-template <int BUF>
-__device__ __forceinline__ void g3_ktile(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1) {
-    g3_phase<BUF, 0>(s, s0, k0, s1, k1);
-    g3_phase<BUF, 1>(s, s0, k0, s1, k1);
-    g3_phase<BUF, 2>(s, s0, k0, s1, k1);
-    g3_phase<BUF, 3>(s, s0, k0, s1, k1);
+template <int BUF, bool TN = false>
+__device__ __forceinline__ void g3_ktile(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1, bool cs_on = false) {
+    g3_phase<BUF, 0, TN>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 1, TN>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 2, TN>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 3, TN>(s, s0, k0, s1, k1, cs_on);
 }
 
 __device__ __forceinline__ void g3_init_lane(G3State& s, const GemmParams& p, char* smem, int wave, int lane) {
@@ -182,6 +220,55 @@ __device__ __forceinline__ void g3_init_lane(G3State& s, const GemmParams& p, ch
     const uint32_t lp = (l15 >> 3) * 1024 + (lane & 7) * 128 + ((((lane >> 4) ^ (l15 >> 1)) & 7) << 4);
     s.ra[0] = wr * 8192 + lp; s.ra[1] = s.ra[0] ^ 64;
     s.rb[0] = wc * 4096 + lp; s.rb[1] = s.rb[0] ^ 64;
+    s.kstep_a = s.kstep_b = G3_BK * 2;
+}
+
+// ---- TN (wgrad: C[M, N] = A[K, M]^T B[K, N], reduction index = the ROW of both operands).
+// A half-tile is 64 k-rows x 128 columns (256-byte rows): A-X = the columns wave rows 0 / 1 need for their quadrant row 0
+// (tile columns 0..63 and 128..191 -> chunks 0..7 / 8..15), A-Y the other 64 + 64; B-X = the four wave columns' first 32
+// (tile columns wc*64 + 0..31 -> chunks 4 wc .. 4 wc + 3), B-Y the second 32.  16-byte chunk c of k-row t sits in slot
+// c ^ 4 (t & 3) ^ 2 ((t >> 3) & 1): the 32 lanes a transposing read services together touch k-rows (p >> 2) + 8 (g & 1),
+// which the permutation spreads over all eight 32-byte sections of the 256-byte bank row.
+__device__ __forceinline__ int g3_tn_swz(int t) { return (4 * (t & 3)) ^ (2 * ((t >> 3) & 1)); }
+__device__ __forceinline__ void g3_init_lane_tn(G3State& s, const GemmParams& p, char* smem, int wave, int lane) {
+    s.smem = smem;
+    s.wave = wave;
+    const int wr = wave >> 2, wc = wave & 3;
+    // DMA sources: instruction i of this wave covers k-rows 8*wave + 4*i + (lane >> 4) of a half-tile, slot lane & 15
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = 8 * wave + 4 * i + (lane >> 4);
+        const int c = (lane & 15) ^ g3_tn_swz(t);
+        const int a_col = (c >> 3) * 128 + (c & 7) * 8, b_col = (c >> 2) * 64 + (c & 3) * 8;
+        s.src[0][i] = (uint32_t)(t * p.ldb * 2 + b_col * 2);
+        s.src[1][i] = (uint32_t)(t * p.lda * 2 + a_col * 2);
+        s.src[2][i] = (uint32_t)(t * p.ldb * 2 + (b_col + 32) * 2);
+        s.src[3][i] = (uint32_t)(t * p.lda * 2 + (a_col + 64) * 2);
+    }
+    // transposing reads: lane (g, pp) addresses k-row 8 g + (pp >> 2) (+ 4 r + 32 ksub as immediates), columns cb + 4 (pp & 3)
+    const int g = lane >> 4, pp = lane & 15;
+    const int trow = 8 * g + (pp >> 2);
+    auto base = [&](int cb) {
+        const int col = cb + 4 * (pp & 3);
+        return (uint32_t)(trow * 256 + ((((col >> 3) ^ g3_tn_swz(trow)) & 15) << 4) + ((col & 7) << 1));
+    };
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) s.ta[mt] = base(wr * 64 + mt * 16);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) s.tb[nt] = base(wc * 32 + nt * 16);
+    s.kstep_a = (int)(G3_BK * p.lda * 2);
+    s.kstep_b = (int)(G3_BK * p.ldb * 2);
+}
+// operand columns [m0, ..) of A and [n0, ..) of B, all K rows: rows past K read as zeros (bounds check on the end of the
+// matrix); columns past the edge of an edge tile read the next row's data -- they only feed outputs that are never stored
+__device__ __forceinline__ G3Src g3_make_src_tn(const GemmParams& p, int tm, int tn) {
+    const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
+    G3Src s;
+    s.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.A)) + m0 * 2, 0,
+                                            (int)(p.K * p.lda * 2 - m0 * 2), 0x00020000);
+    s.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.B)) + n0 * 2, 0,
+                                            (int)(p.K * p.ldb * 2 - n0 * 2), 0x00020000);
+    return s;
 }
 __device__ __forceinline__ void g3_zero(G3State& s) {
 #pragma unroll
@@ -412,9 +499,9 @@ void gemm_g3p_kernel(const GemmParams p, const G3Plan pl, float* __restrict__ sl
     };
     // prologue: half-tiles 0..6 of the stream (first K-tile complete, second without A-Y)
     {
-        const int k = wc.kp * 256;
+        const int k = wc.kp * 2;
         g3_issue<0>(s, cur, 0, k); g3_issue<1>(s, cur, 0, k); g3_issue<2>(s, cur, 0, k); g3_issue<3>(s, cur, 0, k);
-        g3_issue<0>(s, cur, 1, k + 128); g3_issue<1>(s, cur, 1, k + 128); g3_issue<2>(s, cur, 1, k + 128);
+        g3_issue<0>(s, cur, 1, k + 1); g3_issue<1>(s, cur, 1, k + 1); g3_issue<2>(s, cur, 1, k + 1);
     }
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -422,9 +509,9 @@ void gemm_g3p_kernel(const GemmParams p, const G3Plan pl, float* __restrict__ sl
     advance_next();                               // nxt / wn = the second pair of the stream
 
     while (wc.stage != 3) {
-        const int kc = wc.kp * 256, kn = wn.kp * 256;
-        g3_ktile<0>(s, cur, kc + 128, nxt, kn);
-        g3_ktile<1>(s, nxt, kn, nxt, kn + 128);
+        const int kc = wc.kp * 2, kn = wn.kp * 2;
+        g3_ktile<0>(s, cur, kc + 1, nxt, kn);
+        g3_ktile<1>(s, nxt, kn, nxt, kn + 1);
         if (wc.kp + 1 == wc.seg_end) {
             // ---- seam: this workgroup's share [seg_begin, seg_end) of tile wc.tile is accumulated
             const int tm = __builtin_amdgcn_readfirstlane(wc.tile / p.tiles_n), tn = wc.tile - tm * p.tiles_n;
@@ -553,11 +640,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         kt0 = part * p.g3_ktp;
         kt1 = kt0 + p.g3_ktp < nkt ? kt0 + p.g3_ktp : nkt;
     }
-    {
-        const int k = kt0 * 128;
-        g3_issue<0>(s, src, 0, k); g3_issue<1>(s, src, 0, k); g3_issue<2>(s, src, 0, k); g3_issue<3>(s, src, 0, k);
-        g3_issue<0>(s, src, 1, k + 128); g3_issue<1>(s, src, 1, k + 128); g3_issue<2>(s, src, 1, k + 128);
-    }
+    g3_issue<0>(s, src, 0, kt0); g3_issue<1>(s, src, 0, kt0); g3_issue<2>(s, src, 0, kt0); g3_issue<3>(s, src, 0, kt0);
+    g3_issue<0>(s, src, 1, kt0 + 1); g3_issue<1>(s, src, 1, kt0 + 1); g3_issue<2>(s, src, 1, kt0 + 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -565,10 +649,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // past the end of the K-range the source is a null descriptor (see g3_phase)
     const G3Src null = g3_null_src(p);
     for (int kt = kt0; kt < kt1 - 2; kt += 2) {
-        g3_ktile<0>(s, src, (kt + 1) * 128, src, (kt + 2) * 128);
-        g3_ktile<1>(s, src, (kt + 2) * 128, src, (kt + 3) * 128);
+        g3_ktile<0>(s, src, kt + 1, src, kt + 2);
+        g3_ktile<1>(s, src, kt + 2, src, kt + 3);
     }
-    g3_ktile<0>(s, src, (kt1 - 1) * 128, null, 0);
+    g3_ktile<0>(s, src, kt1 - 1, null, 0);
     g3_ktile<1>(s, null, 0, null, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wr == 0) __builtin_amdgcn_s_barrier();
@@ -590,6 +674,87 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
     g3_epilogue<EPI>(p, s, m0, n0, lane);
+}
+
+// ---- wgrad: one (output tile, K-range) per workgroup; raw fp32 partial sums into slab blockIdx.y ... the deterministic
+// fold (splitk_reduce_kernel, gemm.hip) sums the slabs and applies the epilogue.  Work ids are split-major (id = split *
+// tiles + tile): the workgroups an XCD runs together read the SAME rows of dY and X at the same time, so every operand
+// row comes out of HBM once and is shared through that XCD's L2.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g3tn_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int split = __builtin_amdgcn_readfirstlane(wgid / tiles);
+    const int tile = wgid - split * tiles;
+    const int tm = __builtin_amdgcn_readfirstlane(tile / p.tiles_n), tn = tile - tm * p.tiles_n;
+    const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
+
+    G3State s;
+    g3_init_lane_tn(s, p, smem, wave, lane);
+    g3_zero(s);
+    const G3Src src = g3_make_src_tn(p, tm, tn);
+    const int kt0 = split * p.ksteps_per_split, kt1 = kt0 + p.ksteps_per_split;       // (an even count; tiles past K read zeros)
+
+    g3_issue<0>(s, src, 0, kt0); g3_issue<1>(s, src, 0, kt0); g3_issue<2>(s, src, 0, kt0); g3_issue<3>(s, src, 0, kt0);
+    g3_issue<0>(s, src, 1, kt0 + 1); g3_issue<1>(s, src, 1, kt0 + 1); g3_issue<2>(s, src, 1, kt0 + 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    const G3Src null = g3_null_src(p);
+    // bias gradient: the N-tiles of one (M-tile, split) stage the same A rows -- they share the column sums pair by pair of
+    // K-tiles, round-robin (cs_turn = pairs until this workgroup's next turn)
+    const bool do_cs = p.colsum_ws != nullptr;
+    s.cs[0] = s.cs[1] = 0.f;
+    int cs_turn = do_cs ? tn : -1;
+    auto my_turn = [&]() {
+        if (!do_cs) return false;
+        const bool mine = cs_turn == 0;
+        cs_turn = mine ? p.tiles_n - 1 : cs_turn - 1;
+        return mine;
+    };
+    for (int kt = kt0; kt < kt1 - 2; kt += 2) {
+        const bool c = my_turn();
+        g3_ktile<0, true>(s, src, kt + 1, src, kt + 2, c);
+        g3_ktile<1, true>(s, src, kt + 2, src, kt + 3, c);
+    }
+    {
+        const bool c = my_turn();
+        g3_ktile<0, true>(s, src, kt1 - 1, null, 0, c);
+        g3_ktile<1, true>(s, null, 0, null, 0, c);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    if (do_cs) {
+        // lanes l, l+16, l+32, l+48 hold the four k-groups of column l & 15: fold, then one row of partial sums per
+        // (split, N-tile): [split * tiles_n + tn][M]
+        float c0 = s.cs[0], c1 = s.cs[1];
+        c0 += __shfl_xor(c0, 16, 64); c0 += __shfl_xor(c0, 32, 64);
+        c1 += __shfl_xor(c1, 16, 64); c1 += __shfl_xor(c1, 32, 64);
+        if (lane < 16) {
+            float* row = p.colsum_ws + ((int64_t)split * p.tiles_n + tn) * p.M;
+            const int wcol = wave & 3;
+            const int64_t ma = m0 + wr * 128 + wcol * 16 + lane, mb = ma + 64;
+            if (ma < p.M) row[ma] = c0;
+            if (mb < p.M) row[mb] = c1;
+        }
+    }
+#ifdef ME_DEV
+    if (p.debug & 1) {
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) keep += s.acc[i][j][0] + s.acc[i][j][1] + s.acc[i][j][2] + s.acc[i][j][3];
+        if (keep == 1.2345e-30f) reinterpret_cast<float*>(p.C)[0] = keep;
+        return;
+    }
+#endif
+    g3_epilogue<5>(p, s, m0, n0, lane, reinterpret_cast<float*>(p.C) + (int64_t)split * p.M * p.N, 0);
 }
 
 int g3_cus() {
@@ -647,6 +812,23 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
 }
 
 }  // namespace
+
+// TN: p.split_k slabs of p.ksteps_per_split K-tiles (of 64) each into p.C = [split_k][M][N] fp32
+int launch_g3_tn(const GemmParams& p, hipStream_t stream) {
+    static OncePerDevice once;
+    if (once.need())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+    const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+    hipLaunchKernelGGL(gemm_g3tn_kernel, dim3((unsigned)nwg), dim3(512), G3_LDS, stream, p);
+    ME_CHECK_LAUNCH("me_gemm(g3 tn)");
+    return ME_OK;
+}
+
+bool g3_tn_supported(const GemmParams& p) {
+    // 16-byte chunks of 8 columns; lane offsets and per-K-tile steps are 32-bit; the bounds check spans the whole matrix
+    return p.M % 8 == 0 && p.N % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.K * p.lda * 2 < (1ll << 31) &&
+           p.K * p.ldb * 2 < (1ll << 31);
+}
 
 bool g3_supported(const GemmParams& p, int op) {
     if (op != ME_GEMM_NT) return false;

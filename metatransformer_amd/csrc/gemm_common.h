@@ -130,6 +130,8 @@ bool g2b_supported(const GemmParams& p, int op);
 int launch_g3(const GemmParams& p, int epi, void* ws, hipStream_t stream);      // ws = nullptr: one tile per workgroup
 bool g3_supported(const GemmParams& p, int op);
 size_t g3_workspace_bytes();
+int launch_g3_tn(const GemmParams& p, hipStream_t stream);      // p.split_k slabs into p.C, p.ksteps_per_split K-tiles of 64 each
+bool g3_tn_supported(const GemmParams& p);
 
 // Dev switches for A/B runs (tools/gemm_dev): they exist only in the dev build of the library (-DME_DEV, built by
 // `python -m metatransformer_amd.build --dev` into tools/_build/); the shipped library has no knobs and reads no

@@ -4,6 +4,7 @@
 //   tools/_build/gemm_dev [--iters N] [--check] case [case ...]
 //   case  = family:M:N:K:epi[:debug]      family in {auto, g128, g2b, g2w, g3, g3x, g3p}; epi 0 bias, 1 gelu(+preact), 2 residual,
 //           3 gelu'(aux); debug = GemmDev::debug bits (1 = K-loop only)
+//           tn-family:M:N:K               wgrad form C[M, N] = A[K, M]^T B[K, N] (fp32 output), family in {auto, g2b, g3}
 //
 // Every case is checked (all M x N outputs) against a straightforward fp32 kernel on the same bf16 operands, then timed
 // over rotating operand / output sets (3 copies: the 256 MiB Infinity Cache must not hold them -- as inside the model).
@@ -79,6 +80,25 @@ __global__ void ref_kernel(const uint16_t* A, const uint16_t* B, const float* bi
     out[m * N + n] = v;
 }
 
+__global__ void ref_tn_kernel(const uint16_t* A, const uint16_t* B, int64_t M, int64_t N, int64_t K, float* out) {
+    const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int64_t k = 0; k < K; ++k) acc = fmaf(bf2f(A[k * M + m]), bf2f(B[k * N + n]), acc);
+    out[m * N + n] = acc;
+}
+__global__ void cmp_f32_kernel(const float* got, const float* ref, size_t n, float atol, float rtol, unsigned long long* nbad, float* maxerr) {
+    float me = 0.f;
+    unsigned long long bad = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float e = fabsf(got[i] - ref[i]);
+        if (!(e <= atol + rtol * fabsf(ref[i]))) ++bad;
+        me = fmaxf(me, e / (1.0f + fabsf(ref[i])));
+    }
+    if (bad) atomicAdd(nbad, bad);
+    atomicMax(reinterpret_cast<unsigned int*>(maxerr), __float_as_uint(me));
+}
+
 __global__ void cmp_kernel(const uint16_t* got, const float* ref, size_t n, float atol, float rtol, unsigned long long* nbad,
                            float* maxerr) {
     float me = 0.f;
@@ -118,7 +138,97 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (const std::string& c : cases) {
+    for (const std::string& c0 : cases) {
+        if (c0.rfind("tn-", 0) == 0) {
+            // ---- wgrad-shaped case
+            const std::string c = c0.substr(3);
+            char fam[32];
+            long long M, N, K;
+            int debug = 0;
+            if (sscanf(c.c_str(), "%31[^:]:%lld:%lld:%lld:%d", fam, &M, &N, &K, &debug) < 4) { fprintf(stderr, "bad case %s\n", c0.c_str()); return 2; }
+            me_dev_set("family", family_code(fam));
+            me_dev_set("debug", debug);
+            uint16_t *A[NSET], *B[NSET];
+            float* C[NSET];
+            for (int s = 0; s < NSET; ++s) {
+                CK(hipMalloc(&A[s], (size_t)K * M * 2)); CK(hipMalloc(&B[s], (size_t)K * N * 2)); CK(hipMalloc(&C[s], (size_t)M * N * 4));
+                fill_kernel<<<2048, 256, 0, st>>>(A[s], (size_t)K * M, 31, 0.05f);
+                fill_kernel<<<2048, 256, 0, st>>>(B[s], (size_t)K * N, 77, 1.0f);
+                CK(hipMemsetAsync(C[s], 0xff, (size_t)M * N * 4, st));
+            }
+            me_gemm_desc d;
+            memset(&d, 0, sizeof(d));
+            d.op = ME_GEMM_TN; d.ab_dtype = ME_BF16; d.M = M; d.N = N; d.K = K;
+            d.lda = M; d.ldb = N; d.ldc = N; d.c_dtype = ME_F32; d.alpha = 1.0f; d.beta = 0.0f;
+            d.A = A[0]; d.B = B[0]; d.C = C[0];
+            float* csum = nullptr;
+            CK(hipMalloc(&csum, (size_t)M * 4));
+            if (me_gemm_fuses_colsum(&d)) d.colsum_a = csum;
+            const size_t wsb = me_gemm_workspace_bytes(&d);
+            void* ws = nullptr;
+            if (wsb) CK(hipMalloc(&ws, wsb));
+            d.workspace = ws; d.workspace_bytes = (int64_t)wsb;
+            auto run = [&](int s) {
+                d.A = A[s]; d.B = B[s]; d.C = C[s];
+                const int rc = me_gemm(&d, st);
+                if (rc) { fprintf(stderr, "me_gemm failed (%d): %s\n", rc, me_last_error()); exit(3); }
+            };
+            for (int s = 0; s < NSET; ++s) run(s);
+            CK(hipStreamSynchronize(st));
+            std::string verdict = "unchecked";
+            if (check && !(debug & 1)) {
+                float* ref;
+                CK(hipMalloc(&ref, (size_t)M * N * 4));
+                ref_tn_kernel<<<dim3((unsigned)((N + 255) / 256), (unsigned)M), 256, 0, st>>>(A[0], B[0], M, N, K, ref);
+                unsigned long long* nbad; float* maxerr;
+                CK(hipMalloc(&nbad, 8)); CK(hipMalloc(&maxerr, 4));
+                verdict.clear();
+                for (int s = 0; s < NSET; s += NSET - 1) {
+                    CK(hipMemsetAsync(nbad, 0, 8, st)); CK(hipMemsetAsync(maxerr, 0, 4, st));
+                    // fp32 accumulation over K in a different order: |err| ~ 1e-6 * sqrt(K) * |terms|
+                    cmp_f32_kernel<<<1024, 256, 0, st>>>(C[s], ref, (size_t)M * N, 2e-2f, 2e-3f, nbad, maxerr);
+                    unsigned long long hb; float hm;
+                    CK(hipMemcpyAsync(&hb, nbad, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hm, maxerr, 4, hipMemcpyDeviceToHost, st));
+                    CK(hipStreamSynchronize(st));
+                    char buf[128];
+                    snprintf(buf, sizeof(buf), "%s[set%d bad=%llu maxerr=%.3g]%s", verdict.empty() ? "" : " ", s, hb, hm, hb ? " MISMATCH" : "");
+                    verdict += buf;
+                }
+                CK(hipFree(ref)); CK(hipFree(nbad)); CK(hipFree(maxerr));
+                if (d.colsum_a) {           // the fused bias gradient: column sums of A, against a host sum of set 0
+                    run(0);
+                    std::vector<uint16_t> ha((size_t)K * M);
+                    std::vector<float> hc(M);
+                    CK(hipMemcpyAsync(ha.data(), A[0], ha.size() * 2, hipMemcpyDeviceToHost, st));
+                    CK(hipMemcpyAsync(hc.data(), csum, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+                    CK(hipStreamSynchronize(st));
+                    double worst = 0;
+                    for (long long m = 0; m < M; ++m) {
+                        double acc = 0;
+                        for (long long k = 0; k < K; ++k) { uint32_t u = (uint32_t)ha[(size_t)k * M + m] << 16; float f; memcpy(&f, &u, 4); acc += f; }
+                        worst = fmax(worst, fabs(acc - hc[m]) / (1.0 + fabs(acc)));
+                    }
+                    char buf[64];
+                    snprintf(buf, sizeof(buf), " [colsum maxerr=%.3g%s]", worst, worst < 2e-3 ? "" : " MISMATCH");
+                    verdict += buf;
+                }
+            }
+            for (int i = 0; i < 3; ++i) run(i % NSET);
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) run(i % NSET);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = 1e3 * ms / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+            CK(hipFree(csum));
+            printf("%-34s %8.1f us  %7.1f TF/s  %s\n", c0.c_str(), us, tf, verdict.c_str());
+            fflush(stdout);
+            for (int s = 0; s < NSET; ++s) { CK(hipFree(A[s])); CK(hipFree(B[s])); CK(hipFree(C[s])); }
+            if (ws) CK(hipFree(ws));
+            continue;
+        }
+        const std::string& c = c0;
         char fam[32];
         long long M, N, K;
         int epi = 0, debug = 0;
