@@ -216,7 +216,7 @@ def main():
         ms = sum(t for *_, t in nt)
         ach = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma",
-                "kernel": "gemm_g3_kernel<EPI> (bf16 NT MFMA GEMM, 256x256x64 tiles: every forward + dgrad launch)",
+                "kernel": "gemm_g3r_kernel<EPI> (bf16 NT MFMA GEMM, resident 256x256x64-tile workgroups: every forward + dgrad launch)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": None,
                 "traffic_note": "HBM bytes per launch are PMC-only (rocprofv3 --pmc, separate passes): see profiles/r02_pmc_*.json",
@@ -227,7 +227,7 @@ def main():
         if with_wgrad and tn:
             f2 = sum(2.0 * m * n * k for m, n, k, _ in tn)
             ms2 = sum(t for *_, t in tn)
-            roof["wgrad_kernel"] = {"kernel": "gemm_g2_kernel<128,256,TN,5> (wgrad, split-K)",
+            roof["wgrad_kernel"] = {"kernel": "gemm_g3tn_kernel + splitk_reduce_kernel (wgrad dW = dY^T X with the bias-gradient column sums fused; 256x256x64 tiles, split-K folded in fixed order)",
                                     "achieved": round(f2 / (ms2 * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                                     "avg_launch_us": round(1e3 * ms2 / len(tn), 2),
                                     "share_of_step_time": round(ms2 * 1e-3 / nsteps / wall_s, 4)}

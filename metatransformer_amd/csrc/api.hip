@@ -84,7 +84,7 @@ extern "C" int me_gemm_profile_read(me_gemm_profile_rec* out, int max) {
 // does not exist in the shipped library.
 #ifdef ME_DEV
 #include "gemm_common.h"
-GemmDev g_gemm_dev = {-1, 0, 0, 1, 0};
+GemmDev g_gemm_dev = {-1, 0, 0, 1, 1};
 extern "C" int me_dev_set(const char* key, int value) {
     if (!strcmp(key, "family")) g_gemm_dev.family = value;
     else if (!strcmp(key, "bn")) g_gemm_dev.bn = value;
@@ -94,4 +94,6 @@ extern "C" int me_dev_set(const char* key, int value) {
     else return ME_ERR_ARG;
     return ME_OK;
 }
+void* g_gemm_dev_trace = nullptr;
+extern "C" int me_dev_set_trace(void* buf) { g_gemm_dev_trace = buf; return ME_OK; }
 #endif

@@ -370,7 +370,7 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
 #ifdef ME_DEV
             // dev build: the persistent stream-K form (its scratch = one fp32 tile per CU)
             const int64_t tiles = tm * ((d->N + 255) / 256);
-            if (tiles >= 128 && dev.g3_persistent) { pl.ws_bytes = g3_workspace_bytes(); pl.tail_rows = 0; }
+            if (tiles >= 128 && dev.g3_persistent == 2) { pl.ws_bytes = g3_workspace_bytes(); pl.tail_rows = 0; }
 #endif
             return pl;
         }

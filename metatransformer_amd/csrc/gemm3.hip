@@ -33,6 +33,7 @@
 //        >= 2 barriers earlier for both wave rows).  B-X is read in phase i itself: its four reads are issued first
 //        and retired with lgkmcnt(8) before that phase's first barrier, which the issuing wave row passes later.
 #include "gemm_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -52,7 +53,7 @@ struct G3State {
     bf16x8 ax[4][2], ay[4][2];  // token fragments  [m-tile][k-sub]
     uint32_t src[4][2];         // DMA source byte offsets from the tile's first A / B row: [half-tile type][instruction]
     char* smem;
-    uint32_t ra[2], rb[2];      // NT: fragment read byte offsets inside a half-tile for k-sub 0 / 1 (wave + lane part)
+    uint32_t ra[2][2], rb[2][2];// NT: fragment read LDS addresses [buffer][k-sub]: buffer + wave / lane part inside a half-tile
     uint32_t ta[4], tb[2];      // TN: transposing-read byte offsets per m-tile / n-tile of a quadrant (wave + lane part)
     int kstep_a, kstep_b;       // source bytes per K-tile: NT 128 (along the row); TN 64 rows = 128 * ld
     float cs[2];                // TN: running column sums of A (the bias gradient) for m-tiles wc and 4 + wc of this wave row
@@ -93,7 +94,15 @@ template <int J> __device__ __forceinline__ void g3_issue(const G3State& s, cons
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)(dst + 1024), 16, (int)s.src[J][1], koff, 0, 0);
 }
 
-__device__ __forceinline__ bf16x8 g3_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// NT fragment: one 16-byte read at (lane part + buffer) + an IMMEDIATE (half-tile slot, tile).  Inline asm for the same
+// reason as the transposing reads below, and so that the address stays "one register + constant": left to itself hipcc
+// materialises a separate address register for most of the 24 (slot, tile) combinations of the second buffer (its
+// offsets exceed the 16-bit immediate when counted from the start of LDS), which the resident kernel cannot afford.
+template <int OFF> __device__ __forceinline__ bf16x8 g3_frag(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+    return __builtin_bit_cast(bf16x8, v);
+}
 
 // TN operand tiles lie in LDS as in memory, [64 k][128 columns] (256-byte rows); the MFMA wants 8 consecutive k of ONE
 // column per lane.  ds_read_b64_tr_b16 transposes a 4 (k) x 16 (columns) block per 16-lane group: lane (g = l >> 4,
@@ -134,9 +143,11 @@ __device__ __forceinline__ float g3_frag_sum(bf16x8 f) {
 // workgroup's stream the source is a null descriptor (zero records: the DMA writes zeros into a buffer nobody reads any
 // more and touches no memory), so the issue pattern, and with it the counted wait, never changes -- and the 128
 // accumulators never meet a control-flow join inside the K-loop.
-template <int BUF, int P, bool TN = false>
+// SEAM > 0: the first K-tile after an epilogue of the resident kernel (gemm_g3r_kernel): the A-Y half-tile phase 0 would
+// issue went out BEFORE the epilogue, and the counted wait of phase 3 lets the epilogue's SEAM memory operations (which
+// sit between that half-tile and this K-tile's own three in the in-order queue) stay in flight.
+template <int BUF, int P, bool TN = false, int SEAM = 0>
 __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1, bool cs_on = false) {
-    const char* buf = s.smem + BUF * G3_BUF;
     if (TN && (P == 1 || P == 3) && cs_on) {      // (wave-uniform) fragments read one / two phases ago, waited for in that phase
         const int wcol = s.wave & 3;
         if (wcol == 0) s.cs[P >> 1] += g3_frag_sum((P == 1 ? s.ax : s.ay)[0][0]) + g3_frag_sum((P == 1 ? s.ax : s.ay)[0][1]);
@@ -146,8 +157,8 @@ __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, co
     }
     // fragment (tile t, k-sub k) of half-tile slot SL: NT one 16-byte read, TN two transposing 8-byte reads
     const uint32_t lbuf = (uint32_t)(uintptr_t)s.smem + BUF * G3_BUF;      // (TN) 32-bit LDS address of this buffer
-#define G3_RD_B(SL, t, k) (TN ? g3_frag_tn<(SL) * G3_HALF + (k) * 8192>(lbuf + s.tb[t]) : g3_frag(buf + (SL) * G3_HALF + (t) * 2048 + s.rb[k]))
-#define G3_RD_A(SL, t, k) (TN ? g3_frag_tn<(SL) * G3_HALF + (k) * 8192>(lbuf + s.ta[t]) : g3_frag(buf + (SL) * G3_HALF + (t) * 2048 + s.ra[k]))
+#define G3_RD_B(SL, t, k) (TN ? g3_frag_tn<(SL) * G3_HALF + (k) * 8192>(lbuf + s.tb[t]) : g3_frag<(SL) * G3_HALF + (t) * 2048>(s.rb[BUF][k]))
+#define G3_RD_A(SL, t, k) (TN ? g3_frag_tn<(SL) * G3_HALF + (k) * 8192>(lbuf + s.ta[t]) : g3_frag<(SL) * G3_HALF + (t) * 2048>(s.ra[BUF][k]))
     if (P == 0) {
         s.bx[0][0] = G3_RD_B(0, 0, 0); s.bx[0][1] = G3_RD_B(0, 0, 1); s.bx[1][0] = G3_RD_B(0, 1, 0); s.bx[1][1] = G3_RD_B(0, 1, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -162,14 +173,14 @@ __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, co
 #undef G3_RD_A
 #undef G3_RD_B
     __builtin_amdgcn_sched_barrier(0);
-    if (P == 0) g3_issue<3>(s, s0, BUF ^ 1, k0);
+    if (P == 0 && SEAM == 0) g3_issue<3>(s, s0, BUF ^ 1, k0);
     if (P == 1) g3_issue<0>(s, s1, BUF, k1);
     if (P == 2) g3_issue<1>(s, s1, BUF, k1);
     if (P == 3) g3_issue<2>(s, s1, BUF, k1);
     __builtin_amdgcn_sched_barrier(0);
     // (the B-X reads are issued first: NT 4 of 12, TN 8 of 24 DS operations -- retire exactly those before the barrier)
     if (P == 0) { if (TN) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); }
-    if (P == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (P == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + SEAM) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -192,12 +203,12 @@ __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, co
     __builtin_amdgcn_s_barrier();
 }
 
-template <int BUF, bool TN = false>
+template <int BUF, bool TN = false, int SEAM = 0>
 __device__ __forceinline__ void g3_ktile(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1, bool cs_on = false) {
-    g3_phase<BUF, 0, TN>(s, s0, k0, s1, k1, cs_on);
-    g3_phase<BUF, 1, TN>(s, s0, k0, s1, k1, cs_on);
-    g3_phase<BUF, 2, TN>(s, s0, k0, s1, k1, cs_on);
-    g3_phase<BUF, 3, TN>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 0, TN, SEAM>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 1, TN, SEAM>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 2, TN, SEAM>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 3, TN, SEAM>(s, s0, k0, s1, k1, cs_on);
 }
 
 __device__ __forceinline__ void g3_init_lane(G3State& s, const GemmParams& p, char* smem, int wave, int lane) {
@@ -218,8 +229,14 @@ __device__ __forceinline__ void g3_init_lane(G3State& s, const GemmParams& p, ch
     // fragment reads: local row = (wave part) + 16 * tile + (lane & 15), chunk = 4 * ksub + (lane >> 4)
     const int l15 = lane & 15;
     const uint32_t lp = (l15 >> 3) * 1024 + (lane & 7) * 128 + ((((lane >> 4) ^ (l15 >> 1)) & 7) << 4);
-    s.ra[0] = wr * 8192 + lp; s.ra[1] = s.ra[0] ^ 64;
-    s.rb[0] = wc * 4096 + lp; s.rb[1] = s.rb[0] ^ 64;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        s.ra[b][0] = lds0 + b * G3_BUF + wr * 8192 + lp; s.ra[b][1] = s.ra[b][0] ^ 64;
+        s.rb[b][0] = lds0 + b * G3_BUF + wc * 4096 + lp; s.rb[b][1] = s.rb[b][0] ^ 64;
+        // (opaque: eight registers, not two plus arithmetic in front of every read)
+        asm volatile("" : "+v"(s.ra[b][0]), "+v"(s.ra[b][1]), "+v"(s.rb[b][0]), "+v"(s.rb[b][1]));
+    }
     s.kstep_a = s.kstep_b = G3_BK * 2;
 }
 
@@ -613,6 +630,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // carry the same amount of work.
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
+#ifdef ME_DEV
+    if ((p.debug >> 4) && bid < 256) {           // dev: stagger the first round (output bursts of the CUs spread out)
+        const int n = (slot & 7) * (p.debug >> 4);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
+    }
+#endif
     const int F = p.g3_full_tiles;
     const int nf = (F >> 3) + (xcd < (F & 7) ? 1 : 0);
     const int base_f = xcd * (F >> 3) + (xcd < (F & 7) ? xcd : (F & 7));
@@ -674,6 +697,300 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
     g3_epilogue<EPI>(p, s, m0, n0, lane);
+}
+
+// ---- resident form: one workgroup per CU walks its work items (same ids and XCD mapping as gemm_g3_kernel: item
+// (xcd, slot) for slot = c, c + G/8, ...), and the operand stream never stops at a tile boundary:
+//   * the last two K-tiles of an item already fetch the first two of the next one (the K-loop's sources are just
+//     (descriptor, K-tile) pairs), the one half-tile the loop would issue right AFTER the boundary goes out right before
+//     the epilogue, and the epilogue touches no LDS -- so the whole prologue latency of the next tile, and its workgroup
+//     launch, hide under the epilogue of this one;
+//   * vmcnt retires in order and counts stores, so a K-loop that waits for "everything but my last 6 DMAs" right after an
+//     epilogue would first drain the epilogue's stores.  The epilogue therefore issues an EXACT number of memory
+//     operations (buffer stores / loads whose edge handling is the descriptor's bounds check, never a branch), and the
+//     first K-tile after it waits with that many more operations allowed in flight (g3_phase<.., SEAM>): the stores
+//     drain under the next tile's first two K-tiles.
+// bf16 outputs / row operands only (launch3r checks).  Parts of split tiles (EPI 5 slabs) are the last items of a
+// workgroup; should another item follow one, the queue is drained and re-primed.
+// The bias is not added here: the accumulators START at the bias of their columns (g3r_bias / g3r_init_acc; alpha = 1),
+// loaded for the NEXT tile at the top of this epilogue, ahead of its stores -- a load issued behind the stores could only be
+// waited for by draining them.
+struct G3Bias { f32x4 v[4]; };       // this lane's bias for n-tiles 0..3 of its wave column (accumulator layout)
+__device__ __forceinline__ G3Bias g3r_bias(const __amdgpu_buffer_rsrc_t brs, int tn, int wave, int lane) {
+    G3Bias b;
+    asm volatile("" : "+v"(lane));       // (derive the offset here: hoisted out of the item loop it would be spilled)
+    const int col = tn * G3_BN + (wave & 3) * 64 + 4 * (lane >> 4);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)      // (no bias, or columns past N: zero records / out of range -> zeros)
+        b.v[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (col + nt * 16) * 4, 0, 0));
+    return b;
+}
+__device__ __forceinline__ void g3r_init_acc(G3State& s, const G3Bias& b, bool zero) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s.acc[i][j] = zero ? z : b.v[j];
+}
+
+// Store pattern: a store instruction that covers 16 rows x 64 bytes (what the permlane16 re-deal alone gives) costs a CU
+// 4.6 us per 256 x 256 bf16 tile, one that covers 8 rows x 128 bytes -- whole cache lines -- 1.7 us (tools/store_probe).
+// So the two 64-byte halves (q = 0 / 1) of the wave's 128-byte row segment are re-dealt once more, between the lanes of
+// rows r and r + 8 (DPP row_ror:8 under a bank mask): afterwards half A holds rows 0..7 and half B rows 8..15 of the
+// 16-row slab, lane (r = l & 15, g = l >> 4) owning the 16-byte chunk (r >> 3) * 4 + 2 (g & 1) + (g >> 1) of row r & 7.
+__device__ __forceinline__ void g3r_rows8(f32x4& x0, f32x4& x1, f32x4& y0, f32x4& y1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned a0 = __float_as_uint(x0[e]), a1 = __float_as_uint(x1[e]), b0 = __float_as_uint(y0[e]), b1 = __float_as_uint(y1[e]);
+        // lanes 8..15 of every row of 16 take the q = 1 value of the lane 8 below; lanes 0..7 the q = 0 value of the lane 8 above
+        x0[e] = __uint_as_float(__builtin_amdgcn_update_dpp(a0, b0, 0x128, 0xf, 0xc, false));
+        x1[e] = __uint_as_float(__builtin_amdgcn_update_dpp(a1, b1, 0x128, 0xf, 0xc, false));
+        y0[e] = __uint_as_float(__builtin_amdgcn_update_dpp(b0, a0, 0x128, 0xf, 0x3, false));
+        y1[e] = __uint_as_float(__builtin_amdgcn_update_dpp(b1, a1, 0x128, 0xf, 0x3, false));
+    }
+}
+
+template <int EPI, bool PRE>
+__device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int tm, int tn, int lane, const G3Src& nxt, int nk,
+                                              const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero) {
+    asm volatile("" : "+v"(lane));
+    const int wr = s.wave >> 2, wc = s.wave & 3;
+    const int r = lane & 15, g = lane >> 4;
+    const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
+    int64_t rows = p.M - m0, cols = p.N - n0;
+    rows = rows < G3_BM ? rows : G3_BM;
+    cols = cols < G3_BN ? cols : G3_BN;
+    auto tile_rsrc = [&](const void* base, int64_t ld) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (m0 * ld + n0) * 2, 0,
+                                                 (int)(((rows - 1) * ld + cols) * 2), 0x00020000);
+    };
+#ifdef ME_DEV
+    // dev (debug bit 4): the stores go nowhere (zero-record descriptor), everything else unchanged
+    const __amdgpu_buffer_rsrc_t crs = (p.debug & 4) ? __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000) : tile_rsrc(p.C, p.ldc);
+#else
+    const __amdgpu_buffer_rsrc_t crs = tile_rsrc(p.C, p.ldc);
+#endif
+    const __amdgpu_buffer_rsrc_t prs = PRE ? tile_rsrc(p.preact, p.ldpre) : crs;
+    const __amdgpu_buffer_rsrc_t rrs = EPI == 2 ? tile_rsrc(p.residual, p.ldres) : EPI == 3 ? tile_rsrc(p.aux, p.ldaux) : crs;
+    const int rop_ld = (int)(EPI == 2 ? p.ldres : p.ldaux);
+    // per-lane byte offsets inside the tile (row r & 7 of half A of slab 0); a chunk past the column edge gets an offset
+    // no descriptor admits; rows past the row edge fall behind the descriptor's end by themselves
+    const int colb = wc * 128 + (r >> 3) * 64 + (g & 1) * 32 + (g >> 1) * 16;
+    const bool ok = (colb >> 1) + 8 <= (int)cols;
+    const int row = wr * 128 + (r & 7);
+    const uint32_t coff = ok ? (uint32_t)(row * (int)p.ldc * 2 + colb) : 0x80000000u;
+    const uint32_t poff = ok && PRE ? (uint32_t)(row * (int)p.ldpre * 2 + colb) : 0x80000000u;
+    const uint32_t roff = ok ? (uint32_t)(row * rop_ld * 2 + colb) : 0x80000000u;
+    const int cstep = (int)p.ldc * 16, pstep = (int)p.ldpre * 16, rstep = rop_ld * 16;       // 8 rows, bytes
+    auto fetch = [&](const int mt, u32x4 (&raw)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) raw[h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(roff + (2 * mt + h) * rstep), 0, 0);
+    };
+    auto unpack = [](const u32x4& rw, f32x4& a, f32x4& b) {
+        a[0] = __uint_as_float(rw[0] << 16); a[1] = __uint_as_float(rw[0] & 0xffff0000u);
+        a[2] = __uint_as_float(rw[1] << 16); a[3] = __uint_as_float(rw[1] & 0xffff0000u);
+        b[0] = __uint_as_float(rw[2] << 16); b[1] = __uint_as_float(rw[2] & 0xffff0000u);
+        b[2] = __uint_as_float(rw[3] << 16); b[3] = __uint_as_float(rw[3] & 0xffff0000u);
+    };
+    auto pack = [](const f32x4& a, const f32x4& b) {
+        bf16x8 o;
+        o[0] = (bf16_t)a[0]; o[1] = (bf16_t)a[1]; o[2] = (bf16_t)a[2]; o[3] = (bf16_t)a[3];
+        o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
+        return __builtin_bit_cast(u32x4, o);
+    };
+    constexpr int AHEAD = 6;
+    u32x4 rowop[8][2];
+    if (EPI == 2 || EPI == 3) {
+#pragma unroll
+        for (int mt = 0; mt < AHEAD; ++mt) fetch(mt, rowop[mt]);
+    }
+    // the half-tile phase 0 of the next K-tile would issue (see SEAM), behind the first row-operand loads so that their
+    // wait does not include it; then the next tile's bias
+    g3_issue<3>(s, nxt, 1, nk);
+    const G3Bias nb = g3r_bias(brs, ntn, s.wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        f32x4 ro[2][2];
+        if (EPI == 2 || EPI == 3) {
+            unpack(rowop[mt][0], ro[0][0], ro[0][1]);
+            unpack(rowop[mt][1], ro[1][0], ro[1][1]);
+            if (mt + AHEAD < 8) fetch(mt + AHEAD, rowop[mt + AHEAD]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 v[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            v[q][0] = s.acc[mt][2 * q]; v[q][1] = s.acc[mt][2 * q + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[q][0][e]), __float_as_uint(v[q][1][e]), false, false);
+                v[q][0][e] = __uint_as_float(sw[0]);
+                v[q][1][e] = __uint_as_float(sw[1]);
+            }
+        }
+        g3r_rows8(v[0][0], v[0][1], v[1][0], v[1][1]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {           // half A: rows 0..7 of the slab, half B: rows 8..15
+            f32x4 v0 = v[h][0], v1 = v[h][1];
+            if (EPI == 1) {
+                if (PRE) __builtin_amdgcn_raw_buffer_store_b128(pack(v0, v1), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
+                v0 = gelu_erf4(v0);
+                v1 = gelu_erf4(v1);
+            }
+            if (EPI == 3) {
+                v0 *= gelu_erf_grad4(ro[h][0]);
+                v1 *= gelu_erf_grad4(ro[h][1]);
+            }
+            if (EPI == 2) { v0 += ro[h][0]; v1 += ro[h][1]; }
+            __builtin_amdgcn_raw_buffer_store_b128(pack(v0, v1), crs, (int)(coff + (2 * mt + h) * cstep), 0, 0);
+        }
+    }
+    // the next tile's accumulators start at its bias.  HERE, in straight-line code behind a known number of stores: at a
+    // control-flow join hipcc's wait for these loads would be vmcnt(0), i.e. a drain of the stores.
+    __builtin_amdgcn_sched_barrier(0);
+    g3r_init_acc(s, nb, next_zero);
+}
+
+// memory operations one g3_epilogue_r issues per wave behind the next tile's A-Y half-tile: >= the stores (+ the later
+// row-operand loads); an under-count only makes the wait stricter
+template <int EPI, bool PRE> constexpr int g3r_seam() { return PRE ? 32 : EPI >= 2 ? 20 : 16; }
+
+template <int EPI, bool PRE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g3r_kernel(const GemmParams p) {
+    constexpr int SEAM = g3r_seam<EPI, PRE>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2;
+
+    const int bid = blockIdx.x, xcd = bid & 7, c = bid >> 3, G8 = gridDim.x >> 3;
+    const int tiles = p.tiles_m * p.tiles_n, F = p.g3_full_tiles;
+    const int nwork = F + (tiles - F) * p.g3_split;
+    const int nf = (F >> 3) + (xcd < (F & 7) ? 1 : 0);                 // whole tiles / all items of this XCD
+    const int nx = (nwork >> 3) + (xcd < (nwork & 7) ? 1 : 0);
+    const int base_f = xcd * (F >> 3) + (xcd < (F & 7) ? xcd : (F & 7));
+    const int base_all = xcd * (nwork >> 3) + (xcd < (nwork & 7) ? xcd : (nwork & 7));
+    const int nkt = (int)(p.K / G3_BK);
+    auto decode = [&](int slot, int& tile, int& part, int& kt0, int& kt1) {
+        part = -1; kt0 = 0; kt1 = nkt;
+        if (slot < nf) {
+            tile = base_f + slot;
+        } else {
+            const int pi = base_all - base_f + (slot - nf);
+            const int tq = __builtin_amdgcn_readfirstlane(pi / p.g3_split);
+            tile = F + tq;
+            part = pi - tq * p.g3_split;
+            kt0 = part * p.g3_ktp;
+            kt1 = kt0 + p.g3_ktp < nkt ? kt0 + p.g3_ktp : nkt;
+        }
+    };
+    auto src_of = [&](int tile, int& tm, int& tn) {
+        tm = __builtin_amdgcn_readfirstlane(tile / p.tiles_n);
+        tn = tile - tm * p.tiles_n;
+        return g3_make_src(p, tm, tn);
+    };
+    int slot = c;
+    if (slot >= nx) return;
+#ifdef ME_DEV
+    if (p.debug >> 4) {                          // dev: stagger the CUs of an XCD (their output bursts spread out)
+        const int n = c * (p.debug >> 4);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
+    }
+#endif
+
+    G3State s;
+    g3_init_lane(s, p, smem, wave, lane);
+    const G3Src null = g3_null_src(p);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (int)(p.N * 4) : 0, 0x00020000);
+    // SEAM stores nothing admits: the in-order queue looks the same ahead of the first item as behind an epilogue
+    auto prime = [&]() {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < SEAM; ++i) __builtin_amdgcn_raw_buffer_store_b128(z, null.a, 0, 0, 0);
+    };
+
+    int tile, part, kt0, kt1, tm, tn;
+    decode(slot, tile, part, kt0, kt1);
+    G3Src cur = src_of(tile, tm, tn);
+    g3_issue<0>(s, cur, 0, kt0); g3_issue<1>(s, cur, 0, kt0); g3_issue<2>(s, cur, 0, kt0); g3_issue<3>(s, cur, 0, kt0);
+    g3_issue<0>(s, cur, 1, kt0 + 1); g3_issue<1>(s, cur, 1, kt0 + 1); g3_issue<2>(s, cur, 1, kt0 + 1); g3_issue<3>(s, cur, 1, kt0 + 1);
+    {
+        const G3Bias b0 = g3r_bias(brs, tn, wave, lane);
+        g3r_init_acc(s, b0, part >= 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    prime();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+#ifdef ME_DEV
+    // dev: time stamps (s_memtime) of waves 0 and 4: [workgroup][wave row][item][4] = item start, first K-tile pair done,
+    // K-loop done, epilogue done
+    unsigned long long* trace = reinterpret_cast<unsigned long long*>(p.colsum_ws);
+    int item = 0;
+#define G3R_STAMP(i)                                                                                            \
+    if (trace && (wave & 3) == 0 && item < 16) {                                                                \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                             \
+        if (lane == 0) trace[(((size_t)bid * 2 + wr) * 16 + item) * 4 + (i)] = t_;                              \
+    }
+#else
+#define G3R_STAMP(i)
+#endif
+    while (true) {
+        G3R_STAMP(0)
+        const int nslot = slot + G8;
+        const bool has_next = nslot < nx;
+        int ntile = tile, npart = -1, nkt0 = 0, nkt1 = 2, ntm = 0, ntn = 0;
+        G3Src nxt = null;
+        if (has_next) {
+            decode(nslot, ntile, npart, nkt0, nkt1);
+            nxt = src_of(ntile, ntm, ntn);
+        }
+        const int np = (kt1 - kt0) >> 1;
+        {
+            G3Src sb = cur;
+            int kb = kt0 + 2, kc = kt0 + 3;
+            if (np == 1) { sb = nxt; kb = nkt0; kc = nkt0 + 1; }
+            g3_ktile<0, false, SEAM>(s, cur, 0, sb, kb);
+            g3_ktile<1>(s, sb, kb, sb, kc);
+        }
+        G3R_STAMP(1)
+        for (int i = 1; i < np; ++i) {
+            const int k = kt0 + 2 * i;
+            G3Src sb = cur;
+            int kb = k + 2, kc = k + 3;
+            if (i == np - 1) { sb = nxt; kb = nkt0; kc = nkt0 + 1; }
+            g3_ktile<0>(s, cur, k + 1, sb, kb);
+            g3_ktile<1>(s, sb, kb, sb, kc);
+        }
+        // the two wave rows run their epilogues SIDE BY SIDE: left one barrier apart, row 1 could not start its epilogue
+        // before row 0 had finished its own and reached the next K-tile's first barrier, and row 0 would then wait out
+        // row 1's (measured with the time stamps below: 4.6 k of 40 k clocks per tile).  Row 0 gives up its one-barrier
+        // lead here and row 1 re-opens it behind the epilogue.
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        G3R_STAMP(2)
+        if (part >= 0) {
+            g3_issue<3>(s, nxt, 1, nkt0 + 1);
+            const int64_t row0 = (int64_t)(F / p.tiles_n) * G3_BM;
+            g3_epilogue<5>(p, s, (int64_t)tm * G3_BM, (int64_t)tn * G3_BN, lane, p.g3_slabs + (int64_t)part * (p.M - row0) * p.N, row0);
+            const G3Bias nb = g3r_bias(brs, ntn, wave, lane);
+            g3r_init_acc(s, nb, npart >= 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prime();
+        } else {
+            g3_epilogue_r<EPI, PRE>(p, s, tm, tn, lane, nxt, nkt0 + 1, brs, ntn, npart >= 0);
+        }
+        G3R_STAMP(3)
+#ifdef ME_DEV
+        ++item;
+#endif
+        if (!has_next) break;
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        slot = nslot; tile = ntile; part = npart; kt0 = nkt0; kt1 = nkt1; tm = ntm; tn = ntn;
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing null DMAs must land before the LDS is released
 }
 
 // ---- wgrad: one (output tile, K-range) per workgroup; raw fp32 partial sums into slab blockIdx.y ... the deterministic
@@ -767,6 +1084,22 @@ int g3_cus() {
     return n;
 }
 
+template <int EPI, bool PRE> int launch3r(const GemmParams& q, int G, hipStream_t stream) {
+    static OncePerDevice once;
+    if (once.need())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+#ifdef ME_DEV
+    GemmParams qt = q;
+    qt.colsum_ws = (q.debug & 8) ? reinterpret_cast<float*>(g_gemm_dev_trace) : nullptr;
+    hipLaunchKernelGGL((gemm_g3r_kernel<EPI, PRE>), dim3((unsigned)G), dim3(512), G3_LDS, stream, qt);
+    ME_CHECK_LAUNCH("me_gemm(g3 resident)");
+    return ME_OK;
+#endif
+    hipLaunchKernelGGL((gemm_g3r_kernel<EPI, PRE>), dim3((unsigned)G), dim3(512), G3_LDS, stream, q);
+    ME_CHECK_LAUNCH("me_gemm(g3 resident)");
+    return ME_OK;
+}
+
 template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t stream) {
     static OncePerDevice once;
     if (once.need()) {
@@ -806,6 +1139,17 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
     GemmParams q = p;
     if (q.g3_split <= 1 || q.g3_slabs == nullptr) { q.g3_full_tiles = tiles; q.g3_split = 1; q.g3_ktp = 0; q.g3_slabs = nullptr; }
     const int nwg = q.g3_full_tiles + (tiles - q.g3_full_tiles) * q.g3_split;
+    // the resident form (one workgroup per CU, operand stream running through the epilogues) whenever every CU gets work
+    // and the output / row operands are bf16 with tile-local 32-bit offsets
+    if constexpr (EPI <= 3) if (gemm_dev().g3_persistent == 1) {
+        const int G = g3_cus() & ~7;
+        const int64_t ldmax = std::max(std::max(p.ldc, p.preact ? p.ldpre : 0), std::max(p.residual ? p.ldres : 0, p.aux ? p.ldaux : 0));
+        const bool pre = EPI == 1 && p.preact != nullptr;
+        if (G >= 8 && nwg >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!pre || p.preact_dtype == ME_BF16) && 256 * ldmax * 2 < (1ll << 31)) {
+            if (pre) return launch3r<EPI, EPI == 1>(q, G, stream);
+            return launch3r<EPI, false>(q, G, stream);
+        }
+    }
     hipLaunchKernelGGL((gemm_g3_kernel<EPI>), dim3((unsigned)nwg), dim3(512), G3_LDS, stream, q);
     ME_CHECK_LAUNCH("me_gemm(g3)");
     return ME_OK;

@@ -139,6 +139,7 @@ bool g3_tn_supported(const GemmParams& p);
 struct GemmDev { int family, bn, debug, tail_split, g3_persistent; };
 #ifdef ME_DEV
 extern GemmDev g_gemm_dev;
+extern void* g_gemm_dev_trace;      // device buffer for the resident kernel's time stamps (tools/gemm_dev --trace)
 static inline GemmDev gemm_dev() { return g_gemm_dev; }
 #else
 static inline GemmDev gemm_dev() { return GemmDev{-1, 0, 0, 1, 1}; }

@@ -20,6 +20,7 @@
 #include "../include/metaenc.h"
 
 extern "C" int me_dev_set(const char* key, int value);
+extern "C" int me_dev_set_trace(void* buf);
 
 #define CK(x)                                                                                   \
     do {                                                                                        \
@@ -118,7 +119,7 @@ static int family_code(const std::string& f) {
     if (f == "g128") return 0;
     if (f == "g2b") return 2;
     if (f == "g2w") return 3;
-    if (f == "g3" || f == "g3x" || f == "g3p") return 4;      // g3: shipped form; g3x: without the tail split; g3p: persistent stream-K
+    if (f == "g3" || f == "g3x" || f == "g3p" || f == "g3t") return 4;      // g3: shipped form (resident); g3t: one tile per workgroup; g3x: without the tail split; g3p: persistent stream-K
     fprintf(stderr, "unknown family %s\n", f.c_str());
     exit(2);
 }
@@ -237,7 +238,7 @@ int main(int argc, char** argv) {
             return 2;
         }
         me_dev_set("family", family_code(fam));
-        me_dev_set("g3_persistent", strcmp(fam, "g3p") == 0);
+        me_dev_set("g3_persistent", strcmp(fam, "g3p") == 0 ? 2 : strcmp(fam, "g3t") == 0 ? 0 : 1);
         me_dev_set("tail_split", strcmp(fam, "g3x") != 0);
         me_dev_set("debug", debug);
         uint16_t *A[NSET], *C[NSET], *P[NSET], *Bw, *rowop = nullptr;
@@ -320,6 +321,42 @@ int main(int argc, char** argv) {
         const double us = 1e3 * ms / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
         printf("%-34s %8.1f us  %7.1f TF/s  %s\n", c.c_str(), us, tf, verdict.c_str());
         fflush(stdout);
+        if (debug & 8) {
+            // time stamps of the resident kernel (debug bit 8): [256 workgroups][2 wave rows][16 items][4] shader clocks
+            const size_t n = 256 * 2 * 16 * 4;
+            unsigned long long* tb;
+            CK(hipMalloc(&tb, n * 8));
+            CK(hipMemsetAsync(tb, 0, n * 8, st));
+            me_dev_set_trace(tb);
+            run(0);
+            CK(hipStreamSynchronize(st));
+            me_dev_set_trace(nullptr);
+            std::vector<unsigned long long> h(n);
+            CK(hipMemcpy(h.data(), tb, n * 8, hipMemcpyDeviceToHost));
+            CK(hipFree(tb));
+            for (int wrow = 0; wrow < 2; ++wrow) {
+                printf("  wave row %d: item: mean [first pair | rest of K-loop | epilogue | gap to next] in shader clocks (min..max of the item's total)\n", wrow);
+                for (int it = 0; it < 16; ++it) {
+                    double a = 0, b = 0, e = 0, g = 0; int cnt = 0, gc = 0; double tmin = 1e30, tmax = 0;
+                    for (int w = 0; w < 256; ++w) {
+                        const unsigned long long* t = &h[(((size_t)w * 2 + wrow) * 16 + it) * 4];
+                        if (!t[0] || !t[3]) continue;
+                        a += (double)(t[1] - t[0]); b += (double)(t[2] - t[1]); e += (double)(t[3] - t[2]); ++cnt;
+                        const double tot = (double)(t[3] - t[0]);
+                        tmin = tot < tmin ? tot : tmin; tmax = tot > tmax ? tot : tmax;
+                        if (it + 1 < 16 && t[4]) { g += (double)(t[4] - t[3]); ++gc; }
+                    }
+                    if (!cnt) break;
+                    printf("    item %2d (%3d wgs): %7.0f | %7.0f | %7.0f | %6.0f   (%.0f..%.0f)\n", it, cnt, a / cnt, b / cnt, e / cnt, gc ? g / gc : 0.0, tmin, tmax);
+                }
+            }
+            // spread of the start stamps of item 1 across workgroups (how far the CUs drift apart)
+            {
+                unsigned long long lo = ~0ull, hi = 0;
+                for (int w = 0; w < 256; ++w) { const unsigned long long t = h[(((size_t)w * 2) * 16 + 1) * 4]; if (t) { lo = t < lo ? t : lo; hi = t > hi ? t : hi; } }
+                printf("  start of item 1 across workgroups: spread %llu clocks\n", hi - lo);
+            }
+        }
         for (int s = 0; s < NSET; ++s) {
             CK(hipFree(A[s])); CK(hipFree(C[s]));
             if (P[s]) CK(hipFree(P[s]));

@@ -9,6 +9,6 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout 400 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o p -- python $R/bench.py --steps 1 --warmup 1 --mode $MODE --no-cpu-baseline > $OUT/p$i.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o p -- python $R/bench.py --steps 1 --warmup 1 --mode $MODE --no-cpu-baseline --no-fwd-leg > $OUT/p$i.log 2>&1
   echo "pass $i rc=$?"
 done

@@ -7,6 +7,9 @@ def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     return re.sub(r"\(.*", "", name)
 
+ROUND = "r02"
+
+
 def main(mode):
     base = f"gpurun_out/pmc_bench_{mode}"
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -35,7 +38,7 @@ def main(mode):
             e["l2_hit"] = round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3)
         out[k] = e
     out["_meta"] = {"bench_steps_in_pass": 2, "note": "tools/pmc_bench.sh runs bench.py --steps 1 --warmup 1: launch counts cover 2 steps"}
-    json.dump(out, open(f"profiles/r01_pmc_{mode}.json", "w"), indent=1, sort_keys=True)
+    json.dump(out, open(f"profiles/{ROUND}_pmc_{mode}.json", "w"), indent=1, sort_keys=True)
     for k, e in sorted(((k, e) for k, e in out.items() if k != "_meta"), key=lambda kv: -kv[1]["launches"] * kv[1]["avg_us_profiled"])[:12]:
         print(f"{k[:60]:60s}", {x: e[x] for x in e if x != "wave_cycles"})
 
