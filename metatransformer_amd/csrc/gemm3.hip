@@ -56,6 +56,8 @@ struct G3State {
     uint32_t ra[2][2], rb[2][2];// NT: fragment read LDS addresses [buffer][k-sub]: buffer + wave / lane part inside a half-tile
     uint32_t ta[4], tb[2];      // TN: transposing-read byte offsets per m-tile / n-tile of a quadrant (wave + lane part)
     int kstep_a, kstep_b;       // source bytes per K-tile: NT 128 (along the row); TN 64 rows = 128 * ld
+    f32x4 binit[4];             // resident NT kernel: what the accumulators of n-tile 0..3 START at (the columns' bias, or zero) --
+                                // the C operand of the first MFMAs behind an epilogue (g3_phase<.., SEAM>); dead in between
     float cs[2];                // TN: running column sums of A (the bias gradient) for m-tiles wc and 4 + wc of this wave row
     int wave;
 };
@@ -135,7 +137,7 @@ __device__ __forceinline__ float g3_frag_sum(bf16x8 f) {
 // The index is wave-uniform; a scalar if-chain on the state's own arrays keeps every fragment index static (an array
 // passed by reference, or indexed at run time, is demoted to scratch).
 #define G3_MMA(MT, NT, AF, BF)                                                                                   \
-    s.acc[MT][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(NT) & 1][0], AF[(MT) & 3][0], s.acc[MT][NT], 0, 0, 0); \
+    s.acc[MT][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(NT) & 1][0], AF[(MT) & 3][0], SEAM ? s.binit[NT] : s.acc[MT][NT], 0, 0, 0); \
     s.acc[MT][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(NT) & 1][1], AF[(MT) & 3][1], s.acc[MT][NT], 0, 0, 0);
 
 // One phase of K-tile `BUF`.  s0 / k0: where the NEXT K-tile of the stream comes from (phase 0 issues its A-Y);
@@ -145,7 +147,8 @@ __device__ __forceinline__ float g3_frag_sum(bf16x8 f) {
 // accumulators never meet a control-flow join inside the K-loop.
 // SEAM > 0: the first K-tile after an epilogue of the resident kernel (gemm_g3r_kernel): the A-Y half-tile phase 0 would
 // issue went out BEFORE the epilogue, and the counted wait of phase 3 lets the epilogue's SEAM memory operations (which
-// sit between that half-tile and this K-tile's own three in the in-order queue) stay in flight.
+// sit between that half-tile and this K-tile's own three in the in-order queue) stay in flight.  It is also the first K-tile
+// of an output tile: its MFMAs take s.binit as their C operand, so the accumulators need no initialisation pass.
 template <int BUF, int P, bool TN = false, int SEAM = 0>
 __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1, bool cs_on = false) {
     if (TN && (P == 1 || P == 3) && cs_on) {      // (wave-uniform) fragments read one / two phases ago, waited for in that phase
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //     drain under the next tile's first two K-tiles.
 // bf16 outputs / row operands only (launch3r checks).  Parts of split tiles (EPI 5 slabs) are the last items of a
 // workgroup; should another item follow one, the queue is drained and re-primed.
-// The bias is not added here: the accumulators START at the bias of their columns (g3r_bias / g3r_init_acc; alpha = 1),
+// The bias is not added here: the accumulators START at the bias of their columns (g3r_bias / s.binit; alpha = 1),
 // loaded for the NEXT tile at the top of this epilogue, ahead of its stores -- a load issued behind the stores could only be
 // waited for by draining them.
 struct G3Bias { f32x4 v[4]; };       // this lane's bias for n-tiles 0..3 of its wave column (accumulator layout)
@@ -725,12 +728,13 @@ __device__ __forceinline__ G3Bias g3r_bias(const __amdgpu_buffer_rsrc_t brs, int
         b.v[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (col + nt * 16) * 4, 0, 0));
     return b;
 }
-__device__ __forceinline__ void g3r_init_acc(G3State& s, const G3Bias& b, bool zero) {
+__device__ __forceinline__ void g3r_set_binit(G3State& s, const G3Bias& b, bool zero) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s.acc[i][j] = zero ? z : b.v[j];
+    for (int j = 0; j < 4; ++j) s.binit[j] = zero ? z : b.v[j];
+    // (used HERE: the wait for the loads lands in the caller's straight-line code, with the number of younger stores known;
+    // at the first real use, behind the item loop's joins, it would be a drain)
+    asm volatile("" ::"v"(s.binit[0]), "v"(s.binit[1]), "v"(s.binit[2]), "v"(s.binit[3]));
 }
 
 // Store pattern: a store instruction that covers 16 rows x 64 bytes (what the permlane16 re-deal alone gives) costs a CU
@@ -750,6 +754,28 @@ __device__ __forceinline__ void g3r_rows8(f32x4& x0, f32x4& x1, f32x4& y0, f32x4
     }
 }
 
+__device__ __forceinline__ void g3r_rows8_packed(u32x4& x, u32x4& y) {      // the same re-deal on packed bf16 pairs
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned a = x[e], b = y[e];
+        x[e] = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xf, 0xc, false);
+        y[e] = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xf, 0x3, false);
+    }
+}
+
+// Which LANES hold a cache line matters as much as which lines an instruction covers: with the lanes of one 128-byte row
+// segment scattered over the wave (r, r + 8, r + 16 ..: what the re-deals above leave) a store instruction costs the CU
+// ~77 clocks, with eight CONSECUTIVE lanes per line ~31 (time stamps in the kernel, debug bit 8; tools/store_probe).  So the
+// packed 16-byte chunks take one more trip through the lane crossbar (ds_bpermute_b32: no LDS memory involved, the operand
+// buffers stay untouched) into the order lane t = row (t >> 3), chunk (t & 7); row operands are loaded in that order and
+// taken the opposite way.
+__device__ __forceinline__ u32x4 g3r_lanes(const u32x4& v, int addr) {
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v[e]);
+    return o;
+}
+
 template <int EPI, bool PRE>
 __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int tm, int tn, int lane, const G3Src& nxt, int nk,
                                               const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero) {
@@ -766,22 +792,28 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     };
 #ifdef ME_DEV
     // dev (debug bit 4): the stores go nowhere (zero-record descriptor), everything else unchanged
-    const __amdgpu_buffer_rsrc_t crs = (p.debug & 4) ? __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000) : tile_rsrc(p.C, p.ldc);
+    // (debug bit 2 with bit 4: only the first workgroup of every XCD keeps its stores)
+    const bool drop = (p.debug & 4) && !((p.debug & 2) && (blockIdx.x >> 3) == 0);
+    const __amdgpu_buffer_rsrc_t crs = drop ? __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000) : tile_rsrc(p.C, p.ldc);
 #else
     const __amdgpu_buffer_rsrc_t crs = tile_rsrc(p.C, p.ldc);
 #endif
     const __amdgpu_buffer_rsrc_t prs = PRE ? tile_rsrc(p.preact, p.ldpre) : crs;
     const __amdgpu_buffer_rsrc_t rrs = EPI == 2 ? tile_rsrc(p.residual, p.ldres) : EPI == 3 ? tile_rsrc(p.aux, p.ldaux) : crs;
     const int rop_ld = (int)(EPI == 2 ? p.ldres : p.ldaux);
-    // per-lane byte offsets inside the tile (row r & 7 of half A of slab 0); a chunk past the column edge gets an offset
-    // no descriptor admits; rows past the row edge fall behind the descriptor's end by themselves
-    const int colb = wc * 128 + (r >> 3) * 64 + (g & 1) * 32 + (g >> 1) * 16;
+    // memory side: lane t = row t >> 3 of an 8-row half slab, 16-byte chunk t & 7 of the wave's 128-byte row segment.  A
+    // chunk past the column edge gets an offset no descriptor admits; rows past the row edge fall behind the descriptor's end.
+    const int colb = wc * 128 + (lane & 7) * 16;
     const bool ok = (colb >> 1) + 8 <= (int)cols;
-    const int row = wr * 128 + (r & 7);
+    const int row = wr * 128 + (lane >> 3);
     const uint32_t coff = ok ? (uint32_t)(row * (int)p.ldc * 2 + colb) : 0x80000000u;
     const uint32_t poff = ok && PRE ? (uint32_t)(row * (int)p.ldpre * 2 + colb) : 0x80000000u;
     const uint32_t roff = ok ? (uint32_t)(row * rop_ld * 2 + colb) : 0x80000000u;
     const int cstep = (int)p.ldc * 16, pstep = (int)p.ldpre * 16, rstep = rop_ld * 16;       // 8 rows, bytes
+    // register side (after g3r_rows8): lane (r, g) = row r & 7, chunk 4 (r >> 3) + 2 (g & 1) + (g >> 1).  to_mem: the lane
+    // that holds memory lane t's chunk; to_reg: the memory lane that holds this lane's chunk (x 4: bpermute byte addresses)
+    const int to_mem = 4 * ((lane >> 3) + 8 * ((lane >> 2) & 1) + 16 * (((lane >> 1) & 1) | ((lane & 1) << 1)));
+    const int to_reg = 4 * (8 * (r & 7) + 4 * (r >> 3) + 2 * (g & 1) + (g >> 1));
     auto fetch = [&](const int mt, u32x4 (&raw)[2]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) raw[h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(roff + (2 * mt + h) * rstep), 0, 0);
@@ -798,7 +830,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
         o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
         return __builtin_bit_cast(u32x4, o);
     };
-    constexpr int AHEAD = 6;
+    constexpr int AHEAD = EPI == 3 ? 4 : 6;      // (gelu' needs the registers for its arithmetic: six slabs ahead spill into the K-loop)
     u32x4 rowop[8][2];
     if (EPI == 2 || EPI == 3) {
 #pragma unroll
@@ -813,8 +845,8 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     for (int mt = 0; mt < 8; ++mt) {
         f32x4 ro[2][2];
         if (EPI == 2 || EPI == 3) {
-            unpack(rowop[mt][0], ro[0][0], ro[0][1]);
-            unpack(rowop[mt][1], ro[1][0], ro[1][1]);
+            unpack(g3r_lanes(rowop[mt][0], to_reg), ro[0][0], ro[0][1]);
+            unpack(g3r_lanes(rowop[mt][1], to_reg), ro[1][0], ro[1][1]);
             if (mt + AHEAD < 8) fetch(mt + AHEAD, rowop[mt + AHEAD]);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -829,12 +861,25 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                 v[q][1][e] = __uint_as_float(sw[1]);
             }
         }
+        if ((EPI == 0 || EPI == 1) && !PRE) {
+            // no row operand, one output: the arithmetic runs in the old layout and the PACKED result is re-dealt (half the
+            // DPP moves)
+            if (EPI == 1) {
+                v[0][0] = gelu_erf4(v[0][0]); v[0][1] = gelu_erf4(v[0][1]);
+                v[1][0] = gelu_erf4(v[1][0]); v[1][1] = gelu_erf4(v[1][1]);
+            }
+            u32x4 o0 = pack(v[0][0], v[0][1]), o1 = pack(v[1][0], v[1][1]);
+            g3r_rows8_packed(o0, o1);
+            __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(o0, to_mem), crs, (int)(coff + (2 * mt) * cstep), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(o1, to_mem), crs, (int)(coff + (2 * mt + 1) * cstep), 0, 0);
+            continue;
+        }
         g3r_rows8(v[0][0], v[0][1], v[1][0], v[1][1]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {           // half A: rows 0..7 of the slab, half B: rows 8..15
             f32x4 v0 = v[h][0], v1 = v[h][1];
             if (EPI == 1) {
-                if (PRE) __builtin_amdgcn_raw_buffer_store_b128(pack(v0, v1), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
+                if (PRE) __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
                 v0 = gelu_erf4(v0);
                 v1 = gelu_erf4(v1);
             }
@@ -843,13 +888,12 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                 v1 *= gelu_erf_grad4(ro[h][1]);
             }
             if (EPI == 2) { v0 += ro[h][0]; v1 += ro[h][1]; }
-            __builtin_amdgcn_raw_buffer_store_b128(pack(v0, v1), crs, (int)(coff + (2 * mt + h) * cstep), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), crs, (int)(coff + (2 * mt + h) * cstep), 0, 0);
         }
     }
-    // the next tile's accumulators start at its bias.  HERE, in straight-line code behind a known number of stores: at a
-    // control-flow join hipcc's wait for these loads would be vmcnt(0), i.e. a drain of the stores.
+    // the next tile's accumulators start at its bias (s.binit)
     __builtin_amdgcn_sched_barrier(0);
-    g3r_init_acc(s, nb, next_zero);
+    g3r_set_binit(s, nb, next_zero);
 }
 
 // memory operations one g3_epilogue_r issues per wave behind the next tile's A-Y half-tile: >= the stores (+ the later
@@ -917,7 +961,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     g3_issue<0>(s, cur, 1, kt0 + 1); g3_issue<1>(s, cur, 1, kt0 + 1); g3_issue<2>(s, cur, 1, kt0 + 1); g3_issue<3>(s, cur, 1, kt0 + 1);
     {
         const G3Bias b0 = g3r_bias(brs, tn, wave, lane);
-        g3r_init_acc(s, b0, part >= 0);
+        g3r_set_binit(s, b0, part >= 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     prime();
@@ -925,14 +969,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (wr == 1) __builtin_amdgcn_s_barrier();
 
 #ifdef ME_DEV
-    // dev: time stamps (s_memtime) of waves 0 and 4: [workgroup][wave row][item][4] = item start, first K-tile pair done,
-    // K-loop done, epilogue done
+    // dev: time stamps (s_memtime) of waves 0 and 4: [workgroup][wave row][item][8] = item start, first K-tile done,
+    // second K-tile done, K-loop done, rows realigned, epilogue done
     unsigned long long* trace = reinterpret_cast<unsigned long long*>(p.colsum_ws);
     int item = 0;
 #define G3R_STAMP(i)                                                                                            \
     if (trace && (wave & 3) == 0 && item < 16) {                                                                \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                             \
-        if (lane == 0) trace[(((size_t)bid * 2 + wr) * 16 + item) * 4 + (i)] = t_;                              \
+        if (lane == 0) trace[(((size_t)bid * 2 + wr) * 16 + item) * 8 + (i)] = t_;                              \
     }
 #else
 #define G3R_STAMP(i)
@@ -953,9 +997,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             int kb = kt0 + 2, kc = kt0 + 3;
             if (np == 1) { sb = nxt; kb = nkt0; kc = nkt0 + 1; }
             g3_ktile<0, false, SEAM>(s, cur, 0, sb, kb);
+            G3R_STAMP(1)
             g3_ktile<1>(s, sb, kb, sb, kc);
         }
-        G3R_STAMP(1)
+        G3R_STAMP(2)
         for (int i = 1; i < np; ++i) {
             const int k = kt0 + 2 * i;
             G3Src sb = cur;
@@ -968,20 +1013,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // before row 0 had finished its own and reached the next K-tile's first barrier, and row 0 would then wait out
         // row 1's (measured with the time stamps below: 4.6 k of 40 k clocks per tile).  Row 0 gives up its one-barrier
         // lead here and row 1 re-opens it behind the epilogue.
+        G3R_STAMP(3)
         if (wr == 0) __builtin_amdgcn_s_barrier();
-        G3R_STAMP(2)
+        G3R_STAMP(4)
         if (part >= 0) {
             g3_issue<3>(s, nxt, 1, nkt0 + 1);
             const int64_t row0 = (int64_t)(F / p.tiles_n) * G3_BM;
             g3_epilogue<5>(p, s, (int64_t)tm * G3_BM, (int64_t)tn * G3_BN, lane, p.g3_slabs + (int64_t)part * (p.M - row0) * p.N, row0);
             const G3Bias nb = g3r_bias(brs, ntn, wave, lane);
-            g3r_init_acc(s, nb, npart >= 0);
+            g3r_set_binit(s, nb, npart >= 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             prime();
         } else {
             g3_epilogue_r<EPI, PRE>(p, s, tm, tn, lane, nxt, nkt0 + 1, brs, ntn, npart >= 0);
         }
-        G3R_STAMP(3)
+        G3R_STAMP(5)
 #ifdef ME_DEV
         ++item;
 #endif

@@ -323,7 +323,7 @@ int main(int argc, char** argv) {
         fflush(stdout);
         if (debug & 8) {
             // time stamps of the resident kernel (debug bit 8): [256 workgroups][2 wave rows][16 items][4] shader clocks
-            const size_t n = 256 * 2 * 16 * 4;
+            const size_t n = 256 * 2 * 16 * 8;
             unsigned long long* tb;
             CK(hipMalloc(&tb, n * 8));
             CK(hipMemsetAsync(tb, 0, n * 8, st));
@@ -335,25 +335,38 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(h.data(), tb, n * 8, hipMemcpyDeviceToHost));
             CK(hipFree(tb));
             for (int wrow = 0; wrow < 2; ++wrow) {
-                printf("  wave row %d: item: mean [first pair | rest of K-loop | epilogue | gap to next] in shader clocks (min..max of the item's total)\n", wrow);
+                printf("  wave row %d: mean clocks [K-tile 1 | K-tile 2 | rest of K-loop | realign | epilogue | to next item]  (min..max item total)\n", wrow);
                 for (int it = 0; it < 16; ++it) {
-                    double a = 0, b = 0, e = 0, g = 0; int cnt = 0, gc = 0; double tmin = 1e30, tmax = 0;
+                    double d[6] = {0, 0, 0, 0, 0, 0}; int cnt = 0, gc = 0; double tmin = 1e30, tmax = 0;
                     for (int w = 0; w < 256; ++w) {
-                        const unsigned long long* t = &h[(((size_t)w * 2 + wrow) * 16 + it) * 4];
-                        if (!t[0] || !t[3]) continue;
-                        a += (double)(t[1] - t[0]); b += (double)(t[2] - t[1]); e += (double)(t[3] - t[2]); ++cnt;
-                        const double tot = (double)(t[3] - t[0]);
+                        const unsigned long long* t = &h[(((size_t)w * 2 + wrow) * 16 + it) * 8];
+                        if (!t[0] || !t[5]) continue;
+                        for (int k = 0; k < 5; ++k) d[k] += (double)(t[k + 1] - t[k]);
+                        ++cnt;
+                        const double tot = (double)(t[5] - t[0]);
                         tmin = tot < tmin ? tot : tmin; tmax = tot > tmax ? tot : tmax;
-                        if (it + 1 < 16 && t[4]) { g += (double)(t[4] - t[3]); ++gc; }
+                        if (it + 1 < 16 && t[8]) { d[5] += (double)(t[8] - t[5]); ++gc; }
                     }
                     if (!cnt) break;
-                    printf("    item %2d (%3d wgs): %7.0f | %7.0f | %7.0f | %6.0f   (%.0f..%.0f)\n", it, cnt, a / cnt, b / cnt, e / cnt, gc ? g / gc : 0.0, tmin, tmax);
+                    printf("    item %2d (%3d wgs): %6.0f | %6.0f | %7.0f | %6.0f | %6.0f | %5.0f   (%.0f..%.0f)\n", it, cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt,
+                           d[3] / cnt, d[4] / cnt, gc ? d[5] / gc : 0.0, tmin, tmax);
                 }
+            }
+            for (int wrow = 0; wrow < 2; ++wrow) {
+                double d[6] = {0, 0, 0, 0, 0, 0}; int cnt = 0;
+                for (int w = 0; w < 8; ++w)
+                    for (int it = 1; it < 5; ++it) {
+                        const unsigned long long* t = &h[(((size_t)w * 2 + wrow) * 16 + it) * 8];
+                        if (!t[0] || !t[5]) continue;
+                        for (int k = 0; k < 5; ++k) d[k] += (double)(t[k + 1] - t[k]);
+                        ++cnt;
+                    }
+                if (cnt) printf("  workgroups 0..7, items 1..4, wave row %d: %6.0f | %6.0f | %7.0f | %6.0f | %6.0f\n", wrow, d[0] / cnt, d[1] / cnt, d[2] / cnt, d[3] / cnt, d[4] / cnt);
             }
             // spread of the start stamps of item 1 across workgroups (how far the CUs drift apart)
             {
                 unsigned long long lo = ~0ull, hi = 0;
-                for (int w = 0; w < 256; ++w) { const unsigned long long t = h[(((size_t)w * 2) * 16 + 1) * 4]; if (t) { lo = t < lo ? t : lo; hi = t > hi ? t : hi; } }
+                for (int w = 0; w < 256; ++w) { const unsigned long long t = h[(((size_t)w * 2) * 16 + 1) * 8]; if (t) { lo = t < lo ? t : lo; hi = t > hi ? t : hi; } }
                 printf("  start of item 1 across workgroups: spread %llu clocks\n", hi - lo);
             }
         }
