@@ -74,7 +74,8 @@ int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
  *   ME_GEMM_TN : C[M,N] = A[K,M]^T * B[K,N]          (A, B both K-major rows; wgrad: dW = dY^T X)
  *
  * Epilogue, applied in this order on the fp32 accumulator v:
- *   v = alpha * v ; v += bias[n] ; (store preact) ; v = act(v) ; v *= gelu'(aux[m,n]) ;
+ *   v = alpha * v ; v += bias[n] ; (store preact: v, or gelu'(v) with ME_GEMM_SAVE_GELU_GRAD) ; v = act(v) ;
+ *   v *= gelu'(aux[m,n])  (v *= aux[m,n] with ME_GEMM_AUX_IS_FACTOR) ;
  *   v *= colscale[n] ; v += residual[res_row(m), n] ; v += beta * C_old[m,n] ; C[out_row(m), n] = v
  * with res_row(m) = res_row_mod ? m % res_row_mod : m   (pos-embed broadcast over the batch) and
  * out_row(m) = out_group_rows ? (m / out_group_rows) * out_group_stride + m % out_group_rows + out_row_offset : m
@@ -82,6 +83,10 @@ int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
  * 16-byte aligned rows. */
 enum { ME_GEMM_NT = 0, ME_GEMM_TN = 1 };
 enum { ME_ACT_NONE = 0, ME_ACT_GELU = 1 };
+/* me_gemm_desc.flags.  The GELU of Mlp.forward (mlp.py:31) needs gelu'(h) in backward; a forward that saves gelu'(h)
+ * itself (ME_GEMM_SAVE_GELU_GRAD: one exponential serves GELU and its derivative) turns the backward epilogue into a plain
+ * multiplication by the saved factor (ME_GEMM_AUX_IS_FACTOR) -- no transcendental arithmetic in the dgrad GEMM. */
+enum { ME_GEMM_SAVE_GELU_GRAD = 1, ME_GEMM_AUX_IS_FACTOR = 2 };
 
 typedef struct me_gemm_desc {
     int32_t op;            /* ME_GEMM_NT / ME_GEMM_TN */
@@ -98,7 +103,7 @@ typedef struct me_gemm_desc {
     int32_t aux_dtype;
     const void* aux; int64_t ldaux;                          /* optional: multiply by gelu'(aux) (GELU backward) */
     const void* residual; int64_t ldres; int32_t res_dtype;  /* optional */
-    int32_t reserved0;
+    int32_t flags;         /* ME_GEMM_* bits (0 = none) */
     int64_t res_row_mod;
     int64_t out_group_rows, out_group_stride, out_row_offset;
     void* workspace; int64_t workspace_bytes;               /* optional scratch (split-K slabs), see below */

@@ -20,6 +20,8 @@ LIB_PATH = os.path.join(_HERE, "libmetaenc.so")
 ME_F32, ME_BF16, ME_F16 = 0, 1, 2      # ME_F16: storage dtype of me_cast / me_transpose_cast only
 ME_GEMM_NT, ME_GEMM_TN = 0, 1
 ME_ACT_NONE, ME_ACT_GELU = 0, 1
+ME_GEMM_SAVE_GELU_GRAD, ME_GEMM_AUX_IS_FACTOR = 1, 2
+ME_GEMM_SAVE_GELU_GRAD, ME_GEMM_AUX_IS_FACTOR = 1, 2
 ME_PROF_LN_FWD, ME_PROF_LN_BWD, ME_PROF_ATTN_FWD, ME_PROF_ATTN_BWD = 16, 17, 18, 19      # me_gemm_profile_rec.op codes
 ME_COMM_ID_BYTES = 128
 ME_RESIZE_BILINEAR, ME_RESIZE_BICUBIC = 0, 1
@@ -46,7 +48,7 @@ class GemmDesc(ctypes.Structure):
         ("aux_dtype", c_int32),
         ("aux", c_void_p), ("ldaux", c_int64),
         ("residual", c_void_p), ("ldres", c_int64), ("res_dtype", c_int32),
-        ("reserved0", c_int32),
+        ("flags", c_int32),
         ("res_row_mod", c_int64),
         ("out_group_rows", c_int64), ("out_group_stride", c_int64), ("out_row_offset", c_int64),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),

@@ -142,7 +142,8 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     if (rc) return rc;
     gemm_desc(g, ME_GEMM_NT, dt, s.M, s.Hd, s.C, v.xn2, s.C, d->fc1_w, s.C, v.a, s.Hd, dt);
     g.bias = d->fc1_b; g.act = ME_ACT_GELU;
-    if (keep) { g.preact = v.hpre; g.ldpre = s.Hd; g.preact_dtype = dt; }
+    // (saved for backward: gelu'(h), not h -- the fc2 dgrad epilogue then multiplies by a stored factor)
+    if (keep) { g.preact = v.hpre; g.ldpre = s.Hd; g.preact_dtype = dt; g.flags = ME_GEMM_SAVE_GELU_GRAD; }
     g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
     if ((rc = me_gemm(&g, stream))) return rc;
     gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C, s.Hd, v.a, s.Hd, d->fc2_w, s.Hd, y, s.C, rdt);
@@ -182,7 +183,7 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
 
     auto nt = [&](const void* A, int64_t K, const void* Wt, void* C, int64_t N, const void* aux) -> int {
         gemm_desc(g, ME_GEMM_NT, dt, s.M, N, K, A, K, Wt, K, C, N, dt);
-        if (aux) { g.aux = aux; g.ldaux = N; g.aux_dtype = dt; }
+        if (aux) { g.aux = aux; g.ldaux = N; g.aux_dtype = dt; g.flags = ME_GEMM_AUX_IS_FACTOR; }
         g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
         return me_gemm(&g, stream);
     };

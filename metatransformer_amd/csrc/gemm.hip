@@ -229,36 +229,38 @@ int launch_g128(const GemmParams& p, hipStream_t stream) {
     return ME_OK;
 }
 
+// fold the partial column sums of A (fixed order: deterministic).  The LAST workgroups of the grid take 32 columns each,
+// eight threads per column striding over the partial rows, then a fixed-order fold through LDS -- kept off the first
+// workgroups so it overlaps the slab fold instead of delaying it.
+__device__ __forceinline__ void fold_colsum(const GemmParams& p, const float* __restrict__ cs_part, int n_part, float* __restrict__ colsum_out) {
+    __shared__ float red[8][32];
+    const int nblk = (int)((p.M + 31) / 32);
+    const int b = (int)gridDim.x - 1 - (int)blockIdx.x;
+    if (b < nblk || gridDim.x < (unsigned)nblk) {
+        for (int cb = b; cb < nblk; cb += (int)gridDim.x) {
+            const int64_t m = (int64_t)cb * 32 + (threadIdx.x & 31);
+            const int jg = threadIdx.x >> 5;
+            float s = 0.f;
+            if (m < p.M)
+                for (int j = jg; j < n_part; j += 8) s += cs_part[(int64_t)j * p.M + m];
+            red[jg][threadIdx.x & 31] = s;
+            __syncthreads();
+            if (threadIdx.x < 32 && m < p.M) {
+                float t = 0.f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
+                colsum_out[m] = p.beta != 0.0f ? t + p.beta * colsum_out[m] : t;      // follows C's beta
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- split-K fold: sum the fp32 slabs [S][M][N] and apply the real epilogue
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ slabs, int S,
                                                             const float* __restrict__ cs_part, int n_part,
                                                             float* __restrict__ colsum_out) {
-    if (colsum_out) {
-        // fold the partial column sums of A (fixed order: deterministic).  The LAST workgroups of the grid take 32 columns
-        // each, eight threads per column striding over the partial rows, then a fixed-order fold through LDS -- kept off
-        // the first workgroups so it overlaps the slab fold instead of delaying it.
-        __shared__ float red[8][32];
-        const int nblk = (int)((p.M + 31) / 32);
-        const int b = (int)gridDim.x - 1 - (int)blockIdx.x;
-        if (b < nblk || gridDim.x < (unsigned)nblk) {
-            for (int cb = b; cb < nblk; cb += (int)gridDim.x) {
-                const int64_t m = (int64_t)cb * 32 + (threadIdx.x & 31);
-                const int jg = threadIdx.x >> 5;
-                float s = 0.f;
-                if (m < p.M)
-                    for (int j = jg; j < n_part; j += 8) s += cs_part[(int64_t)j * p.M + m];
-                red[jg][threadIdx.x & 31] = s;
-                __syncthreads();
-                if (threadIdx.x < 32 && m < p.M) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
-                    colsum_out[m] = p.beta != 0.0f ? t + p.beta * colsum_out[m] : t;      // follows C's beta
-                }
-                __syncthreads();
-            }
-        }
-    }
+    if (colsum_out) fold_colsum(p, cs_part, n_part, colsum_out);
     const int64_t nq = p.N / 4;
     const int64_t total = p.M * nq;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -432,6 +434,9 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     }
     ME_CHECK_ARG(((uintptr_t)d->A | (uintptr_t)d->B | (uintptr_t)d->C) % 16 == 0, "me_gemm: operands must be 16-byte aligned");
     ME_CHECK_ARG(d->act == ME_ACT_NONE || d->act == ME_ACT_GELU, "me_gemm: bad act");
+    ME_CHECK_ARG((d->flags & ~(ME_GEMM_SAVE_GELU_GRAD | ME_GEMM_AUX_IS_FACTOR)) == 0, "me_gemm: unknown flags");
+    ME_CHECK_ARG(!(d->flags & ME_GEMM_SAVE_GELU_GRAD) || (d->act == ME_ACT_GELU && d->preact), "me_gemm: ME_GEMM_SAVE_GELU_GRAD needs act = GELU and preact");
+    ME_CHECK_ARG(!(d->flags & ME_GEMM_AUX_IS_FACTOR) || d->aux, "me_gemm: ME_GEMM_AUX_IS_FACTOR needs aux");
     if (d->preact) ME_CHECK_ARG(me_dtype_ok(d->preact_dtype) && d->ldpre % 4 == 0, "me_gemm: bad preact");
     if (d->aux) ME_CHECK_ARG(me_dtype_ok(d->aux_dtype) && d->ldaux % 4 == 0, "me_gemm: bad aux");
     if (d->residual) ME_CHECK_ARG(me_dtype_ok(d->res_dtype) && d->ldres % 4 == 0, "me_gemm: bad residual");
@@ -440,6 +445,7 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     p.c_dtype = d->c_dtype; p.act = d->act; p.alpha = d->alpha; p.beta = d->beta;
     p.bias = d->bias; p.colscale = d->colscale;
     p.preact = d->preact; p.ldpre = d->ldpre; p.preact_dtype = d->preact_dtype;
+    p.flags = d->flags;
     p.aux = d->aux; p.ldaux = d->ldaux; p.aux_dtype = d->aux_dtype;
     p.residual = d->residual; p.ldres = d->ldres; p.res_dtype = d->res_dtype;
     p.res_row_mod = d->res_row_mod; p.out_group_rows = d->out_group_rows;

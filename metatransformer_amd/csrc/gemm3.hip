@@ -776,7 +776,9 @@ __device__ __forceinline__ u32x4 g3r_lanes(const u32x4& v, int addr) {
     return o;
 }
 
-template <int EPI, bool PRE>
+// EPI: 0 bias, 1 GELU (PRE: 0 nothing saved, 1 pre-activation saved, 2 gelu'(pre-activation) saved), 2 + residual row
+// operand, 3 * gelu'(row operand), 6 * row operand
+template <int EPI, int PRE>
 __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int tm, int tn, int lane, const G3Src& nxt, int nk,
                                               const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero) {
     asm volatile("" : "+v"(lane));
@@ -799,7 +801,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     const __amdgpu_buffer_rsrc_t crs = tile_rsrc(p.C, p.ldc);
 #endif
     const __amdgpu_buffer_rsrc_t prs = PRE ? tile_rsrc(p.preact, p.ldpre) : crs;
-    const __amdgpu_buffer_rsrc_t rrs = EPI == 2 ? tile_rsrc(p.residual, p.ldres) : EPI == 3 ? tile_rsrc(p.aux, p.ldaux) : crs;
+    const __amdgpu_buffer_rsrc_t rrs = EPI == 2 ? tile_rsrc(p.residual, p.ldres) : (EPI == 3 || EPI == 6) ? tile_rsrc(p.aux, p.ldaux) : crs;
     const int rop_ld = (int)(EPI == 2 ? p.ldres : p.ldaux);
     // memory side: lane t = row t >> 3 of an 8-row half slab, 16-byte chunk t & 7 of the wave's 128-byte row segment.  A
     // chunk past the column edge gets an offset no descriptor admits; rows past the row edge fall behind the descriptor's end.
@@ -832,7 +834,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     };
     constexpr int AHEAD = EPI == 3 ? 4 : 6;      // (gelu' needs the registers for its arithmetic: six slabs ahead spill into the K-loop)
     u32x4 rowop[8][2];
-    if (EPI == 2 || EPI == 3) {
+    if (EPI == 2 || EPI == 3 || EPI == 6) {
 #pragma unroll
         for (int mt = 0; mt < AHEAD; ++mt) fetch(mt, rowop[mt]);
     }
@@ -844,7 +846,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         f32x4 ro[2][2];
-        if (EPI == 2 || EPI == 3) {
+        if (EPI == 2 || EPI == 3 || EPI == 6) {
             unpack(g3r_lanes(rowop[mt][0], to_reg), ro[0][0], ro[0][1]);
             unpack(g3r_lanes(rowop[mt][1], to_reg), ro[1][0], ro[1][1]);
             if (mt + AHEAD < 8) fetch(mt + AHEAD, rowop[mt + AHEAD]);
@@ -879,10 +881,22 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
         for (int h = 0; h < 2; ++h) {           // half A: rows 0..7 of the slab, half B: rows 8..15
             f32x4 v0 = v[h][0], v1 = v[h][1];
             if (EPI == 1) {
-                if (PRE) __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
-                v0 = gelu_erf4(v0);
-                v1 = gelu_erf4(v1);
+                if (PRE == 2) {
+                    // gelu and gelu' from the same Phi / Gaussian parts: the backward GEMM multiplies by the saved factor
+                    f32x4 ph0, ga0, ph1, ga1;
+                    phi_parts4(v0, ph0, ga0);
+                    phi_parts4(v1, ph1, ga1);
+                    const f32x4 d0 = ph0 + v0 * ga0 * 0.3989422804014327f, d1 = ph1 + v1 * ga1 * 0.3989422804014327f;
+                    __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(d0, d1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
+                    v0 *= ph0;
+                    v1 *= ph1;
+                } else {
+                    if (PRE) __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
+                    v0 = gelu_erf4(v0);
+                    v1 = gelu_erf4(v1);
+                }
             }
+            if (EPI == 6) { v0 *= ro[h][0]; v1 *= ro[h][1]; }
             if (EPI == 3) {
                 v0 *= gelu_erf_grad4(ro[h][0]);
                 v1 *= gelu_erf_grad4(ro[h][1]);
@@ -898,9 +912,9 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
 
 // memory operations one g3_epilogue_r issues per wave behind the next tile's A-Y half-tile: >= the stores (+ the later
 // row-operand loads); an under-count only makes the wait stricter
-template <int EPI, bool PRE> constexpr int g3r_seam() { return PRE ? 32 : EPI >= 2 ? 20 : 16; }
+template <int EPI, int PRE> constexpr int g3r_seam() { return PRE ? 32 : EPI >= 2 ? 20 : 16; }
 
-template <int EPI, bool PRE>
+template <int EPI, int PRE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g3r_kernel(const GemmParams p) {
     constexpr int SEAM = g3r_seam<EPI, PRE>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1130,7 +1144,7 @@ int g3_cus() {
     return n;
 }
 
-template <int EPI, bool PRE> int launch3r(const GemmParams& q, int G, hipStream_t stream) {
+template <int EPI, int PRE> int launch3r(const GemmParams& q, int G, hipStream_t stream) {
     static OncePerDevice once;
     if (once.need())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
@@ -1144,6 +1158,16 @@ template <int EPI, bool PRE> int launch3r(const GemmParams& q, int G, hipStream_
     hipLaunchKernelGGL((gemm_g3r_kernel<EPI, PRE>), dim3((unsigned)G), dim3(512), G3_LDS, stream, q);
     ME_CHECK_LAUNCH("me_gemm(g3 resident)");
     return ME_OK;
+}
+
+int launch3r_any(int epi, int pre, const GemmParams& q, int G, hipStream_t stream) {
+    switch (epi) {
+        case 0: return launch3r<0, 0>(q, G, stream);
+        case 1: return pre == 2 ? launch3r<1, 2>(q, G, stream) : pre ? launch3r<1, 1>(q, G, stream) : launch3r<1, 0>(q, G, stream);
+        case 2: return launch3r<2, 0>(q, G, stream);
+        case 3: return launch3r<3, 0>(q, G, stream);
+        default: return launch3r<6, 0>(q, G, stream);
+    }
 }
 
 template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t stream) {
@@ -1187,14 +1211,19 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
     const int nwg = q.g3_full_tiles + (tiles - q.g3_full_tiles) * q.g3_split;
     // the resident form (one workgroup per CU, operand stream running through the epilogues) whenever every CU gets work
     // and the output / row operands are bf16 with tile-local 32-bit offsets
-    if constexpr (EPI <= 3) if (gemm_dev().g3_persistent == 1) {
+    if (gemm_dev().g3_persistent == 1) {
+        int repi = EPI <= 3 ? EPI : -1, pre = (EPI == 1 && p.preact) ? 1 : 0;
+        if (EPI == 4 && p.flags) {
+            // the two halves of the "save gelu'" pair (pick_epi sends flagged descriptors to the generic epilogue)
+            const bool plain = p.beta == 0.0f && p.out_group_rows == 0 && p.res_row_mod == 0 && !p.colscale && !p.residual;
+            if (plain && p.flags == ME_GEMM_SAVE_GELU_GRAD && p.act == ME_ACT_GELU && p.preact && !p.aux) { repi = 1; pre = 2; }
+            if (plain && p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_BF16 && !p.preact) repi = 6;
+        }
         const int G = g3_cus() & ~7;
         const int64_t ldmax = std::max(std::max(p.ldc, p.preact ? p.ldpre : 0), std::max(p.residual ? p.ldres : 0, p.aux ? p.ldaux : 0));
-        const bool pre = EPI == 1 && p.preact != nullptr;
-        if (G >= 8 && nwg >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!pre || p.preact_dtype == ME_BF16) && 256 * ldmax * 2 < (1ll << 31)) {
-            if (pre) return launch3r<EPI, EPI == 1>(q, G, stream);
-            return launch3r<EPI, false>(q, G, stream);
-        }
+        if (repi >= 0 && G >= 8 && nwg >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!pre || p.preact_dtype == ME_BF16) &&
+            256 * ldmax * 2 < (1ll << 31))
+            return launch3r_any(repi, pre, q, G, stream);
     }
     hipLaunchKernelGGL((gemm_g3_kernel<EPI>), dim3((unsigned)nwg), dim3(512), G3_LDS, stream, q);
     ME_CHECK_LAUNCH("me_gemm(g3)");

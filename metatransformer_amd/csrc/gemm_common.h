@@ -6,6 +6,7 @@ struct GemmParams {
     const void* A; const void* B; void* C;
     int64_t M, N, K, lda, ldb, ldc;
     int c_dtype, act;
+    int flags;                              // ME_GEMM_SAVE_GELU_GRAD / ME_GEMM_AUX_IS_FACTOR
     float alpha, beta;
     const float* bias; const float* colscale;
     void* preact; int64_t ldpre; int preact_dtype;
@@ -27,11 +28,11 @@ struct GemmParams {
 __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, int64_t n, f32x4 v) {
     v *= p.alpha;
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-    if (p.preact) store4_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v);
+    if (p.preact) store4_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, (p.flags & ME_GEMM_SAVE_GELU_GRAD) ? gelu_erf_grad4(v) : v);
     if (p.act == ME_ACT_GELU) v = gelu_erf4(v);
     if (p.aux) {
         const f32x4 a = load4_as_f32(p.aux, p.aux_dtype, m * p.ldaux + n);
-        v *= gelu_erf_grad4(a);
+        v *= (p.flags & ME_GEMM_AUX_IS_FACTOR) ? a : gelu_erf_grad4(a);
     }
     if (p.colscale) v *= *reinterpret_cast<const f32x4*>(p.colscale + n);
     if (p.residual) {
@@ -77,7 +78,10 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
         v0 += *reinterpret_cast<const f32x4*>(p.bias + n);
         v1 += *reinterpret_cast<const f32x4*>(p.bias + n + 4);
     }
-    if (p.preact) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
+    if (p.preact) {
+        if (p.flags & ME_GEMM_SAVE_GELU_GRAD) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, gelu_erf_grad4(v0), gelu_erf_grad4(v1));
+        else store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
+    }
     if (p.act == ME_ACT_GELU) {
         v0 = gelu_erf4(v0);
         v1 = gelu_erf4(v1);
@@ -85,8 +89,8 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
     if (p.aux) {
         f32x4 a0, a1;
         load8_as_f32(p.aux, p.aux_dtype, m * p.ldaux + n, a0, a1);
-        v0 *= gelu_erf_grad4(a0);
-        v1 *= gelu_erf_grad4(a1);
+        if (p.flags & ME_GEMM_AUX_IS_FACTOR) { v0 *= a0; v1 *= a1; }
+        else { v0 *= gelu_erf_grad4(a0); v1 *= gelu_erf_grad4(a1); }
     }
     if (p.colscale) {
         v0 *= *reinterpret_cast<const f32x4*>(p.colscale + n);
@@ -114,6 +118,7 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
 //   3 ... * gelu'(bf16 aux row operand)   4 generic (anything include/metaenc.h allows)   5 raw fp32 split-K slab
 static inline int pick_epi(const GemmParams& p) {
     if (p.split_k > 1) return 5;
+    if (p.flags) return 4;                  // (the resident g3 kernel has its own forms of these: launch_g3)
     if (p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return 4;
     const int nrow = (p.residual ? 1 : 0) + (p.aux ? 1 : 0);
     if (nrow > 1) return 4;

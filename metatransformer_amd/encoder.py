@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import _capi, ops
-from ._capi import ME_ACT_GELU, ME_GEMM_TN, MetaEncError
+from ._capi import ME_ACT_GELU, ME_GEMM_AUX_IS_FACTOR, ME_GEMM_SAVE_GELU_GRAD, ME_GEMM_TN, MetaEncError
 
 
 def _resolve_eps(norm_layer) -> float:
@@ -222,7 +222,8 @@ class _BlockFn(torch.autograd.Function):
             x1 = ops.dropout_add(t1, x2, N, p_drop, p_path, seed + 1, colscale=g1 if ls_grad else None)
         xn2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w, n2b, blk.eps, cdt, save_stats=need_grad)
         hpre = torch.empty((M, fc1w.shape[0]), dtype=cdt, device=x.device) if need_grad else None
-        a = ops.gemm(xn2, cache.fwd("fc1", fc1w, cdt), bias=fc1b, act=ME_ACT_GELU, preact=hpre)
+        a = ops.gemm(xn2, cache.fwd("fc1", fc1w, cdt), bias=fc1b, act=ME_ACT_GELU, preact=hpre,
+                     flags=ME_GEMM_SAVE_GELU_GRAD if need_grad else 0)      # saved: gelu'(h) (as me_block_fwd does)
         if stoch is None and not ls_grad:
             y = ops.gemm(a, cache.fwd("fc2", fc2w, cdt), bias=fc2b, residual=x1, out_dtype=rdt, colscale=g2)
         else:                 # Mlp: fc1 -> act -> drop -> fc2 -> drop (mlp.py:29-35), then drop_path + residual
@@ -378,7 +379,7 @@ class _BlockFn(torch.autograd.Function):
 
         # ---- MLP branch: y = x1 + gamma2 * fc2(gelu(fc1(LN2(x1))))
         dy_c, d_g2 = branch_grad(dy2, t2, g2, seed + 3)
-        dh = ops.gemm(dy_c, cache.transposed("fc2", fc2w, cdt), aux=hpre)            # dA * gelu'(h)
+        dh = ops.gemm(dy_c, cache.transposed("fc2", fc2w, cdt), aux=hpre, flags=ME_GEMM_AUX_IS_FACTOR)   # dA * gelu'(h)
         if stoch is not None and p_drop > 0:
             dh = ops.dropout_add(dh, None, N, p_drop, 0.0, seed + 2)
         d_fc2w, d_fc2b = wgrad(dy_c, a, blk.mlp.fc2, ng[11], ng[12] and ctx.has_bias[3])

@@ -100,11 +100,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
          residual: Optional[torch.Tensor] = None, res_row_mod: int = 0, preact: Optional[torch.Tensor] = None,
          aux: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, alpha: float = 1.0,
          beta: float = 0.0, out_rows: Optional[int] = None, out_group: Tuple[int, int, int] = (0, 0, 0),
-         want_colsum_a: bool = False, colsum_out: Optional[torch.Tensor] = None):
+         want_colsum_a: bool = False, colsum_out: Optional[torch.Tensor] = None, flags: int = 0):
     """NT: out[M,N] = a[M,K] @ b[N,K]^T ;  TN: out[M,N] = a[K,M]^T @ b[K,N]; fused epilogue per include/metaenc.h.
     want_colsum_a (TN): also return sum_k a[k, :] (fp32 [M]) -- the bias gradient that goes with a weight gradient --
     from the same kernel when the library can fuse it, else from me_colsum; the result is then (out, colsum).
-    colsum_out: fp32 [M] buffer for it, accumulated with the same beta as out (only used when the kernel fuses it)."""
+    colsum_out: fp32 [M] buffer for it, accumulated with the same beta as out (only used when the kernel fuses it).
+    flags: ME_GEMM_SAVE_GELU_GRAD (preact receives gelu'(pre-activation)) / ME_GEMM_AUX_IS_FACTOR (multiply by aux itself)."""
     lib = _capi.load()
     _req(a, "a"); _req(b, "b")
     if a.dtype != b.dtype:
@@ -129,6 +130,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
     d.B, d.ldb = ptr(b2), b2.stride(0)
     d.C, d.ldc, d.c_dtype = ptr(out), out.stride(-2), dtype_code(out.dtype)
     d.act, d.alpha, d.beta = act, alpha, beta
+    d.flags = flags
     keep = []
     if bias is not None:
         bias = _f32(bias).contiguous(); keep.append(bias)

@@ -4,7 +4,7 @@ CPU oracle restatements, on seeded inputs.  fp32 tolerance 1e-3 relative (north 
 import pytest
 import torch
 
-from conftest import TOL_BF16_OP, TOL_F32, rel_err
+from conftest import TOL_BF16_OP, TOL_F32, check_close, rel_err
 from metatransformer_amd import _capi, ops
 from oracle import block_oracle as bo
 from oracle import tokenizer_oracle as to
@@ -111,6 +111,28 @@ def test_gemm_nt_epilogues(dev, dt):
     ref = (a2.double() @ w.double().t()).reshape(Bn, tps, N) + pos.double()
     out = out.reshape(Bn, 197, N).cpu()
     assert torch.all(out[:, 0] == 0) and rel_err(out[:, 1:], ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 1536, 256), (256 * 160, 3072, 256), (256 * 160 + 40, 1032, 128)])
+def test_gemm_gelu_grad_pair(dev, M, N, K):
+    """ME_GEMM_SAVE_GELU_GRAD / ME_GEMM_AUX_IS_FACTOR: the forward saves gelu'(h) instead of h, the backward multiplies by
+    the saved factor (mlp.py:31 and its autograd).  Small shape: generic epilogues; large shapes: the resident kernel's own
+    forms (whole and ragged tiles)."""
+    dt = torch.bfloat16
+    a, w, bias = rnd(M, K, seed=1).to(dt), (0.05 * rnd(N, K, seed=2)).to(dt), 0.1 * rnd(N, seed=3)
+    h = (a.double() @ w.double().t() + bias.double()).requires_grad_(True)
+    bo.gelu_erf(h).sum().backward()
+    sav = torch.empty(M, N, dtype=dt, device=dev)
+    y = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), act=_capi.ME_ACT_GELU, preact=sav, flags=_capi.ME_GEMM_SAVE_GELU_GRAD)
+    assert rel_err(y.float(), bo.gelu_erf(h.detach())) < 8e-3 and rel_err(sav.float(), h.grad) < 8e-3
+    check_close(sav.float().cpu(), h.grad.float(), 8e-3, "saved gelu'")
+    # backward half: dA * saved factor, against the product with the factor AS STORED (bf16)
+    g, wt = rnd(M, K, seed=4).to(dt), (0.05 * rnd(N, K, seed=5)).to(dt)
+    dh = ops.gemm(g.to(dev), wt.to(dev), aux=sav, flags=_capi.ME_GEMM_AUX_IS_FACTOR, out_dtype=dt)
+    ref = (g.double() @ wt.double().t()) * sav.double().cpu()
+    assert rel_err(dh.float(), ref) < 8e-3
+    with pytest.raises(_capi.MetaEncError):
+        ops.gemm(a.to(dev), w.to(dev), flags=_capi.ME_GEMM_SAVE_GELU_GRAD)          # needs act = GELU and preact
 
 
 @pytest.mark.parametrize("T,M,N", [(394, 768, 768), (1000, 3072, 768), (130, 136, 72), (65, 8, 8)])

@@ -3,7 +3,7 @@
 //   python -m metatransformer_amd.build --dev      # builds tools/_build/libmetaenc_dev.so and tools/_build/gemm_dev
 //   tools/_build/gemm_dev [--iters N] [--check] case [case ...]
 //   case  = family:M:N:K:epi[:debug]      family in {auto, g128, g2b, g2w, g3, g3x, g3p}; epi 0 bias, 1 gelu(+preact), 2 residual,
-//           3 gelu'(aux); debug = GemmDev::debug bits (1 = K-loop only)
+//           3 gelu'(aux), 6 * aux (ME_GEMM_AUX_IS_FACTOR), 7 gelu + saved gelu' (ME_GEMM_SAVE_GELU_GRAD); debug = GemmDev::debug bits
 //           tn-family:M:N:K               wgrad form C[M, N] = A[K, M]^T B[K, N] (fp32 output), family in {auto, g2b, g3}
 //
 // Every case is checked (all M x N outputs) against a straightforward fp32 kernel on the same bf16 operands, then timed
@@ -69,9 +69,11 @@ __global__ void ref_kernel(const uint16_t* A, const uint16_t* B, const float* bi
     float acc = 0.f;
     for (int64_t k = 0; k < K; ++k) acc = fmaf(bf2f(a[k]), bf2f(b[k]), acc);
     float v = acc + (bias ? bias[n] : 0.f);
-    if (epi == 1) {
-        out_pre[m * N + n] = v;
+    if (epi == 1 || epi == 7) {
+        out_pre[m * N + n] = epi == 7 ? 0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v) : v;
         v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    } else if (epi == 6) {
+        v *= bf2f(rowop[m * N + n]);
     } else if (epi == 2) {
         v += bf2f(rowop[m * N + n]);
     } else if (epi == 3) {
@@ -247,7 +249,7 @@ int main(int argc, char** argv) {
             CK(hipMalloc(&A[s], (size_t)M * K * 2));
             CK(hipMalloc(&C[s], (size_t)M * N * 2));
             P[s] = nullptr;
-            if (epi == 1) CK(hipMalloc(&P[s], (size_t)M * N * 2));
+            if (epi == 1 || epi == 7) CK(hipMalloc(&P[s], (size_t)M * N * 2));
             fill_kernel<<<2048, 256, 0, st>>>(A[s], (size_t)M * K, 17, 1.0f);     // same content in every set
             CK(hipMemsetAsync(C[s], 0xff, (size_t)M * N * 2, st));
         }
@@ -255,7 +257,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&bias, (size_t)N * 4));
         fill_kernel<<<2048, 256, 0, st>>>(Bw, (size_t)N * K, 99, 0.05f);
         fill_f32_kernel<<<64, 256, 0, st>>>(bias, (size_t)N, 5, 0.5f);
-        if (epi == 2 || epi == 3) {
+        if (epi == 2 || epi == 3 || epi == 6) {
             CK(hipMalloc(&rowop, (size_t)M * N * 2));
             fill_kernel<<<2048, 256, 0, st>>>(rowop, (size_t)M * N, 1234, 1.0f);
         }
@@ -264,7 +266,9 @@ int main(int argc, char** argv) {
         d.op = ME_GEMM_NT; d.ab_dtype = ME_BF16; d.M = M; d.N = N; d.K = K;
         d.lda = K; d.B = Bw; d.ldb = K; d.ldc = N; d.c_dtype = ME_BF16;
         d.alpha = 1.0f; d.beta = 0.0f; d.bias = bias;
-        if (epi == 1) { d.act = ME_ACT_GELU; d.ldpre = N; d.preact_dtype = ME_BF16; }
+        if (epi == 1 || epi == 7) { d.act = ME_ACT_GELU; d.ldpre = N; d.preact_dtype = ME_BF16; }
+        if (epi == 7) d.flags = ME_GEMM_SAVE_GELU_GRAD;
+        if (epi == 6) { d.aux = rowop; d.ldaux = N; d.aux_dtype = ME_BF16; d.flags = ME_GEMM_AUX_IS_FACTOR; }
         if (epi == 2) { d.residual = rowop; d.ldres = N; d.res_dtype = ME_BF16; }
         if (epi == 3) { d.aux = rowop; d.ldaux = N; d.aux_dtype = ME_BF16; }
         d.A = A[0]; d.C = C[0]; d.preact = P[0];
@@ -282,7 +286,7 @@ int main(int argc, char** argv) {
         std::string verdict = "unchecked";
         if (check && !(debug & 1)) {
             CK(hipMalloc(&ref, (size_t)M * N * 4));
-            if (epi == 1) CK(hipMalloc(&ref_pre, (size_t)M * N * 4));
+            if (epi == 1 || epi == 7) CK(hipMalloc(&ref_pre, (size_t)M * N * 4));
             ref_kernel<<<dim3((unsigned)((N + 255) / 256), (unsigned)M), 256, 0, st>>>(A[0], Bw, bias, rowop, epi, M, N, K, ref, ref_pre);
             unsigned long long* nbad;
             float* maxerr;
@@ -291,7 +295,7 @@ int main(int argc, char** argv) {
             char buf[256];
             verdict.clear();
             for (int s = 0; s < NSET; s += NSET - 1) {          // first and last set
-                for (int which = 0; which < (epi == 1 ? 2 : 1); ++which) {
+                for (int which = 0; which < ((epi == 1 || epi == 7) ? 2 : 1); ++which) {
                     CK(hipMemsetAsync(nbad, 0, 8, st));
                     CK(hipMemsetAsync(maxerr, 0, 4, st));
                     // bf16 output rounding (2^-9 relative) + accumulation-order noise
