@@ -718,10 +718,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // The bias is not added here: the accumulators START at the bias of their columns (g3r_bias / s.binit; alpha = 1),
 // loaded for the NEXT tile at the top of this epilogue, ahead of its stores -- a load issued behind the stores could only be
 // waited for by draining them.
+// this lane's index, recomputed from the hardware where it is needed (two VALU operations): a lane id kept in a register
+// across the item loop of the resident kernel is the first thing hipcc spills
+__device__ __forceinline__ int g3_lane_now() {
+    unsigned z = 0;
+    asm volatile("" : "+v"(z));          // (opaque: not common-subexpression'd with, or hoisted to, an earlier copy)
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+}
 struct G3Bias { f32x4 v[4]; };       // this lane's bias for n-tiles 0..3 of its wave column (accumulator layout)
 __device__ __forceinline__ G3Bias g3r_bias(const __amdgpu_buffer_rsrc_t brs, int tn, int wave, int lane) {
     G3Bias b;
-    asm volatile("" : "+v"(lane));       // (derive the offset here: hoisted out of the item loop it would be spilled)
+    (void)lane;
+    lane = g3_lane_now();                // (derive the offset here: hoisted out of the item loop it would be spilled)
     const int col = tn * G3_BN + (wave & 3) * 64 + 4 * (lane >> 4);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)      // (no bias, or columns past N: zero records / out of range -> zeros)
@@ -781,7 +789,8 @@ __device__ __forceinline__ u32x4 g3r_lanes(const u32x4& v, int addr) {
 template <int EPI, int PRE>
 __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int tm, int tn, int lane, const G3Src& nxt, int nk,
                                               const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero) {
-    asm volatile("" : "+v"(lane));
+    (void)lane;
+    lane = g3_lane_now();
     const int wr = s.wave >> 2, wc = s.wave & 3;
     const int r = lane & 15, g = lane >> 4;
     const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
@@ -832,7 +841,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
         o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
         return __builtin_bit_cast(u32x4, o);
     };
-    constexpr int AHEAD = EPI == 3 ? 4 : 6;      // (gelu' needs the registers for its arithmetic: six slabs ahead spill into the K-loop)
+    constexpr int AHEAD = EPI == 3 ? 4 : 8;      // all sixteen row-operand loads of the tile go out ahead of its first store      // (gelu' needs the registers for its arithmetic: six slabs ahead spill into the K-loop)
     u32x4 rowop[8][2];
     if (EPI == 2 || EPI == 3 || EPI == 6) {
 #pragma unroll
@@ -1033,13 +1042,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (part >= 0) {
             g3_issue<3>(s, nxt, 1, nkt0 + 1);
             const int64_t row0 = (int64_t)(F / p.tiles_n) * G3_BM;
-            g3_epilogue<5>(p, s, (int64_t)tm * G3_BM, (int64_t)tn * G3_BN, lane, p.g3_slabs + (int64_t)part * (p.M - row0) * p.N, row0);
-            const G3Bias nb = g3r_bias(brs, ntn, wave, lane);
+            g3_epilogue<5>(p, s, (int64_t)tm * G3_BM, (int64_t)tn * G3_BN, g3_lane_now(), p.g3_slabs + (int64_t)part * (p.M - row0) * p.N, row0);
+            const G3Bias nb = g3r_bias(brs, ntn, wave, 0);
             g3r_set_binit(s, nb, npart >= 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             prime();
         } else {
-            g3_epilogue_r<EPI, PRE>(p, s, tm, tn, lane, nxt, nkt0 + 1, brs, ntn, npart >= 0);
+            g3_epilogue_r<EPI, PRE>(p, s, tm, tn, 0, nxt, nkt0 + 1, brs, ntn, npart >= 0);
         }
         G3R_STAMP(5)
 #ifdef ME_DEV

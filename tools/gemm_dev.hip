@@ -367,6 +367,22 @@ int main(int argc, char** argv) {
                     }
                 if (cnt) printf("  workgroups 0..7, items 1..4, wave row %d: %6.0f | %6.0f | %7.0f | %6.0f | %6.0f\n", wrow, d[0] / cnt, d[1] / cnt, d[2] / cnt, d[3] / cnt, d[4] / cnt);
             }
+            {   // per-workgroup busy time (first stamp to last stamp): how unevenly do the CUs finish?
+                double mn = 1e30, mx = 0, sum = 0; int cnt = 0;
+                double xs[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int xc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int w = 0; w < 256; ++w) {
+                    const unsigned long long* t = &h[((size_t)w * 2) * 16 * 8];
+                    if (!t[0]) continue;
+                    unsigned long long last = 0;
+                    for (int it = 0; it < 16; ++it) if (t[it * 8 + 5]) last = t[it * 8 + 5];
+                    const double d = (double)(last - t[0]);
+                    mn = d < mn ? d : mn; mx = d > mx ? d : mx; sum += d; ++cnt;
+                    xs[w & 7] += d; ++xc[w & 7];
+                }
+                printf("  per-workgroup busy clocks: min %.0f  mean %.0f  max %.0f   per XCD mean:", mn, sum / cnt, mx);
+                for (int x = 0; x < 8; ++x) printf(" %.0f", xc[x] ? xs[x] / xc[x] : 0.0);
+                printf("\n");
+            }
             // spread of the start stamps of item 1 across workgroups (how far the CUs drift apart)
             {
                 unsigned long long lo = ~0ull, hi = 0;
