@@ -256,7 +256,8 @@ __device__ __forceinline__ void fold_colsum(const GemmParams& p, const float* __
     }
 }
 
-// ---- split-K fold: sum the fp32 slabs [S][M][N] and apply the real epilogue
+// ---- split-K fold: sum the fp32 slabs [S][M][N] and apply the real epilogue (LIN: the descriptor has no GELU form)
+template <bool LIN>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ slabs, int S,
                                                             const float* __restrict__ cs_part, int n_part,
                                                             float* __restrict__ colsum_out) {
@@ -265,10 +266,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     const int64_t total = p.M * nq;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t m = i / nq, n = (i % nq) * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(slabs + m * p.N + n);
-        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(slabs + ((int64_t)s * p.M + m) * p.N + n);
-        epilogue_quad(p, m, n, v);
+        const float* s0 = slabs + m * p.N + n;
+        const int64_t sstride = p.M * p.N;
+        f32x4 v = *reinterpret_cast<const f32x4*>(s0);
+        int s = 1;
+        for (; s + 3 < S; s += 4) {               // four slab reads in flight, added in slab order (deterministic)
+            const f32x4 a = *reinterpret_cast<const f32x4*>(s0 + (int64_t)s * sstride);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + 1) * sstride);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + 2) * sstride);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + 3) * sstride);
+            v += a; v += b; v += c; v += d;
+        }
+        for (; s < S; ++s) v += *reinterpret_cast<const f32x4*>(s0 + (int64_t)s * sstride);
+        if (LIN) epilogue_quad_lin(p, m, n, v);
+        else epilogue_quad(p, m, n, v);
     }
+}
+static void launch_splitk_reduce(const GemmParams& p, unsigned nb, hipStream_t stream, const float* slabs, int S, const float* cs_part,
+                                 int n_part, float* colsum_out) {
+    if (p.act == ME_ACT_NONE && !p.preact && !p.aux)
+        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out);
 }
 
 struct GemmPlan {
@@ -513,8 +532,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
             const int64_t quads = d->M * (d->N / 4);
             int64_t nb = (quads + 255) / 256;
             if (nb > 2048) nb = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p,
-                               reinterpret_cast<const float*>(d->workspace), pl.split_k, ps.colsum_ws, pl.split_k * p.tiles_n,
+            launch_splitk_reduce(p, (unsigned)nb, stream, reinterpret_cast<const float*>(d->workspace), pl.split_k, ps.colsum_ws, pl.split_k * p.tiles_n,
                                d->colsum_a);
             ME_CHECK_LAUNCH("me_gemm(g3 tn fold)");
             return ME_OK;
@@ -544,8 +562,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
                 const int64_t quads = pt.M * (d->N / 4);
                 int64_t nb = (quads + 255) / 256;
                 if (nb > 2048) nb = 2048;
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, pt,
-                                   reinterpret_cast<const float*>(d->workspace), pl.tail_split, nullptr, 0, nullptr);
+                launch_splitk_reduce(pt, (unsigned)nb, stream, reinterpret_cast<const float*>(d->workspace), pl.tail_split, nullptr, 0, nullptr);
                 ME_CHECK_LAUNCH("me_gemm(g3 tail fold)");
                 return ME_OK;
             }
@@ -572,8 +589,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
             const int64_t quads = d->M * (d->N / 4);
             int64_t nb = (quads + 255) / 256;
             if (nb > 2048) nb = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p,
-                               reinterpret_cast<const float*>(d->workspace), pl.split_k, ps.colsum_ws, n_part,
+            launch_splitk_reduce(p, (unsigned)nb, stream, reinterpret_cast<const float*>(d->workspace), pl.split_k, ps.colsum_ws, n_part,
                                d->colsum_a);
             ME_CHECK_LAUNCH("me_gemm(splitk reduce)");
             return ME_OK;
@@ -606,8 +622,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
             const int64_t quads = pt.M * (d->N / 4);
             int64_t nb = (quads + 255) / 256;
             if (nb > 2048) nb = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, pt,
-                               reinterpret_cast<const float*>(d->workspace), pl.tail_split, nullptr, 0, nullptr);
+            launch_splitk_reduce(pt, (unsigned)nb, stream, reinterpret_cast<const float*>(d->workspace), pl.tail_split, nullptr, 0, nullptr);
             ME_CHECK_LAUNCH("me_gemm(tail fold)");
             return ME_OK;
         }

@@ -48,6 +48,24 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, in
 
 
 
+// The same without the GELU forms (no act / preact / aux): what the split-K folds of the weight gradients and of the
+// residual GEMMs need.  A separate function so that those fold kernels do not carry the registers of the erf arithmetic
+// (they are bandwidth-bound: occupancy is their throughput).
+__device__ __forceinline__ void epilogue_quad_lin(const GemmParams& p, int64_t m, int64_t n, f32x4 v) {
+    v *= p.alpha;
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.colscale) v *= *reinterpret_cast<const f32x4*>(p.colscale + n);
+    if (p.residual) {
+        const int64_t rr = p.res_row_mod ? (m % p.res_row_mod) : m;
+        v += load4_as_f32(p.residual, p.res_dtype, rr * p.ldres + n);
+    }
+    const int64_t orow = p.out_group_rows
+                             ? (m / p.out_group_rows) * p.out_group_stride + (m % p.out_group_rows) + p.out_row_offset
+                             : m;
+    if (p.beta != 0.0f) v += p.beta * load4_as_f32(p.C, p.c_dtype, orow * p.ldc + n);
+    store4_from_f32(p.C, p.c_dtype, orow * p.ldc + n, v);
+}
+
 // Eight consecutive output columns n..n+7 of output row m (two quads), with 16-byte accesses on the bf16 side.
 __device__ __forceinline__ void load8_as_f32(const void* base, int dt, int64_t idx, f32x4& a, f32x4& b) {
     if (dt == ME_BF16) {

@@ -28,13 +28,17 @@ from . import _capi, ops
 from ._capi import ME_GEMM_TN, MetaEncError, check, dtype_code, ptr, stream_ptr
 
 
-def _compute_dtype(weight: torch.Tensor) -> torch.dtype:
-    if torch.is_autocast_enabled():
-        dt = torch.get_autocast_dtype("cuda")
-        if dt != torch.bfloat16:
-            raise MetaEncError(f"autocast dtype {dt} unsupported")
-        return dt
-    return weight.dtype
+def _boundary_dtypes(weight: torch.Tensor):
+    """(compute dtype, output dtype) at a tokenizer's boundary, the rule Block follows: fp32 parameters -> exact fp32
+    kernels; bf16 (parameters or autocast) -> bf16 MFMA kernels; fp16 (``.half()`` models, ``torch.autocast(float16)`` --
+    Audio/src/traintest.py) is a STORAGE dtype of the boundary only: tensors are converted by me_cast, the kernels compute
+    in bf16 and the result goes back out as fp16."""
+    dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else weight.dtype
+    if dt == torch.float16:
+        return torch.bfloat16, torch.float16
+    if dt in (torch.bfloat16, torch.float32):
+        return dt, dt
+    raise MetaEncError(f"tokenizer dtype {dt} unsupported (fp32, bf16, fp16)")
 
 
 class _PatchEmbedFn(torch.autograd.Function):
@@ -42,11 +46,14 @@ class _PatchEmbedFn(torch.autograd.Function):
     optional pos-embed add and cls-token row offset into the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pos, geom, cdt, prefix_rows):
+    def forward(ctx, x, weight, bias, pos, geom, cdt, prefix_rows, odt=None):
         kt, kh, kw, st, sh, sw = geom
         B = x.shape[0]
         Cout = weight.shape[0]
+        x_dtype = x.dtype
         x = x.contiguous()
+        if x.dtype == torch.float16:                      # fp16 is converted at the boundary (me_cast), never computed in
+            x = ops.cast(x, torch.bfloat16)
         cols, tps = ops.patchify(x, kt, kh, kw, st, sh, sw, cdt)
         w2 = ops.cast(weight.detach().reshape(Cout, -1).contiguous(), cdt)
         out_tps = tps + prefix_rows
@@ -63,13 +70,15 @@ class _PatchEmbedFn(torch.autograd.Function):
         ops.gemm(cols, w2, out=y, bias=bias, residual=pos2, res_row_mod=tps if pos2 is not None else 0,
                  out_group=(tps, out_tps, prefix_rows) if prefix_rows else (0, 0, 0))
         ctx.save_for_backward(cols, weight)
-        ctx.meta = (tuple(x.shape), geom, cdt, tps, out_tps, prefix_rows, bias is not None, pos is not None)
+        ctx.meta = (tuple(x.shape), geom, cdt, tps, out_tps, prefix_rows, bias is not None, pos is not None, x_dtype)
+        if odt is not None and odt != y.dtype:
+            y = ops.cast(y, odt)
         return y.reshape(B, out_tps, Cout)
 
     @staticmethod
     def backward(ctx, dy):
         cols, weight = ctx.saved_tensors
-        x_shape, geom, cdt, tps, out_tps, prefix_rows, has_bias, has_pos = ctx.meta
+        x_shape, geom, cdt, tps, out_tps, prefix_rows, has_bias, has_pos, x_dtype = ctx.meta
         kt, kh, kw, st, sh, sw = geom
         B = x_shape[0]
         Cout = weight.shape[0]
@@ -80,16 +89,19 @@ class _PatchEmbedFn(torch.autograd.Function):
         ng = ctx.needs_input_grad
         dW = db = dx = dpos = None
         if ng[1]:
-            dW = ops.gemm(dy2, cols, op=ME_GEMM_TN, out_dtype=weight.dtype).reshape(weight.shape)
+            wdt = torch.float32 if weight.dtype == torch.float16 else weight.dtype
+            dW = ops.cast(ops.gemm(dy2, cols, op=ME_GEMM_TN, out_dtype=wdt), weight.dtype).reshape(weight.shape)
         if ng[2] and has_bias:
             db = ops.colsum(dy2).to(weight.dtype)
         if ng[0]:
             wT = ops.transpose_cast(weight.detach().reshape(Cout, -1).contiguous(), cdt)     # [K, Cout]
             dcols = ops.gemm(dy2, wT)                                                        # [B*tps, K]
             dx = ops.unpatchify_add(dcols, x_shape, kt, kh, kw, st, sh, sw)
+            if dx.dtype != x_dtype:
+                dx = ops.cast(dx, x_dtype)
         if has_pos and ng[3]:
             raise MetaEncError("gradient w.r.t. a fused pos-embed is not implemented; add it outside the tokenizer")
-        return dx, dW, db, dpos, None, None, None
+        return dx, dW, db, dpos, None, None, None, None
 
 
 class _ConvPatchEmbed(nn.Module):
@@ -99,8 +111,8 @@ class _ConvPatchEmbed(nn.Module):
         if not x.is_cuda:
             raise MetaEncError(f"{type(self).__name__} runs on MI355X only (CPU tensor given; no CPU fallback)")
         self._check_input(x)
-        cdt = _compute_dtype(self.proj.weight)
-        return _PatchEmbedFn.apply(x, self.proj.weight, self.proj.bias, pos_embed, self.geom, cdt, prefix_rows)
+        cdt, odt = _boundary_dtypes(self.proj.weight)
+        return _PatchEmbedFn.apply(x, self.proj.weight, self.proj.bias, pos_embed, self.geom, cdt, prefix_rows, odt)
 
     def _check_input(self, x):
         pass
@@ -251,12 +263,19 @@ class DataEmbedding(nn.Module):
             tabs = [t.detach().float().contiguous() for t in self.temporal_embedding.tables()]
             if x_mark.shape[-1] < len(tabs):
                 raise MetaEncError(f"x_mark has {x_mark.shape[-1]} columns, need {len(tabs)}")
+            if x_mark.device != x.device:
+                raise MetaEncError(f"x_mark is on {x_mark.device}, the series on {x.device}: move it first (no implicit copies; "
+                                   "a host pointer handed to the kernel would fault the GPU)")
             marks = x_mark[..., :len(tabs)].long().to(torch.int32).contiguous()      # == x.long() (Time_Series.py:83)
-        out_dtype = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16) else torch.float32
+        acast = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
+        if acast not in (None, torch.bfloat16, torch.float16, torch.float32):
+            raise MetaEncError(f"autocast dtype {acast} unsupported")
+        out_dtype = torch.bfloat16 if acast in (torch.bfloat16, torch.float16) else torch.float32      # fp16: bf16 compute, cast out
         p = float(self.dropout.p) if self.training else 0.0
         seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
-        return _TSEmbedFn.apply(x.detach().float().contiguous(), self.value_embedding.tokenConv.weight, marks, tabs,
-                                pe.contiguous(), out_dtype, p, seed)
+        y = _TSEmbedFn.apply(x.detach().float().contiguous(), self.value_embedding.tokenConv.weight, marks, tabs,
+                             pe.contiguous(), out_dtype, p, seed)
+        return y.to(torch.float16) if acast == torch.float16 else y
 
 
 class _TSEmbedFn(torch.autograd.Function):

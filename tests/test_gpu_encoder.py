@@ -595,6 +595,42 @@ def test_time_series_tokenizer_backward_and_dropout(dev, cin, L):
     assert rel_err(g_drop, w2.grad) < 1e-5
 
 
+def test_tokenizers_fp16_boundary_and_mark_device(dev):
+    """fp16 at the tokenizer boundary follows Block's rule (Audio/src/traintest.py trains under autocast(float16)): fp16 in /
+    out, bf16 compute; a time-mark tensor on the wrong device is rejected before its pointer reaches a kernel."""
+    torch.manual_seed(3)
+    pe = M.PatchEmbed(img_size=64, patch_size=16, in_c=3, embed_dim=256).to(dev)
+    x = torch.randn(2, 3, 64, 64, device=dev)
+    with torch.no_grad():
+        ref = pe(x)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = pe(x)
+    assert y.dtype == torch.float16 and rel_err(y.float(), ref) < 1e-2
+    # a .half() module with fp16 input, forward and backward
+    ph = M.PatchEmbed(img_size=64, patch_size=16, in_c=3, embed_dim=256).to(dev)
+    ph.load_state_dict(pe.state_dict())
+    ph = ph.half()
+    xh = x.half().requires_grad_(True)
+    yh = ph(xh)
+    assert yh.dtype == torch.float16 and rel_err(yh.float(), ref) < 1e-2
+    go = torch.randn_like(ref)
+    (yh.float() * go).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    (pe(xr) * go).sum().backward()
+    assert xh.grad.dtype == torch.float16 and ph.proj.weight.grad.dtype == torch.float16
+    assert rel_err(xh.grad.float(), xr.grad) < 2e-2 and rel_err(ph.proj.weight.grad.float(), pe.proj.weight.grad) < 2e-2
+    ts = M.DataEmbedding(c_in=7, d_model=256).to(dev).eval()
+    xs = torch.randn(2, 48, 7, device=dev)
+    mark = torch.stack([torch.randint(0, n, (2, 48)) for n in (13, 32, 7, 24)], dim=-1).float()
+    with torch.no_grad():
+        r32 = ts(xs, mark.to(dev))
+        with torch.autocast("cuda", dtype=torch.float16):
+            r16 = ts(xs, mark.to(dev))
+    assert r16.dtype == torch.float16 and rel_err(r16.float(), r32) < 1e-2
+    with pytest.raises(M.MetaEncError, match="x_mark is on"):
+        ts(xs, mark)                                      # CPU marks
+
+
 def test_multimodal_concat_through_encoder(dev):
     """README.md:118-149 demo: tokens of several modalities concatenated along N, one shared encoder."""
     torch.manual_seed(0)

@@ -1,6 +1,7 @@
 #!/bin/bash
-# round profile: rocprofv3 --kernel-trace --stats over the default bench command (train + fwd leg) and over --mode fwd,
-# then the PMC passes.  Everything lands under gpurun_out/; tools/prof_collect.py folds it into profiles/.
+# round profile: rocprofv3 --kernel-trace --stats over the bench command (train leg, and --mode fwd), the PMC passes, and
+# the bench lines of the other BASELINE configurations.  Everything lands under gpurun_out/; tools/prof_summary.py and
+# tools/pmc_summary.py fold it into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_r02
 mkdir -p $O
@@ -9,9 +10,17 @@ timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o 
 echo "train rc=$?"
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fwd -o t -- python $R/bench.py --steps 5 --warmup 2 --mode fwd --no-cpu-baseline > $O/fwd.json 2> $O/fwd.err
 echo "fwd rc=$?"
-find $O -name "*.csv" | head; ls -la $O/train $O/fwd
-# the agent trace / big csvs are not needed back
 find $O -name "*agent*" -delete
 MODE=train bash $R/tools/pmc_bench.sh
 MODE=fwd bash $R/tools/pmc_bench.sh
+cd $R
+timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_base.json 2> $O/bench_base.err; echo "base rc=$?"
+timeout 300 python bench.py --workload large512 --mode fwd --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_large512_fwd.json 2>> $O/bench_other.err; echo rc=$?
+timeout 300 python bench.py --workload large512 --steps 6 --warmup 2 --no-cpu-baseline --no-fwd-leg > $O/bench_large512_train.json 2>> $O/bench_other.err; echo rc=$?
+timeout 300 python bench.py --workload large1568 --mode fwd --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_large1568_fwd.json 2>> $O/bench_other.err; echo rc=$?
+timeout 300 python bench.py --workload large1568 --mode fwd --attn-dtype fp8 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_large1568_fwd_fp8attn.json 2>> $O/bench_other.err; echo rc=$?
+timeout 300 python bench.py --workload large1568 --steps 6 --warmup 2 --no-cpu-baseline --no-fwd-leg > $O/bench_large1568_train.json 2>> $O/bench_other.err; echo rc=$?
+timeout 300 python bench.py --workload mixed --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_mixed.json 2>> $O/bench_other.err; echo rc=$?
+timeout 200 python tools/attn_fp8_bench.py > $O/attn_fp8.json 2>> $O/bench_other.err; echo rc=$?
+tail -3 $O/bench_other.err
 du -sh $R/gpurun_out/*
