@@ -260,14 +260,13 @@ __device__ __forceinline__ void fold_colsum(const GemmParams& p, const float* __
 template <bool LIN>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ slabs, int S,
                                                             const float* __restrict__ cs_part, int n_part,
-                                                            float* __restrict__ colsum_out) {
+                                                            float* __restrict__ colsum_out, int64_t sstride) {
     if (colsum_out) fold_colsum(p, cs_part, n_part, colsum_out);
     const int64_t nq = p.N / 4;
     const int64_t total = p.M * nq;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t m = i / nq, n = (i % nq) * 4;
         const float* s0 = slabs + m * p.N + n;
-        const int64_t sstride = p.M * p.N;
         f32x4 v = *reinterpret_cast<const f32x4*>(s0);
         int s = 1;
         for (; s + 3 < S; s += 4) {               // four slab reads in flight, added in slab order (deterministic)
@@ -283,11 +282,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     }
 }
 static void launch_splitk_reduce(const GemmParams& p, unsigned nb, hipStream_t stream, const float* slabs, int S, const float* cs_part,
-                                 int n_part, float* colsum_out) {
+                                 int n_part, float* colsum_out, int64_t sstride = 0) {
+    if (sstride == 0) sstride = p.M * p.N;
     if (p.act == ME_ACT_NONE && !p.preact && !p.aux)
-        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out);
+        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride);
     else
-        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out);
+        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride);
 }
 
 struct GemmPlan {
@@ -341,7 +341,7 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         if (ktp < 2) ktp = 2;
         pl.ksteps_per_split = ktp;
         pl.split_k = (nkt + ktp - 1) / ktp;
-        pl.ws_bytes = (size_t)pl.split_k * (size_t)d->M * (size_t)d->N * sizeof(float);
+        pl.ws_bytes = (size_t)pl.split_k * (size_t)g3_tn_slab_stride(d->M, d->N) * sizeof(float);
         if (d->colsum_a)                  // partial column sums of A: one [M] row per (split, N-tile)
             pl.ws_bytes += (size_t)pl.split_k * (size_t)((d->N + 255) / 256) * (size_t)d->M * sizeof(float);
     } else if (d->op == ME_GEMM_TN) {
@@ -373,7 +373,10 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
             const int SL = 256;
             const int64_t R4 = tiles4 / SL, rem4 = tiles4 - R4 * SL;
             const int nkt = (int)(d->K / 64);
-            if (d->N <= 1024 && d->K >= 2048 && dev.tail_split && R4 >= 1 && rem4 * 20 >= SL && rem4 * 10 <= SL * 6 && d->res_row_mod == 0 &&
+            // (not for the shapes the resident kernel takes: with its cheap tile seams the split's slabs + fold cost more
+            // than the idle CUs of the last round -- measured 230 vs 241 us on fc2 forward, 170 vs 185 us on qkv dgrad)
+            const bool resident = d->c_dtype == ME_BF16 && d->alpha == 1.0f && dev.g3_persistent == 1;
+            if (!resident && d->N <= 1024 && d->K >= 2048 && dev.tail_split && R4 >= 1 && rem4 * 20 >= SL && rem4 * 10 <= SL * 6 && d->res_row_mod == 0 &&
                 d->out_group_rows == 0) {
                 const int64_t m_main = (R4 * SL) / tn_;
                 const int64_t tail_tiles = (tm - m_main) * tn_;
@@ -471,7 +474,7 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     p.out_group_stride = d->out_group_stride; p.out_row_offset = d->out_row_offset;
     p.split_k = 1; p.ksteps_per_split = 0;
     p.colsum_ws = nullptr;
-    p.g3_full_tiles = 0; p.g3_split = 0; p.g3_ktp = 0; p.g3_slabs = nullptr;
+    p.g3_full_tiles = 0; p.g3_split = 0; p.g3_ktp = 0; p.g3_slabs = nullptr; p.slab_stride = 0;
     if (d->colsum_a) ME_CHECK_ARG(d->op == ME_GEMM_TN, "me_gemm: colsum_a is defined for ME_GEMM_TN only");
     p.debug = gemm_dev().debug;
     p.tiles_m = (int)((d->M + BM - 1) / BM);
@@ -524,8 +527,8 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
             ps.C = d->workspace;
             ps.split_k = pl.split_k;
             ps.ksteps_per_split = pl.ksteps_per_split;
-            if (d->colsum_a)
-                ps.colsum_ws = reinterpret_cast<float*>(d->workspace) + (size_t)pl.split_k * (size_t)d->M * (size_t)d->N;
+            ps.slab_stride = g3_tn_slab_stride(d->M, d->N);
+            if (d->colsum_a) ps.colsum_ws = reinterpret_cast<float*>(d->workspace) + (size_t)pl.split_k * (size_t)ps.slab_stride;
             rc = launch_g3_tn(ps, stream);
             if (rc) return rc;
             p.split_k = 1;
@@ -533,7 +536,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
             int64_t nb = (quads + 255) / 256;
             if (nb > 2048) nb = 2048;
             launch_splitk_reduce(p, (unsigned)nb, stream, reinterpret_cast<const float*>(d->workspace), pl.split_k, ps.colsum_ws, pl.split_k * p.tiles_n,
-                               d->colsum_a);
+                               d->colsum_a, ps.slab_stride);
             ME_CHECK_LAUNCH("me_gemm(g3 tn fold)");
             return ME_OK;
         }

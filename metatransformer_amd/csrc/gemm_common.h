@@ -21,6 +21,7 @@ struct GemmParams {
     // part, raw fp32 partial sums into g3_slabs [g3_split][rows past the full tiles][N]; 0 = every tile is a full tile
     int g3_full_tiles, g3_split, g3_ktp;
     float* g3_slabs;
+    int64_t slab_stride;                    // g3 wgrad: floats between the split-K slabs in C (>= M * N, padded: see g3_tn_slab_stride)
 };
 
 
@@ -155,6 +156,9 @@ bool g3_supported(const GemmParams& p, int op);
 size_t g3_workspace_bytes();
 int launch_g3_tn(const GemmParams& p, hipStream_t stream);      // p.split_k slabs into p.C, p.ksteps_per_split K-tiles of 64 each
 bool g3_tn_supported(const GemmParams& p);
+// floats between the split-K slabs of the g3 wgrad kernel.  (Padding the stride off the 256 KiB multiples the encoder's
+// shapes give was tried against HBM channel aliasing in the fold: 34 us against 23, i.e. worse -- the slabs stay dense.)
+static inline int64_t g3_tn_slab_stride(int64_t M, int64_t N) { return M * N; }
 
 // Dev switches for A/B runs (tools/gemm_dev): they exist only in the dev build of the library (-DME_DEV, built by
 // `python -m metatransformer_amd.build --dev` into tools/_build/); the shipped library has no knobs and reads no
