@@ -95,12 +95,26 @@ def main():
     from metatransformer_amd import ops, parallel, _capi
 
     comm = None
+    tgroup = None                # fallback only: a torch.distributed nccl (= RCCL) group
+    comm_fallback = None
     if use_dist:
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             # host-side rendezvous only: carries the RCCL id to the ranks and the max-over-ranks of the timings
             dist.init_process_group("gloo")
-            comm = parallel.Comm.from_torch_distributed()
+            ok, why = 1, ""
+            try:
+                comm = parallel.Comm.from_torch_distributed()
+            except Exception as e:       # noqa: BLE001 -- e.g. librccl not loadable outside torch's copy on this node
+                ok, why = 0, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same path
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.destroy()
+                    comm = None
+                tgroup = dist.new_group(backend="nccl")
+                comm_fallback = f"torch.distributed nccl (RCCL) group -- the C-ABI communicator did not come up ({why or 'on another rank'})"
         else:
             comm = parallel.Comm(parallel.Comm.new_unique_id(), 0, 1)
 
@@ -143,7 +157,7 @@ def main():
         # 1-D parameters and biases carry no weight decay, as in the reference recipes (Video/optim_factory.py:67-73)
         flat = parallel.FlatParams(enc.named_parameters(), no_decay=parallel.no_decay_rule)
         opt = parallel.FusedAdamW(flat, lr=1e-4, weight_decay=0.05)
-        reducer = parallel.OverlappedGradReducer(flat, comm=comm, force=use_dist) if use_dist else None
+        reducer = parallel.OverlappedGradReducer(flat, group=tgroup, comm=comm, force=use_dist) if use_dist else None
         x.requires_grad_(True)                   # the tokenizer in front of the encoder needs dL/dx
 
         def step():
@@ -283,7 +297,8 @@ def main():
                    "grad_allreduce": (f"me_allreduce_bucket (RCCL behind the C ABI, own stream, event hand-off): one all-reduce(sum) per "
                                       f"64 MiB flat fp32 bucket launched from grad hooks, 1/world folded into AdamW; "
                                       f"{comm_info['buckets_reduced'] // max(1, args.steps + args.warmup + psteps)} buckets/step, "
-                                      f"RCCL world {comm_info['world']}") if (comm_info and train) else None},
+                                      f"RCCL world {comm_info['world']}") if (comm_info and train) else
+                                     (f"{comm_fallback}: one all_reduce(sum) per 64 MiB flat fp32 bucket from grad hooks" if (comm_fallback and train) else None)},
         "model_tflops_per_s": round(value * model_flops / 1e12, 2),
         "mfma_frac_end_to_end": round(value * model_flops / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "roofline": gemm_roofline(prof, step_s, psteps, train),

@@ -56,9 +56,16 @@ class Comm:
     def from_torch_distributed(cls, group=None, device: Optional[int] = None) -> "Comm":
         """Rank 0 draws the id, torch.distributed (any backend) carries it to the other ranks."""
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.new_unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.new_unique_id()
+            except Exception as e:       # noqa: BLE001 -- the other ranks are waiting in the broadcast: tell them, then raise
+                box[0] = e
         if world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if isinstance(box[0], Exception):
+            raise MetaEncError(f"Comm: rank 0 could not draw an RCCL id: {box[0]}")
         return cls(box[0], rank, world, device)
 
     def allreduce(self, t: torch.Tensor, producer_stream: Optional[int] = None) -> None:

@@ -83,6 +83,38 @@ def test_flat_bucket_allreduce_world2():
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
+def _id_failure_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def boom():
+            raise RuntimeError("librccl not found (simulated)")
+        parallel.Comm.new_unique_id = staticmethod(boom)         # what rank 0 would see without a loadable RCCL
+        try:
+            parallel.Comm.from_torch_distributed(device=0)
+            q.put((rank, "no error"))
+        except parallel.MetaEncError as e:
+            q.put((rank, "raised" if "could not draw an RCCL id" in str(e) else f"other: {e}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_comm_id_failure_reaches_every_rank():
+    """rank 0 failing to draw the RCCL id must not leave the other ranks waiting in the broadcast: every rank raises the
+    same MetaEncError (bench.py then falls back, collectively, to a torch.distributed nccl group)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_id_failure_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "raised"), (1, "raised")], res
+
+
 def test_flatparams_single_process_semantics():
     m = _model()
     before = [p.detach().clone() for p in m.parameters()]
