@@ -221,6 +221,24 @@ def main():
         enc.train()
         fwd = (fwd_el, fwd_prof)
 
+    def pmc_traffic(mode):
+        """HBM bytes per launch of the roofline kernel from the committed PMC passes of this same command (rocprofv3 --pmc
+        cannot run inside the process: tools/pmc_bench.sh collects FETCH_SIZE / WRITE_SIZE in separate passes and
+        tools/pmc_summary.py folds them, traffic = 2 * FETCH_SIZE + WRITE_SIZE).  None when the file is not there."""
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_pmc_{mode}.json")
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+        except (OSError, ValueError):
+            return None, None
+        rows = [(v["launches"], v["hbm_traffic_MB"]) for k, v in pm.items()
+                if k.startswith("gemm_g3r_kernel") and isinstance(v, dict) and "hbm_traffic_MB" in v and v.get("launches")]
+        if not rows:
+            return None, None
+        mb = sum(n * t for n, t in rows) / sum(n for n, _ in rows)
+        return round(mb * 1e6), (f"profiles/r02_pmc_{mode}.json: rocprofv3 --pmc passes of this command (separate runs, 2*FETCH_SIZE + "
+                                 f"WRITE_SIZE), launch-weighted mean over the gemm_g3r_kernel launches; not re-measured in this run")
+
     def gemm_roofline(recs, wall_s, nsteps, with_wgrad):
         nt = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_NT and dt == _capi.ME_BF16]
         tn = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_TN and dt == _capi.ME_BF16]
@@ -229,11 +247,11 @@ def main():
         flops = sum(2.0 * m * n * k for m, n, k, _ in nt)
         ms = sum(t for *_, t in nt)
         ach = flops / (ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic("train" if with_wgrad else "fwd") if args.workload == "base" and B == 256 else (None, None)
         roof = {"bound": "mfma",
                 "kernel": "gemm_g3r_kernel<EPI> (bf16 NT MFMA GEMM, resident 256x256x64-tile workgroups: every forward + dgrad launch)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": None,
-                "traffic_note": "HBM bytes per launch are PMC-only (rocprofv3 --pmc, separate passes): see profiles/r02_pmc_*.json",
+                "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": len(nt) // nsteps, "avg_launch_us": round(1e3 * ms / len(nt), 2),
                 "avg_launch_gflop": round(flops / len(nt) / 1e9, 2),
                 "algorithmic_bytes_per_launch": round(sum(2.0 * (m * k + n * k + m * n) for m, n, k, _ in nt) / len(nt)),
