@@ -34,6 +34,9 @@
 //        and retired with lgkmcnt(8) before that phase's first barrier, which the issuing wave row passes later.
 #include "gemm_common.h"
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -725,6 +728,31 @@ __device__ __forceinline__ int g3_lane_now() {
     asm volatile("" : "+v"(z));          // (opaque: not common-subexpression'd with, or hoisted to, an earlier copy)
     return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
 }
+// One ticket from a work counter, drawn by lane 0 alone.  Inline asm with the exec mask narrowed by hand: written as
+// `if (lane == 0) atomic` hipcc waits for the result with vmcnt(0) at the join of the branch -- a drain of every store and DMA
+// in flight.  The instruction is invisible to the compiler's own wait counting (it is OLDER than everything the callers
+// wait for afterwards, which only makes their waits stricter); the caller retires it with a counted s_waitcnt.
+__device__ __forceinline__ unsigned g3r_draw(unsigned* ctr) {
+    unsigned old, zero = 0, one = 1;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                 : "=&v"(old), "=&s"(saved)
+                 : "v"(zero), "v"(one), "s"(ctr)
+                 : "memory");
+    return old;      // valid in lane 0 once the operation has retired
+}
+// wave 0 hands the ticket to the other waves through the LDS word behind the operand buffers; whoever draws the last ticket
+// of the launch (nx - 1) puts the counter back to zero
+__device__ __forceinline__ void g3r_publish(unsigned drawn, unsigned* ctr, int nx, uint32_t lds_tick) {
+    const unsigned t = __builtin_amdgcn_readfirstlane(drawn);
+    if (t == (unsigned)(nx - 1)) {
+        unsigned zero = 0;
+        unsigned long long saved;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_store_dword %1, %1, %2\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(zero), "s"(ctr) : "memory");
+    }
+    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_tick), "v"(t) : "memory");
+}
 struct G3Bias { f32x4 v[4]; };       // this lane's bias for n-tiles 0..3 of its wave column (accumulator layout)
 __device__ __forceinline__ G3Bias g3r_bias(const __amdgpu_buffer_rsrc_t brs, int tn, int wave, int lane) {
     G3Bias b;
@@ -788,7 +816,11 @@ __device__ __forceinline__ u32x4 g3r_lanes(const u32x4& v, int addr) {
 // operand, 3 * gelu'(row operand), 6 * row operand
 template <int EPI, int PRE>
 __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int tm, int tn, int lane, const G3Src& nxt, int nk,
-                                              const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero) {
+                                              const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero, unsigned* ctr, int nx,
+                                              uint32_t lds_tick) {
+    // (claimed schedule: wave 0 draws the ticket for the item after next FIRST, ahead of every store of this epilogue)
+    unsigned drawn = 0;
+    if (ctr && s.wave == 0) drawn = g3r_draw(ctr);
     (void)lane;
     lane = g3_lane_now();
     const int wr = s.wave >> 2, wc = s.wave & 3;
@@ -841,7 +873,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
         o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
         return __builtin_bit_cast(u32x4, o);
     };
-    constexpr int AHEAD = EPI == 3 ? 4 : 8;      // all sixteen row-operand loads of the tile go out ahead of its first store      // (gelu' needs the registers for its arithmetic: six slabs ahead spill into the K-loop)
+    constexpr int AHEAD = EPI == 3 ? 4 : 6;      // row-operand slabs in flight ahead of their use (more spills: into the K-loop for gelu', onto the ticket register otherwise)
     u32x4 rowop[8][2];
     if (EPI == 2 || EPI == 3 || EPI == 6) {
 #pragma unroll
@@ -917,6 +949,12 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     // the next tile's accumulators start at its bias (s.binit)
     __builtin_amdgcn_sched_barrier(0);
     g3r_set_binit(s, nb, next_zero);
+    if (ctr && s.wave == 0) {
+        // everything this epilogue issued behind the draw may stay in flight: the A-Y half-tile (2), the bias (4), the
+        // stores (16 / 32) and the row operands (16)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 4 + 16 + (PRE ? 16 : 0) + ((EPI == 2 || EPI == 3 || EPI == 6) ? 16 : 0)) : "memory");
+        g3r_publish(drawn, ctr, nx, lds_tick);
+    }
 }
 
 // memory operations one g3_epilogue_r issues per wave behind the next tile's A-Y half-tile: >= the stores (+ the later
@@ -977,6 +1015,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < SEAM; ++i) __builtin_amdgcn_raw_buffer_store_b128(z, null.a, 0, 0, 0);
     };
 
+    const bool dyn = p.g3_tickets != nullptr;
+    unsigned* const ctr = dyn ? p.g3_tickets + xcd * 16 : nullptr;
+    const uint32_t lds_tick = (uint32_t)(uintptr_t)smem + G3_LDS;
+    unsigned drawn0 = 0;
+    if (dyn && wave == 0) drawn0 = g3r_draw(ctr);          // item 1 (item 0 is this workgroup's own slot)
+
     int tile, part, kt0, kt1, tm, tn;
     decode(slot, tile, part, kt0, kt1);
     G3Src cur = src_of(tile, tm, tn);
@@ -987,6 +1031,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         g3r_set_binit(s, b0, part >= 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (dyn && wave == 0) g3r_publish(drawn0, ctr, nx, lds_tick);
     prime();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -1004,16 +1049,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #else
 #define G3R_STAMP(i)
 #endif
+    // Which item comes next: static (slot + G8: every workgroup owns a fixed list) or, with p.g3_tickets, CLAIMED from the
+    // XCD's counter -- a CU that is slow, or that could not take its workgroup for a while because a communication kernel
+    // sat on it, then simply ends up with fewer tiles instead of holding the whole launch back (the first item stays static:
+    // no round trip before the first DMA).  Wave 0 draws one item ahead: in the prologue for item 1, at the top of the
+    // epilogue of item i (ahead of its stores, so that retiring the draw does not drain them) for item i + 2, and leaves the
+    // ticket in one LDS word; every wave picks it up behind the first K-tile pair of the following item (>= 2 pairs per item
+    // and whole tiles only in this mode: launch3r).  Tickets 0 .. nx - 1 are drawn per XCD and launch (nx - G8 hits, one miss
+    // per workgroup): whoever draws the last one zeroes the counter for the next launch on this stream.
     while (true) {
         G3R_STAMP(0)
-        const int nslot = slot + G8;
-        const bool has_next = nslot < nx;
-        int ntile = tile, npart = -1, nkt0 = 0, nkt1 = 2, ntm = 0, ntn = 0;
+        int nslot = 0, ntile = tile, npart = -1, nkt0 = 0, nkt1 = 2, ntm = 0, ntn = 0;
+        bool has_next = false;
         G3Src nxt = null;
-        if (has_next) {
-            decode(nslot, ntile, npart, nkt0, nkt1);
-            nxt = src_of(ntile, ntm, ntn);
-        }
+        auto resolve_next = [&](int ns) {
+            nslot = ns;
+            has_next = ns < nx;
+            if (has_next) {
+                decode(nslot, ntile, npart, nkt0, nkt1);
+                nxt = src_of(ntile, ntm, ntn);
+            }
+        };
+        if (!dyn) resolve_next(slot + G8);
         const int np = (kt1 - kt0) >> 1;
         {
             G3Src sb = cur;
@@ -1024,6 +1081,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             g3_ktile<1>(s, sb, kb, sb, kc);
         }
         G3R_STAMP(2)
+        if (dyn) {
+            unsigned t;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(lds_tick) : "memory");
+            resolve_next(G8 + (int)__builtin_amdgcn_readfirstlane(t));
+        }
         for (int i = 1; i < np; ++i) {
             const int k = kt0 + 2 * i;
             G3Src sb = cur;
@@ -1048,7 +1110,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             prime();
         } else {
-            g3_epilogue_r<EPI, PRE>(p, s, tm, tn, 0, nxt, nkt0 + 1, brs, ntn, npart >= 0);
+            g3_epilogue_r<EPI, PRE>(p, s, tm, tn, 0, nxt, nkt0 + 1, brs, ntn, npart >= 0, has_next ? ctr : nullptr, nx, lds_tick);
         }
         G3R_STAMP(5)
 #ifdef ME_DEV
@@ -1153,18 +1215,35 @@ int g3_cus() {
     return n;
 }
 
-template <int EPI, int PRE> int launch3r(const GemmParams& q, int G, hipStream_t stream) {
+// The work counters of the resident kernel: one set per (device, stream) -- launches on a stream are serialised, and the
+// kernel leaves its counters at zero -- allocated and zeroed at the first launch on that stream (never during a graph
+// capture: warm up first, as for every other once-per-device setup here).
+unsigned* g3r_tickets(hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, unsigned*> pool;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pool.find({dev, stream});
+    if (it != pool.end()) return it->second;
+    unsigned* buf = nullptr;
+    if (hipMalloc(&buf, 8 * 16 * sizeof(unsigned)) != hipSuccess || hipMemset(buf, 0, 8 * 16 * sizeof(unsigned)) != hipSuccess) buf = nullptr;
+    pool[{dev, stream}] = buf;      // (null: the static schedule)
+    return buf;
+}
+
+template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_t stream) {
     static OncePerDevice once;
     if (once.need())
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS + 64);
+    GemmParams q = q0;
+    // claimed items need >= 2 K-tile pairs per item and whole tiles only (see the kernel)
+    q.g3_tickets = (q.K >= 4 * G3_BK && q.g3_split <= 1 && gemm_dev().g3_persistent == 1) ? g3r_tickets(stream) : nullptr;
 #ifdef ME_DEV
-    GemmParams qt = q;
-    qt.colsum_ws = (q.debug & 8) ? reinterpret_cast<float*>(g_gemm_dev_trace) : nullptr;
-    hipLaunchKernelGGL((gemm_g3r_kernel<EPI, PRE>), dim3((unsigned)G), dim3(512), G3_LDS, stream, qt);
-    ME_CHECK_LAUNCH("me_gemm(g3 resident)");
-    return ME_OK;
+    if (gemm_dev().tail_split == 2) q.g3_tickets = nullptr;          // dev: "g3s" = static schedule
+    q.colsum_ws = (q.debug & 8) ? reinterpret_cast<float*>(g_gemm_dev_trace) : nullptr;
 #endif
-    hipLaunchKernelGGL((gemm_g3r_kernel<EPI, PRE>), dim3((unsigned)G), dim3(512), G3_LDS, stream, q);
+    hipLaunchKernelGGL((gemm_g3r_kernel<EPI, PRE>), dim3((unsigned)G), dim3(512), G3_LDS + 64, stream, q);
     ME_CHECK_LAUNCH("me_gemm(g3 resident)");
     return ME_OK;
 }

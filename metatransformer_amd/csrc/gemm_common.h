@@ -21,6 +21,7 @@ struct GemmParams {
     // part, raw fp32 partial sums into g3_slabs [g3_split][rows past the full tiles][N]; 0 = every tile is a full tile
     int g3_full_tiles, g3_split, g3_ktp;
     float* g3_slabs;
+    unsigned* g3_tickets;                   // resident g3 kernel: per-XCD work counters (16 words apart), null = static schedule
     int64_t slab_stride;                    // g3 wgrad: floats between the split-K slabs in C (>= M * N, padded: see g3_tn_slab_stride)
 };
 

@@ -121,7 +121,7 @@ static int family_code(const std::string& f) {
     if (f == "g128") return 0;
     if (f == "g2b") return 2;
     if (f == "g2w") return 3;
-    if (f == "g3" || f == "g3x" || f == "g3p" || f == "g3t") return 4;      // g3: shipped form (resident); g3t: one tile per workgroup; g3x: without the tail split; g3p: persistent stream-K
+    if (f == "g3" || f == "g3x" || f == "g3p" || f == "g3t" || f == "g3s") return 4;      // g3: shipped form (resident); g3t: one tile per workgroup; g3x: without the tail split; g3p: persistent stream-K
     fprintf(stderr, "unknown family %s\n", f.c_str());
     exit(2);
 }
@@ -241,7 +241,7 @@ int main(int argc, char** argv) {
         }
         me_dev_set("family", family_code(fam));
         me_dev_set("g3_persistent", strcmp(fam, "g3p") == 0 ? 2 : strcmp(fam, "g3t") == 0 ? 0 : 1);
-        me_dev_set("tail_split", strcmp(fam, "g3x") != 0);
+        me_dev_set("tail_split", strcmp(fam, "g3s") == 0 ? 2 : strcmp(fam, "g3x") != 0);      // g3s: resident, static schedule
         me_dev_set("debug", debug);
         uint16_t *A[NSET], *C[NSET], *P[NSET], *Bw, *rowop = nullptr;
         float *bias, *ref = nullptr, *ref_pre = nullptr;
