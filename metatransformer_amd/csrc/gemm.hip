@@ -269,12 +269,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
         const float* s0 = slabs + m * p.N + n;
         f32x4 v = *reinterpret_cast<const f32x4*>(s0);
         int s = 1;
-        for (; s + 3 < S; s += 4) {               // four slab reads in flight, added in slab order (deterministic)
-            const f32x4 a = *reinterpret_cast<const f32x4*>(s0 + (int64_t)s * sstride);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + 1) * sstride);
-            const f32x4 c = *reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + 2) * sstride);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + 3) * sstride);
-            v += a; v += b; v += c; v += d;
+        // eight slab reads in flight (the fold is latency-bound otherwise: S reads in dependent rounds of a few), added in
+        // slab order -- deterministic
+        for (; s + 7 < S; s += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + j) * sstride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v += t[j];
+        }
+        if (s + 3 < S) {
+            f32x4 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + j) * sstride);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v += t[j];
+            s += 4;
         }
         for (; s < S; ++s) v += *reinterpret_cast<const f32x4*>(s0 + (int64_t)s * sstride);
         if (LIN) epilogue_quad_lin(p, m, n, v);
