@@ -1215,21 +1215,43 @@ int g3_cus() {
     return n;
 }
 
-// The work counters of the resident kernel: one set per (device, stream) -- launches on a stream are serialised, and the
-// kernel leaves its counters at zero -- allocated and zeroed at the first launch on that stream (never during a graph
-// capture: warm up first, as for every other once-per-device setup here).
+// The work counters of the resident kernel: every stream gets its own set (launches on a stream are serialised, and the
+// kernel leaves its counters at zero), handed out on the host from a per-device pool that is allocated and zeroed ONCE, at
+// the first resident launch on the device.  Assigning a set to a new stream touches no device state, so a stream that is
+// first seen while it is being captured into a hipGraph (torch's capture streams) is fine; only the pool allocation itself
+// must not fall into a capture -- then, and when the pool is exhausted, the launch runs the static schedule.
 unsigned* g3r_tickets(hipStream_t stream) {
+    constexpr int SETS = 64, SET_WORDS = 8 * 16;
+    struct Pool {
+        unsigned* base = nullptr;
+        bool failed = false;
+        int next = 0;
+        std::map<hipStream_t, int> idx;
+    };
     static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, unsigned*> pool;
+    static std::map<int, Pool> pools;
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
-    auto it = pool.find({dev, stream});
-    if (it != pool.end()) return it->second;
-    unsigned* buf = nullptr;
-    if (hipMalloc(&buf, 8 * 16 * sizeof(unsigned)) != hipSuccess || hipMemset(buf, 0, 8 * 16 * sizeof(unsigned)) != hipSuccess) buf = nullptr;
-    pool[{dev, stream}] = buf;      // (null: the static schedule)
-    return buf;
+    Pool& P = pools[dev];
+    if (!P.base) {
+        if (P.failed) return nullptr;
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;      // not now
+        unsigned* buf = nullptr;
+        if (hipMalloc(&buf, (size_t)SETS * SET_WORDS * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(buf, 0, (size_t)SETS * SET_WORDS * sizeof(unsigned)) != hipSuccess) {
+            P.failed = true;
+            return nullptr;
+        }
+        P.base = buf;
+    }
+    auto it = P.idx.find(stream);
+    if (it == P.idx.end()) {
+        if (P.next >= SETS) return nullptr;
+        it = P.idx.emplace(stream, P.next++).first;
+    }
+    return P.base + (size_t)it->second * SET_WORDS;
 }
 
 template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_t stream) {
