@@ -161,6 +161,68 @@ __device__ __forceinline__ f32x4 gelu_erf_grad4(f32x4 x) {
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf4(f32x4{x, x, x, x})[0]; }
 __device__ __forceinline__ float gelu_erf_grad(float x) { return gelu_erf_grad4(f32x4{x, x, x, x})[0]; }
 
+// ---- bf16-mode GELU: what the epilogues use when the result is ROUNDED TO BF16 (8 significant bits).
+// The erf form above spends two quarter-rate transcendentals (v_rcp_f32, v_exp_f32) and ~14 plain VALU operations per element
+// on 1.5e-7 accuracy that the bf16 store throws away again; in the GEMM epilogues that arithmetic is what the matrix pipe
+// waits for (fc1: 14-23 k of ~50 k clocks per 256 x 256 tile).  Here both functions are written as "the piecewise-linear part
+// plus a remainder that is smooth on t = |x| >= 0 and flat beyond T = 4":
+//     gelu(x)  = max(x, 0) + r(t),          r(t) = t (Phi(t) - 1)              -> 0    for t -> inf
+//     gelu'(x) = 1/2 + copysign(e(t), x),   e(t) = Phi(t) + t phi(t) - 1/2     -> 1/2  for t -> inf
+// with r ~ t P(t), e ~ t Q(t) (degree-7 P, Q; t clamped at T): one v_min, seven FMAs and two more operations each, no
+// transcendental.  Minimax over the whole real line in the ABSOLUTE error of the result (tools/gelu_poly_fit.py, which also
+// evaluates this exact float32 formula): |gelu err| <= 1.9e-4 (2^-12.4), |gelu' err| <= 4.2e-4 -- a fraction of the bf16
+// rounding of the stored value for all but the smallest outputs, and P(0) = -1/2, Q(0) = 2 phi(0) are pinned so that
+// gelu(x) -> x / 2 and gelu'(x) - 1/2 -> 2 phi(0) x keep their RELATIVE accuracy around zero.  fp32 outputs keep the erf form.
+// (inline asm for the clamp and the ramp: written as fminf(fabsf(x), 4) / fmaxf(x, 0) hipcc first canonicalises the operand with
+// a v_max_f32 x, x each -- two of the ten operations per element.  The NEGATIVE leading coefficients go through an opaque
+// register: hipcc rewrites t * (-c) as (-t) * c and then, finding no negation modifier it can use on the packed FMA, negates t
+// with a v_xor per element.)
+__device__ __forceinline__ f32x4 gelu_clamp4(f32x4 x) {
+    f32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm("v_min_f32_e64 %0, |%1|, 4.0" : "=v"(t[i]) : "v"(x[i]));
+    return t;
+}
+__device__ __forceinline__ float gelu_opaque(float c) {
+    asm("" : "+v"(c));
+    return c;
+}
+__device__ __forceinline__ f32x4 gelu_bf16_from_t4(f32x4 x, f32x4 t) {
+    f32x4 p = t * gelu_opaque(-7.715494112e-06f) + 7.679707389e-04f;
+    p = p * t - 1.074723536e-02f;
+    p = p * t + 6.040871459e-02f;
+    p = p * t - 1.453980336e-01f;
+    p = p * t + 4.842520777e-02f;
+    p = p * t + 3.880065109e-01f;
+    p = p * t - 0.5f;
+    f32x4 relu;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm("v_max_f32_e32 %0, 0, %1" : "=v"(relu[i]) : "v"(x[i]));
+    return t * p + relu;
+}
+__device__ __forceinline__ f32x4 gelu_bf16_grad_from_t4(f32x4 x, f32x4 t) {
+    f32x4 q = t * gelu_opaque(-5.104965709e-04f) + 7.796528677e-03f;
+    q = q * t - 4.375422062e-02f;
+    q = q * t + 9.542723363e-02f;
+    q = q * t + 1.391019310e-02f;
+    q = q * t - 3.006181013e-01f;
+    q = q * t + 1.278037861e-02f;
+    q = q * t + 7.978845608e-01f;
+    const f32x4 e = t * q;
+    return f32x4{0.5f + copysignf(e[0], x[0]), 0.5f + copysignf(e[1], x[1]), 0.5f + copysignf(e[2], x[2]), 0.5f + copysignf(e[3], x[3])};
+}
+__device__ __forceinline__ f32x4 gelu_bf16_4(f32x4 x) { return gelu_bf16_from_t4(x, gelu_clamp4(x)); }
+__device__ __forceinline__ f32x4 gelu_bf16_grad4(f32x4 x) { return gelu_bf16_grad_from_t4(x, gelu_clamp4(x)); }
+// both at once (the fc1 epilogue of a training step stores gelu(h) and gelu'(h)): the clamp is shared
+__device__ __forceinline__ void gelu_bf16_pair4(f32x4 x, f32x4& y, f32x4& d) {
+    const f32x4 t = gelu_clamp4(x);
+    y = gelu_bf16_from_t4(x, t);
+    d = gelu_bf16_grad_from_t4(x, t);
+}
+// form by the dtype the result is stored in (wave-uniform)
+__device__ __forceinline__ f32x4 gelu_for4(f32x4 x, int out_dtype) { return out_dtype == ME_BF16 ? gelu_bf16_4(x) : gelu_erf4(x); }
+__device__ __forceinline__ f32x4 gelu_grad_for4(f32x4 x, int out_dtype) { return out_dtype == ME_BF16 ? gelu_bf16_grad4(x) : gelu_erf_grad4(x); }
+
 // ---- MFMA "16-byte chunk" abstraction.
 // A chunk is 16 bytes of an operand row along the reduction dimension: 8 bf16 or 4 fp32.
 // For the 32x32 MFMA shapes lane l supplies, for output row/col (l & 31), the reduction slice owned by

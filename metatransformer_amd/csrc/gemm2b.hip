@@ -321,14 +321,14 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             v1 = v1 * p.alpha + bias1;
             if (EPI == 1) {
                 if (p.preact && ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
-                v0 = gelu_erf4(v0);
-                v1 = gelu_erf4(v1);
+                v0 = gelu_for4(v0, p.c_dtype);
+                v1 = gelu_for4(v1, p.c_dtype);
             }
             f32x4 ra, rb;
             if (EPI == 2 || EPI == 3) unpack(cur.raw[i], ra, rb);
             if (EPI == 3) {
-                v0 *= gelu_erf_grad4(ra);
-                v1 *= gelu_erf_grad4(rb);
+                v0 *= gelu_grad_for4(ra, p.c_dtype);
+                v1 *= gelu_grad_for4(rb, p.c_dtype);
             }
             v0 *= cs0; v1 *= cs1;
             if (EPI == 2) { v0 += ra; v1 += rb; }

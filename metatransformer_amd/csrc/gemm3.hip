@@ -394,13 +394,13 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
             v1 = v1 * alpha4 + bias[q][1];
             if (EPI == 1) {
                 if (p.preact && ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n[q], v0, v1);
-                v0 = gelu_erf4(v0);
-                v1 = gelu_erf4(v1);
+                v0 = gelu_for4(v0, p.c_dtype);
+                v1 = gelu_for4(v1, p.c_dtype);
             }
             const f32x4 qa = ro[q][0], qb = ro[q][1];
             if (EPI == 3) {
-                v0 *= gelu_erf_grad4(qa);
-                v1 *= gelu_erf_grad4(qb);
+                v0 *= gelu_grad_for4(qa, p.c_dtype);
+                v1 *= gelu_grad_for4(qb, p.c_dtype);
             }
             if (EPI == 2) { v0 += qa; v1 += qb; }
 #ifdef ME_DEV
@@ -908,8 +908,8 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
             // no row operand, one output: the arithmetic runs in the old layout and the PACKED result is re-dealt (half the
             // DPP moves)
             if (EPI == 1) {
-                v[0][0] = gelu_erf4(v[0][0]); v[0][1] = gelu_erf4(v[0][1]);
-                v[1][0] = gelu_erf4(v[1][0]); v[1][1] = gelu_erf4(v[1][1]);
+                v[0][0] = gelu_bf16_4(v[0][0]); v[0][1] = gelu_bf16_4(v[0][1]);
+                v[1][0] = gelu_bf16_4(v[1][0]); v[1][1] = gelu_bf16_4(v[1][1]);
             }
             u32x4 o0 = pack(v[0][0], v[0][1]), o1 = pack(v[1][0], v[1][1]);
             g3r_rows8_packed(o0, o1);
@@ -923,24 +923,23 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
             f32x4 v0 = v[h][0], v1 = v[h][1];
             if (EPI == 1) {
                 if (PRE == 2) {
-                    // gelu and gelu' from the same Phi / Gaussian parts: the backward GEMM multiplies by the saved factor
-                    f32x4 ph0, ga0, ph1, ga1;
-                    phi_parts4(v0, ph0, ga0);
-                    phi_parts4(v1, ph1, ga1);
-                    const f32x4 d0 = ph0 + v0 * ga0 * 0.3989422804014327f, d1 = ph1 + v1 * ga1 * 0.3989422804014327f;
+                    // gelu and gelu' (bf16-mode forms, common.h: one shared clamp): the backward GEMM multiplies by the saved factor
+                    f32x4 y0, d0, y1, d1;
+                    gelu_bf16_pair4(v0, y0, d0);
+                    gelu_bf16_pair4(v1, y1, d1);
                     __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(d0, d1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
-                    v0 *= ph0;
-                    v1 *= ph1;
+                    v0 = y0;
+                    v1 = y1;
                 } else {
                     if (PRE) __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
-                    v0 = gelu_erf4(v0);
-                    v1 = gelu_erf4(v1);
+                    v0 = gelu_bf16_4(v0);
+                    v1 = gelu_bf16_4(v1);
                 }
             }
             if (EPI == 6) { v0 *= ro[h][0]; v1 *= ro[h][1]; }
             if (EPI == 3) {
-                v0 *= gelu_erf_grad4(ro[h][0]);
-                v1 *= gelu_erf_grad4(ro[h][1]);
+                v0 *= gelu_bf16_grad4(ro[h][0]);
+                v1 *= gelu_bf16_grad4(ro[h][1]);
             }
             if (EPI == 2) { v0 += ro[h][0]; v1 += ro[h][1]; }
             __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), crs, (int)(coff + (2 * mt + h) * cstep), 0, 0);
