@@ -326,9 +326,11 @@ int me_pool_tokens_bwd(const float* dy, const int32_t* argmax, void* dx, int dx_
 /* ------------------------------------------------------------------ point-cloud tokenizer front end
  * The index-producing part of PointPatchEmbed (PointCloud/openpoints/models/layers/group_embed.py:138-172); the per-point
  * MLP behind it is me_gemm + me_pool_tokens(ME_POOL_MAX).
- * me_fps: farthest point sampling, restating furthest_point_sampling_kernel
- *   (PointCloud/openpoints/cpp/pointnet2_batch/src/sampling_gpu.cu:101-210) selection rule and tie-breaking exactly:
- *   points [B, n, 3] fp32 -> idx [B, m] int32 (idx[:, 0] = 0); temp = [B, n] fp32 scratch.
+ * me_fps: farthest point sampling with the selection rule AND tie order of furthest_point_sampling_kernel
+ *   (PointCloud/openpoints/cpp/pointnet2_batch/src/sampling_gpu.cu:101-210; its thread-strided scan + shared-memory tree
+ *   amount to: largest min-distance, then smallest bit-reversed thread id, then smallest index), one workgroup per cloud with
+ *   the points and running distances held in registers for all m rounds: points [B, n, 3] fp32 -> idx [B, m] int32
+ *   (idx[:, 0] = 0).  temp = [B, n] fp32 scratch, touched only by the memory-resident form (n > 24 576).
  * me_knn: for every query [B, m, 3] the k nearest of support [B, n, 3] (squared distance, ascending, ties -> lower
  *   index): what KNN.forward's cdist + topk(largest=False) selects (openpoints/models/layers/group.py:12-28). n <= 10240.
  * me_group_relative: rows[(b, s, j), 0:3] = points[b, idx[b, s, j]] - centers[b, s] (grouping_operation + relative_xyz,

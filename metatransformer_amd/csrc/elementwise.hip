@@ -482,51 +482,116 @@ __global__ __launch_bounds__(EW_THREADS) void pool_tokens_bwd_kernel(const float
 //   grouping_operation + "relative_xyz"  (group.py:310-313)
 // Index arithmetic is integer; the sampled / neighbour INDICES are what the parity tests compare bit-exactly.
 //
-// FPS restates the reference kernel's selection rule exactly, ties included: start at point 0; every round each of T
-// threads walks its points k = t, t+T, ... keeping the FIRST strict maximum of min(d, temp[k]); the per-thread winners
-// are folded by the same binary tree (partner t + s for s = T/2 .. 1, the higher-indexed side wins only when strictly
-// larger).  T = the largest power of two <= n, capped at 1024, as opt_n_threads() picks it.  The distance is evaluated as
-// fma(dz, dz, fma(dy, dy, dx*dx)) -- nvcc's default contraction of the reference's expression.
-template <int T>
-__global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ pts, float* __restrict__ temp, int32_t* __restrict__ idxs, int n, int m) {
-    __shared__ float dists[T];
-    __shared__ int dists_i[T];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// FPS.  What the reference kernel computes per round -- the next sample is the point that maximises min(d(p, last sample),
+// temp[p]) -- is an arg-max with a SPECIFIC order among equal values, fixed by its thread-strided scan and its shared-memory
+// tree (thread t = k mod T walks k = t, t + T, ... keeping the first strict maximum; partners (t, t + s), s = T/2 .. 1, fold
+// with `v2 > v1 ? i2 : i1`): the winner is the candidate with the largest value, then the smallest BIT-REVERSED thread id,
+// then the smallest k.  That is a total order, so here it is one 64-bit key per candidate
+//     key = value bits (a non-negative float: monotone as an integer) << 32 | ~(bitrev(t) << ibits | k / T)
+// and the arg-max is an unsigned maximum, taken in any association:
+//   * one workgroup per cloud, T = the reference's thread count (opt_n_threads: largest power of two <= n, <= 1024), thread t
+//     owns the same points k = t + i T as there -- but holds them, and their running minimum distances, in REGISTERS for all
+//     m rounds (x, y, z, temp: 4 registers per point, up to 24 points per lane = 24 576 points; the reference re-reads
+//     12 n bytes and read-modify-writes 4 n bytes of global memory every round);
+//   * a lane's own scan is the reference's (first strict maximum in slot order); across the lanes of a wave the keys meet in
+//     four DPP steps (quad_perm, row_half_mirror, row_mirror) + four v_readlane + scalar maxima, across the <= 16 waves in
+//     one LDS word pair per wave and ONE barrier per round (slots alternate by round parity), against log2(T) + 1 barriers;
+//   * larger clouds (n > 24 576) run the same rounds with the points and temp left in memory (FPS_MEM).
+// The distance is evaluated exactly as hipcc evaluates the reference's expression (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) +
+// (z2-z1)*(z2-z1) on gfx950 -- fma(dy, dy, dx*dx) + dz*dz, read off the ISA of the reference kernel built for this GPU -- so that the indices
+// agree with the reference kernel built for this GPU bit for bit, not only on tie-rich lattices (tests/test_gpu_pointcloud_ref.py).
+__device__ __forceinline__ float fps_dist(float dx, float dy, float dz) {
+#pragma clang fp contract(off)
+    const float xx = dx * dx, zz = dz * dz;
+    const float xy = __builtin_fmaf(dy, dy, xx);
+    return xy + zz;
+}
+template <int CTRL> __device__ __forceinline__ unsigned long long fps_dpp_max(unsigned long long v) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o > v ? o : v;
+}
+// maximum over the wave, wave-uniform result
+__device__ __forceinline__ unsigned long long fps_wave_max(unsigned long long v) {
+    v = fps_dpp_max<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = fps_dpp_max<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = fps_dpp_max<0x141>(v);      // row_half_mirror
+    v = fps_dpp_max<0x140>(v);      // row_mirror: every lane of a row of 16 holds the row's maximum
+    unsigned long long r = 0;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned long long x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), row * 16) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, row * 16);
+        r = x > r ? x : r;
+    }
+    return r;
+}
+// R > 0: register-resident, R points per lane.  R == 0 (FPS_MEM): points and temp stay in memory.
+template <int R>
+__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ pts, float* __restrict__ temp, int32_t* __restrict__ idxs,
+                                                   int n, int m, int logT, int ibits) {
+    __shared__ unsigned long long wave_key[2][16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = 1 << logT, nwaves = (int)(blockDim.x >> 6);
     pts += (int64_t)b * n * 3;
     temp += (int64_t)b * n;
     idxs += (int64_t)b * m;
-    for (int k = tid; k < n; k += T) temp[k] = 1e10f;
+    // ~(bitrev(t) << ibits): the thread part of the tie order (threads past T, in a wave that T does not fill, own nothing)
+    const bool lane_on = tid < T;
+    const unsigned rev = logT ? (__builtin_bitreverse32((unsigned)tid) >> (32 - logT)) : 0u;
+    const unsigned tie_hi = ~(rev << ibits);
+    constexpr int RR = R > 0 ? R : 1;
+    float px[RR], py[RR], pz[RR], tmin[RR];
+    if (R > 0) {
+#pragma unroll
+        for (int i = 0; i < RR; ++i) {
+            // slots past the end of the cloud repeat point 0: their distance is 0 from the first round on, and a lane's scan keeps
+            // the FIRST maximum, so they never displace a real point
+            const int k = tid + i * T;
+            const int kk = (lane_on && k < n) ? k : 0;
+            px[i] = pts[kk * 3 + 0]; py[i] = pts[kk * 3 + 1]; pz[i] = pts[kk * 3 + 2];
+            tmin[i] = 1e10f;          // the reference's caller fills temp with 1e10 (subsample.py: fill_(1e10))
+        }
+    } else {
+        for (int k = tid; k < n; k += T) if (lane_on) temp[k] = 1e10f;
+    }
     int old = 0;
     if (tid == 0) idxs[0] = 0;
-    __syncthreads();
     for (int j = 1; j < m; ++j) {
-        int besti = 0;
+        const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];      // (wave-uniform address)
         float best = -1.f;
-        const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
-        for (int k = tid; k < n; k += T) {
-            const float dx = pts[k * 3 + 0] - x1, dy = pts[k * 3 + 1] - y1, dz = pts[k * 3 + 2] - z1;
-            const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            const float d2 = fminf(d, temp[k]);
-            temp[k] = d2;
-            besti = d2 > best ? k : besti;
-            best = d2 > best ? d2 : best;
-        }
-        dists[tid] = best;
-        dists_i[tid] = besti;
-        __syncthreads();
+        unsigned bi = 0;
+        if (R > 0) {
 #pragma unroll
-        for (int s = T / 2; s >= 1; s >>= 1) {
-            if (tid < s) {
-                const float v1 = dists[tid], v2 = dists[tid + s];
-                const int i1 = dists_i[tid], i2 = dists_i[tid + s];
-                dists[tid] = fmaxf(v1, v2);
-                dists_i[tid] = v2 > v1 ? i2 : i1;
+            for (int i = 0; i < RR; ++i) {
+                const float d2 = fminf(fps_dist(px[i] - x1, py[i] - y1, pz[i] - z1), tmin[i]);
+                tmin[i] = d2;
+                bi = d2 > best ? (unsigned)i : bi;
+                best = d2 > best ? d2 : best;
             }
-            __syncthreads();
+        } else if (lane_on) {
+            unsigned i = 0;
+            for (int k = tid; k < n; k += T, ++i) {
+                const float d2 = fminf(fps_dist(pts[k * 3 + 0] - x1, pts[k * 3 + 1] - y1, pts[k * 3 + 2] - z1), temp[k]);
+                temp[k] = d2;
+                bi = d2 > best ? i : bi;
+                best = d2 > best ? d2 : best;
+            }
         }
-        old = dists_i[0];
+        unsigned long long key = lane_on ? (((unsigned long long)__float_as_uint(best) << 32) | (tie_hi - bi)) : 0ull;
+        key = fps_wave_max(key);
+        if (nwaves > 1) {
+            if (lane == 0) wave_key[j & 1][wave] = key;
+            __syncthreads();
+            key = fps_wave_max(lane < nwaves ? wave_key[j & 1][lane] : 0ull);
+        }
+        const unsigned tie = ~(unsigned)key;                              // bitrev(t) << ibits | slot
+        const unsigned t = logT ? (__builtin_bitreverse32(tie >> ibits) >> (32 - logT)) : 0u;
+        old = (int)(((tie & ((1u << ibits) - 1u)) << logT) | t);
+        old = __builtin_amdgcn_readfirstlane(old);
         if (tid == 0) idxs[j] = old;
-        __syncthreads();
     }
 }
 
@@ -680,13 +745,20 @@ extern "C" int me_pool_tokens_bwd(const float* dy, const int32_t* argmax, void* 
 extern "C" int me_fps(const float* points, int32_t* idx, float* temp, int B, int n, int m, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ME_CHECK_ARG(points && idx && temp && B > 0 && n > 0 && m > 0 && m <= n, "me_fps: bad args (B=%d n=%d m=%d)", B, n, m);
-    int T = 1;
-    while (T * 2 <= n && T < 1024) T *= 2;          // opt_n_threads(n) of the reference launcher
-#define ME_FPS_CASE(TT) case TT: hipLaunchKernelGGL(fps_kernel<TT>, dim3((unsigned)B), dim3(TT), 0, stream, points, temp, idx, n, m); break;
-    switch (T) {
-        ME_FPS_CASE(1024) ME_FPS_CASE(512) ME_FPS_CASE(256) ME_FPS_CASE(128) ME_FPS_CASE(64) ME_FPS_CASE(32) ME_FPS_CASE(16)
-        ME_FPS_CASE(8) ME_FPS_CASE(4) ME_FPS_CASE(2) default: ME_FPS_CASE(1)
-    }
+    int logT = 0;
+    while ((2 << logT) <= n && logT < 10) ++logT;          // opt_n_threads(n) of the reference launcher: T = 1 << logT
+    const int T = 1 << logT, threads = T < 64 ? 64 : T;
+    const int per_lane = (n + T - 1) / T;                   // points per reference thread
+    int ibits = 1;
+    while ((1 << ibits) < per_lane) ++ibits;
+#define ME_FPS_CASE(RR) hipLaunchKernelGGL(fps_kernel<RR>, dim3((unsigned)B), dim3((unsigned)threads), 0, stream, points, temp, idx, n, m, logT, ibits)
+    if (per_lane <= 1) ME_FPS_CASE(1);
+    else if (per_lane <= 2) ME_FPS_CASE(2);
+    else if (per_lane <= 4) ME_FPS_CASE(4);
+    else if (per_lane <= 8) ME_FPS_CASE(8);
+    else if (per_lane <= 16) ME_FPS_CASE(16);
+    else if (per_lane <= 24) ME_FPS_CASE(24);
+    else ME_FPS_CASE(0);
 #undef ME_FPS_CASE
     ME_CHECK_LAUNCH("me_fps");
     return ME_OK;

@@ -85,13 +85,15 @@ class _LinearFn(torch.autograd.Function):
         y = ops.gemm(xc, wc.contiguous(), bias=bc, out_dtype=torch.float32)
         ctx.save_for_backward(xc, wc)
         ctx.meta = (N, Np, x.shape, b is not None, w.dtype, x.dtype)
-        return y[:, :N].reshape(*x.shape[:-1], N)
+        # never a VIEW of a tensor made in here: the reference's ClsHead puts nn.ReLU(inplace=True) straight behind its Linear
+        # (cls_base.py:112-118 with norm_args=None), and autograd refuses in-place writes to a custom Function's view output
+        return y if Np == N else y[:, :N].contiguous()
 
     @staticmethod
     def backward(ctx, dy):
         xc, wc = ctx.saved_tensors
         N, Np, xshape, has_b, wdt, xdt = ctx.meta
-        d2 = dy.reshape(-1, N).to(xc.dtype)
+        d2 = dy.to(xc.dtype)
         if Np != N:
             d2 = torch.cat([d2, d2.new_zeros(d2.shape[0], Np - N)], dim=1)
         d2 = d2.contiguous()
@@ -113,7 +115,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) 
         raise MetaEncError("heads.linear: CUDA tensors only (no CPU fallback)")
     if x.shape[-1] % 8 != 0:
         raise MetaEncError(f"heads.linear: in_features {x.shape[-1]} must be a multiple of 8")
-    return _LinearFn.apply(x, weight, bias)
+    y = _LinearFn.apply(x, weight, bias)                        # [rows, out_features]
+    return y if x.dim() == 2 else y.reshape(*x.shape[:-1], weight.shape[0])
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -163,7 +166,7 @@ class ClsHead(nn.Module):
     blocks follow create_linearblock: nn.Sequential(Linear, [BatchNorm1d], [ReLU]) -> keys ``head.{i}.0.weight`` ..."""
 
     def __init__(self, num_classes: int, in_channels: int, mlps=(256,), norm_args=None, act_args=None, dropout: float = 0.5,
-                 global_feat: Optional[str] = None, point_dim: int = 1):
+                 global_feat: Optional[str] = None, point_dim: int = 2):
         super().__init__()
         self.global_feat = global_feat.split(",") if global_feat is not None else None
         self.point_dim = point_dim

@@ -292,6 +292,75 @@ def gen_variants(check):
     print("wrote variants", sum(v.nbytes for v in out.values()) // 1024, "KiB")
 
 
+def gen_pointcloud(check):
+    """Row f4 (point-cloud front end and head) from the reference's own classes: PointPatchEmbed
+    (PointCloud/openpoints/models/layers/group_embed.py:60-172) in the configuration of
+    cfgs/modelnet40ply2048/metatransformer.yaml:19-33 (fps / knn / 'dp' / bn / conv-norm-act / max; narrower channels to
+    keep the fixture small) and ClsHead (models/classification/cls_base.py:77-136) in three constructions.  The two CUDA
+    extension calls inside are served as ref_loader.reference_pointcloud_modules documents."""
+    ge, cb = ref_loader.reference_pointcloud_modules()
+    out = {}
+    g = torch.Generator().manual_seed(4001)
+
+    def randomize(mod):
+        for m in mod.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+                m.weight.data.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=g))
+                m.bias.data.copy_(0.05 * torch.randn(m.bias.shape, generator=g))
+            elif isinstance(m, (torch.nn.Linear, torch.nn.Conv2d)):
+                m.weight.data.copy_(torch.randn(m.weight.shape, generator=g) * (m.weight[0].numel() ** -0.5))
+                if m.bias is not None:
+                    m.bias.data.copy_(0.05 * torch.randn(m.bias.shape, generator=g))
+
+    # ---- PointPatchEmbed: [2, 512, 3] -> centres [2, 128, 3], tokens [2, 192, 128]
+    cfg = dict(sample_ratio=0.25, group_size=32, in_channels=3, layers=4, embed_dim=192, channels=[32, 64, 128], subsample="fps",
+               group="knn", feature_type="dp", normalize_dp=False, norm_args={"norm": "bn"}, conv_args={"order": "conv-norm-act"},
+               reduction="max")
+    ppe = ge.PointPatchEmbed(**cfg).eval()
+    randomize(ppe)
+    p = torch.rand(2, 512, 3, generator=g) * 2 - 1
+    p[1, 300:] = p[1, :212].clone()                       # duplicated points: ties in both the sampler and the neighbour search
+    with torch.no_grad():
+        (_, center), (_, out_f) = ppe(p)
+    out.update({"ppe/config": json.dumps(cfg), "ppe/p": p.numpy(), "ppe/center": center.numpy(), "ppe/out_f": out_f.numpy()})
+    for k, v in ppe.state_dict().items():
+        out["ppe/w/" + k] = v.numpy()
+    if check:
+        ref, _, _ = to.point_patch_embed_reference(p, ppe)
+        err = ((ref - out_f).abs().max() / out_f.abs().max()).item()
+        assert err < 1e-5, err
+        print("  point_patch_embed restatement rel", err)
+
+    # ---- ClsHead: (a) the pipeline's construction (bn1d, two hidden layers), eval; (b) the class defaults (no norm, in-place
+    # ReLU straight behind the Linear), eval + a training-mode forward/backward with dropout off; (c) global_feat 'max,avg'
+    # over channel-first features (point_dim = 2, the default)
+    cases = {"a": (dict(num_classes=40, in_channels=192, mlps=[64, 64], norm_args={"norm": "bn1d"}), (5, 192)),
+             "b": (dict(num_classes=10, in_channels=64, dropout=0.0), (6, 64)),
+             "c": (dict(num_classes=12, in_channels=48, mlps=[32], global_feat="max,avg"), (3, 48, 17))}
+    for tag, (kw, shape) in cases.items():
+        head = cb.ClsHead(**kw).eval()
+        randomize(head)
+        x = torch.randn(*shape, generator=g)
+        with torch.no_grad():
+            y = head(x)
+        out.update({f"cls_{tag}/config": json.dumps(kw), f"cls_{tag}/x": x.numpy(), f"cls_{tag}/y": y.numpy()})
+        for k, v in head.state_dict().items():
+            out[f"cls_{tag}/w/" + k] = v.numpy()
+        if tag == "b":
+            head.train()
+            xr = x.clone().requires_grad_(True)
+            go = torch.randn(shape[0], kw["num_classes"], generator=g)
+            yt = head(xr)
+            (yt * go).sum().backward()
+            out.update({"cls_b/go": go.numpy(), "cls_b/y_train": yt.detach().numpy(), "cls_b/dx": xr.grad.numpy()})
+            for k, v in head.named_parameters():
+                out["cls_b/g/" + k] = v.grad.numpy()
+    np.savez(os.path.join(GOLDEN_DIR, "pointcloud.npz"), **out)
+    print("wrote pointcloud", sum(v.nbytes for v in out.values() if hasattr(v, "nbytes")) // 1024, "KiB")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -304,6 +373,7 @@ def main():
         gen_encoder_case(name, c, args.check)
     gen_tokenizers(args.check)
     gen_variants(args.check)
+    gen_pointcloud(args.check)
 
 
 if __name__ == "__main__":

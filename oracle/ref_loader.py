@@ -187,3 +187,88 @@ def reference_detection_vit_module():
     })
     del att
     return _load_file("_ref_det_vit", "Image/detection/mmdet_custom/models/backbones/base/vit.py", stubs)
+
+
+def reference_pointcloud_modules():
+    """PointCloud/openpoints/models/layers/group_embed.py (PointPatchEmbed, :60-172) and
+    models/classification/cls_base.py (ClsHead, :77-136), both UNMODIFIED, for the row-f4 fixtures.
+
+    The files are loaded under a synthetic mirror of the package tree (`_ref_op.models.layers.*`,
+    `_ref_op.models.classification.cls_base`) so that their relative imports resolve to the reference's own sibling files
+    (conv.py / norm.py / activation.py / group.py / subsample.py / local_aggregation.py).  What cannot run here is stubbed,
+    and only that:
+      * `openpoints.cpp[.pointnet2_batch].pointnet2_cuda` (the built CUDA extension) and the two autograd Functions that
+        call it: `furthest_point_sample` -> the literal CPU restatement of the kernel
+        (oracle.tokenizer_oracle.fps_reference, itself compared on the GPU with the reference kernel built by
+        oracle/build_ref.py), `grouping_operation` -> the gather it performs (group_points_gpu.cu:53-70: out[b,c,p,s] =
+        features[b,c,idx[b,p,s]]);
+      * the registry / checkpoint / loss helpers (`..build.MODELS`, `...utils`, `...loss`): decorators and loaders, no
+        arithmetic.
+    Returns (group_embed module, cls_base module)."""
+    import torch
+    import torch.nn as nn
+    load_reference_layers()          # easydict stub (norm.py) etc.
+    root = os.path.join(REF_ROOT, "PointCloud", "openpoints")
+
+    def pkg(name, path=None, **attrs):
+        m = sys.modules.get(name)
+        if m is None:
+            m = types.ModuleType(name)
+            m.__path__ = [path] if path else []
+            sys.modules[name] = m
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+
+    class _Registry:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+
+        def build(self, *a, **k):
+            raise RuntimeError("registry stub: not used by the fixtures")
+
+    noop = lambda *a, **k: None          # noqa: E731
+    pkg("_ref_op", root)
+    pkg("_ref_op.utils", get_missing_parameters_message=noop, get_unexpected_parameters_message=noop, load_checkpoint=noop,
+        registry=types.SimpleNamespace(Registry=lambda *a, **k: _Registry()))
+    pkg("_ref_op.loss", build_criterion_from_cfg=noop)
+    models = pkg("_ref_op.models", os.path.join(root, "models"))
+    pkg("_ref_op.models.build", MODELS=_Registry(), build_model_from_cfg=noop)
+    layers = pkg("_ref_op.models.layers", _LAYERS)
+    pkg("_ref_op.models.classification", os.path.join(root, "models", "classification"))
+    ext = types.SimpleNamespace()        # the CUDA extension: never called (its two callers are replaced below)
+    pkg("openpoints"); pkg("openpoints.cpp", pointnet2_cuda=ext); pkg("openpoints.cpp.pointnet2_batch", pointnet2_cuda=ext)
+
+    def load(full, path):
+        if full in sys.modules and getattr(sys.modules[full], "__file__", None):
+            return sys.modules[full]
+        spec = importlib.util.spec_from_file_location(full, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[full] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    L = "_ref_op.models.layers."
+    for name in ("weight_init", "helpers", "activation", "norm", "conv"):
+        load(L + name, os.path.join(_LAYERS, name + ".py"))
+    conv = sys.modules[L + "conv"]
+    layers.create_linearblock = conv.create_linearblock
+    sub = load(L + "subsample", os.path.join(_LAYERS, "subsample.py"))
+    grp = load(L + "group", os.path.join(_LAYERS, "group.py"))
+
+    def cpu_fps(xyz, npoint):
+        from . import tokenizer_oracle as to
+        return torch.from_numpy(to.fps_reference(xyz.detach().cpu().numpy(), int(npoint)))
+
+    def cpu_grouping(features, idx):
+        B, C, N = features.shape
+        _, P, S = idx.shape
+        return torch.gather(features.unsqueeze(2).expand(B, C, P, N), 3, idx.long().unsqueeze(1).expand(B, C, P, S))
+
+    sub.furthest_point_sample = cpu_fps
+    grp.grouping_operation = cpu_grouping
+    load(L + "local_aggregation", os.path.join(_LAYERS, "local_aggregation.py"))
+    ge = load(L + "group_embed", os.path.join(_LAYERS, "group_embed.py"))
+    cb = load("_ref_op.models.classification.cls_base", os.path.join(root, "models", "classification", "cls_base.py"))
+    del models, nn
+    return ge, cb

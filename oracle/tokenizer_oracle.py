@@ -193,10 +193,13 @@ def fps_reference(points, m: int):
         old = 0
         for j in range(1, m):
             d = P - P[old]
-            # fma(dz, dz, fma(dy, dy, dx*dx)) evaluated in double and rounded after each step (products of floats are exact there)
+            # the reference's expression (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1) as hipcc evaluates it on gfx950
+            # (ISA of oracle/_ref/libref_fps.so, all block sizes): fma(dy, dy, dx*dx) + dz*dz.  Evaluated in double and rounded
+            # after each step (products of two floats are exact there)
             t0 = (d[:, 0].astype(np.float64) * d[:, 0]).astype(np.float32)
             t1 = (d[:, 1].astype(np.float64) * d[:, 1] + t0).astype(np.float32)
-            dist = (d[:, 2].astype(np.float64) * d[:, 2] + t1).astype(np.float32)
+            t2 = (d[:, 2].astype(np.float64) * d[:, 2]).astype(np.float32)
+            dist = (t1 + t2).astype(np.float32)
             temp = np.minimum(dist, temp)
             best = np.full(T, -1.0, dtype=np.float32)
             besti = np.zeros(T, dtype=np.int64)
