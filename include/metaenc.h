@@ -313,6 +313,28 @@ int me_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
 /* bf16_mirror (optional, n bf16 elements, same indexing as param): receives the updated parameters rounded to bf16 --
  * the forward-layout compute copies of the weights come out of the optimizer pass instead of one cast launch per weight. */
 
+/* The fine-tune recipe around AdamW, fused and decided on the device (no host synchronisation between backward and the step):
+ *   * parameter groups: layer-wise lr decay by block index and the no-decay groups of Video/optim_factory.py:28-41, 56-95 and
+ *     Image/segmentation/mmcv_custom/layer_decay_optimizer_constructor.py:17-41 -> a table of contiguous segments of the flat
+ *     bucket, each with its lr scale and weight decay (me_adamw_segment, device memory, sorted, the last end == n);
+ *   * NativeScalerWithGradNormCount (Video/utils.py:376-404) = GradScaler.unscale_ + clip_grad_norm_ + "skip the step when
+ *     a gradient is non-finite": me_grad_stats reduces the bucket to {sum of squares, number of non-finite values} (device),
+ *     me_adamw_prepare turns that into the control block -- gradient multiplier = grad_scale / *loss_scale * min(1, max_norm /
+ *     (norm + 1e-6)), skip flag, step counter (advanced only when the step is taken) and its bias corrections -- and
+ *     me_adamw_step_segments applies (or skips) the step.  total_norm / found_inf stay readable in the control block (the
+ *     caller's dynamic loss scale reads found_inf the same way torch's _amp_update_scale_ does).
+ * stats / loss_scale may be NULL (no clipping statistics / no loss scaling); max_norm <= 0 disables clipping.  The control block
+ * is caller-owned device memory, zeroed once before the first step. */
+typedef struct me_adamw_segment { int64_t end; float lr_scale, weight_decay; } me_adamw_segment;      /* covers [previous end, end) */
+typedef struct me_adamw_ctl { float grad_mul, skip, bc1, bc2_sqrt, total_norm, found_inf; int32_t step, reserved; } me_adamw_ctl;
+size_t me_grad_stats_workspace(void);
+int me_grad_stats(const float* grad, int64_t n, float* stats /* [2], device */, void* workspace, void* stream);
+int me_adamw_prepare(me_adamw_ctl* ctl, const float* stats, const float* loss_scale, float grad_scale, float max_norm,
+                     float beta1, float beta2, void* stream);
+int me_adamw_step_segments(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                           const me_adamw_segment* segments, int n_segments, float lr, float beta1, float beta2, float eps,
+                           const me_adamw_ctl* ctl, void* bf16_mirror, void* stream);
+
 /* ------------------------------------------------------------------ token pooling for the task heads
  * [B, N, C] tokens -> [B, C] fp32 features: x.mean(1) ahead of fc_norm / x[:, 0] (Video/models/modeling_finetune.py:445-454),
  * and the 'max' / 'avg' global features of the PointCloud ClsHead (openpoints/models/classification/cls_base.py:126-133).

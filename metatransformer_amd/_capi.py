@@ -91,6 +91,17 @@ class BlockGrads(ctypes.Structure):
                 + [("w_dtype", c_int32), ("accumulate", c_int32)])
 
 
+class AdamwSegment(ctypes.Structure):
+    """Mirror of ``struct me_adamw_segment``: the flat bucket's elements [previous end, end) share one lr scale / weight decay."""
+    _fields_ = [("end", c_int64), ("lr_scale", c_float), ("weight_decay", c_float)]
+
+
+class AdamwCtl(ctypes.Structure):
+    """Mirror of ``struct me_adamw_ctl`` (device-resident control block of the fused fine-tune step)."""
+    _fields_ = [("grad_mul", c_float), ("skip", c_float), ("bc1", c_float), ("bc2_sqrt", c_float), ("total_norm", c_float),
+                ("found_inf", c_float), ("step", c_int32), ("reserved", c_int32)]
+
+
 # name -> (restype, argtypes).  Every symbol include/metaenc.h declares must be listed here
 # (tests/test_boundary.py cross-checks the header against this table and against the built .so).
 SIGNATURES = {
@@ -141,6 +152,11 @@ SIGNATURES = {
     "me_timeseries_unfold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "me_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                               c_float, c_int, c_float, c_void_p, c_void_p]),
+    "me_grad_stats_workspace": (c_size_t, []),
+    "me_grad_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "me_adamw_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p]),
+    "me_adamw_step_segments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_float, c_float, c_float,
+                                       c_float, c_void_p, c_void_p, c_void_p]),
     "me_fps": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "me_knn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "me_group_relative": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -172,7 +172,9 @@ __device__ __forceinline__ float gelu_erf_grad(float x) { return gelu_erf_grad4(
 // transcendental.  Minimax over the whole real line in the ABSOLUTE error of the result (tools/gelu_poly_fit.py, which also
 // evaluates this exact float32 formula): |gelu err| <= 1.9e-4 (2^-12.4), |gelu' err| <= 4.2e-4 -- a fraction of the bf16
 // rounding of the stored value for all but the smallest outputs, and P(0) = -1/2, Q(0) = 2 phi(0) are pinned so that
-// gelu(x) -> x / 2 and gelu'(x) - 1/2 -> 2 phi(0) x keep their RELATIVE accuracy around zero.  fp32 outputs keep the erf form.
+// gelu(x) -> x / 2 and gelu'(x) - 1/2 -> 2 phi(0) x keep their RELATIVE accuracy around zero.  fp32 outputs keep the erf form, and so
+// does the training forward that stores gelu AND gelu' (one exponential serves both there: measured no slower than two chains).
+// Measured (MI355X, fc1 of config 2): forward-only epilogue 261 -> 236 us per launch, with the pre-activation saved 335 -> 308 us.
 // (inline asm for the clamp and the ramp: written as fminf(fabsf(x), 4) / fmaxf(x, 0) hipcc first canonicalises the operand with
 // a v_max_f32 x, x each -- two of the ten operations per element.  The NEGATIVE leading coefficients go through an opaque
 // register: hipcc rewrites t * (-c) as (-t) * c and then, finding no negation modifier it can use on the packed FMA, negates t
@@ -213,12 +215,6 @@ __device__ __forceinline__ f32x4 gelu_bf16_grad_from_t4(f32x4 x, f32x4 t) {
 }
 __device__ __forceinline__ f32x4 gelu_bf16_4(f32x4 x) { return gelu_bf16_from_t4(x, gelu_clamp4(x)); }
 __device__ __forceinline__ f32x4 gelu_bf16_grad4(f32x4 x) { return gelu_bf16_grad_from_t4(x, gelu_clamp4(x)); }
-// both at once (the fc1 epilogue of a training step stores gelu(h) and gelu'(h)): the clamp is shared
-__device__ __forceinline__ void gelu_bf16_pair4(f32x4 x, f32x4& y, f32x4& d) {
-    const f32x4 t = gelu_clamp4(x);
-    y = gelu_bf16_from_t4(x, t);
-    d = gelu_bf16_grad_from_t4(x, t);
-}
 // form by the dtype the result is stored in (wave-uniform)
 __device__ __forceinline__ f32x4 gelu_for4(f32x4 x, int out_dtype) { return out_dtype == ME_BF16 ? gelu_bf16_4(x) : gelu_erf4(x); }
 __device__ __forceinline__ f32x4 gelu_grad_for4(f32x4 x, int out_dtype) { return out_dtype == ME_BF16 ? gelu_bf16_grad4(x) : gelu_erf_grad4(x); }

@@ -369,6 +369,110 @@ __global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p
     }
 }
 
+// ---- fine-tune recipe of the fused optimizer: what the reference's training loops wrap around AdamW --
+// layer-wise lr decay / no-decay parameter groups (Video/optim_factory.py:28-41, 56-95;
+// Image/segmentation/mmcv_custom/layer_decay_optimizer_constructor.py:17-41), GradScaler.unscale_ + clip_grad_norm_ and the
+// skipped step on a non-finite gradient (Video/utils.py:376-404) -- on the flat bucket, with the decisions taken ON THE
+// DEVICE: no host round trip between backward and the optimizer step.
+//   grad_stats_kernel + grad_stats_fold_kernel : sum of squares and number of non-finite values of the bucket (deterministic
+//                                                two-level sum, fp32 partials of <= 4 K elements folded in double)
+//   adamw_prepare_kernel                       : one thread: total norm, clip coefficient, found-inf, the step counter and its
+//                                                bias corrections -> me_adamw_ctl
+//   adamw_seg_kernel                           : the AdamW pass with a per-segment (lr scale, weight decay) table in LDS
+constexpr int GS_BLOCKS = 1024;
+__global__ __launch_bounds__(EW_THREADS) void grad_stats_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ part) {
+    float ss = 0.f, bad = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ss = __builtin_fmaf(v[e], v[e], ss);
+            bad += (__float_as_uint(v[e]) & 0x7f800000u) == 0x7f800000u ? 1.f : 0.f;       // inf or nan
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
+        const float v = g[n4 * 4 + threadIdx.x];
+        ss = __builtin_fmaf(v, v, ss);
+        bad += (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u ? 1.f : 0.f;
+    }
+    __shared__ double sh[2][EW_THREADS / 64];
+    double dss = ss, dbad = bad;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { dss += __shfl_xor(dss, o, 64); dbad += __shfl_xor(dbad, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = dss; sh[1][threadIdx.x >> 6] = dbad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0;
+        for (int w = 0; w < EW_THREADS / 64; ++w) { a += sh[0][w]; b += sh[1][w]; }
+        part[blockIdx.x * 2] = a;
+        part[blockIdx.x * 2 + 1] = b;
+    }
+}
+__global__ __launch_bounds__(64) void grad_stats_fold_kernel(const double* __restrict__ part, int nb, float* __restrict__ stats) {
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < nb; i += 64) { a += part[i * 2]; b += part[i * 2 + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (threadIdx.x == 0) { stats[0] = (float)a; stats[1] = (float)b; }
+}
+__global__ void adamw_prepare_kernel(me_adamw_ctl* __restrict__ ctl, const float* __restrict__ stats, const float* __restrict__ loss_scale,
+                                     float grad_scale, float max_norm, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float mul = grad_scale;
+    if (loss_scale) mul /= *loss_scale;                               // GradScaler.unscale_: grads were computed on loss * scale
+    float norm = 0.f, bad = 0.f;
+    if (stats) {
+        norm = sqrtf(stats[0]) * fabsf(mul);                          // norm of the UNSCALED, averaged gradient
+        bad = (stats[1] > 0.f || !(norm == norm) || norm > 3.0e38f) ? 1.f : 0.f;
+        if (max_norm > 0.f) {
+            // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped at 1
+            const float coef = max_norm / (norm + 1e-6f);
+            mul *= coef < 1.f ? coef : 1.f;
+        }
+    }
+    int step = ctl->step;
+    if (bad == 0.f) ++step;                                           // GradScaler.step skips optimizer.step(): no state moves
+    ctl->step = step;
+    ctl->grad_mul = mul;
+    ctl->skip = bad;
+    ctl->bc1 = 1.0f - powf(b1, (float)step);
+    ctl->bc2_sqrt = sqrtf(1.0f - powf(b2, (float)step));
+    ctl->total_norm = norm;
+    ctl->found_inf = bad;
+}
+constexpr int ADAMW_MAX_SEG = 512;
+__global__ __launch_bounds__(EW_THREADS) void adamw_seg_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                               float* __restrict__ v, int64_t n, const me_adamw_segment* __restrict__ seg,
+                                                               int ns, float lr, float b1, float b2, float eps,
+                                                               const me_adamw_ctl* __restrict__ ctl, bf16_t* __restrict__ mirror) {
+    __shared__ int64_t s_end[ADAMW_MAX_SEG];
+    __shared__ float s_lr[ADAMW_MAX_SEG], s_wd[ADAMW_MAX_SEG];
+    for (int k = threadIdx.x; k < ns; k += EW_THREADS) { s_end[k] = seg[k].end; s_lr[k] = lr * seg[k].lr_scale; s_wd[k] = seg[k].weight_decay; }
+    __syncthreads();
+    const float gscale = ctl->grad_mul, bc1 = ctl->bc1, bc2_sqrt = ctl->bc2_sqrt;
+    if (ctl->skip != 0.f) return;                                     // (uniform) non-finite gradient: parameters and moments stay
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        int lo = 0, hi = ns - 1;                                      // the segment that holds i: first k with i < end[k]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (i < s_end[mid]) hi = mid; else lo = mid + 1;
+        }
+        const float lri = s_lr[lo], wd = s_wd[lo];
+        const float gi = g[i] * gscale;
+        float pi = p[i];
+        pi *= (1.0f - lri * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lri / bc1) * (mi / denom);
+        p[i] = pi;
+        if (mirror) mirror[i] = (bf16_t)pi;
+    }
+}
+
 // ---- position-embedding table resize (cls/pos-embed glue).
 // Replaces TIMMVisionTransformer.resize_pos_embed (Image/detection/mmdet_custom/models/backbones/base/vit.py:459-486:
 // reshape the [h*w, C] table to [1, C, h, w], F.interpolate(size=(H, W), mode, align_corners=False), flatten back) on the
@@ -941,6 +1045,43 @@ extern "C" int me_adamw_step(float* param, const float* grad, float* exp_avg, fl
     hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, param, grad, exp_avg, exp_avg_sq, n, lr,
                        beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale, reinterpret_cast<bf16_t*>(bf16_mirror));
     ME_CHECK_LAUNCH("me_adamw_step");
+    return ME_OK;
+}
+
+extern "C" size_t me_grad_stats_workspace(void) { return (size_t)GS_BLOCKS * 2 * sizeof(double); }
+
+extern "C" int me_grad_stats(const float* grad, int64_t n, float* stats, void* workspace, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(grad && stats && workspace && n > 0, "me_grad_stats: bad args");
+    ME_CHECK_ARG((uintptr_t)grad % 16 == 0, "me_grad_stats: the gradient buffer must be 16-byte aligned");
+    int nb = ew_blocks(n / 4 + 1);
+    nb = nb < GS_BLOCKS ? nb : GS_BLOCKS;
+    double* part = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(grad_stats_kernel, dim3((unsigned)nb), dim3(EW_THREADS), 0, stream, grad, n, part);
+    hipLaunchKernelGGL(grad_stats_fold_kernel, dim3(1), dim3(64), 0, stream, part, nb, stats);
+    ME_CHECK_LAUNCH("me_grad_stats");
+    return ME_OK;
+}
+
+extern "C" int me_adamw_prepare(me_adamw_ctl* ctl, const float* stats, const float* loss_scale, float grad_scale, float max_norm,
+                                float beta1, float beta2, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(ctl != nullptr, "me_adamw_prepare: null control block");
+    hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(1), 0, stream, ctl, stats, loss_scale, grad_scale, max_norm, beta1, beta2);
+    ME_CHECK_LAUNCH("me_adamw_prepare");
+    return ME_OK;
+}
+
+extern "C" int me_adamw_step_segments(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                      const me_adamw_segment* segments, int n_segments, float lr, float beta1, float beta2, float eps,
+                                      const me_adamw_ctl* ctl, void* bf16_mirror, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && segments && ctl && n >= 0, "me_adamw_step_segments: bad args");
+    ME_CHECK_ARG(n_segments >= 1 && n_segments <= ADAMW_MAX_SEG, "me_adamw_step_segments: 1 .. %d segments (got %d)", ADAMW_MAX_SEG, n_segments);
+    if (n == 0) return ME_OK;
+    hipLaunchKernelGGL(adamw_seg_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, param, grad, exp_avg, exp_avg_sq, n, segments,
+                       n_segments, lr, beta1, beta2, eps, ctl, reinterpret_cast<bf16_t*>(bf16_mirror));
+    ME_CHECK_LAUNCH("me_adamw_step_segments");
     return ME_OK;
 }
 

@@ -923,13 +923,16 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
             f32x4 v0 = v[h][0], v1 = v[h][1];
             if (EPI == 1) {
                 if (PRE == 2) {
-                    // gelu and gelu' (bf16-mode forms, common.h: one shared clamp): the backward GEMM multiplies by the saved factor
-                    f32x4 y0, d0, y1, d1;
-                    gelu_bf16_pair4(v0, y0, d0);
-                    gelu_bf16_pair4(v1, y1, d1);
+                    // gelu and gelu' from the same Phi / Gaussian parts: the backward GEMM multiplies by the saved factor.  (The
+                    // erf form stays here: with BOTH outputs wanted it shares one exponential between them, and the two
+                    // polynomial chains of the bf16-mode forms measured no faster -- 344 against 339 us per fc1 launch.)
+                    f32x4 ph0, ga0, ph1, ga1;
+                    phi_parts4(v0, ph0, ga0);
+                    phi_parts4(v1, ph1, ga1);
+                    const f32x4 d0 = ph0 + v0 * ga0 * 0.3989422804014327f, d1 = ph1 + v1 * ga1 * 0.3989422804014327f;
                     __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(d0, d1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
-                    v0 = y0;
-                    v1 = y1;
+                    v0 *= ph0;
+                    v1 *= ph1;
                 } else {
                     if (PRE) __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
                     v0 = gelu_bf16_4(v0);
@@ -1215,10 +1218,13 @@ int g3_cus() {
 }
 
 // The work counters of the resident kernel: every stream gets its own set (launches on a stream are serialised, and the
-// kernel leaves its counters at zero), handed out on the host from a per-device pool that is allocated and zeroed ONCE, at
-// the first resident launch on the device.  Assigning a set to a new stream touches no device state, so a stream that is
-// first seen while it is being captured into a hipGraph (torch's capture streams) is fine; only the pool allocation itself
-// must not fall into a capture -- then, and when the pool is exhausted, the launch runs the static schedule.
+// kernel leaves its counters at zero), handed out on the host from a per-device pool (keyed by the STREAM's device) that is
+// allocated and zeroed once, at the first resident launch on the device; a set is zeroed again, on its own stream, when it is
+// first handed to a stream.  A launch that is being CAPTURED into a hipGraph always runs the static schedule: a kernel node
+// keeps the counter set of its capture stream, but replays run on whatever stream launches the graph (torch.cuda.graph
+// captures every graph on one shared stream), so replays on different streams -- or a replay next to eager work on the capture
+// stream -- would draw from ONE set and break the "exactly nx draws, the last one resets" invariant.  On a free GPU the two
+// schedules time the same (tools/gemm_dev g3 / g3s); claiming matters next to a communication kernel, i.e. in eager training.
 unsigned* g3r_tickets(hipStream_t stream) {
     constexpr int SETS = 64, SET_WORDS = 8 * 16;
     struct Pool {
@@ -1229,14 +1235,14 @@ unsigned* g3r_tickets(hipStream_t stream) {
     };
     static std::mutex mu;
     static std::map<int, Pool> pools;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;      // static schedule
     int dev = 0;
-    (void)hipGetDevice(&dev);
+    if (hipStreamGetDevice(stream, &dev) != hipSuccess) (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
     Pool& P = pools[dev];
     if (!P.base) {
         if (P.failed) return nullptr;
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;      // not now
         unsigned* buf = nullptr;
         if (hipMalloc(&buf, (size_t)SETS * SET_WORDS * sizeof(unsigned)) != hipSuccess ||
             hipMemset(buf, 0, (size_t)SETS * SET_WORDS * sizeof(unsigned)) != hipSuccess) {
@@ -1248,6 +1254,8 @@ unsigned* g3r_tickets(hipStream_t stream) {
     auto it = P.idx.find(stream);
     if (it == P.idx.end()) {
         if (P.next >= SETS) return nullptr;
+        unsigned* set = P.base + (size_t)P.next * SET_WORDS;
+        if (hipMemsetAsync(set, 0, SET_WORDS * sizeof(unsigned), stream) != hipSuccess) return nullptr;
         it = P.idx.emplace(stream, P.next++).first;
     }
     return P.base + (size_t)it->second * SET_WORDS;

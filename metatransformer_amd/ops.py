@@ -446,3 +446,48 @@ def adamw_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
                             eps, weight_decay, step, grad_scale, ptr(bf16_mirror), stream_ptr()), "me_adamw_step")
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
+
+
+def grad_stats(grad: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """{sum of squares, number of non-finite values} of a flat fp32 gradient buffer as a 2-element DEVICE tensor
+    (me_grad_stats: deterministic two-level sum; nothing is synchronised)."""
+    _req(grad, "grad")
+    if grad.dtype != torch.float32 or grad.dim() != 1:
+        raise MetaEncError("grad_stats: a flat float32 buffer is required")
+    lib = _capi.load()
+    if out is None:
+        out = torch.empty(2, dtype=torch.float32, device=grad.device)
+    ws = torch.empty(lib.me_grad_stats_workspace(), dtype=torch.uint8, device=grad.device)
+    check(lib.me_grad_stats(ptr(grad), grad.numel(), ptr(out), ptr(ws), stream_ptr()), "me_grad_stats")
+    return out
+
+
+def adamw_step_segments(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+                        segments: torch.Tensor, n_segments: int, ctl: torch.Tensor, *, lr: float, betas=(0.9, 0.999),
+                        eps: float = 1e-8, grad_scale: float = 1.0, stats: Optional[torch.Tensor] = None,
+                        loss_scale: Optional[torch.Tensor] = None, max_norm: float = 0.0,
+                        bf16_mirror: Optional[torch.Tensor] = None) -> None:
+    """me_adamw_prepare + me_adamw_step_segments on flat fp32 buffers (see include/metaenc.h): per-segment lr scale / weight
+    decay, gradient unscale, global-norm clipping and the found-inf skip, all decided on the device.  `segments` is a uint8
+    device tensor holding n_segments me_adamw_segment records, `ctl` a 32-byte device control block (zeroed once by the caller;
+    its step counter lives there).  Same cache-invalidation contract as adamw_step."""
+    lib = _capi.load()
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, n)
+        if t.dtype != torch.float32:
+            raise MetaEncError(f"adamw_step_segments: {n} must be float32")
+    if bf16_mirror is not None and (bf16_mirror.dtype != torch.bfloat16 or bf16_mirror.numel() != param.numel()):
+        raise MetaEncError("adamw_step_segments: bf16_mirror must be a bfloat16 tensor of the parameter buffer's size")
+    if ctl.numel() * ctl.element_size() < ctypes_sizeof_ctl() or not ctl.is_cuda:
+        raise MetaEncError("adamw_step_segments: ctl must be a device buffer of sizeof(me_adamw_ctl) bytes")
+    check(lib.me_adamw_prepare(ptr(ctl), ptr(stats), ptr(loss_scale), grad_scale, max_norm, betas[0], betas[1], stream_ptr()),
+          "me_adamw_prepare")
+    check(lib.me_adamw_step_segments(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), ptr(segments), n_segments,
+                                     lr, betas[0], betas[1], eps, ptr(ctl), ptr(bf16_mirror), stream_ptr()), "me_adamw_step_segments")
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def ctypes_sizeof_ctl() -> int:
+    import ctypes
+    return ctypes.sizeof(_capi.AdamwCtl)

@@ -108,6 +108,32 @@ def no_decay_rule(name: str, p: torch.nn.Parameter) -> bool:
     return p.dim() == 1 or name.endswith(".bias")
 
 
+def layer_id_for_vit(name: str, num_layers: int) -> int:
+    """get_num_layer_for_vit (Video/optim_factory.py:28-41; the same rule keyed on `backbone.blocks.N` in
+    Image/segmentation/mmcv_custom/layer_decay_optimizer_constructor.py:17-41): embeddings -> 0, block N -> N + 1, the rest
+    (final norm / head) -> num_layers - 1, where num_layers = depth + 2.  Accepts the wrapped (`blocks.3.attn...`,
+    `backbone.blocks.3...`) and the bare nn.Sequential (`3.attn...`) spellings of a block parameter."""
+    import re
+    base = name.split(".")[-1] if "." not in name else name
+    if base in ("cls_token", "mask_token", "pos_embed") or name.endswith(("cls_token", "mask_token", "pos_embed")):
+        return 0
+    if name.startswith("patch_embed") or ".patch_embed" in name:
+        return 0
+    if name.startswith("rel_pos_bias"):
+        return num_layers - 1
+    m = re.match(r"^(?:.*\.)?blocks\.(\d+)\.", name) or re.match(r"^(\d+)\.", name)
+    if m:
+        return int(m.group(1)) + 1
+    return num_layers - 1
+
+
+def layer_decay_scales(depth: int, layer_decay: float) -> List[float]:
+    """LayerDecayValueAssigner's table (Video/run_class_finetuning.py: `layer_decay ** (num_layers + 1 - i)` for
+    i in range(num_layers + 2)), indexed by layer id."""
+    n = depth + 2
+    return [layer_decay ** (n - 1 - i) for i in range(n)]
+
+
 class FlatParams:
     """Re-homes parameters (and their gradients) into flat fp32 buffers; `p.data` / `p.grad` become views.
 
@@ -129,6 +155,7 @@ class FlatParams:
             tail = [(n, p) for n, p in named if not no_decay(n, p)]
             named = head + tail
         self.params: List[torch.nn.Parameter] = [p for _, p in named]
+        self.names: List[str] = [n for n, _ in named]
         if not self.params:
             raise MetaEncError("FlatParams: no trainable parameters")
         dev = self.params[0].device
@@ -210,6 +237,13 @@ class FlatParams:
                 raise MetaEncError(f"FlatParams: parameter #{i} {tuple(p.shape)} has .grad = None at step time -- use "
                                    "flat.zero_grad() instead of model.zero_grad() / optimizer.zero_grad(set_to_none=True)")
             if g.data_ptr() != gbase + o * es or g.shape != p.shape:
+                if self._listeners:
+                    # a gradient reducer watches this buffer: its bucket all-reduce was launched on the flat slice when the
+                    # hook fired, i.e. WITHOUT this gradient -- re-homing it now would step every rank with its local,
+                    # unreduced values and let the replicas drift apart silently
+                    raise MetaEncError(f"FlatParams: parameter #{i} {tuple(p.shape)} received its gradient in a fresh tensor "
+                                       "while an OverlappedGradReducer is attached (p.grad was set to None / replaced): the "
+                                       "bucket all-reduce has already run without it -- use flat.zero_grad()")
                 view = self.flat_grad[o:o + p.numel()].view(p.shape)
                 view.copy_(g)
                 p.grad = view
@@ -390,9 +424,21 @@ def allreduce_coalesced(tensors: Sequence[torch.Tensor], group=None, bucket_byte
 
 
 class FusedAdamW:
-    """AdamW over a FlatParams with ONE kernel launch (me_adamw_step); torch.optim.AdamW semantics."""
+    """AdamW over a FlatParams on the device; torch.optim.AdamW semantics.
 
-    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bf16_mirror: bool = True):
+    Plain form (the default): one launch per weight-decay slice (me_adamw_step).
+    Fine-tune form -- any of `lr_scale`, `max_norm`, `loss_scale` given: the reference recipes' parameter groups and gradient
+    scaler in one pass, decided on the device (me_grad_stats -> me_adamw_prepare -> me_adamw_step_segments):
+      * lr_scale: callable(name) -> float, e.g. ``lambda n: scales[layer_id_for_vit(n, len(scales))]`` with
+        ``scales = layer_decay_scales(depth, 0.75)`` -- layer-wise lr decay (Video/optim_factory.py:28-95); weight decay per
+        parameter still follows FlatParams(no_decay=...);
+      * max_norm: torch.nn.utils.clip_grad_norm_ over ALL parameters of the FlatParams (Video/utils.py:391-395);
+      * loss_scale: a 1-element device tensor holding the current loss scale (GradScaler semantics: gradients are divided by
+        it, and a non-finite gradient SKIPS the step: parameters, moments and the step counter stay); `step()` then returns the
+        device tensors (total_norm, found_inf) without synchronising -- feed found_inf to `DynamicLossScale.update`."""
+
+    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bf16_mirror: bool = True,
+                 lr_scale=None, max_norm: float = 0.0, loss_scale: Optional[torch.Tensor] = None):
         """bf16_mirror: also emit the updated parameters in bf16 (FlatParams.flat_bf16) from the same kernel; Blocks
         running in bf16 then take their forward weight copies from it instead of re-casting every weight."""
         if flat.flat_param.dtype != torch.float32:
@@ -402,19 +448,75 @@ class FusedAdamW:
         self.exp_avg = torch.zeros_like(flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(flat.flat_param)
         self.t = 0
+        self.max_norm, self.loss_scale = float(max_norm or 0.0), loss_scale
+        self.fine_tune = lr_scale is not None or self.max_norm > 0 or loss_scale is not None
+        self.groups = None
+        if self.fine_tune:
+            self._build_segments(lr_scale)
 
-    def step(self, grad_scale: float = 1.0) -> None:
+    def _build_segments(self, lr_scale) -> None:
+        import ctypes
+        from . import _capi
+        f = self.flat
+        segs = []                                        # (end, lr_scale, weight_decay), merged while equal
+        for i, (name, p, off) in enumerate(zip(f.names, f.params, f.offsets)):
+            end = f.offsets[i + 1] if i + 1 < len(f.offsets) else f.numel
+            sc = float(lr_scale(name)) if lr_scale is not None else 1.0
+            wd = 0.0 if off < f.no_decay_numel else float(self.wd)
+            if segs and segs[-1][1] == sc and segs[-1][2] == wd:
+                segs[-1] = (end, sc, wd)
+            else:
+                segs.append((end, sc, wd))
+        arr = (_capi.AdamwSegment * len(segs))(*[_capi.AdamwSegment(e, sc, wd) for e, sc, wd in segs])
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+        self.groups = segs
+        self._segments = raw.to(f.flat_param.device)
+        self._ctl = torch.zeros(ctypes.sizeof(_capi.AdamwCtl) // 4, dtype=torch.float32, device=f.flat_param.device)
+        self._stats = torch.zeros(2, dtype=torch.float32, device=f.flat_param.device)
+
+    def step(self, grad_scale: float = 1.0):
         self.t += 1
         f = self.flat
         f.check()
         if self.bf16_mirror and f.flat_bf16 is None:
             f.flat_bf16 = torch.empty(f.numel, dtype=torch.bfloat16, device=f.flat_param.device)
-        # parameters exempt from weight decay (FlatParams(no_decay=...)) sit in [0, no_decay_numel): two launches
-        for lo, hi, wd in ((0, f.no_decay_numel, 0.0), (f.no_decay_numel, f.numel, self.wd)):
-            if hi > lo:
-                ops.adamw_step(f.flat_param[lo:hi], f.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], lr=self.lr,
-                               betas=self.betas, eps=self.eps, weight_decay=wd, step=self.t, grad_scale=grad_scale,
-                               bf16_mirror=f.flat_bf16[lo:hi] if self.bf16_mirror else None)
+        out = None
+        if self.fine_tune:
+            need_stats = self.max_norm > 0 or self.loss_scale is not None
+            if need_stats:
+                ops.grad_stats(f.flat_grad, out=self._stats)
+            ops.adamw_step_segments(f.flat_param, f.flat_grad, self.exp_avg, self.exp_avg_sq, self._segments, len(self.groups),
+                                    self._ctl, lr=self.lr, betas=self.betas, eps=self.eps, grad_scale=grad_scale,
+                                    stats=self._stats if need_stats else None, loss_scale=self.loss_scale, max_norm=self.max_norm,
+                                    bf16_mirror=f.flat_bf16 if self.bf16_mirror else None)
+            out = (self._ctl[4:5], self._ctl[5:6])       # total_norm, found_inf (device views; no synchronisation)
+        else:
+            # parameters exempt from weight decay (FlatParams(no_decay=...)) sit in [0, no_decay_numel): two launches
+            for lo, hi, wd in ((0, f.no_decay_numel, 0.0), (f.no_decay_numel, f.numel, self.wd)):
+                if hi > lo:
+                    ops.adamw_step(f.flat_param[lo:hi], f.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], lr=self.lr,
+                                   betas=self.betas, eps=self.eps, weight_decay=wd, step=self.t, grad_scale=grad_scale,
+                                   bf16_mirror=f.flat_bf16[lo:hi] if self.bf16_mirror else None)
         if self.bf16_mirror:      # valid for this weight epoch as long as nobody else writes the parameters
             f._mirror_epoch = ops.WEIGHT_EPOCH
             f._mirror_versions = [p._version for p in f.params]
+        return out
+
+
+class DynamicLossScale:
+    """torch.cuda.amp.GradScaler's scale bookkeeping (Video/utils.py:379, 398: `self._scaler.update()`), on the device: the scale
+    is a 1-element tensor handed to FusedAdamW(loss_scale=...); `update(found_inf)` grows / backs it off with torch's own
+    `_amp_update_scale_` -- PyTorch plumbing, no host synchronisation.  `scale(loss)` multiplies the loss."""
+
+    def __init__(self, device, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000):
+        self.scale_t = torch.full((1,), float(init_scale), dtype=torch.float32, device=device)
+        self._growth_tracker = torch.zeros(1, dtype=torch.int32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+
+    def scale(self, loss: torch.Tensor) -> torch.Tensor:
+        return loss * self.scale_t.to(loss.dtype)
+
+    def update(self, found_inf: torch.Tensor) -> None:
+        torch._amp_update_scale_(self.scale_t, self._growth_tracker, found_inf.reshape(1).float(), self.growth_factor,
+                                 self.backoff_factor, self.growth_interval)

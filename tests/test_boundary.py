@@ -43,7 +43,8 @@ def test_header_symbols_all_bound_and_exported(lib):
 
 
 @pytest.mark.parametrize("cname,pyname", [("me_gemm_desc", "GemmDesc"), ("me_block_desc", "BlockDesc"),
-                                          ("me_block_grads", "BlockGrads"), ("me_gemm_profile_rec", "GemmProfileRec")])
+                                          ("me_block_grads", "BlockGrads"), ("me_gemm_profile_rec", "GemmProfileRec"),
+                                          ("me_adamw_segment", "AdamwSegment"), ("me_adamw_ctl", "AdamwCtl")])
 def test_struct_layouts_match_c(cname, pyname):
     """every struct that crosses the C ABI: size and field offsets of the ctypes mirror == what gcc lays out from the header"""
     cls = getattr(_capi, pyname)
