@@ -88,3 +88,68 @@ def test_bench_forced_dist_on_one_gpu():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and "me_allreduce_bucket" in line["config"]["grad_allreduce"]
     assert line["roofline"]["achieved"] > 0 and line["value"] > 0
+
+
+def _multirank_worker(rank, world, port, q):
+    """one process per GPU: gloo rendezvous carries the RCCL id, gradients go through me_allreduce_bucket from the
+    reducer's hooks (real Blocks: the fused backward accumulates weight gradients in place and announces them itself)"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import metatransformer_amd as M
+        from metatransformer_amd import parallel
+        comm = parallel.Comm.from_torch_distributed()
+        torch.manual_seed(0)                                   # same weights everywhere
+        enc = M.build_encoder(2, 128, 4).to(dev)
+        for b in enc:
+            b.compute_dtype = torch.bfloat16
+        flat = parallel.FlatParams(enc.named_parameters(), no_decay=parallel.no_decay_rule)
+        red = parallel.OverlappedGradReducer(flat, comm=comm, bucket_bytes=256 << 10)
+        x = torch.randn(4, 33, 128, generator=torch.Generator().manual_seed(100 + rank)).to(dev).bfloat16().requires_grad_(True)
+        with red.no_sync():                                    # this rank's own gradient: a backward the reducer ignores
+            flat.zero_grad()
+            enc(x).float().square().mean().backward()
+            local = flat.flat_grad.clone().cpu()
+        parts = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(parts, local)
+        want = sum(parts)
+        for it in range(2):                                    # reusable step after step
+            flat.zero_grad()
+            enc(x).float().square().mean().backward()
+            red.finish()
+            torch.cuda.synchronize()
+            err = float((flat.flat_grad.cpu() - want).abs().max() / want.abs().max())
+            assert err < 1e-5, (it, err)
+        assert comm.info()["world"] == world and comm.info()["buckets_reduced"] == 2 * len(red.bucket_slices)
+        red.remove()
+        comm.destroy()
+        q.put((rank, "ok"))
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()[-1500:] or repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multirank_reducer_sums_over_every_visible_gpu():
+    """world = torch.cuda.device_count() ranks through the C-ABI RCCL path (skipped on the 1-GPU test box; on a multi-GPU
+    node it is the first thing that exercises me_comm_init(world > 1) outside bench.py)"""
+    import socket
+    import torch.multiprocessing as mp
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("needs >= 2 visible GPUs (one rank per GPU)")
+    world = min(world, 8)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_multirank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
