@@ -225,7 +225,7 @@ def main():
         """HBM bytes per launch of the roofline kernel from the committed PMC passes of this same command (rocprofv3 --pmc
         cannot run inside the process: tools/pmc_bench.sh collects FETCH_SIZE / WRITE_SIZE in separate passes and
         tools/pmc_summary.py folds them, traffic = 2 * FETCH_SIZE + WRITE_SIZE).  None when the file is not there."""
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_pmc_{mode}.json")
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r03_pmc_{mode}.json")
         try:
             with open(path) as f:
                 pm = json.load(f)
@@ -235,11 +235,23 @@ def main():
                 if k.startswith("gemm_g3r_kernel") and isinstance(v, dict) and "hbm_traffic_MB" in v and v.get("launches")]
         if not rows:
             return None, None
-        mb = sum(n * t for n, t in rows) / sum(n for n, _ in rows)
-        return round(mb * 1e6), (f"profiles/r02_pmc_{mode}.json: rocprofv3 --pmc passes of this command (separate runs, 2*FETCH_SIZE + "
-                                 f"WRITE_SIZE), launch-weighted mean over the gemm_g3r_kernel launches; not re-measured in this run")
+        mib = sum(n * t for n, t in rows) / sum(n for n, _ in rows)        # (tools/pmc_summary.py reports MiB)
+        return round(mib * 1048576), (f"profiles/r03_pmc_{mode}.json: rocprofv3 --pmc passes of this command (separate runs, 2*FETCH_SIZE + "
+                                      f"WRITE_SIZE), launch-weighted mean over the gemm_g3r_kernel launches; not re-measured in this run")
+
+    def aux_arrays(m, n, k):
+        """how many extra [M, N] bf16 arrays the epilogue of this launch reads or writes (by the encoder's launch sequence)"""
+        hid = 4 * C
+        if n == hid:                       # fc1 (+ the saved gelu' in a training step) and the fc2 dgrad (* that saved factor)
+            return 1.0 if train_now[0] else 0.0
+        if n == C and k in (C, hid):       # forward proj / fc2: + residual.  A training step launches each of these two shapes
+            return 0.5 if train_now[0] else 1.0      # twice, once as a forward (residual) and once as a dgrad (no row operand)
+        return 0.0
+
+    train_now = [False]                    # whether the record list being summarised comes from a training step
 
     def gemm_roofline(recs, wall_s, nsteps, with_wgrad):
+        train_now[0] = bool(with_wgrad)
         nt = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_NT and dt == _capi.ME_BF16]
         tn = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_TN and dt == _capi.ME_BF16]
         if not nt:
@@ -254,7 +266,9 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": len(nt) // nsteps, "avg_launch_us": round(1e3 * ms / len(nt), 2),
                 "avg_launch_gflop": round(flops / len(nt) / 1e9, 2),
-                "algorithmic_bytes_per_launch": round(sum(2.0 * (m * k + n * k + m * n) for m, n, k, _ in nt) / len(nt)),
+                # operands + output, 2 bytes each, plus the second [M, N] array the fused epilogues move: the residual read by
+                # proj / fc2 (N = C), the saved gelu' written by fc1 in a training step and read by the fc2 dgrad (N or K = 4C)
+                "algorithmic_bytes_per_launch": round(sum(2.0 * (m * k + n * k + m * n) + 2.0 * m * n * aux_arrays(m, n, k) for m, n, k, _ in nt) / len(nt)),
                 "share_of_step_time": round(ms * 1e-3 / nsteps / wall_s, 4)}
         if with_wgrad and tn:
             f2 = sum(2.0 * m * n * k for m, n, k, _ in tn)
@@ -281,7 +295,8 @@ def main():
                 o["TFLOPs"] = round(sum(work_fn(m, n, k) for m, n, k, _ in rs) / (ms * 1e-3) / 1e12, 1)
             return o
         es = 2      # bf16 token stream
-        d = {"layernorm_fwd": _class(_capi.ME_PROF_LN_FWD, None, lambda m, n, k: 2.0 * m * n * es),
+        d = {"row_stats": _class(_capi.ME_PROF_ROW_STATS, None, lambda m, n, k: 1.0 * m * n * es),
+             "layernorm_fwd": _class(_capi.ME_PROF_LN_FWD, None, lambda m, n, k: 2.0 * m * n * es),
              "layernorm_bwd": _class(_capi.ME_PROF_LN_BWD, None, lambda m, n, k: 4.0 * m * n * es),
              "attention_fwd": _class(_capi.ME_PROF_ATTN_FWD, lambda m, n, k: 4.0 * m * n * n * k, lambda m, n, k: 4.0 * m * n * k * es),
              "attention_bwd": _class(_capi.ME_PROF_ATTN_BWD, lambda m, n, k: 10.0 * m * n * n * k, lambda m, n, k: 8.0 * m * n * k * es)}

@@ -50,6 +50,9 @@ int me_device_info(int dev, int* num_cus, int* lds_bytes, int* clock_mhz, char* 
  * Replaces nn.LayerNorm(C, eps) on [rows, C] tokens: Block.norm1 / Block.norm2
  * (PointCloud/openpoints/models/layers/attention.py:46,50 via norm.py:65).
  * mean/rstd ([rows], fp32) may be NULL in inference; they are what backward needs. */
+/* me_row_stats: per row of [rows, cols] the pair (rstd, -rstd * mean) -> out [rows][2] fp32: the statistics of the same
+ * LayerNorm for a Linear that has the normalisation folded in (me_gemm_desc.row_affine).  One read of x, no write of x. */
+int me_row_stats(const void* x, int x_dtype, float* out, int64_t rows, int cols, float eps, void* stream);
 int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
                      void* y, int y_dtype, float* mean, float* rstd,
                      int64_t rows, int cols, float eps, void* stream);
@@ -112,6 +115,13 @@ typedef struct me_gemm_desc {
                             * the operand tiles the kernel stages anyway instead of a second pass over dY; accumulated like C
                             * (colsum_a = beta * colsum_a + sums).  Only when
                             * me_gemm_fuses_colsum(d) != 0; otherwise me_gemm rejects the descriptor (use me_colsum). */
+    /* optional, ME_GEMM_NT: a LayerNorm folded into this Linear (inference).  With W' = gamma o W as the B operand,
+     *   Linear(LayerNorm(x)) = rstd_m * (x W'^T)[m, n] - rstd_m * mean_m * s[n] + c[n],   s[n] = sum_k W'[n, k],
+     *   c[n] = sum_k beta[k] W[n, k] + b[n]  (passed as `bias`),
+     * so the normalised activations are never written or re-read: row_affine = [M][2] fp32 pairs (rstd, -rstd * mean) from
+     * me_row_stats, col_shift = s [N] fp32.  Applied ahead of bias / activation: v = ra[m][0] * acc + ra[m][1] * s[n]. */
+    const float* row_affine;
+    const float* col_shift;
 } me_gemm_desc;
 
 /* Scratch the kernel selected for this problem can use (0 = none).  wgrad-shaped problems (tiny output, very long
@@ -125,10 +135,10 @@ int me_gemm(const me_gemm_desc* d, void* stream);
 /* Per-launch timing for roofline accounting (bench.py): while enabled, every me_gemm call -- including those made from
  * me_block_fwd / me_block_bwd -- and every LayerNorm / attention call is bracketed by HIP events on its stream.  Records
  * carry op = ME_GEMM_NT / ME_GEMM_TN with (M, N, K), or one of the codes below with (M, N, K) = (rows, cols, 0) for
- * LayerNorm and (B * heads, N, head_dim) for attention.  me_gemm_profile_read synchronises
+ * LayerNorm / me_row_stats and (B * heads, N, head_dim) for attention.  me_gemm_profile_read synchronises
  * on the recorded events, fills up to `max` records in call order and returns how many there are (and clears them).
  * Off by default; costs two event records per GEMM when on. */
-enum { ME_PROF_LN_FWD = 16, ME_PROF_LN_BWD = 17, ME_PROF_ATTN_FWD = 18, ME_PROF_ATTN_BWD = 19 };
+enum { ME_PROF_LN_FWD = 16, ME_PROF_LN_BWD = 17, ME_PROF_ATTN_FWD = 18, ME_PROF_ATTN_BWD = 19, ME_PROF_ROW_STATS = 20 };
 typedef struct me_gemm_profile_rec {
     int32_t op, ab_dtype;
     int64_t M, N, K;
@@ -198,6 +208,12 @@ typedef struct me_block_desc {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
     const float *gamma1, *gamma2;      /* layer-scale (forward only in this entry point) */
+    /* optional, inference only (me_block_fwd with saved == NULL, me_encoder_fwd): both LayerNorms folded into the Linear
+     * behind them (me_gemm_desc.row_affine): qkv_wf / fc1_wf = (gamma o W) in the compute dtype, *_s[n] = sum_k W'[n, k]
+     * of THOSE rounded values, *_c[n] = sum_k beta[k] W[n, k] + bias[n].  All six set -> the block runs me_row_stats + folded
+     * GEMMs instead of me_layernorm_fwd + GEMMs (the normalised tokens are neither written nor re-read); any NULL -> as before. */
+    const void *qkv_wf, *fc1_wf;
+    const float *qkv_s, *qkv_c, *fc1_s, *fc1_c;
 } me_block_desc;
 
 /* Gradient destinations of me_block_bwd; any pointer may be NULL (that gradient is skipped -- frozen encoder).

@@ -22,7 +22,7 @@ ME_GEMM_NT, ME_GEMM_TN = 0, 1
 ME_ACT_NONE, ME_ACT_GELU = 0, 1
 ME_GEMM_SAVE_GELU_GRAD, ME_GEMM_AUX_IS_FACTOR = 1, 2
 ME_GEMM_SAVE_GELU_GRAD, ME_GEMM_AUX_IS_FACTOR = 1, 2
-ME_PROF_LN_FWD, ME_PROF_LN_BWD, ME_PROF_ATTN_FWD, ME_PROF_ATTN_BWD = 16, 17, 18, 19      # me_gemm_profile_rec.op codes
+ME_PROF_LN_FWD, ME_PROF_LN_BWD, ME_PROF_ATTN_FWD, ME_PROF_ATTN_BWD, ME_PROF_ROW_STATS = 16, 17, 18, 19, 20      # me_gemm_profile_rec.op codes
 ME_COMM_ID_BYTES = 128
 ME_RESIZE_BILINEAR, ME_RESIZE_BICUBIC = 0, 1
 ME_POOL_MEAN, ME_POOL_MAX, ME_POOL_FIRST = 0, 1, 2
@@ -53,6 +53,7 @@ class GemmDesc(ctypes.Structure):
         ("out_group_rows", c_int64), ("out_group_stride", c_int64), ("out_row_offset", c_int64),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
         ("colsum_a", c_void_p),
+        ("row_affine", c_void_p), ("col_shift", c_void_p),
     ]
 
 
@@ -81,7 +82,7 @@ class BlockDesc(ctypes.Structure):
                  ("heads", c_int32), ("hidden", c_int32), ("eps", c_float), ("scale", c_float)]
                 + [(n, c_void_p) for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_wt", "proj_wt", "fc1_wt", "fc2_wt",
                                            "ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_b", "proj_b", "fc1_b", "fc2_b",
-                                           "gamma1", "gamma2")])
+                                           "gamma1", "gamma2", "qkv_wf", "fc1_wf", "qkv_s", "qkv_c", "fc1_s", "fc1_c")])
 
 
 class BlockGrads(ctypes.Structure):
@@ -109,6 +110,7 @@ SIGNATURES = {
     "me_last_error": (c_char_p, []),
     "me_build_arch": (c_char_p, []),
     "me_device_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "me_row_stats": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "me_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                  c_int64, c_int, c_float, c_void_p]),
     "me_layernorm_bwd_workspace": (c_size_t, [c_int]),

@@ -118,6 +118,7 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     ME_CHECK_ARG(x && y && workspace, "me_block_fwd: null pointer");
     ME_CHECK_ARG(d->qkv_w && d->proj_w && d->fc1_w && d->fc2_w && d->ln1_g && d->ln1_b && d->ln2_g && d->ln2_b,
                  "me_block_fwd: missing parameter");
+    ME_CHECK_ARG(s.M * 2 * 4 <= 2 * (int64_t)align256(s.M * 4), "me_block_fwd: stash layout");
     ME_CHECK_ARG(workspace_bytes >= me_block_workspace_bytes(d, 0), "me_block_fwd: workspace too small");
     char* ws = reinterpret_cast<char*>(workspace);
     const size_t gsz = gemm_scratch(d, s, false);
@@ -127,10 +128,22 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     const int dt = d->dtype, rdt = d->res_dtype;
     me_gemm_desc g;
 
-    rc = me_layernorm_fwd(x, rdt, d->ln1_g, d->ln1_b, v.xn1, dt, keep ? v.mean1 : nullptr, keep ? v.rstd1 : nullptr, s.M, s.C, d->eps, stream);
-    if (rc) return rc;
-    gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C3, s.C, v.xn1, s.C, d->qkv_w, s.C, v.qkv, s.C3, dt);
-    g.bias = d->qkv_b; g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+    // inference with both LayerNorms folded into the Linear behind them (me_block_desc.qkv_wf ...): the token stream itself is
+    // the GEMM's A operand (it must already be in the compute dtype), the statistics come from one read-only pass, and the
+    // epilogue applies rstd * acc - rstd * mean * s + c -- the normalised tokens are neither written nor read back.  The pair
+    // buffer [M][2] takes the place of the (adjacent) mean / rstd arrays of the activation stash.
+    const bool fold = !keep && d->qkv_wf && d->fc1_wf && d->qkv_s && d->qkv_c && d->fc1_s && d->fc1_c && rdt == dt;
+    if (fold) {
+        if ((rc = me_row_stats(x, rdt, v.mean1, s.M, s.C, d->eps, stream))) return rc;
+        gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C3, s.C, x, s.C, d->qkv_wf, s.C, v.qkv, s.C3, dt);
+        g.bias = d->qkv_c; g.row_affine = v.mean1; g.col_shift = d->qkv_s;
+    } else {
+        rc = me_layernorm_fwd(x, rdt, d->ln1_g, d->ln1_b, v.xn1, dt, keep ? v.mean1 : nullptr, keep ? v.rstd1 : nullptr, s.M, s.C, d->eps, stream);
+        if (rc) return rc;
+        gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C3, s.C, v.xn1, s.C, d->qkv_w, s.C, v.qkv, s.C3, dt);
+        g.bias = d->qkv_b;
+    }
+    g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
     if ((rc = me_gemm(&g, stream))) return rc;
     rc = me_attention_fwd(v.qkv, s.C3, v.o, s.C, keep ? v.lse : nullptr, d->B, d->N, d->heads, s.hd, d->scale, dt, 0.f, 0, stream);
     if (rc) return rc;
@@ -138,10 +151,17 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     g.bias = d->proj_b; g.colscale = d->gamma1; g.residual = x; g.ldres = s.C; g.res_dtype = rdt;
     g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
     if ((rc = me_gemm(&g, stream))) return rc;
-    rc = me_layernorm_fwd(v.x1, rdt, d->ln2_g, d->ln2_b, v.xn2, dt, keep ? v.mean2 : nullptr, keep ? v.rstd2 : nullptr, s.M, s.C, d->eps, stream);
-    if (rc) return rc;
-    gemm_desc(g, ME_GEMM_NT, dt, s.M, s.Hd, s.C, v.xn2, s.C, d->fc1_w, s.C, v.a, s.Hd, dt);
-    g.bias = d->fc1_b; g.act = ME_ACT_GELU;
+    if (fold) {
+        if ((rc = me_row_stats(v.x1, rdt, v.mean2, s.M, s.C, d->eps, stream))) return rc;
+        gemm_desc(g, ME_GEMM_NT, dt, s.M, s.Hd, s.C, v.x1, s.C, d->fc1_wf, s.C, v.a, s.Hd, dt);
+        g.bias = d->fc1_c; g.row_affine = v.mean2; g.col_shift = d->fc1_s;
+    } else {
+        rc = me_layernorm_fwd(v.x1, rdt, d->ln2_g, d->ln2_b, v.xn2, dt, keep ? v.mean2 : nullptr, keep ? v.rstd2 : nullptr, s.M, s.C, d->eps, stream);
+        if (rc) return rc;
+        gemm_desc(g, ME_GEMM_NT, dt, s.M, s.Hd, s.C, v.xn2, s.C, d->fc1_w, s.C, v.a, s.Hd, dt);
+        g.bias = d->fc1_b;
+    }
+    g.act = ME_ACT_GELU;
     // (saved for backward: gelu'(h), not h -- the fc2 dgrad epilogue then multiplies by a stored factor)
     if (keep) { g.preact = v.hpre; g.ldpre = s.Hd; g.preact_dtype = dt; g.flags = ME_GEMM_SAVE_GELU_GRAD; }
     g.workspace = gws; g.workspace_bytes = (int64_t)gsz;

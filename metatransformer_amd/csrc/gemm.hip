@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 static void launch_splitk_reduce(const GemmParams& p, unsigned nb, hipStream_t stream, const float* slabs, int S, const float* cs_part,
                                  int n_part, float* colsum_out, int64_t sstride = 0) {
     if (sstride == 0) sstride = p.M * p.N;
-    if (p.act == ME_ACT_NONE && !p.preact && !p.aux)
+    if (p.act == ME_ACT_NONE && !p.preact && !p.aux && !p.row_affine)
         hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride);
     else
         hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride);
@@ -484,6 +484,9 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     p.out_group_stride = d->out_group_stride; p.out_row_offset = d->out_row_offset;
     p.split_k = 1; p.ksteps_per_split = 0;
     p.colsum_ws = nullptr;
+    ME_CHECK_ARG((d->row_affine == nullptr) == (d->col_shift == nullptr), "me_gemm: row_affine and col_shift go together");
+    ME_CHECK_ARG(!d->row_affine || d->op == ME_GEMM_NT, "me_gemm: row_affine (folded LayerNorm) is defined for ME_GEMM_NT");
+    p.row_affine = d->row_affine; p.col_shift = d->col_shift;
     p.g3_full_tiles = 0; p.g3_split = 0; p.g3_ktp = 0; p.g3_slabs = nullptr; p.slab_stride = 0; p.g3_tickets = nullptr;
     if (d->colsum_a) ME_CHECK_ARG(d->op == ME_GEMM_TN, "me_gemm: colsum_a is defined for ME_GEMM_TN only");
     p.debug = gemm_dev().debug;
@@ -572,6 +575,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
                 if (p.preact) pt.preact = reinterpret_cast<char*>(p.preact) + (size_t)m1 * p.ldpre * me_dtype_size(p.preact_dtype);
                 if (p.aux) pt.aux = reinterpret_cast<const char*>(p.aux) + (size_t)m1 * p.ldaux * me_dtype_size(p.aux_dtype);
                 if (p.residual) pt.residual = reinterpret_cast<const char*>(p.residual) + (size_t)m1 * p.ldres * me_dtype_size(p.res_dtype);
+                if (p.row_affine) pt.row_affine = p.row_affine + 2 * m1;
                 const int64_t quads = pt.M * (d->N / 4);
                 int64_t nb = (quads + 255) / 256;
                 if (nb > 2048) nb = 2048;
@@ -626,6 +630,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
             if (p.preact) pt.preact = reinterpret_cast<char*>(p.preact) + (size_t)m1 * p.ldpre * me_dtype_size(p.preact_dtype);
             if (p.aux) pt.aux = reinterpret_cast<const char*>(p.aux) + (size_t)m1 * p.ldaux * me_dtype_size(p.aux_dtype);
             if (p.residual) pt.residual = reinterpret_cast<const char*>(p.residual) + (size_t)m1 * p.ldres * me_dtype_size(p.res_dtype);
+            if (p.row_affine) pt.row_affine = p.row_affine + 2 * m1;
             GemmParams ps = pt;                      // the split launch writes slabs [S][tail_rows][N]
             ps.C = d->workspace;
             ps.split_k = pl.tail_split;

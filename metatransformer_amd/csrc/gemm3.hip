@@ -813,11 +813,15 @@ __device__ __forceinline__ u32x4 g3r_lanes(const u32x4& v, int addr) {
 }
 
 // EPI: 0 bias, 1 GELU (PRE: 0 nothing saved, 1 pre-activation saved, 2 gelu'(pre-activation) saved), 2 + residual row
-// operand, 3 * gelu'(row operand), 6 * row operand
+// operand, 3 * gelu'(row operand), 6 * row operand.
+// PRE 3 (EPI 0 / 1): a LayerNorm folded into this Linear (GemmParams::row_affine / col_shift): the accumulators start at zero
+// and the epilogue applies v = rstd_m * acc + (-rstd_m mean_m) * s[n] + c[n] in the accumulator layout (one row per lane and
+// 16-row slab, four consecutive columns per register quad), ahead of the activation; nothing is saved.
 template <int EPI, int PRE>
 __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int tm, int tn, int lane, const G3Src& nxt, int nk,
                                               const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero, unsigned* ctr, int nx,
                                               uint32_t lds_tick) {
+    constexpr bool SAVE = PRE == 1 || PRE == 2, LNF = PRE == 3;
     // (claimed schedule: wave 0 draws the ticket for the item after next FIRST, ahead of every store of this epilogue)
     unsigned drawn = 0;
     if (ctr && s.wave == 0) drawn = g3r_draw(ctr);
@@ -841,7 +845,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
 #else
     const __amdgpu_buffer_rsrc_t crs = tile_rsrc(p.C, p.ldc);
 #endif
-    const __amdgpu_buffer_rsrc_t prs = PRE ? tile_rsrc(p.preact, p.ldpre) : crs;
+    const __amdgpu_buffer_rsrc_t prs = SAVE ? tile_rsrc(p.preact, p.ldpre) : crs;
     const __amdgpu_buffer_rsrc_t rrs = EPI == 2 ? tile_rsrc(p.residual, p.ldres) : (EPI == 3 || EPI == 6) ? tile_rsrc(p.aux, p.ldaux) : crs;
     const int rop_ld = (int)(EPI == 2 ? p.ldres : p.ldaux);
     // memory side: lane t = row t >> 3 of an 8-row half slab, 16-byte chunk t & 7 of the wave's 128-byte row segment.  A
@@ -850,7 +854,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     const bool ok = (colb >> 1) + 8 <= (int)cols;
     const int row = wr * 128 + (lane >> 3);
     const uint32_t coff = ok ? (uint32_t)(row * (int)p.ldc * 2 + colb) : 0x80000000u;
-    const uint32_t poff = ok && PRE ? (uint32_t)(row * (int)p.ldpre * 2 + colb) : 0x80000000u;
+    const uint32_t poff = ok && SAVE ? (uint32_t)(row * (int)p.ldpre * 2 + colb) : 0x80000000u;
     const uint32_t roff = ok ? (uint32_t)(row * rop_ld * 2 + colb) : 0x80000000u;
     const int cstep = (int)p.ldc * 16, pstep = (int)p.ldpre * 16, rstep = rop_ld * 16;       // 8 rows, bytes
     // register side (after g3r_rows8): lane (r, g) = row r & 7, chunk 4 (r >> 3) + 2 (g & 1) + (g >> 1).  to_mem: the lane
@@ -879,6 +883,18 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
 #pragma unroll
         for (int mt = 0; mt < AHEAD; ++mt) fetch(mt, rowop[mt]);
     }
+    // folded LayerNorm: this tile's per-row pairs (rows wr*128 + 16 mt + r) and per-column s / c, all ahead of the DMA below
+    f32x2 lnf_row[8];
+    G3Bias lnf_s, lnf_c;
+    if (LNF) {
+        const __amdgpu_buffer_rsrc_t rars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.row_affine) + m0 * 2, 0, (int)(rows * 8), 0x00020000);
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.col_shift), 0, (int)(p.N * 4), 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)      // (rows past the edge: out of range -> zeros; their outputs are never stored)
+            lnf_row[mt] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rars, (wr * 128 + mt * 16 + r) * 8, 0, 0));
+        lnf_s = g3r_bias(srs, tn, s.wave, lane);
+        lnf_c = g3r_bias(brs, tn, s.wave, lane);
+    }
     // the half-tile phase 0 of the next K-tile would issue (see SEAM), behind the first row-operand loads so that their
     // wait does not include it; then the next tile's bias
     g3_issue<3>(s, nxt, 1, nk);
@@ -897,6 +913,10 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             v[q][0] = s.acc[mt][2 * q]; v[q][1] = s.acc[mt][2 * q + 1];
+            if (LNF) {
+                v[q][0] = v[q][0] * lnf_row[mt][0] + (lnf_s.v[2 * q] * lnf_row[mt][1] + lnf_c.v[2 * q]);
+                v[q][1] = v[q][1] * lnf_row[mt][0] + (lnf_s.v[2 * q + 1] * lnf_row[mt][1] + lnf_c.v[2 * q + 1]);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[q][0][e]), __float_as_uint(v[q][1][e]), false, false);
@@ -904,7 +924,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                 v[q][1][e] = __uint_as_float(sw[1]);
             }
         }
-        if ((EPI == 0 || EPI == 1) && !PRE) {
+        if ((EPI == 0 || EPI == 1) && !SAVE) {
             // no row operand, one output: the arithmetic runs in the old layout and the PACKED result is re-dealt (half the
             // DPP moves)
             if (EPI == 1) {
@@ -934,7 +954,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                     v0 *= ph0;
                     v1 *= ph1;
                 } else {
-                    if (PRE) __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
+                    if (SAVE) __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
                     v0 = gelu_bf16_4(v0);
                     v1 = gelu_bf16_4(v1);
                 }
@@ -954,14 +974,14 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     if (ctr && s.wave == 0) {
         // everything this epilogue issued behind the draw may stay in flight: the A-Y half-tile (2), the bias (4), the
         // stores (16 / 32) and the row operands (16)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 4 + 16 + (PRE ? 16 : 0) + ((EPI == 2 || EPI == 3 || EPI == 6) ? 16 : 0)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 4 + 16 + (SAVE ? 16 : 0) + ((EPI == 2 || EPI == 3 || EPI == 6) ? 16 : 0)) : "memory");
         g3r_publish(drawn, ctr, nx, lds_tick);
     }
 }
 
 // memory operations one g3_epilogue_r issues per wave behind the next tile's A-Y half-tile: >= the stores (+ the later
 // row-operand loads); an under-count only makes the wait stricter
-template <int EPI, int PRE> constexpr int g3r_seam() { return PRE ? 32 : EPI >= 2 ? 20 : 16; }
+template <int EPI, int PRE> constexpr int g3r_seam() { return (PRE == 1 || PRE == 2) ? 32 : EPI >= 2 ? 20 : 16; }
 
 template <int EPI, int PRE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g3r_kernel(const GemmParams p) {
@@ -1030,7 +1050,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     g3_issue<0>(s, cur, 1, kt0 + 1); g3_issue<1>(s, cur, 1, kt0 + 1); g3_issue<2>(s, cur, 1, kt0 + 1); g3_issue<3>(s, cur, 1, kt0 + 1);
     {
         const G3Bias b0 = g3r_bias(brs, tn, wave, lane);
-        g3r_set_binit(s, b0, part >= 0);
+        g3r_set_binit(s, b0, part >= 0 || PRE == 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (dyn && wave == 0) g3r_publish(drawn0, ctr, nx, lds_tick);
@@ -1108,11 +1128,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int64_t row0 = (int64_t)(F / p.tiles_n) * G3_BM;
             g3_epilogue<5>(p, s, (int64_t)tm * G3_BM, (int64_t)tn * G3_BN, g3_lane_now(), p.g3_slabs + (int64_t)part * (p.M - row0) * p.N, row0);
             const G3Bias nb = g3r_bias(brs, ntn, wave, 0);
-            g3r_set_binit(s, nb, npart >= 0);
+            g3r_set_binit(s, nb, npart >= 0 || PRE == 3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             prime();
         } else {
-            g3_epilogue_r<EPI, PRE>(p, s, tm, tn, 0, nxt, nkt0 + 1, brs, ntn, npart >= 0, has_next ? ctr : nullptr, nx, lds_tick);
+            g3_epilogue_r<EPI, PRE>(p, s, tm, tn, 0, nxt, nkt0 + 1, brs, ntn, npart >= 0 || PRE == 3, has_next ? ctr : nullptr, nx, lds_tick);
         }
         G3R_STAMP(5)
 #ifdef ME_DEV
@@ -1279,8 +1299,8 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
 
 int launch3r_any(int epi, int pre, const GemmParams& q, int G, hipStream_t stream) {
     switch (epi) {
-        case 0: return launch3r<0, 0>(q, G, stream);
-        case 1: return pre == 2 ? launch3r<1, 2>(q, G, stream) : pre ? launch3r<1, 1>(q, G, stream) : launch3r<1, 0>(q, G, stream);
+        case 0: return pre == 3 ? launch3r<0, 3>(q, G, stream) : launch3r<0, 0>(q, G, stream);
+        case 1: return pre == 3 ? launch3r<1, 3>(q, G, stream) : pre == 2 ? launch3r<1, 2>(q, G, stream) : pre ? launch3r<1, 1>(q, G, stream) : launch3r<1, 0>(q, G, stream);
         case 2: return launch3r<2, 0>(q, G, stream);
         case 3: return launch3r<3, 0>(q, G, stream);
         default: return launch3r<6, 0>(q, G, stream);
@@ -1330,15 +1350,19 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
     // and the output / row operands are bf16 with tile-local 32-bit offsets
     if (gemm_dev().g3_persistent == 1) {
         int repi = EPI <= 3 ? EPI : -1, pre = (EPI == 1 && p.preact) ? 1 : 0;
-        if (EPI == 4 && p.flags) {
+        const bool plain = p.beta == 0.0f && p.out_group_rows == 0 && p.res_row_mod == 0 && !p.colscale && !p.residual;
+        if (EPI == 4 && p.row_affine && !p.flags && plain && !p.preact && !p.aux) {       // folded LayerNorm (bias / GELU forms)
+            repi = p.act == ME_ACT_GELU ? 1 : 0;
+            pre = 3;
+        }
+        if (EPI == 4 && p.flags && !p.row_affine) {
             // the two halves of the "save gelu'" pair (pick_epi sends flagged descriptors to the generic epilogue)
-            const bool plain = p.beta == 0.0f && p.out_group_rows == 0 && p.res_row_mod == 0 && !p.colscale && !p.residual;
             if (plain && p.flags == ME_GEMM_SAVE_GELU_GRAD && p.act == ME_ACT_GELU && p.preact && !p.aux) { repi = 1; pre = 2; }
             if (plain && p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_BF16 && !p.preact) repi = 6;
         }
         const int G = g3_cus() & ~7;
         const int64_t ldmax = std::max(std::max(p.ldc, p.preact ? p.ldpre : 0), std::max(p.residual ? p.ldres : 0, p.aux ? p.ldaux : 0));
-        if (repi >= 0 && G >= 8 && nwg >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!pre || p.preact_dtype == ME_BF16) &&
+        if (repi >= 0 && G >= 8 && nwg >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!(pre == 1 || pre == 2) || p.preact_dtype == ME_BF16) &&
             256 * ldmax * 2 < (1ll << 31))
             return launch3r_any(repi, pre, q, G, stream);
     }

@@ -23,12 +23,15 @@ struct GemmParams {
     float* g3_slabs;
     unsigned* g3_tickets;                   // resident g3 kernel: per-XCD work counters (16 words apart), null = static schedule
     int64_t slab_stride;                    // g3 wgrad: floats between the split-K slabs in C (>= M * N, padded: see g3_tn_slab_stride)
+    const float* row_affine;                // folded LayerNorm (me_gemm_desc.row_affine): [M][2] = (rstd, -rstd * mean), or null
+    const float* col_shift;                 // ... and s[n] = sum_k W'[n, k]
 };
 
 
 // One accumulator quad: 4 consecutive output columns n..n+3 of output row m (see include/metaenc.h for the order).
 __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, int64_t n, f32x4 v) {
     v *= p.alpha;
+    if (p.row_affine) v = v * p.row_affine[2 * m] + *reinterpret_cast<const f32x4*>(p.col_shift + n) * p.row_affine[2 * m + 1];
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.preact) store4_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, (p.flags & ME_GEMM_SAVE_GELU_GRAD) ? gelu_erf_grad4(v) : v);
     if (p.act == ME_ACT_GELU) v = (p.flags & ME_GEMM_SAVE_GELU_GRAD) ? gelu_erf4(v) : gelu_for4(v, p.c_dtype);
@@ -94,6 +97,11 @@ __device__ __forceinline__ void store8_from_f32(void* base, int dt, int64_t idx,
 }
 __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int64_t n, f32x4 v0, f32x4 v1) {
     v0 *= p.alpha; v1 *= p.alpha;
+    if (p.row_affine) {
+        const float ra = p.row_affine[2 * m], rb = p.row_affine[2 * m + 1];
+        v0 = v0 * ra + *reinterpret_cast<const f32x4*>(p.col_shift + n) * rb;
+        v1 = v1 * ra + *reinterpret_cast<const f32x4*>(p.col_shift + n + 4) * rb;
+    }
     if (p.bias) {
         v0 += *reinterpret_cast<const f32x4*>(p.bias + n);
         v1 += *reinterpret_cast<const f32x4*>(p.bias + n + 4);
@@ -138,7 +146,7 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
 //   3 ... * gelu'(bf16 aux row operand)   4 generic (anything include/metaenc.h allows)   5 raw fp32 split-K slab
 static inline int pick_epi(const GemmParams& p) {
     if (p.split_k > 1) return 5;
-    if (p.flags) return 4;                  // (the resident g3 kernel has its own forms of these: launch_g3)
+    if (p.flags || p.row_affine) return 4;  // (the resident g3 kernel has its own forms of these: launch_g3)
     if (p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return 4;
     const int nrow = (p.residual ? 1 : 0) + (p.aux ? 1 : 0);
     if (nrow > 1) return 4;

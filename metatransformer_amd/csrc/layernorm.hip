@@ -75,6 +75,50 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const void* __restri
     }
 }
 
+// ---- row statistics only (inference with the LayerNorm FOLDED into the next Linear, see me_row_stats in include/metaenc.h):
+// the same one-wave-per-row, row-in-registers two-pass statistics as ln_fwd_kernel, but nothing is normalised or written
+// back -- per row the pair (rstd, -rstd * mean) that the folded GEMM's epilogue applies.  Reads rows * C elements once.
+template <int VPL, typename TX>
+__global__ __launch_bounds__(LN_THREADS) void ln_stats_kernel(const void* __restrict__ x, float* __restrict__ out, int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] = ld4<TX>(x, row * C + (int64_t)(lane + 64 * i) * 4);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            q += d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) *reinterpret_cast<float2*>(out + row * 2) = float2{rstd, -rstd * mean};
+}
+__global__ __launch_bounds__(LN_THREADS) void ln_stats_generic_kernel(const void* __restrict__ x, int x_dt, float* __restrict__ out,
+                                                                      int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += load1_as_f32(x, x_dt, row * C + c);
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = load1_as_f32(x, x_dt, row * C + c) - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) *reinterpret_cast<float2*>(out + row * 2) = float2{rstd, -rstd * mean};
+}
+
 // generic fallback: any C, scalar accesses, row re-read from cache instead of registers
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_generic_kernel(const void* __restrict__ x, int x_dt,
                                                                     const float* __restrict__ gamma,
@@ -343,6 +387,29 @@ extern "C" int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
 #undef LN_FWD_CASE
 #undef LN_FWD_LAUNCH
     ME_CHECK_LAUNCH("me_layernorm_fwd");
+    return ME_OK;
+}
+
+extern "C" int me_row_stats(const void* x, int x_dtype, float* out, int64_t rows, int cols, float eps, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(x && out, "me_row_stats: null pointer");
+    ME_CHECK_ARG(me_dtype_ok(x_dtype), "me_row_stats: bad dtype");
+    ME_CHECK_ARG(rows >= 0 && cols > 0, "me_row_stats: bad shape");
+    if (rows == 0) return ME_OK;
+    ProfScope prof(ME_PROF_ROW_STATS, x_dtype, rows, cols, 0, stream);
+    const unsigned nblk = (unsigned)((rows + 3) / 4);
+#define LN_ST_CASE(V)                                                                                                          \
+    case V:                                                                                                                    \
+        if (x_dtype == ME_BF16) hipLaunchKernelGGL((ln_stats_kernel<V, bf16_t>), dim3(nblk), dim3(LN_THREADS), 0, stream, x, out, rows, cols, eps); \
+        else hipLaunchKernelGGL((ln_stats_kernel<V, float>), dim3(nblk), dim3(LN_THREADS), 0, stream, x, out, rows, cols, eps);   \
+        break;
+    if (cols % 256 == 0 && cols / 256 <= 8) {
+        switch (cols / 256) { LN_ST_CASE(1) LN_ST_CASE(2) LN_ST_CASE(3) LN_ST_CASE(4) LN_ST_CASE(5) LN_ST_CASE(6) LN_ST_CASE(7) LN_ST_CASE(8) }
+    } else {
+        hipLaunchKernelGGL(ln_stats_generic_kernel, dim3(nblk), dim3(LN_THREADS), 0, stream, x, x_dtype, out, rows, cols, eps);
+    }
+#undef LN_ST_CASE
+    ME_CHECK_LAUNCH("me_row_stats");
     return ME_OK;
 }
 

@@ -86,6 +86,7 @@ class _WeightCache:
         import weakref
         self._fwd = {}
         self._tr = {}
+        self._fold = {}
         self._owner = None          # weakref to the Block, set by Block.__init__
         if _WeightCache._live is None:
             _WeightCache._live = weakref.WeakSet()
@@ -128,6 +129,27 @@ class _WeightCache:
         if hit is None or hit[0] != k:
             hit = (k, ops.cast(p.detach().contiguous(), dtype))
             self._fwd[slot] = hit
+        return hit[1]
+
+    def folded(self, name: str, w: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, bias: Optional[torch.Tensor], dtype):
+        """LayerNorm folded into the Linear behind it (inference; me_gemm_desc.row_affine):
+            Linear(LN(x))[m, n] = rstd_m (x W'^T)[m, n] - rstd_m mean_m s[n] + c[n]
+        with W' = gamma o W rounded to the compute dtype, s[n] = sum_k W'[n, k] of the ROUNDED values (so that the mean
+        component cancels exactly as the kernel sees it) and c = W beta + bias from the fp32 masters.  One-off weight
+        preparation in torch (plumbing), cached like the other compute copies."""
+        k = tuple(self._key(t, dtype) for t in (w, ln_w, ln_b) + ((bias,) if bias is not None else ()))
+        slot = (name, w.device)
+        hit = self._fold.get(slot)
+        if hit is None or hit[0] != k:
+            with torch.no_grad():
+                w32, g32, b32 = w.detach().float(), ln_w.detach().float(), ln_b.detach().float()
+                wf = (w32 * g32[None, :]).to(dtype).contiguous()
+                s_vec = wf.float().sum(dim=1).contiguous()
+                c_vec = (w32 @ b32)
+                if bias is not None:
+                    c_vec = c_vec + bias.detach().float()
+                hit = (k, (wf, s_vec, c_vec.contiguous()))
+            self._fold[slot] = hit
         return hit[1]
 
     def _weights(self):
@@ -186,7 +208,8 @@ class _BlockFn(torch.autograd.Function):
         if stoch is None and win is None and blk.c_side and not fp8 and not (need_grad and g1 is not None):
             # plain path: the whole block is ONE library call (me_block_fwd), the launch sequence lives on the C side
             d, keep = _BlockFn._desc(blk, cache, cdt, rdt, B, N, C, H, (n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb,
-                                                                        fc1w, fc1b, fc2w, fc2b, g1, g2), False)
+                                                                        fc1w, fc1b, fc2w, fc2b, g1, g2), False,
+                                     fold=not need_grad and blk.fold_norm)
             y, saved = ops.block_fwd(d, x2, keep=need_grad)
             del keep
             if need_grad:
@@ -243,8 +266,10 @@ class _BlockFn(torch.autograd.Function):
         return ops.cast(y, in_dtype).reshape(B, N, C)
 
     @staticmethod
-    def _desc(blk, cache, cdt, rdt, B, N, C, H, params, transposed):
-        """me_block_desc for this block + the list of tensors that must stay alive while the call is in flight"""
+    def _desc(blk, cache, cdt, rdt, B, N, C, H, params, transposed, fold=False):
+        """me_block_desc for this block + the list of tensors that must stay alive while the call is in flight.
+        fold: inference with both LayerNorms folded into qkv / fc1 (bf16 compute on a bf16 token stream; the library falls
+        back to LayerNorm + GEMM by itself when the descriptor carries no folded weights)."""
         (n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb, fc1w, fc1b, fc2w, fc2b, g1, g2) = params
         ws = {"qkv": qkvw, "proj": projw, "fc1": fc1w, "fc2": fc2w}
         w = {k: cache.fwd(k, t, cdt) for k, t in ws.items()}
@@ -253,7 +278,11 @@ class _BlockFn(torch.autograd.Function):
         vec = dict(ln1_g=f(n1w), ln1_b=f(n1b), ln2_g=f(n2w), ln2_b=f(n2b), qkv_b=f(qkvb), proj_b=f(projb), fc1_b=f(fc1b),
                    fc2_b=f(fc2b), gamma1=f(g1), gamma2=f(g2))
         d = ops.block_desc(B, N, C, H, fc1w.shape[0], blk.eps, blk.attn.scale, cdt, rdt, w, wt, vec)
-        return d, (w, wt, vec)
+        folded = None
+        if fold and cdt == torch.bfloat16 and rdt == torch.bfloat16:
+            folded = (cache.folded("qkv", qkvw, n1w, n1b, qkvb, cdt), cache.folded("fc1", fc1w, n2w, n2b, fc1b, cdt))
+            (d.qkv_wf, d.qkv_s, d.qkv_c), (d.fc1_wf, d.fc1_s, d.fc1_c) = [tuple(ops.ptr(t) for t in trip) for trip in folded]
+        return d, (w, wt, vec, folded)
 
     @staticmethod
     def _backward_c(ctx, dy):
@@ -445,6 +474,8 @@ class Block(nn.Module):
         self.compute_dtype: Optional[torch.dtype] = None     # override; None = infer (autocast / param dtype)
         self.c_side = True          # plain blocks run as one me_block_fwd / me_block_bwd call; False = op-by-op composition
         self.attn_fp8 = False       # True: e4m3 attention forward (me_attention_fwd_fp8; bf16 compute, head_dim 64) -- config 5
+        self.fold_norm = True       # inference (no gradient wanted), bf16 compute on a bf16 token stream: norm1 / norm2 folded into
+                                    # qkv / fc1 (me_row_stats + row_affine GEMM epilogue instead of me_layernorm_fwd + GEMM)
         self._wcache = _WeightCache()
 
     def _compute_dtype(self, x: torch.Tensor) -> torch.dtype:
@@ -573,7 +604,8 @@ def encoder_forward_inference(encoder: nn.Sequential, x: torch.Tensor) -> torch.
         g2 = b.gamma2 if b.layer_scale else None
         d, k = _BlockFn._desc(b, b._wcache, cdt, x.dtype, B, N, C, a.num_heads,
                               (b.norm1.weight, b.norm1.bias, b.norm2.weight, b.norm2.bias, a.qkv.weight, a.qkv.bias,
-                               a.proj.weight, a.proj.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, g1, g2), False)
+                               a.proj.weight, a.proj.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, g1, g2), False,
+                              fold=b.fold_norm)
         descs.append(d)
         keep.append(k)
     y = ops.encoder_fwd(descs, x2)

@@ -100,7 +100,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
          residual: Optional[torch.Tensor] = None, res_row_mod: int = 0, preact: Optional[torch.Tensor] = None,
          aux: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, alpha: float = 1.0,
          beta: float = 0.0, out_rows: Optional[int] = None, out_group: Tuple[int, int, int] = (0, 0, 0),
-         want_colsum_a: bool = False, colsum_out: Optional[torch.Tensor] = None, flags: int = 0):
+         want_colsum_a: bool = False, colsum_out: Optional[torch.Tensor] = None, flags: int = 0,
+         row_affine: Optional[torch.Tensor] = None, col_shift: Optional[torch.Tensor] = None):
     """NT: out[M,N] = a[M,K] @ b[N,K]^T ;  TN: out[M,N] = a[K,M]^T @ b[K,N]; fused epilogue per include/metaenc.h.
     want_colsum_a (TN): also return sum_k a[k, :] (fp32 [M]) -- the bias gradient that goes with a weight gradient --
     from the same kernel when the library can fuse it, else from me_colsum; the result is then (out, colsum).
@@ -132,6 +133,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
     d.act, d.alpha, d.beta = act, alpha, beta
     d.flags = flags
     keep = []
+    if row_affine is not None:        # folded LayerNorm: [M, 2] fp32 pairs from row_stats + s [N] (include/metaenc.h)
+        if row_affine.dtype != torch.float32 or row_affine.shape != (M, 2) or col_shift is None or col_shift.numel() != N:
+            raise MetaEncError("gemm: row_affine must be [M, 2] float32 (ops.row_stats) and col_shift [N]")
+        col_shift = _f32(col_shift).contiguous(); keep.append(col_shift)
+        d.row_affine, d.col_shift = ptr(_req(row_affine, "row_affine")), ptr(col_shift)
     if bias is not None:
         bias = _f32(bias).contiguous(); keep.append(bias)
         d.bias = ptr(bias)
@@ -491,3 +497,14 @@ def adamw_step_segments(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.
 def ctypes_sizeof_ctl() -> int:
     import ctypes
     return ctypes.sizeof(_capi.AdamwCtl)
+
+
+def row_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
+    """[rows, C] -> [rows, 2] fp32 pairs (rstd, -rstd * mean): the statistics of LayerNorm(C, eps) for a Linear that has the
+    normalisation folded in (me_row_stats; gemm(..., row_affine=, col_shift=))."""
+    _req(x, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    out = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    check(_capi.load().me_row_stats(ptr(x), dtype_code(x.dtype), ptr(out), rows, C, float(eps), stream_ptr()), "me_row_stats")
+    return out

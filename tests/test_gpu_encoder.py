@@ -80,6 +80,14 @@ def test_backward_fp32_matches_reference_golden(dev, name):
         assert abs(p.grad.double().abs().sum().item() - stats[1]) < 1e-3 * max(stats[1], 1e-6), k
         head = p.grad.flatten()[:16].cpu().numpy()
         assert np.allclose(head, z["dparam_head/" + k], rtol=5e-3, atol=1e-3 * stats[1] / p.numel() + 1e-6), k
+    # EVERY element of every gradient (the fixture keeps sums and heads only: a wrong tail column of a 3072-wide weight
+    # gradient would pass those): against the CPU restatement on the fixture's inputs, which tests/test_oracle.py pins to the
+    # same reference-generated statistics
+    sd = bo.make_encoder_state_dict(c["depth"], c["dim"], seed=c["seed"])
+    _, dx_o, dp_o = bo.encoder_forward_backward(x, sd, c["heads"], go, eps=c["eps"])
+    check_close(xr.grad, dx_o, TOL_F32, name + " dx (all elements)")
+    for k, p in enc.named_parameters():
+        check_close(p.grad, dp_o[k], TOL_F32, f"{name} d{k} (all elements)")
 
 
 def test_backward_full_parity_vs_oracle(dev):
@@ -794,6 +802,9 @@ def test_base_config2_full_batch_backward_vs_oracle(dev):
     for k, p in enc.named_parameters():
         e = rel_err(p.grad, params[k].grad)
         worst[k.split(".", 1)[1]] = max(worst.get(k.split(".", 1)[1], 0.0), e)
+        # per element too: an error confined to a few columns of a weight gradient -- a wrong tail tile
+        # of the split-K fold, a dropped slab -- sits far below the tensor's max-abs scale
+        check_close(p.grad, params[k].grad, TOL_BF16_STREAM12, f"config 2 d{k}")
     print("config-2 full-batch gradient errors (worst over layers):", {k: f"{v:.1e}" for k, v in worst.items()})
     for k, e in worst.items():
         assert e < TOL_BF16_STREAM12, (k, e)
@@ -841,3 +852,122 @@ def test_block_with_fp8_attention_config5_shape(dev):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         y16 = enc(x.to(dev))
     assert rel_err(y16, y_ref) < TOL_BF16_FWD          # the bf16 attention on the same block, for scale
+
+
+# ---------------------------------------------------------------- LayerNorm folded into the Linear behind it (inference)
+@pytest.mark.parametrize("M_rows,N_out,act", [(8192, 2304, False), (8192, 3072, True), (333, 64, False), (64 * 197, 3072, True)])
+def test_gemm_with_folded_layernorm_matches_layernorm_then_linear(dev, M_rows, N_out, act):
+    """me_row_stats + me_gemm(row_affine, col_shift) == Linear(LayerNorm(x)) [+ GELU] (attention.py:56 / mlp.py:29-31), resident
+    and generic kernel families, token stream with a mean offset well above its spread (the rank-1 correction must cancel it)"""
+    from metatransformer_amd import ops
+    from metatransformer_amd._capi import ME_ACT_GELU, ME_ACT_NONE
+    g = torch.Generator().manual_seed(M_rows + N_out)
+    K = 768
+    x = (torch.randn(M_rows, K, generator=g) * torch.rand(M_rows, 1, generator=g) * 2 + 3.0 * torch.randn(M_rows, 1, generator=g)).bfloat16()
+    w, b = torch.randn(N_out, K, generator=g) * 0.03, torch.randn(N_out, generator=g) * 0.1
+    ln_w, ln_b = 1.0 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.double(), (K,), ln_w.double(), ln_b.double(), 1e-6), w.double(), b.double())
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    wf = (w * ln_w[None, :]).bfloat16()
+    s_vec, c_vec = wf.float().sum(1), w @ ln_b + b
+    xd = x.to(dev)
+    st = ops.row_stats(xd, 1e-6)
+    mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
+    rstd = (var + 1e-6).rsqrt()
+    assert rel_err(st[:, 0], rstd) < 1e-5 and float((st[:, 1].double().cpu() + rstd * mean).abs().max()) < 1e-4 * float((rstd * mean).abs().max() + 1)
+    y = ops.gemm(xd, wf.to(dev), bias=c_vec.to(dev), act=ME_ACT_GELU if act else ME_ACT_NONE, row_affine=st, col_shift=s_vec.to(dev))
+    assert y.dtype == torch.bfloat16
+    check_close(y.float(), ref, TOL_BF16, f"folded LN GEMM M={M_rows} N={N_out}")
+
+
+@pytest.mark.parametrize("name", ["base_1blk", "base_12blk", "large_2blk"])
+def test_inference_with_folded_layernorm_matches_reference_golden(dev, name):
+    """bf16 parameters + bf16 token stream + no_grad: norm1 / norm2 are folded into qkv / fc1 (Block.fold_norm).  Same bound
+    as the unfolded bf16 stream, the folded and unfolded outputs agree to bf16 noise, and the one-call serving entry point
+    (me_encoder_fwd) takes the same path."""
+    z, c = golden(name)
+    x, _ = _inputs(c)
+    enc = make_encoder(c, dev, torch.bfloat16)
+    xd = x.to(dev).bfloat16()
+    tol = TOL_BF16_STREAM12 if c["depth"] > 2 else TOL_BF16_STREAM1
+    with torch.no_grad():
+        y_fold = enc(xd)
+        y_one = M.encoder_forward_inference(enc, xd)
+        for b in enc:
+            b.fold_norm = False
+        y_plain = enc(xd)
+    ref = torch.from_numpy(z["y"])
+    s = c["tok_stride"]
+    check_close(y_fold[:, ::s].float(), ref, tol, name + " folded")
+    check_close(y_plain[:, ::s].float(), ref, tol, name + " unfolded")
+    assert torch.equal(y_one, y_fold)
+    assert rel_err(y_fold.float(), y_plain.float()) < tol
+    assert not torch.equal(y_fold, y_plain)            # (they are different kernels: identical bits would mean the fold is off)
+    # a weight update invalidates the folded copies
+    with torch.no_grad():
+        enc[0].norm1.weight.mul_(1.5)
+        for b in enc:
+            b.fold_norm = True
+        y2 = enc(xd)
+    assert rel_err(y2.float(), y_fold.float()) > 1e-3
+
+
+def test_graph_capture_replays_on_other_streams(dev):
+    """a captured forward at a batch the resident GEMM takes must not share claimed-tile counters between replays.
+    Captured launches run the static schedule; replays on two other streams, back to back with eager work, reproduce eager."""
+    enc = make_encoder(dict(depth=2, dim=768, heads=12, eps=1e-5, seed=21), dev, torch.bfloat16)
+    x = torch.randn(128, 197, 768, generator=torch.Generator().manual_seed(3)).to(dev).bfloat16()
+    with torch.no_grad():
+        y = enc(x)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            enc(x)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            yg = enc(x)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for st in (s1, s2, s1):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                g.replay()
+                outs.append(yg.clone())
+            y_eager = enc(x)                                   # eager work on the default stream next to the replay
+            torch.cuda.current_stream().wait_stream(st)
+            assert torch.equal(y_eager, y)
+        torch.cuda.synchronize()
+    assert all(torch.equal(o, y) for o in outs)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "autocast"])
+def test_data_parallel_replicas_share_the_weight_cache(dev, mode):
+    """nn.DataParallel call site (Audio/src/traintest.py:45-46): replicas are shallow copies of the Blocks that share one
+    weight-copy cache and run in threads.  Two replicas on the one visible GPU exercise exactly that; outputs and gradients
+    must equal the plain module's."""
+    c = dict(depth=2, dim=128, heads=4, eps=1e-5, seed=31)
+    enc = make_encoder(c, dev).train()
+    dp = torch.nn.DataParallel(enc, device_ids=[0, 0])
+    g = torch.Generator().manual_seed(8)
+    x, go = torch.randn(6, 40, 128, generator=g).to(dev), torch.randn(6, 40, 128, generator=g).to(dev)
+    ac = mode == "autocast"
+    xr = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+        y_ref = enc(xr)
+    (y_ref * go).sum().backward()
+    want = {k: p.grad.clone() for k, p in enc.named_parameters()}
+    dx_want = xr.grad.clone()
+    for p in enc.parameters():
+        p.grad = None
+    for it in range(2):                                    # twice: the second pass hits the warm shared cache
+        xd = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+            y = dp(xd)
+        (y * go).sum().backward()
+        tol = 2e-2 if ac else 1e-4                         # (two half batches: wgrad sums in a different order)
+        assert rel_err(y, y_ref) < (5e-3 if ac else 1e-5) and rel_err(xd.grad, dx_want) < tol
+        for k, p in enc.named_parameters():
+            assert rel_err(p.grad, want[k]) < tol, (it, k)
+            p.grad = None
