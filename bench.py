@@ -59,6 +59,12 @@ def parse():
     ap.add_argument("--attn-dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: e4m3 attention forward on the block-scaled MFMA (config 5; head_dim 64)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--grad-wire", choices=["fp32", "bf16"], default="fp32",
+                    help="dtype of the gradient buckets on xGMI (bf16: rounded per bucket, summed by RCCL in bf16, restored to the "
+                         "fp32 flat buffer before the optimizer; local accumulation stays fp32)")
+    ap.add_argument("--mixed-per-rank", action="store_true",
+                    help="workload mixed, second reading of BASELINE config 4: rank r tokenizes ONE modality (image / time series / "
+                         "audio by r %% 3) instead of the README's sequence-concat of all three; encoder and gradient exchange shared")
     return ap.parse_args()
 
 
@@ -142,9 +148,15 @@ def main():
             xi = img(torch.randn(B, 3, 224, 224, generator=g).to(dev))
             xt = ts(torch.randn(B, 96, 7, generator=g).to(dev))
             xa = aud(torch.randn(B, 1, 128, 256, generator=g).to(dev))
-            x = torch.cat([xi, xt, xa], dim=1).bfloat16().contiguous()
+            if args.mixed_per_rank:
+                # every rank feeds the shared encoder from a different tokenizer (sequence lengths differ per rank; nothing in
+                # forward / backward depends on another rank, the gradient buckets have the same shape everywhere)
+                x = (xi, xt, xa)[rank % 3].bfloat16().contiguous()
+            else:
+                x = torch.cat([xi, xt, xa], dim=1).bfloat16().contiguous()
         N = x.shape[1]
-        tok_note = f"Image 224/16 -> {xi.shape[1]} + Time-Series L96/c7 -> {xt.shape[1]} + Audio 128x256 k16/s10 -> {xa.shape[1]} tokens"
+        tok_note = (f"Image 224/16 -> {xi.shape[1]} + Time-Series L96/c7 -> {xt.shape[1]} + Audio 128x256 k16/s10 -> {xa.shape[1]} tokens"
+                    + ("; per-rank modality (rank r: modality r % 3), tokens = rank 0's" if args.mixed_per_rank else ""))
     else:
         N = args.tokens or N0
         x = torch.randn(B, N, C, generator=g).to(dev).bfloat16()
@@ -157,7 +169,8 @@ def main():
         # 1-D parameters and biases carry no weight decay, as in the reference recipes (Video/optim_factory.py:67-73)
         flat = parallel.FlatParams(enc.named_parameters(), no_decay=parallel.no_decay_rule)
         opt = parallel.FusedAdamW(flat, lr=1e-4, weight_decay=0.05)
-        reducer = parallel.OverlappedGradReducer(flat, group=tgroup, comm=comm, force=use_dist) if use_dist else None
+        reducer = parallel.OverlappedGradReducer(flat, group=tgroup, comm=comm, force=use_dist,
+                                                 wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None) if use_dist else None
         x.requires_grad_(True)                   # the tokenizer in front of the encoder needs dL/dx
 
         def step():
@@ -303,6 +316,16 @@ def main():
         return {k: v for k, v in d.items() if v is not None}
 
     comm_info = comm.info() if comm is not None else None
+    per_rank = None
+    if world > 1:
+        # per-rank averages of the two GEMM classes from the same event records: a communication kernel that holds CUs shows up
+        # as slower NT / wgrad launches on that rank (the resident NT kernel claims its tiles, the wgrad kernel does not)
+        def _avg(recs, code):
+            v = [ms_ for (op, dt, M_, N_, K_, ms_) in recs if op == code and dt == _capi.ME_BF16]
+            return round(1e3 * sum(v) / len(v), 2) if v else None
+        mine = {"rank": rank, "tokens": int(N), "nt_avg_us": _avg(prof, _capi.ME_GEMM_NT), "wgrad_avg_us": _avg(prof, _capi.ME_GEMM_TN)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -328,12 +351,13 @@ def main():
                    "mode": args.mode, "per_gpu_batch": B, "global_batch": B * world, "tokens": N,
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "grad_allreduce": (f"me_allreduce_bucket (RCCL behind the C ABI, own stream, event hand-off): one all-reduce(sum) per "
-                                      f"64 MiB flat fp32 bucket launched from grad hooks, 1/world folded into AdamW; "
+                                      f"64 MiB flat fp32 bucket ({args.grad_wire} on the wire) launched from grad hooks, 1/world folded into AdamW; "
                                       f"{comm_info['buckets_reduced'] // max(1, args.steps + args.warmup + psteps)} buckets/step, "
                                       f"RCCL world {comm_info['world']}") if (comm_info and train) else
                                      (f"{comm_fallback}: one all_reduce(sum) per 64 MiB flat fp32 bucket from grad hooks" if (comm_fallback and train) else None)},
         "model_tflops_per_s": round(value * model_flops / 1e12, 2),
         "mfma_frac_end_to_end": round(value * model_flops / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+        "per_rank_gemm": per_rank,
         "roofline": gemm_roofline(prof, step_s, psteps, train),
         "other_kernels": other_kernels(prof, step_s, psteps),
     }

@@ -487,7 +487,7 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     ME_CHECK_ARG((d->row_affine == nullptr) == (d->col_shift == nullptr), "me_gemm: row_affine and col_shift go together");
     ME_CHECK_ARG(!d->row_affine || d->op == ME_GEMM_NT, "me_gemm: row_affine (folded LayerNorm) is defined for ME_GEMM_NT");
     p.row_affine = d->row_affine; p.col_shift = d->col_shift;
-    p.g3_full_tiles = 0; p.g3_split = 0; p.g3_ktp = 0; p.g3_slabs = nullptr; p.slab_stride = 0; p.g3_tickets = nullptr;
+    p.g3_full_tiles = 0; p.g3_split = 0; p.g3_ktp = 0; p.g3_slabs = nullptr; p.slab_stride = 0; p.g3_tickets = nullptr; p.g3_half = 0;
     if (d->colsum_a) ME_CHECK_ARG(d->op == ME_GEMM_TN, "me_gemm: colsum_a is defined for ME_GEMM_TN only");
     p.debug = gemm_dev().debug;
     p.tiles_m = (int)((d->M + BM - 1) / BM);

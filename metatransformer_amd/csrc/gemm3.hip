@@ -32,594 +32,12 @@
 //   WAR  slot reuse: half-tile i+8 is issued in phase i+1.  A-X, B-Y, A-Y were last read in phase i-1 (two phases and
 //        >= 2 barriers earlier for both wave rows).  B-X is read in phase i itself: its four reads are issued first
 //        and retired with lgkmcnt(8) before that phase's first barrier, which the issuing wave row passes later.
-#include "gemm_common.h"
-#include <algorithm>
-#include <map>
-#include <mutex>
-#include <utility>
+// The shared device code -- state, DMA issue, the 4-phase K-tile, the LDS-free epilogue -- lives in gemm3_core.h; this file holds the
+// kernels the library ships (one tile per workgroup, resident, wgrad) and their launchers.  Dev-build hooks are `if (kMeDev && ...)`
+// (a compile-time false in libmetaenc.so); the dev-only stream-K kernel is in gemm3_dev.hip.
+#include "gemm3_core.h"
 
 namespace {
-
-typedef __attribute__((address_space(3))) void lds_void3;
-
-constexpr int G3_BM = 256, G3_BN = 256, G3_BK = 64;
-constexpr int G3_HALF = 128 * 128;              // bytes in a half-tile
-constexpr int G3_BUF = 4 * G3_HALF;             // 64 KiB
-constexpr int G3_LDS = 2 * G3_BUF;              // 128 KiB
-constexpr int G3_SLAB_FLOATS = G3_BM * G3_BN;   // one fp32 partial tile per workgroup (stream-K fix-up)
-
-// Everything the K-loop keeps in registers.  All arrays are indexed with compile-time constants only.
-struct G3State {
-    f32x4 acc[8][4];            // [m-tile of 16 rows][n-tile of 16 cols] of the wave's 128 x 64 output (transposed MFMA:
-                                //  lane l holds row (l & 15), cols 4*(l >> 4) .. +3 of the 16 x 16 tile)
-    bf16x8 bx[2][2], by[2][2];  // weight fragments [n-tile][k-sub]
-    bf16x8 ax[4][2], ay[4][2];  // token fragments  [m-tile][k-sub]
-    uint32_t src[4][2];         // DMA source byte offsets from the tile's first A / B row: [half-tile type][instruction]
-    char* smem;
-    uint32_t ra[2][2], rb[2][2];// NT: fragment read LDS addresses [buffer][k-sub]: buffer + wave / lane part inside a half-tile
-    uint32_t ta[4], tb[2];      // TN: transposing-read byte offsets per m-tile / n-tile of a quadrant (wave + lane part)
-    int kstep_a, kstep_b;       // source bytes per K-tile: NT 128 (along the row); TN 64 rows = 128 * ld
-    f32x4 binit[4];             // resident NT kernel: what the accumulators of n-tile 0..3 START at (the columns' bias, or zero) --
-                                // the C operand of the first MFMAs behind an epilogue (g3_phase<.., SEAM>); dead in between
-    float cs[2];                // TN: running column sums of A (the bias gradient) for m-tiles wc and 4 + wc of this wave row
-    int wave;
-};
-
-// Wave-uniform source of one output tile's operand rows: buffer descriptors over rows [m0, m0+256) of A and [n0, n0+256)
-// of B (clipped at the matrix edge: rows past the edge read as zeros through the descriptor's bounds check, so edge
-// tiles need no clamping and every lane keeps ONE set of offsets for the whole kernel).
-struct G3Src {
-    __amdgpu_buffer_rsrc_t a, b;
-};
-__device__ __forceinline__ G3Src g3_make_src(const GemmParams& p, int tm, int tn) {
-    const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
-    int64_t ra = p.M - m0, rb = p.N - n0;
-    ra = ra < G3_BM ? ra : G3_BM;
-    rb = rb < G3_BN ? rb : G3_BN;
-    G3Src s;
-    s.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.A)) + m0 * p.lda * 2, 0,
-                                            (int)((ra - 1) * p.lda * 2 + p.K * 2), 0x00020000);
-    s.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.B)) + n0 * p.ldb * 2, 0,
-                                            (int)((rb - 1) * p.ldb * 2 + p.K * 2), 0x00020000);
-    return s;
-}
-__device__ __forceinline__ G3Src g3_null_src(const GemmParams& p) {
-    G3Src s;
-    s.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, 0, 0x00020000);
-    s.b = s.a;
-    return s;
-}
-
-// half-tile type J of K-tile kt (of the source's own numbering) into buffer buf
-template <int J> __device__ __forceinline__ void g3_issue(const G3State& s, const G3Src& src, int buf, int kt) {
-    char* dst = s.smem + buf * G3_BUF + J * G3_HALF + s.wave * 2048;
-    const __amdgpu_buffer_rsrc_t r = (J & 1) ? src.a : src.b;
-    const int koff = kt * ((J & 1) ? s.kstep_a : s.kstep_b);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)dst, 16, (int)s.src[J][0], koff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)(dst + 1024), 16, (int)s.src[J][1], koff, 0, 0);
-}
-
-// NT fragment: one 16-byte read at (lane part + buffer) + an IMMEDIATE (half-tile slot, tile).  Inline asm for the same
-// reason as the transposing reads below, and so that the address stays "one register + constant": left to itself hipcc
-// materialises a separate address register for most of the 24 (slot, tile) combinations of the second buffer (its
-// offsets exceed the 16-bit immediate when counted from the start of LDS), which the resident kernel cannot afford.
-template <int OFF> __device__ __forceinline__ bf16x8 g3_frag(uint32_t addr) {
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-// TN operand tiles lie in LDS as in memory, [64 k][128 columns] (256-byte rows); the MFMA wants 8 consecutive k of ONE
-// column per lane.  ds_read_b64_tr_b16 transposes a 4 (k) x 16 (columns) block per 16-lane group: lane (g = l >> 4,
-// p = l & 15) ADDRESSES 4 columns (4 (p & 3)..) of k-row (p >> 2) and RECEIVES column p's four k-values; two reads
-// (k-rows 4r + 0..3, r = 0, 1) make the fragment of k-group g.  `base` carries everything lane- and tile-dependent
-// (ta / tb); the k-sub (x 32 rows) and r (x 4 rows) parts are immediates.
-// The reads are inline asm: with LDS-DMA in flight hipcc guards every compiler-visible transposing read with
-// s_waitcnt vmcnt(0) (it cannot prove the intrinsic does not alias the DMA's destination), which would drain the stream
-// four times per K-tile.  Their results are consumed only behind the phase's own `s_waitcnt lgkmcnt(0)` + sched_barrier.
-template <int OFF> __device__ __forceinline__ bf16x8 g3_frag_tn(uint32_t addr) {
-    u32x2 lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "i"(OFF) : "memory");
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "i"(OFF + 1024) : "memory");
-    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-// sum of a fragment's eight bf16 values (one column of A, eight consecutive k) in fp32
-__device__ __forceinline__ float g3_frag_sum(bf16x8 f) {
-    // v_dot2_f32_bf16 with a vector of ones: two elements per instruction, fp32 accumulation
-    const bf16x2 one = {(bf16_t)1.0f, (bf16_t)1.0f};
-    float a = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) a = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{f[2 * e], f[2 * e + 1]}, one, a, false);
-    return a;
-}
-// bias gradient on the side (wgrad): the column sums of A over this workgroup's K-range come from the A fragments the
-// wave already holds -- a few VALU additions in the LOAD part of a phase, no extra pass over dY and no extra MFMA.  The
-// four wave columns of a wave row hold the same A fragments: wave column wc takes m-tiles wc (A-X) and 4 + wc (A-Y).
-// The index is wave-uniform; a scalar if-chain on the state's own arrays keeps every fragment index static (an array
-// passed by reference, or indexed at run time, is demoted to scratch).
-#define G3_MMA(MT, NT, AF, BF)                                                                                   \
-    s.acc[MT][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(NT) & 1][0], AF[(MT) & 3][0], SEAM ? s.binit[NT] : s.acc[MT][NT], 0, 0, 0); \
-    s.acc[MT][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(NT) & 1][1], AF[(MT) & 3][1], s.acc[MT][NT], 0, 0, 0);
-
-// One phase of K-tile `BUF`.  s0 / k0: where the NEXT K-tile of the stream comes from (phase 0 issues its A-Y);
-// s1 / k1: the K-tile after that (phases 1..3 issue its B-X, A-X, B-Y).  There is ONE code path: past the end of a
-// workgroup's stream the source is a null descriptor (zero records: the DMA writes zeros into a buffer nobody reads any
-// more and touches no memory), so the issue pattern, and with it the counted wait, never changes -- and the 128
-// accumulators never meet a control-flow join inside the K-loop.
-// SEAM > 0: the first K-tile after an epilogue of the resident kernel (gemm_g3r_kernel): the A-Y half-tile phase 0 would
-// issue went out BEFORE the epilogue, and the counted wait of phase 3 lets the epilogue's SEAM memory operations (which
-// sit between that half-tile and this K-tile's own three in the in-order queue) stay in flight.  It is also the first K-tile
-// of an output tile: its MFMAs take s.binit as their C operand, so the accumulators need no initialisation pass.
-template <int BUF, int P, bool TN = false, int SEAM = 0>
-__device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1, bool cs_on = false) {
-    if (TN && (P == 1 || P == 3) && cs_on) {      // (wave-uniform) fragments read one / two phases ago, waited for in that phase
-        const int wcol = s.wave & 3;
-        if (wcol == 0) s.cs[P >> 1] += g3_frag_sum((P == 1 ? s.ax : s.ay)[0][0]) + g3_frag_sum((P == 1 ? s.ax : s.ay)[0][1]);
-        else if (wcol == 1) s.cs[P >> 1] += g3_frag_sum((P == 1 ? s.ax : s.ay)[1][0]) + g3_frag_sum((P == 1 ? s.ax : s.ay)[1][1]);
-        else if (wcol == 2) s.cs[P >> 1] += g3_frag_sum((P == 1 ? s.ax : s.ay)[2][0]) + g3_frag_sum((P == 1 ? s.ax : s.ay)[2][1]);
-        else s.cs[P >> 1] += g3_frag_sum((P == 1 ? s.ax : s.ay)[3][0]) + g3_frag_sum((P == 1 ? s.ax : s.ay)[3][1]);
-    }
-    // fragment (tile t, k-sub k) of half-tile slot SL: NT one 16-byte read, TN two transposing 8-byte reads
-    const uint32_t lbuf = (uint32_t)(uintptr_t)s.smem + BUF * G3_BUF;      // (TN) 32-bit LDS address of this buffer
-#define G3_RD_B(SL, t, k) (TN ? g3_frag_tn<(SL) * G3_HALF + (k) * 8192>(lbuf + s.tb[t]) : g3_frag<(SL) * G3_HALF + (t) * 2048>(s.rb[BUF][k]))
-#define G3_RD_A(SL, t, k) (TN ? g3_frag_tn<(SL) * G3_HALF + (k) * 8192>(lbuf + s.ta[t]) : g3_frag<(SL) * G3_HALF + (t) * 2048>(s.ra[BUF][k]))
-    if (P == 0) {
-        s.bx[0][0] = G3_RD_B(0, 0, 0); s.bx[0][1] = G3_RD_B(0, 0, 1); s.bx[1][0] = G3_RD_B(0, 1, 0); s.bx[1][1] = G3_RD_B(0, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        s.ax[0][0] = G3_RD_A(1, 0, 0); s.ax[0][1] = G3_RD_A(1, 0, 1); s.ax[1][0] = G3_RD_A(1, 1, 0); s.ax[1][1] = G3_RD_A(1, 1, 1);
-        s.ax[2][0] = G3_RD_A(1, 2, 0); s.ax[2][1] = G3_RD_A(1, 2, 1); s.ax[3][0] = G3_RD_A(1, 3, 0); s.ax[3][1] = G3_RD_A(1, 3, 1);
-    } else if (P == 1) {
-        s.by[0][0] = G3_RD_B(2, 0, 0); s.by[0][1] = G3_RD_B(2, 0, 1); s.by[1][0] = G3_RD_B(2, 1, 0); s.by[1][1] = G3_RD_B(2, 1, 1);
-    } else if (P == 2) {
-        s.ay[0][0] = G3_RD_A(3, 0, 0); s.ay[0][1] = G3_RD_A(3, 0, 1); s.ay[1][0] = G3_RD_A(3, 1, 0); s.ay[1][1] = G3_RD_A(3, 1, 1);
-        s.ay[2][0] = G3_RD_A(3, 2, 0); s.ay[2][1] = G3_RD_A(3, 2, 1); s.ay[3][0] = G3_RD_A(3, 3, 0); s.ay[3][1] = G3_RD_A(3, 3, 1);
-    }
-#undef G3_RD_A
-#undef G3_RD_B
-    __builtin_amdgcn_sched_barrier(0);
-    if (P == 0 && SEAM == 0) g3_issue<3>(s, s0, BUF ^ 1, k0);
-    if (P == 1) g3_issue<0>(s, s1, BUF, k1);
-    if (P == 2) g3_issue<1>(s, s1, BUF, k1);
-    if (P == 3) g3_issue<2>(s, s1, BUF, k1);
-    __builtin_amdgcn_sched_barrier(0);
-    // (the B-X reads are issued first: NT 4 of 12, TN 8 of 24 DS operations -- retire exactly those before the barrier)
-    if (P == 0) { if (TN) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); }
-    if (P == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + SEAM) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    if (P == 0) {
-        G3_MMA(0, 0, s.ax, s.bx) G3_MMA(0, 1, s.ax, s.bx) G3_MMA(1, 0, s.ax, s.bx) G3_MMA(1, 1, s.ax, s.bx)
-        G3_MMA(2, 0, s.ax, s.bx) G3_MMA(2, 1, s.ax, s.bx) G3_MMA(3, 0, s.ax, s.bx) G3_MMA(3, 1, s.ax, s.bx)
-    } else if (P == 1) {
-        G3_MMA(0, 2, s.ax, s.by) G3_MMA(0, 3, s.ax, s.by) G3_MMA(1, 2, s.ax, s.by) G3_MMA(1, 3, s.ax, s.by)
-        G3_MMA(2, 2, s.ax, s.by) G3_MMA(2, 3, s.ax, s.by) G3_MMA(3, 2, s.ax, s.by) G3_MMA(3, 3, s.ax, s.by)
-    } else if (P == 2) {
-        G3_MMA(4, 2, s.ay, s.by) G3_MMA(4, 3, s.ay, s.by) G3_MMA(5, 2, s.ay, s.by) G3_MMA(5, 3, s.ay, s.by)
-        G3_MMA(6, 2, s.ay, s.by) G3_MMA(6, 3, s.ay, s.by) G3_MMA(7, 2, s.ay, s.by) G3_MMA(7, 3, s.ay, s.by)
-    } else {
-        G3_MMA(4, 0, s.ay, s.bx) G3_MMA(4, 1, s.ay, s.bx) G3_MMA(5, 0, s.ay, s.bx) G3_MMA(5, 1, s.ay, s.bx)
-        G3_MMA(6, 0, s.ay, s.bx) G3_MMA(6, 1, s.ay, s.bx) G3_MMA(7, 0, s.ay, s.bx) G3_MMA(7, 1, s.ay, s.bx)
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-}
-
-template <int BUF, bool TN = false, int SEAM = 0>
-__device__ __forceinline__ void g3_ktile(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1, bool cs_on = false) {
-    g3_phase<BUF, 0, TN, SEAM>(s, s0, k0, s1, k1, cs_on);
-    g3_phase<BUF, 1, TN, SEAM>(s, s0, k0, s1, k1, cs_on);
-    g3_phase<BUF, 2, TN, SEAM>(s, s0, k0, s1, k1, cs_on);
-    g3_phase<BUF, 3, TN, SEAM>(s, s0, k0, s1, k1, cs_on);
-}
-
-__device__ __forceinline__ void g3_init_lane(G3State& s, const GemmParams& p, char* smem, int wave, int lane) {
-    s.smem = smem;
-    s.wave = wave;
-    const int wr = wave >> 2, wc = wave & 3;
-    // DMA sources: instruction i of this wave covers local rows 16*wave + 8*i + (lane >> 3) of a half-tile, slot lane & 7
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rl = 16 * wave + 8 * i + (lane >> 3);
-        const int c = (lane & 7) ^ ((rl >> 1) & 7);
-        const int ax_row = (rl >> 6) * 128 + (rl & 63), bx_row = (rl >> 5) * 64 + (rl & 31);
-        s.src[0][i] = (uint32_t)(bx_row * p.ldb * 2 + c * 16);
-        s.src[1][i] = (uint32_t)(ax_row * p.lda * 2 + c * 16);
-        s.src[2][i] = (uint32_t)((bx_row + 32) * p.ldb * 2 + c * 16);
-        s.src[3][i] = (uint32_t)((ax_row + 64) * p.lda * 2 + c * 16);
-    }
-    // fragment reads: local row = (wave part) + 16 * tile + (lane & 15), chunk = 4 * ksub + (lane >> 4)
-    const int l15 = lane & 15;
-    const uint32_t lp = (l15 >> 3) * 1024 + (lane & 7) * 128 + ((((lane >> 4) ^ (l15 >> 1)) & 7) << 4);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        s.ra[b][0] = lds0 + b * G3_BUF + wr * 8192 + lp; s.ra[b][1] = s.ra[b][0] ^ 64;
-        s.rb[b][0] = lds0 + b * G3_BUF + wc * 4096 + lp; s.rb[b][1] = s.rb[b][0] ^ 64;
-        // (opaque: eight registers, not two plus arithmetic in front of every read)
-        asm volatile("" : "+v"(s.ra[b][0]), "+v"(s.ra[b][1]), "+v"(s.rb[b][0]), "+v"(s.rb[b][1]));
-    }
-    s.kstep_a = s.kstep_b = G3_BK * 2;
-}
-
-// ---- TN (wgrad: C[M, N] = A[K, M]^T B[K, N], reduction index = the ROW of both operands).
-// A half-tile is 64 k-rows x 128 columns (256-byte rows): A-X = the columns wave rows 0 / 1 need for their quadrant row 0
-// (tile columns 0..63 and 128..191 -> chunks 0..7 / 8..15), A-Y the other 64 + 64; B-X = the four wave columns' first 32
-// (tile columns wc*64 + 0..31 -> chunks 4 wc .. 4 wc + 3), B-Y the second 32.  16-byte chunk c of k-row t sits in slot
-// c ^ 4 (t & 3) ^ 2 ((t >> 3) & 1): the 32 lanes a transposing read services together touch k-rows (p >> 2) + 8 (g & 1),
-// which the permutation spreads over all eight 32-byte sections of the 256-byte bank row.
-__device__ __forceinline__ int g3_tn_swz(int t) { return (4 * (t & 3)) ^ (2 * ((t >> 3) & 1)); }
-__device__ __forceinline__ void g3_init_lane_tn(G3State& s, const GemmParams& p, char* smem, int wave, int lane) {
-    s.smem = smem;
-    s.wave = wave;
-    const int wr = wave >> 2, wc = wave & 3;
-    // DMA sources: instruction i of this wave covers k-rows 8*wave + 4*i + (lane >> 4) of a half-tile, slot lane & 15
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int t = 8 * wave + 4 * i + (lane >> 4);
-        const int c = (lane & 15) ^ g3_tn_swz(t);
-        const int a_col = (c >> 3) * 128 + (c & 7) * 8, b_col = (c >> 2) * 64 + (c & 3) * 8;
-        s.src[0][i] = (uint32_t)(t * p.ldb * 2 + b_col * 2);
-        s.src[1][i] = (uint32_t)(t * p.lda * 2 + a_col * 2);
-        s.src[2][i] = (uint32_t)(t * p.ldb * 2 + (b_col + 32) * 2);
-        s.src[3][i] = (uint32_t)(t * p.lda * 2 + (a_col + 64) * 2);
-    }
-    // transposing reads: lane (g, pp) addresses k-row 8 g + (pp >> 2) (+ 4 r + 32 ksub as immediates), columns cb + 4 (pp & 3)
-    const int g = lane >> 4, pp = lane & 15;
-    const int trow = 8 * g + (pp >> 2);
-    auto base = [&](int cb) {
-        const int col = cb + 4 * (pp & 3);
-        return (uint32_t)(trow * 256 + ((((col >> 3) ^ g3_tn_swz(trow)) & 15) << 4) + ((col & 7) << 1));
-    };
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) s.ta[mt] = base(wr * 64 + mt * 16);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) s.tb[nt] = base(wc * 32 + nt * 16);
-    s.kstep_a = (int)(G3_BK * p.lda * 2);
-    s.kstep_b = (int)(G3_BK * p.ldb * 2);
-}
-// operand columns [m0, ..) of A and [n0, ..) of B, all K rows: rows past K read as zeros (bounds check on the end of the
-// matrix); columns past the edge of an edge tile read the next row's data -- they only feed outputs that are never stored
-__device__ __forceinline__ G3Src g3_make_src_tn(const GemmParams& p, int tm, int tn) {
-    const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
-    G3Src s;
-    s.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.A)) + m0 * 2, 0,
-                                            (int)(p.K * p.lda * 2 - m0 * 2), 0x00020000);
-    s.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.B)) + n0 * 2, 0,
-                                            (int)(p.K * p.ldb * 2 - n0 * 2), 0x00020000);
-    return s;
-}
-__device__ __forceinline__ void g3_zero(G3State& s) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s.acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-}
-
-// ---- epilogue without LDS.  Two neighbouring 16 x 16 accumulator tiles (n-tiles 2q, 2q+1) are re-dealt inside the wave
-// with v_permlane16_swap (rows of 16 lanes: odd rows of the first operand <-> even rows of the second), after which lane
-// (r = l & 15, g = l >> 4) holds EIGHT consecutive output columns of row r: n-tile 2q + (g & 1), columns 8 (g >> 1) ..
-// +7 -- one 16-byte bf16 store / row-operand load per lane, 64 contiguous bytes per row and instruction.  The operand
-// buffers in LDS are not touched, so the DMA stream of the next tile keeps running under the epilogue.
-// EPI: 0 bias, 1 + GELU (+ pre-activation save), 2 + residual row operand, 3 * gelu'(aux row operand), 4 generic
-// (epilogue_oct: colscale, beta, row remaps, fp32 row operands ...)
-// EPI 5: raw fp32 partial sums into a split-K slab (row-major [rows][N], first row = slab_row0)
-template <int EPI>
-__device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int64_t m0, int64_t n0, int lane,
-                                            float* slab = nullptr, int64_t slab_row0 = 0) {
-    // everything lane-dependent below is derived HERE: an address hoisted out of the persistent loop would sit in
-    // registers across the K-loops (which have none to spare) and come back from scratch
-    asm volatile("" : "+v"(lane));
-    const int wr = s.wave >> 2, wc = s.wave & 3;
-    const int r = lane & 15, g = lane >> 4;
-    const f32x4 alpha4 = {p.alpha, p.alpha, p.alpha, p.alpha};
-    int64_t n[2];
-    bool n_ok[2];
-    f32x4 bias[2][2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        n[q] = n0 + wc * 64 + (2 * q + (g & 1)) * 16 + 8 * (g >> 1);
-        n_ok[q] = n[q] + 8 <= p.N;
-        const int64_t nc = n_ok[q] ? n[q] : 0;
-        bias[q][0] = bias[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EPI != 4 && EPI != 5 && p.bias) {
-            bias[q][0] = *reinterpret_cast<const f32x4*>(p.bias + nc);
-            bias[q][1] = *reinterpret_cast<const f32x4*>(p.bias + nc + 4);
-        }
-    }
-    // pin the per-column operands in registers NOW (straight-line code): otherwise hipcc waits for them with vmcnt(0)
-    // inside every guarded store block, which drains the stores of the previous rows each time
-    asm volatile("" ::"v"(bias[0][0]), "v"(bias[0][1]), "v"(bias[1][0]), "v"(bias[1][1]));
-    const uint16_t* rop = reinterpret_cast<const uint16_t*>(EPI == 2 ? p.residual : p.aux);
-    const int64_t rop_ld = EPI == 2 ? p.ldres : p.ldaux;
-    const int64_t mrow = m0 + wr * 128 + r;
-    auto fetch = [&](const int mt, u32x4 (&raw)[2]) {
-        int64_t m = mrow + mt * 16;
-        m = m < p.M ? m : p.M - 1;                       // unconditional loads with clamped coordinates (no wait in a branch)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) raw[q] = *reinterpret_cast<const u32x4*>(rop + m * rop_ld + (n_ok[q] ? n[q] : 0));
-    };
-    auto unpack = [](const u32x4& rw, f32x4& a, f32x4& b) {
-        a[0] = __uint_as_float(rw[0] << 16); a[1] = __uint_as_float(rw[0] & 0xffff0000u);
-        a[2] = __uint_as_float(rw[1] << 16); a[3] = __uint_as_float(rw[1] & 0xffff0000u);
-        b[0] = __uint_as_float(rw[2] << 16); b[1] = __uint_as_float(rw[2] & 0xffff0000u);
-        b[2] = __uint_as_float(rw[3] << 16); b[3] = __uint_as_float(rw[3] & 0xffff0000u);
-    };
-    // row operand (residual / gelu' input): twelve of the tile's sixteen 16-byte loads go out at once, the last four as
-    // soon as the first slabs have freed their registers and BEFORE those slabs' stores (vmcnt retires in order) -- one
-    // memory latency per tile instead of one per 16-row slab (the K-loop's fragment registers are free here)
-    constexpr int AHEAD = 6;
-    u32x4 rowop[8][2];
-    if (EPI == 2 || EPI == 3) {
-#pragma unroll
-        for (int mt = 0; mt < AHEAD; ++mt) fetch(mt, rowop[mt]);
-    }
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        f32x4 ro[2][2];
-        if (EPI == 2 || EPI == 3) {
-            unpack(rowop[mt][0], ro[0][0], ro[0][1]);
-            unpack(rowop[mt][1], ro[1][0], ro[1][1]);
-            if (mt + AHEAD < 8) fetch(mt + AHEAD, rowop[mt + AHEAD]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const int64_t m = mrow + mt * 16;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            f32x4 v0 = s.acc[mt][2 * q], v1 = s.acc[mt][2 * q + 1];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0[e]), __float_as_uint(v1[e]), false, false);
-                v0[e] = __uint_as_float(sw[0]);
-                v1[e] = __uint_as_float(sw[1]);
-            }
-            const bool ok = m < p.M && n_ok[q];
-            if (EPI == 5) {
-                if (ok) {
-                    float* d = slab + (m - slab_row0) * p.N + n[q];
-                    *reinterpret_cast<f32x4*>(d) = v0;
-                    *reinterpret_cast<f32x4*>(d + 4) = v1;
-                }
-                continue;
-            }
-            if (EPI == 4) {
-                if (ok) epilogue_oct(p, m, n[q], v0, v1);
-                continue;
-            }
-            v0 = v0 * alpha4 + bias[q][0];
-            v1 = v1 * alpha4 + bias[q][1];
-            if (EPI == 1) {
-                if (p.preact && ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n[q], v0, v1);
-                v0 = gelu_for4(v0, p.c_dtype);
-                v1 = gelu_for4(v1, p.c_dtype);
-            }
-            const f32x4 qa = ro[q][0], qb = ro[q][1];
-            if (EPI == 3) {
-                v0 *= gelu_grad_for4(qa, p.c_dtype);
-                v1 *= gelu_grad_for4(qb, p.c_dtype);
-            }
-            if (EPI == 2) { v0 += qa; v1 += qb; }
-#ifdef ME_DEV
-            if (p.debug & 4) {                         // dev: epilogue arithmetic without the stores
-                asm volatile("" ::"v"(v0), "v"(v1));
-                continue;
-            }
-#endif
-            if (ok) store8_from_f32(p.C, p.c_dtype, m * p.ldc + n[q], v0, v1);
-        }
-    }
-}
-
-#ifdef ME_DEV
-// (dev build only: correct and tested with tools/gemm_dev, but not faster than one tile per workgroup yet -- see DESIGN.md)
-// ---- persistent kernel: data-parallel rounds + a stream-K remainder.
-// Work unit = a PAIR of K-tiles (buffer 0 / buffer 1).  With G workgroups (one per CU) and T tiles of hk pairs each:
-//   * R = T / G (rounded down, minus one when the rest would be less than a tile per workgroup) rounds are plain
-//     data-parallel: in round j workgroup v owns tile j G + v, so at any time the 32 CUs of an XCD work on 32
-//     neighbouring tiles and share their operand panels through the XCD's L2 (v is the XCD-chunked id);
-//   * the remaining tiles' pairs are dealt out in contiguous ranges [v q + min(v, r), ...), 1 .. 2 tiles' worth each:
-//     every CU gets the same amount of MFMA work whatever T is (N = 768: 591 tiles on 256 CUs used to be 3 rounds for
-//     2.31 rounds of work).  A range generally starts inside a tile; that leading fragment is computed FIRST, then the
-//     data-parallel rounds, then the rest of the range.  The leading fragments have every length between nothing and
-//     a whole tile, so the CUs reach their epilogues at different times for the rest of the launch: the output bursts
-//     (all 256 CUs storing at once, then all computing) become a steady stream that overlaps the other CUs' MFMAs.
-// A tile split between workgroups is finished by the workgroup that holds its FIRST K-tiles (the end of that
-// workgroup's stream); the others (v+1, ...: the very start of theirs) hand over raw fp32 accumulators through `slabs`
-// [G][8 waves][32 regs][64 lanes] x 16 B with the release / acquire protocol of cdna_hip_programming.md, Guideline 16
-// (flags zeroed by a memset node ahead of every launch).  A workgroup writes its only partial before it ever waits, and
-// it waits only for workgroups with a higher id: no cycles.
-struct G3Plan {
-    int hk;          // K-tile pairs per tile
-    int rounds;      // data-parallel rounds R
-    int rem_q, rem_r;// remainder pairs per workgroup: total = G rem_q + rem_r
-};
-
-// Walks one workgroup's stream of (tile, K-tile pair) on the scalar unit.
-struct G3Walk {
-    int stage;       // 0 leading fragment, 1 data-parallel rounds, 2 rest of the remainder range, 3 done
-    int j;           // round (stage 1)
-    int rr;          // position in the remainder pair space (stages 0 / 2): next pair to visit
-    int tile, kp, seg_begin, seg_end;       // current tile, current pair in it, this workgroup's share [seg_begin, seg_end)
-};
-__device__ __forceinline__ void g3_walk_segment(G3Walk& w, const G3Plan& pl, int v, int G, int r1) {
-    // enter the next segment; w.stage / w.j / w.rr say where we are
-    if (w.stage == 1 && w.j < pl.rounds) {
-        w.tile = w.j * G + v; w.kp = 0; w.seg_begin = 0; w.seg_end = pl.hk;
-        ++w.j;
-        return;
-    }
-    if (w.stage <= 1) w.stage = 2;
-    if (w.rr >= r1) { w.stage = 3; w.kp = 0; w.seg_begin = 0; w.seg_end = 0; return; }
-    const int t = __builtin_amdgcn_readfirstlane(w.rr / pl.hk);
-    const int kb = w.rr - t * pl.hk;
-    int ke = kb + (r1 - w.rr);
-    ke = ke < pl.hk ? ke : pl.hk;
-    w.tile = pl.rounds * G + t; w.kp = kb; w.seg_begin = kb; w.seg_end = ke;
-    w.rr += ke - kb;
-}
-__device__ __forceinline__ void g3_walk_init(G3Walk& w, const G3Plan& pl, int v, int G, int r0, int r1, bool lead_first) {
-    w.j = 0; w.rr = r0;
-    const int t = __builtin_amdgcn_readfirstlane(r0 / pl.hk);
-    if (lead_first && r0 < r1 && r0 - t * pl.hk != 0) {           // the range starts inside a tile: that fragment goes first
-        w.stage = 0;
-        g3_walk_segment(w, pl, v, G, r1);
-        w.stage = 0;
-    } else {
-        w.stage = 1;
-        g3_walk_segment(w, pl, v, G, r1);
-    }
-}
-// one pair forward; returns true when that moved to another tile
-__device__ __forceinline__ bool g3_walk_next(G3Walk& w, const G3Plan& pl, int v, int G, int r1) {
-    if (++w.kp < w.seg_end) return false;
-    if (w.stage == 0) w.stage = 1;
-    g3_walk_segment(w, pl, v, G, r1);
-    return true;
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void gemm_g3p_kernel(const GemmParams p, const G3Plan pl, float* __restrict__ slabs, unsigned* flags) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2;
-    const int G = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, gq = G >> 3, gr = G & 7;
-    const int v = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (bid >> 3);
-    auto range_begin = [&](int w) { return w * pl.rem_q + (w < pl.rem_r ? w : pl.rem_r); };
-    const int r0 = range_begin(v), r1 = range_begin(v + 1);
-
-    G3State s;
-    g3_init_lane(s, p, smem, wave, lane);
-    g3_zero(s);
-
-    G3Walk wc, wn;                                 // compute cursor / the pair after it (DMA source)
-#ifdef ME_DEV
-    g3_walk_init(wc, pl, v, G, r0, r1, (p.debug & 2) != 0);
-#else
-    g3_walk_init(wc, pl, v, G, r0, r1, false);
-#endif
-    if (wc.stage == 3) return;                     // nothing to do (more workgroups than work)
-    wn = wc;
-    auto src_of = [&](const G3Walk& w) {
-        const int tm = __builtin_amdgcn_readfirstlane(w.tile / p.tiles_n);
-        return g3_make_src(p, tm, w.tile - tm * p.tiles_n);
-    };
-    G3Src cur = src_of(wc);
-    G3Src nxt = cur;
-    auto advance_next = [&]() {
-        if (wn.stage == 3) return;
-        if (g3_walk_next(wn, pl, v, G, r1)) {
-            if (wn.stage == 3) nxt = g3_null_src(p);
-            else nxt = src_of(wn);
-        }
-    };
-    // prologue: half-tiles 0..6 of the stream (first K-tile complete, second without A-Y)
-    {
-        const int k = wc.kp * 2;
-        g3_issue<0>(s, cur, 0, k); g3_issue<1>(s, cur, 0, k); g3_issue<2>(s, cur, 0, k); g3_issue<3>(s, cur, 0, k);
-        g3_issue<0>(s, cur, 1, k + 1); g3_issue<1>(s, cur, 1, k + 1); g3_issue<2>(s, cur, 1, k + 1);
-    }
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();    // wave row 1 runs one barrier behind (wave-uniform scalar branch)
-    advance_next();                               // nxt / wn = the second pair of the stream
-
-    while (wc.stage != 3) {
-        const int kc = wc.kp * 2, kn = wn.kp * 2;
-        g3_ktile<0>(s, cur, kc + 1, nxt, kn);
-        g3_ktile<1>(s, nxt, kn, nxt, kn + 1);
-        if (wc.kp + 1 == wc.seg_end) {
-            // ---- seam: this workgroup's share [seg_begin, seg_end) of tile wc.tile is accumulated
-            const int tm = __builtin_amdgcn_readfirstlane(wc.tile / p.tiles_n), tn = wc.tile - tm * p.tiles_n;
-            const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
-            bool skip = false;
-#ifdef ME_DEV
-            if (p.debug & 1) {                    // dev: K-loops only
-                float keep = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) keep += s.acc[i][j][0] + s.acc[i][j][1] + s.acc[i][j][2] + s.acc[i][j][3];
-                if (keep == 1.2345e-30f) reinterpret_cast<float*>(p.C)[0] = keep;
-                skip = true;
-            }
-#endif
-#ifdef ME_DEV
-            if ((p.debug & 8) && (wc.seg_begin != 0 || wc.seg_end < pl.hk)) skip = true;     // dev: no hand-over at all
-#endif
-            if (skip) {
-            } else if (wc.seg_begin != 0) {
-                // hand my partial sums to the workgroup that owns the tile's first K-tiles
-                int le = lane;
-                asm volatile("" : "+v"(le));      // (derive the address here, not ahead of the loop)
-                // write-through (sc1) 16-byte stores: visible at agent scope once this wave's vmcnt drains, without the
-                // release fence's write-back of the whole L2 (Guideline 16, form R1 / "publish-large")
-                const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc(
-                    slabs + (int64_t)v * G3_SLAB_FLOATS, 0, G3_SLAB_FLOATS * 4, 0x00020000);
-                const int voff = ((wave * 32) * 64 + le) * 16;
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s.acc[i][j]), slab, voff + (i * 4 + j) * 1024, 0, /*sc1*/ 16);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave drains
-                if (wr == 0) __builtin_amdgcn_s_barrier();          // realign the wave rows for a true workgroup barrier
-                __syncthreads();
-                if (tid == 0) __hip_atomic_store(flags + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (wr == 1) __builtin_amdgcn_s_barrier();          // and stagger them again
-            } else {
-                if (wc.seg_end < pl.hk) {
-                    // I hold the first K-tiles: collect the partial sums of the workgroups after me that cover the rest
-                    const int tile_end = (wc.tile - pl.rounds * G + 1) * pl.hk;      // in the remainder pair space
-                    int le = lane;
-                    asm volatile("" : "+v"(le));
-                    if (wr == 0) __builtin_amdgcn_s_barrier();
-                    for (int w = v + 1; w < G && range_begin(w) < tile_end; ++w) {
-                        if (range_begin(w) >= range_begin(w + 1)) continue;
-                        if (tid == 0) {
-                            unsigned spins = 0;
-                            while (__hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                                __builtin_amdgcn_s_sleep(8);
-                                if (++spins > (1u << 26)) { flags[G] = 1u + (unsigned)w; break; }   // give up: error word
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        }
-                        __syncthreads();
-                        const f32x4* slab = reinterpret_cast<const f32x4*>(slabs + (int64_t)w * G3_SLAB_FLOATS) + (wave * 32) * 64 + le;
-#pragma unroll
-                        for (int i0 = 0; i0 < 8; i0 += 4) {          // 16 loads in flight
-                            f32x4 t[4][4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) t[i][j] = slab[((i0 + i) * 4 + j) * 64];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) s.acc[i0 + i][j] += t[i][j];
-                        }
-                    }
-                    if (wr == 1) __builtin_amdgcn_s_barrier();
-                }
-                g3_epilogue<EPI>(p, s, m0, n0, lane);
-            }
-            g3_zero(s);
-        }
-        wc = wn;
-        cur = nxt;
-        advance_next();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing null DMAs must land before the LDS is released
-    if (wr == 0) __builtin_amdgcn_s_barrier();   // match wave row 1's final barrier
-}
-#endif  // ME_DEV
 
 // ---- one tile per workgroup
 template <int EPI>
@@ -636,12 +54,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // carry the same amount of work.
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
-#ifdef ME_DEV
-    if ((p.debug >> 4) && bid < 256) {           // dev: stagger the first round (output bursts of the CUs spread out)
+    if (kMeDev && (p.debug >> 4) && bid < 256) { // dev: stagger the first round (output bursts of the CUs spread out)
         const int n = (slot & 7) * (p.debug >> 4);
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
     }
-#endif
     const int F = p.g3_full_tiles;
     const int nf = (F >> 3) + (xcd < (F & 7) ? 1 : 0);
     const int base_f = xcd * (F >> 3) + (xcd < (F & 7) ? xcd : (F & 7));
@@ -685,8 +101,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     g3_ktile<1>(s, null, 0, null, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wr == 0) __builtin_amdgcn_s_barrier();
-#ifdef ME_DEV
-    if (p.debug & 1) {                           // dev: K-loop only
+    if (kMeDev && (p.debug & 1)) {               // dev: K-loop only
         float keep = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -695,7 +110,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (keep == 1.2345e-30f) reinterpret_cast<float*>(p.C)[0] = keep;
         return;
     }
-#endif
     if (part >= 0) {
         // a part of a split tile: raw partial sums; the fold that follows the launch applies the real epilogue
         const int64_t row0 = (int64_t)(F / p.tiles_n) * G3_BM;
@@ -817,11 +231,15 @@ __device__ __forceinline__ u32x4 g3r_lanes(const u32x4& v, int addr) {
 // PRE 3 (EPI 0 / 1): a LayerNorm folded into this Linear (GemmParams::row_affine / col_shift): the accumulators start at zero
 // and the epilogue applies v = rstd_m * acc + (-rstd_m mean_m) * s[n] + c[n] in the accumulator layout (one row per lane and
 // 16-row slab, four consecutive columns per register quad), ahead of the activation; nothing is saved.
-template <int EPI, int PRE>
-__device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int tm, int tn, int lane, const G3Src& nxt, int nk,
+// HALF: a 128 x 256 item (g3_make_src_half): accumulator slabs 0..3 only, this wave row's rows are m0 + 64 wr + ..; the
+// epilogue is padded with stores no descriptor admits up to the whole tile's operation count, so that the counted waits behind it
+// (g3_phase<.., SEAM>, the ticket wait) are the same for both item kinds.
+template <int EPI, int PRE, bool HALF = false>
+__device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int64_t m0, int tn, int lane, const G3Src& nxt, int nk,
                                               const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero, unsigned* ctr, int nx,
                                               uint32_t lds_tick) {
     constexpr bool SAVE = PRE == 1 || PRE == 2, LNF = PRE == 3;
+    constexpr int NMT = HALF ? 4 : 8, WROWS = HALF ? 64 : 128;      // 16-row slabs per wave, rows per wave row
     // (claimed schedule: wave 0 draws the ticket for the item after next FIRST, ahead of every store of this epilogue)
     unsigned drawn = 0;
     if (ctr && s.wave == 0) drawn = g3r_draw(ctr);
@@ -829,22 +247,21 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     lane = g3_lane_now();
     const int wr = s.wave >> 2, wc = s.wave & 3;
     const int r = lane & 15, g = lane >> 4;
-    const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
+    const int64_t n0 = (int64_t)tn * G3_BN;
     int64_t rows = p.M - m0, cols = p.N - n0;
-    rows = rows < G3_BM ? rows : G3_BM;
+    rows = rows < 2 * WROWS ? rows : 2 * WROWS;
+    rows = rows < 1 ? 1 : rows;                 // (an item past the last row: every access below is then out of range)
     cols = cols < G3_BN ? cols : G3_BN;
+    const bool item_ok = p.M > m0;
     auto tile_rsrc = [&](const void* base, int64_t ld) {
+        if (!item_ok) return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0, 0x00020000);
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (m0 * ld + n0) * 2, 0,
                                                  (int)(((rows - 1) * ld + cols) * 2), 0x00020000);
     };
-#ifdef ME_DEV
     // dev (debug bit 4): the stores go nowhere (zero-record descriptor), everything else unchanged
     // (debug bit 2 with bit 4: only the first workgroup of every XCD keeps its stores)
-    const bool drop = (p.debug & 4) && !((p.debug & 2) && (blockIdx.x >> 3) == 0);
+    const bool drop = kMeDev && (p.debug & 4) && !((p.debug & 2) && (blockIdx.x >> 3) == 0);
     const __amdgpu_buffer_rsrc_t crs = drop ? __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000) : tile_rsrc(p.C, p.ldc);
-#else
-    const __amdgpu_buffer_rsrc_t crs = tile_rsrc(p.C, p.ldc);
-#endif
     const __amdgpu_buffer_rsrc_t prs = SAVE ? tile_rsrc(p.preact, p.ldpre) : crs;
     const __amdgpu_buffer_rsrc_t rrs = EPI == 2 ? tile_rsrc(p.residual, p.ldres) : (EPI == 3 || EPI == 6) ? tile_rsrc(p.aux, p.ldaux) : crs;
     const int rop_ld = (int)(EPI == 2 ? p.ldres : p.ldaux);
@@ -852,7 +269,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     // chunk past the column edge gets an offset no descriptor admits; rows past the row edge fall behind the descriptor's end.
     const int colb = wc * 128 + (lane & 7) * 16;
     const bool ok = (colb >> 1) + 8 <= (int)cols;
-    const int row = wr * 128 + (lane >> 3);
+    const int row = wr * WROWS + (lane >> 3);
     const uint32_t coff = ok ? (uint32_t)(row * (int)p.ldc * 2 + colb) : 0x80000000u;
     const uint32_t poff = ok && SAVE ? (uint32_t)(row * (int)p.ldpre * 2 + colb) : 0x80000000u;
     const uint32_t roff = ok ? (uint32_t)(row * rop_ld * 2 + colb) : 0x80000000u;
@@ -877,7 +294,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
         o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
         return __builtin_bit_cast(u32x4, o);
     };
-    constexpr int AHEAD = EPI == 3 ? 4 : 6;      // row-operand slabs in flight ahead of their use (more spills: into the K-loop for gelu', onto the ticket register otherwise)
+    constexpr int AHEAD = HALF ? 4 : EPI == 3 ? 4 : 6;      // row-operand slabs in flight ahead of their use (more spills: into the K-loop for gelu', onto the ticket register otherwise)
     u32x4 rowop[8][2];
     if (EPI == 2 || EPI == 3 || EPI == 6) {
 #pragma unroll
@@ -887,11 +304,11 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     f32x2 lnf_row[8];
     G3Bias lnf_s, lnf_c;
     if (LNF) {
-        const __amdgpu_buffer_rsrc_t rars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.row_affine) + m0 * 2, 0, (int)(rows * 8), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.row_affine) + m0 * 2, 0, item_ok ? (int)(rows * 8) : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.col_shift), 0, (int)(p.N * 4), 0x00020000);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)      // (rows past the edge: out of range -> zeros; their outputs are never stored)
-            lnf_row[mt] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rars, (wr * 128 + mt * 16 + r) * 8, 0, 0));
+        for (int mt = 0; mt < NMT; ++mt)    // (rows past the edge: out of range -> zeros; their outputs are never stored)
+            lnf_row[mt] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rars, (wr * WROWS + mt * 16 + r) * 8, 0, 0));
         lnf_s = g3r_bias(srs, tn, s.wave, lane);
         lnf_c = g3r_bias(brs, tn, s.wave, lane);
     }
@@ -901,12 +318,12 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     const G3Bias nb = g3r_bias(brs, ntn, s.wave, lane);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
+    for (int mt = 0; mt < NMT; ++mt) {
         f32x4 ro[2][2];
         if (EPI == 2 || EPI == 3 || EPI == 6) {
             unpack(g3r_lanes(rowop[mt][0], to_reg), ro[0][0], ro[0][1]);
             unpack(g3r_lanes(rowop[mt][1], to_reg), ro[1][0], ro[1][1]);
-            if (mt + AHEAD < 8) fetch(mt + AHEAD, rowop[mt + AHEAD]);
+            if (mt + AHEAD < NMT) fetch(mt + AHEAD, rowop[mt + AHEAD]);
             __builtin_amdgcn_sched_barrier(0);
         }
         f32x4 v[2][2];
@@ -968,13 +385,22 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
             __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), crs, (int)(coff + (2 * mt + h) * cstep), 0, 0);
         }
     }
+    if (HALF) {
+        // as many memory operations as a whole tile's epilogue issues behind the A-Y half-tile (stores: half of them went out
+        // above; late row-operand loads: a whole tile issues 2 (8 - AHEAD) of them, this one none)
+        constexpr int PAD = (SAVE ? 16 : 8) + ((EPI == 2 || EPI == 6) ? 4 : EPI == 3 ? 8 : 0);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < PAD; ++i) __builtin_amdgcn_raw_buffer_store_b128(z, none, 0, 0, 0);
+    }
     // the next tile's accumulators start at its bias (s.binit)
     __builtin_amdgcn_sched_barrier(0);
     g3r_set_binit(s, nb, next_zero);
     if (ctr && s.wave == 0) {
         // everything this epilogue issued behind the draw may stay in flight: the A-Y half-tile (2), the bias (4), the
-        // stores (16 / 32) and the row operands (16)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 4 + 16 + (SAVE ? 16 : 0) + ((EPI == 2 || EPI == 3 || EPI == 6) ? 16 : 0)) : "memory");
+        // stores (16 / 32, padding included) and the row operands (16; a 128-row item 8 + 4 or 8 of the padding)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 4 + 16 + (SAVE ? 16 : 0) + ((EPI == 2 || EPI == 3 || EPI == 6) ? (HALF ? 8 : 16) : 0)) : "memory");
         g3r_publish(drawn, ctr, nx, lds_tick);
     }
 }
@@ -993,7 +419,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int bid = blockIdx.x, xcd = bid & 7, c = bid >> 3, G8 = gridDim.x >> 3;
     const int tiles = p.tiles_m * p.tiles_n, F = p.g3_full_tiles;
-    const int nwork = F + (tiles - F) * p.g3_split;
+    const int nwork = F + (tiles - F) * 2;                             // (F == tiles unless p.g3_half)
     const int nf = (F >> 3) + (xcd < (F & 7) ? 1 : 0);                 // whole tiles / all items of this XCD
     const int nx = (nwork >> 3) + (xcd < (nwork & 7) ? 1 : 0);
     const int base_f = xcd * (F >> 3) + (xcd < (F & 7) ? xcd : (F & 7));
@@ -1004,27 +430,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (slot < nf) {
             tile = base_f + slot;
         } else {
+            // a tile of the last, mostly empty round: two 128-row items (part = which half), the whole reduction each
             const int pi = base_all - base_f + (slot - nf);
-            const int tq = __builtin_amdgcn_readfirstlane(pi / p.g3_split);
-            tile = F + tq;
-            part = pi - tq * p.g3_split;
-            kt0 = part * p.g3_ktp;
-            kt1 = kt0 + p.g3_ktp < nkt ? kt0 + p.g3_ktp : nkt;
+            tile = F + (pi >> 1);
+            part = pi & 1;
         }
     };
-    auto src_of = [&](int tile, int& tm, int& tn) {
+    auto src_of = [&](int tile, int part, int& tm, int& tn) {
         tm = __builtin_amdgcn_readfirstlane(tile / p.tiles_n);
         tn = tile - tm * p.tiles_n;
-        return g3_make_src(p, tm, tn);
+        return part >= 0 ? g3_make_src_half(p, tm, tn, part, wr) : g3_make_src(p, tm, tn);
     };
     int slot = c;
     if (slot >= nx) return;
-#ifdef ME_DEV
-    if (p.debug >> 4) {                          // dev: stagger the CUs of an XCD (their output bursts spread out)
+    if (kMeDev && (p.debug >> 4)) {              // dev: stagger the CUs of an XCD (their output bursts spread out)
         const int n = c * (p.debug >> 4);
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
     }
-#endif
 
     G3State s;
     g3_init_lane(s, p, smem, wave, lane);
@@ -1045,12 +467,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     int tile, part, kt0, kt1, tm, tn;
     decode(slot, tile, part, kt0, kt1);
-    G3Src cur = src_of(tile, tm, tn);
+    G3Src cur = src_of(tile, part, tm, tn);
     g3_issue<0>(s, cur, 0, kt0); g3_issue<1>(s, cur, 0, kt0); g3_issue<2>(s, cur, 0, kt0); g3_issue<3>(s, cur, 0, kt0);
     g3_issue<0>(s, cur, 1, kt0 + 1); g3_issue<1>(s, cur, 1, kt0 + 1); g3_issue<2>(s, cur, 1, kt0 + 1); g3_issue<3>(s, cur, 1, kt0 + 1);
     {
         const G3Bias b0 = g3r_bias(brs, tn, wave, lane);
-        g3r_set_binit(s, b0, part >= 0 || PRE == 3);
+        g3r_set_binit(s, b0, PRE == 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (dyn && wave == 0) g3r_publish(drawn0, ctr, nx, lds_tick);
@@ -1058,19 +480,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
 
-#ifdef ME_DEV
     // dev: time stamps (s_memtime) of waves 0 and 4: [workgroup][wave row][item][8] = item start, first K-tile done,
-    // second K-tile done, K-loop done, rows realigned, epilogue done
-    unsigned long long* trace = reinterpret_cast<unsigned long long*>(p.colsum_ws);
+    // second K-tile done, K-loop done, rows realigned, epilogue done (tools/gemm_dev, debug bit 8; dead code in the product build)
+    unsigned long long* trace = kMeDev ? reinterpret_cast<unsigned long long*>(p.colsum_ws) : nullptr;
     int item = 0;
 #define G3R_STAMP(i)                                                                                            \
-    if (trace && (wave & 3) == 0 && item < 16) {                                                                \
+    if (kMeDev && trace && (wave & 3) == 0 && item < 16) {                                                      \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                             \
         if (lane == 0) trace[(((size_t)bid * 2 + wr) * 16 + item) * 8 + (i)] = t_;                              \
     }
-#else
-#define G3R_STAMP(i)
-#endif
     // Which item comes next: static (slot + G8: every workgroup owns a fixed list) or, with p.g3_tickets, CLAIMED from the
     // XCD's counter -- a CU that is slow, or that could not take its workgroup for a while because a communication kernel
     // sat on it, then simply ends up with fewer tiles instead of holding the whole launch back (the first item stays static:
@@ -1089,55 +507,51 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             has_next = ns < nx;
             if (has_next) {
                 decode(nslot, ntile, npart, nkt0, nkt1);
-                nxt = src_of(ntile, ntm, ntn);
+                nxt = src_of(ntile, npart, ntm, ntn);
             }
         };
         if (!dyn) resolve_next(slot + G8);
         const int np = (kt1 - kt0) >> 1;
-        {
-            G3Src sb = cur;
-            int kb = kt0 + 2, kc = kt0 + 3;
-            if (np == 1) { sb = nxt; kb = nkt0; kc = nkt0 + 1; }
-            g3_ktile<0, false, SEAM>(s, cur, 0, sb, kb);
-            G3R_STAMP(1)
-            g3_ktile<1>(s, sb, kb, sb, kc);
-        }
-        G3R_STAMP(2)
-        if (dyn) {
-            unsigned t;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(lds_tick) : "memory");
-            resolve_next(G8 + (int)__builtin_amdgcn_readfirstlane(t));
-        }
-        for (int i = 1; i < np; ++i) {
-            const int k = kt0 + 2 * i;
-            G3Src sb = cur;
-            int kb = k + 2, kc = k + 3;
-            if (i == np - 1) { sb = nxt; kb = nkt0; kc = nkt0 + 1; }
-            g3_ktile<0>(s, cur, k + 1, sb, kb);
-            g3_ktile<1>(s, sb, kb, sb, kc);
-        }
-        // the two wave rows run their epilogues SIDE BY SIDE: left one barrier apart, row 1 could not start its epilogue
-        // before row 0 had finished its own and reached the next K-tile's first barrier, and row 0 would then wait out
-        // row 1's (measured with the time stamps below: 4.6 k of 40 k clocks per tile).  Row 0 gives up its one-barrier
-        // lead here and row 1 re-opens it behind the epilogue.
-        G3R_STAMP(3)
-        if (wr == 0) __builtin_amdgcn_s_barrier();
-        G3R_STAMP(4)
-        if (part >= 0) {
-            g3_issue<3>(s, nxt, 1, nkt0 + 1);
-            const int64_t row0 = (int64_t)(F / p.tiles_n) * G3_BM;
-            g3_epilogue<5>(p, s, (int64_t)tm * G3_BM, (int64_t)tn * G3_BN, g3_lane_now(), p.g3_slabs + (int64_t)part * (p.M - row0) * p.N, row0);
-            const G3Bias nb = g3r_bias(brs, ntn, wave, 0);
-            g3r_set_binit(s, nb, npart >= 0 || PRE == 3);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            prime();
-        } else {
-            g3_epilogue_r<EPI, PRE>(p, s, tm, tn, 0, nxt, nkt0 + 1, brs, ntn, npart >= 0 || PRE == 3, has_next ? ctr : nullptr, nx, lds_tick);
-        }
+        // One item: the K-loop and the epilogue, instantiated for whole tiles and for 128-row items (HALF).  The two forms meet
+        // only behind their epilogues, where no accumulator is live.
+        auto run_item = [&](auto half_tag) {
+            constexpr bool HALF = decltype(half_tag)::value;
+            {
+                G3Src sb = cur;
+                int kb = kt0 + 2, kc = kt0 + 3;
+                if (np == 1) { sb = nxt; kb = nkt0; kc = nkt0 + 1; }
+                g3_ktile<0, false, SEAM, HALF>(s, cur, 0, sb, kb);
+                G3R_STAMP(1)
+                g3_ktile<1, false, 0, HALF>(s, sb, kb, sb, kc);
+            }
+            G3R_STAMP(2)
+            if (dyn) {
+                unsigned t;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(lds_tick) : "memory");
+                resolve_next(G8 + (int)__builtin_amdgcn_readfirstlane(t));
+            }
+            for (int i = 1; i < np; ++i) {
+                const int k = kt0 + 2 * i;
+                G3Src sb = cur;
+                int kb = k + 2, kc = k + 3;
+                if (i == np - 1) { sb = nxt; kb = nkt0; kc = nkt0 + 1; }
+                g3_ktile<0, false, 0, HALF>(s, cur, k + 1, sb, kb);
+                g3_ktile<1, false, 0, HALF>(s, sb, kb, sb, kc);
+            }
+            // the two wave rows run their epilogues SIDE BY SIDE: left one barrier apart, row 1 could not start its epilogue
+            // before row 0 had finished its own and reached the next K-tile's first barrier, and row 0 would then wait out
+            // row 1's (measured with the time stamps below: 4.6 k of 40 k clocks per tile).  Row 0 gives up its one-barrier
+            // lead here and row 1 re-opens it behind the epilogue.
+            G3R_STAMP(3)
+            if (wr == 0) __builtin_amdgcn_s_barrier();
+            G3R_STAMP(4)
+            g3_epilogue_r<EPI, PRE, HALF>(p, s, (int64_t)tm * G3_BM + (HALF ? part * 128 : 0), tn, 0, nxt, nkt0 + 1, brs, ntn, PRE == 3,
+                                          has_next ? ctr : nullptr, nx, lds_tick);
+        };
+        if (part >= 0) run_item(std::true_type{});
+        else run_item(std::false_type{});
         G3R_STAMP(5)
-#ifdef ME_DEV
-        ++item;
-#endif
+        if (kMeDev) ++item;
         if (!has_next) break;
         if (wr == 1) __builtin_amdgcn_s_barrier();
         slot = nslot; tile = ntile; part = npart; kt0 = nkt0; kt1 = nkt1; tm = ntm; tn = ntn;
@@ -1213,8 +627,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (mb < p.M) row[mb] = c1;
         }
     }
-#ifdef ME_DEV
-    if (p.debug & 1) {
+    if (kMeDev && (p.debug & 1)) {
         float keep = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -1223,7 +636,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (keep == 1.2345e-30f) reinterpret_cast<float*>(p.C)[0] = keep;
         return;
     }
-#endif
     g3_epilogue<5>(p, s, m0, n0, lane, reinterpret_cast<float*>(p.C) + (int64_t)split * p.slab_stride, 0);
 }
 
@@ -1286,12 +698,19 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
     if (once.need())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS + 64);
     GemmParams q = q0;
-    // claimed items need >= 2 K-tile pairs per item and whole tiles only (see the kernel)
-    q.g3_tickets = (q.K >= 4 * G3_BK && q.g3_split <= 1 && gemm_dev().g3_persistent == 1) ? g3r_tickets(stream) : nullptr;
-#ifdef ME_DEV
-    if (gemm_dev().tail_split == 2) q.g3_tickets = nullptr;          // dev: "g3s" = static schedule
-    q.colsum_ws = (q.debug & 8) ? reinterpret_cast<float*>(g_gemm_dev_trace) : nullptr;
-#endif
+    // Tile quantisation: T tiles on G resident workgroups take ceil(T / G) rounds, and the encoder's N = 768 outputs are 591 tiles =
+    // 2.31 rounds (N = 3072: 9.23).  When at most half the CUs would work in the last round, its tiles run as two 128-row items
+    // each -- same kernel, same epilogue, no slabs (g3_phase<.., HALF>): the last round then costs a little over half a round.
+    const int tiles = q.tiles_m * q.tiles_n, rem = tiles % G;
+    q.g3_full_tiles = tiles; q.g3_split = 1; q.g3_half = 0;
+    if (tiles >= G && rem > 0 && 2 * rem <= G && q.K >= 4 * G3_BK && gemm_dev().tail_split != 3) {
+        q.g3_full_tiles = tiles - rem;
+        q.g3_half = 1;
+    }
+    // claimed items need >= 2 K-tile pairs per item (see the kernel)
+    q.g3_tickets = (q.K >= 4 * G3_BK && gemm_dev().g3_persistent == 1) ? g3r_tickets(stream) : nullptr;
+    if (kMeDev && gemm_dev().tail_split == 2) q.g3_tickets = nullptr;          // dev: "g3s" = static schedule
+    ME_DEV_ONLY(q.colsum_ws = (q.debug & 8) ? reinterpret_cast<float*>(g_gemm_dev_trace) : nullptr;)
     hipLaunchKernelGGL((gemm_g3r_kernel<EPI, PRE>), dim3((unsigned)G), dim3(512), G3_LDS + 64, stream, q);
     ME_CHECK_LAUNCH("me_gemm(g3 resident)");
     return ME_OK;
@@ -1312,36 +731,9 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
     if (once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3_kernel<EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
-#ifdef ME_DEV
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3p_kernel<EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
-#endif
     }
     const int tiles = p.tiles_m * p.tiles_n;
-#ifdef ME_DEV
-    if (ws) {
-        G3Plan pl;
-        pl.hk = (int)(p.K / (2 * G3_BK));
-        int G = g3_cus();
-        G = G < tiles ? G : tiles;
-        pl.rounds = tiles / G;
-        // keep at least one tile's worth of remainder per workgroup (that is what de-phases the epilogues) when there
-        // are rounds to take it from
-        if (pl.rounds > 0 && (int64_t)(tiles - pl.rounds * G) * pl.hk < (int64_t)G * pl.hk) --pl.rounds;
-        const int64_t rem_pairs = (int64_t)(tiles - pl.rounds * G) * pl.hk;
-        pl.rem_q = (int)(rem_pairs / G);
-        pl.rem_r = (int)(rem_pairs % G);
-        float* slabs = reinterpret_cast<float*>(ws);
-        unsigned* flags = reinterpret_cast<unsigned*>(slabs + (size_t)G * G3_SLAB_FLOATS);
-        if (hipMemsetAsync(flags, 0, (size_t)(G + 1) * sizeof(unsigned), stream) != hipSuccess) {
-            me_set_error("me_gemm(g3): flag reset failed");
-            return ME_ERR_HIP;
-        }
-        hipLaunchKernelGGL((gemm_g3p_kernel<EPI>), dim3((unsigned)G), dim3(512), G3_LDS, stream, p, pl, slabs, flags);
-        ME_CHECK_LAUNCH("me_gemm(g3p)");
-        return ME_OK;
-    }
-#endif
+    if (kMeDev && ws) return launch_g3p(p, EPI, ws, stream);       // dev build: the persistent stream-K form (gemm3_dev.hip)
     (void)ws;
     GemmParams q = p;
     if (q.g3_split <= 1 || q.g3_slabs == nullptr) { q.g3_full_tiles = tiles; q.g3_split = 1; q.g3_ktp = 0; q.g3_slabs = nullptr; }
@@ -1362,7 +754,7 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
         }
         const int G = g3_cus() & ~7;
         const int64_t ldmax = std::max(std::max(p.ldc, p.preact ? p.ldpre : 0), std::max(p.residual ? p.ldres : 0, p.aux ? p.ldaux : 0));
-        if (repi >= 0 && G >= 8 && nwg >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!(pre == 1 || pre == 2) || p.preact_dtype == ME_BF16) &&
+        if (repi >= 0 && G >= 8 && nwg >= G && q.g3_split <= 1 && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!(pre == 1 || pre == 2) || p.preact_dtype == ME_BF16) &&
             256 * ldmax * 2 < (1ll << 31))
             return launch3r_any(repi, pre, q, G, stream);
     }

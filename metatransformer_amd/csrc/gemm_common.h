@@ -21,6 +21,7 @@ struct GemmParams {
     // part, raw fp32 partial sums into g3_slabs [g3_split][rows past the full tiles][N]; 0 = every tile is a full tile
     int g3_full_tiles, g3_split, g3_ktp;
     float* g3_slabs;
+    int g3_half;                            // resident kernel: tiles [g3_full_tiles, tiles) run as two 128-row items each (real epilogue, no slabs)
     unsigned* g3_tickets;                   // resident g3 kernel: per-XCD work counters (16 words apart), null = static schedule
     int64_t slab_stride;                    // g3 wgrad: floats between the split-K slabs in C (>= M * N, padded: see g3_tn_slab_stride)
     const float* row_affine;                // folded LayerNorm (me_gemm_desc.row_affine): [M][2] = (rstd, -rstd * mean), or null
@@ -174,9 +175,15 @@ static inline int64_t g3_tn_slab_stride(int64_t M, int64_t N) { return M * N; }
 // environment variables.
 struct GemmDev { int family, bn, debug, tail_split, g3_persistent; };
 #ifdef ME_DEV
+constexpr bool kMeDev = true;
+#define ME_DEV_ONLY(...) __VA_ARGS__
+int launch_g3p(const GemmParams& p, int epi, void* ws, hipStream_t stream);      // gemm3_dev.hip
 extern GemmDev g_gemm_dev;
 extern void* g_gemm_dev_trace;      // device buffer for the resident kernel's time stamps (tools/gemm_dev --trace)
 static inline GemmDev gemm_dev() { return g_gemm_dev; }
 #else
+constexpr bool kMeDev = false;
+#define ME_DEV_ONLY(...)
+static inline int launch_g3p(const GemmParams&, int, void*, hipStream_t) { return ME_ERR_UNSUPPORTED; }
 static inline GemmDev gemm_dev() { return GemmDev{-1, 0, 0, 1, 1}; }
 #endif

@@ -286,12 +286,14 @@ def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse:
 
 # ----------------------------------------------------------------------------- element-wise
 
-def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    if x.dtype == dtype:
+def cast(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if x.dtype == dtype and out is None:
         return x
     lib = _capi.load()
     _req(x, "x")
-    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    if out is not None and (out.dtype != dtype or out.numel() != x.numel() or not out.is_contiguous() or out.device != x.device):
+        raise MetaEncError("cast: `out` must be a contiguous tensor of the target dtype with as many elements as x")
+    y = out if out is not None else torch.empty(x.shape, dtype=dtype, device=x.device)
     check(lib.me_cast(ptr(x), dtype_code(x.dtype, True), ptr(y), dtype_code(dtype, True), x.numel(), stream_ptr()), "me_cast")
     return y
 

@@ -135,3 +135,16 @@ def test_flop_model():
     # BASELINE.md section 3
     assert abs(M.encoder_flops_per_sample(197, 768, 12) / 1e9 - 34.895) < 0.01
     assert abs(M.encoder_flops_per_sample(512, 1024, 24) / 1e9 - 335.0) < 0.1
+
+
+def test_resident_gemm_isa_has_no_inner_loop_spills_and_keeps_its_ticket_register():
+    """tools/check_g3r_isa.py on the assembly hipcc emits for gemm3.hip: the hand-counted waits of the resident kernel assume
+    that nothing the compiler does not show (a spill, a clobbered ticket register) sits inside its loops."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_g3r_isa", os.path.join(ROOT, "tools", "check_g3r_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with tempfile.TemporaryDirectory() as d:
+        asm = mod.compile_asm(d)
+    report, findings = mod.check(asm)
+    assert len(report) >= 7 and not findings, findings

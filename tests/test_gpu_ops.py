@@ -348,3 +348,38 @@ def test_attention_fp8_rejects_what_it_does_not_implement(dev):
         ops.attention_fwd(qkv, 2, 64, 2, 32, 0.1, need_lse=False, fp8=True)          # head_dim 32
     with pytest.raises(MetaEncError):
         ops.attention_fwd(qkv.float(), 2, 64, 1, 64, 0.1, need_lse=False, fp8=True)   # fp32 qkv
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 90 + 77, 768, 256), (256 * 88 + 200, 768, 768), (256 * 30 + 130, 3072, 256)])
+def test_gemm_resident_half_items_every_epilogue(dev, M, N, K):
+    """Tile quantisation on the resident NT kernel: when the last round holds at most half the CUs' worth of tiles, those tiles
+    run as two 128-row items each (gemm3.hip, g3_phase<.., HALF>).  Shapes chosen so that this happens (273 / 267 / 372 tiles on
+    256 CUs) with a ragged last tile row -- 77 rows: its second half is EMPTY; 200 rows: its second half is partial -- through
+    every epilogue form of the kernel, every output element checked."""
+    dt = torch.bfloat16
+    a, w, bias = rnd(M, K, seed=1).to(dt), (0.05 * rnd(N, K, seed=2)).to(dt), 0.1 * rnd(N, seed=3)
+    lin = a.double() @ w.double().t() + bias.double()
+    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
+    check_close(ops.gemm(ad, wd, bias=bd).float(), lin, 8e-3, "bias")
+    check_close(ops.gemm(ad, wd, bias=bd, act=_capi.ME_ACT_GELU).float(), bo.gelu_erf(lin), 8e-3, "gelu")
+    res = rnd(M, N, seed=4).to(dt)
+    check_close(ops.gemm(ad, wd, bias=bd, residual=res.to(dev)).float(), lin + res.double(), 8e-3, "residual")
+    pre = torch.full((M, N), float("nan"), dtype=dt, device=dev)
+    y = ops.gemm(ad, wd, bias=bd, act=_capi.ME_ACT_GELU, preact=pre)
+    check_close(pre.float(), lin, 8e-3, "saved pre-activation")
+    check_close(y.float(), bo.gelu_erf(lin), 8e-3, "gelu next to the saved pre-activation")
+    h = lin.clone().requires_grad_(True)
+    bo.gelu_erf(h).sum().backward()
+    sav = torch.full((M, N), float("nan"), dtype=dt, device=dev)
+    y = ops.gemm(ad, wd, bias=bd, act=_capi.ME_ACT_GELU, preact=sav, flags=_capi.ME_GEMM_SAVE_GELU_GRAD)
+    check_close(sav.float(), h.grad, 8e-3, "saved gelu'")
+    check_close(y.float(), bo.gelu_erf(lin), 8e-3, "gelu next to the saved gelu'")
+    fac = rnd(M, N, seed=6).to(dt)
+    check_close(ops.gemm(ad, wd, aux=fac.to(dev), flags=_capi.ME_GEMM_AUX_IS_FACTOR).float(), (a.double() @ w.double().t()) * fac.double(), 8e-3, "* factor")
+    st = ops.row_stats(ad, 1e-5)
+    want = (st[:, 0:1].double().cpu() * (a.double() @ w.double().t()) + st[:, 1:2].double().cpu() * w.double().sum(1)[None, :] + bias.double())
+    check_close(ops.gemm(ad, wd, bias=bd, row_affine=st, col_shift=w.float().sum(1).to(dev)).float(), want, 8e-3, "folded LayerNorm form")
+    # same bits as the whole-tile schedule's rows (the items only regroup rows; each output element's reduction is unchanged)
+    y1 = ops.gemm(ad, wd, bias=bd)
+    y2 = ops.gemm(ad[: 256 * 20].contiguous(), wd, bias=bd)        # fewer tiles than CUs: one tile per workgroup, no items
+    assert torch.equal(y1[: 256 * 20], y2)

@@ -230,6 +230,17 @@ def _mixed_route_worker(rank, world, port, q):
             red.finish()
             for n, p in m.named_parameters():
                 assert torch.allclose(p.grad.reshape(-1), want[n], atol=1e-6), (it, n)
+        # bf16 on the wire: same sums up to the bf16 rounding of each rank's bucket
+        red.remove()
+        red = parallel.OverlappedGradReducer(flat, bucket_bytes=4096, wire_dtype=torch.bfloat16)
+        for it in range(2):
+            flat.zero_grad()
+            fwd().square().mean().backward()
+            red.finish()
+            for n, p in m.named_parameters():
+                assert p.grad.dtype == torch.float32
+                assert torch.allclose(p.grad.reshape(-1), want[n], atol=2e-2 * float(want[n].abs().max()) + 1e-6), (it, n)
+            assert not all(torch.equal(p.grad.reshape(-1), want[n]) for n, p in m.named_parameters())
         # a gradient that arrives in a fresh tensor next to a reducer is refused (its bucket was reduced without it)
         from metatransformer_amd import MetaEncError
         m[2].bias.grad = None

@@ -2,7 +2,7 @@
 //
 //   python -m metatransformer_amd.build --dev      # builds tools/_build/libmetaenc_dev.so and tools/_build/gemm_dev
 //   tools/_build/gemm_dev [--iters N] [--check] case [case ...]
-//   case  = family:M:N:K:epi[:debug]      family in {auto, g128, g2b, g2w, g3, g3x, g3p}; epi 0 bias, 1 gelu(+preact), 2 residual,
+//   case  = family:M:N:K:epi[:debug]      family in {auto, g128, g2b, g2w, g3, g3x, g3p, g3s, g3t, g3f}; epi 0 bias, 1 gelu(+preact), 2 residual,
 //           3 gelu'(aux), 6 * aux (ME_GEMM_AUX_IS_FACTOR), 7 gelu + saved gelu' (ME_GEMM_SAVE_GELU_GRAD); debug = GemmDev::debug bits
 //           tn-family:M:N:K               wgrad form C[M, N] = A[K, M]^T B[K, N] (fp32 output), family in {auto, g2b, g3}
 //
@@ -121,7 +121,7 @@ static int family_code(const std::string& f) {
     if (f == "g128") return 0;
     if (f == "g2b") return 2;
     if (f == "g2w") return 3;
-    if (f == "g3" || f == "g3x" || f == "g3p" || f == "g3t" || f == "g3s") return 4;      // g3: shipped form (resident); g3t: one tile per workgroup; g3x: without the tail split; g3p: persistent stream-K
+    if (f == "g3" || f == "g3x" || f == "g3p" || f == "g3t" || f == "g3s" || f == "g3f") return 4;      // g3f: resident, whole tiles only (no 128-row items in the last round)      // g3: shipped form (resident); g3t: one tile per workgroup; g3x: without the tail split; g3p: persistent stream-K
     fprintf(stderr, "unknown family %s\n", f.c_str());
     exit(2);
 }
@@ -241,7 +241,7 @@ int main(int argc, char** argv) {
         }
         me_dev_set("family", family_code(fam));
         me_dev_set("g3_persistent", strcmp(fam, "g3p") == 0 ? 2 : strcmp(fam, "g3t") == 0 ? 0 : 1);
-        me_dev_set("tail_split", strcmp(fam, "g3s") == 0 ? 2 : strcmp(fam, "g3x") != 0);      // g3s: resident, static schedule
+        me_dev_set("tail_split", strcmp(fam, "g3s") == 0 ? 2 : strcmp(fam, "g3f") == 0 ? 3 : strcmp(fam, "g3x") != 0);      // g3s: resident, static schedule; g3f: no half items
         me_dev_set("debug", debug);
         uint16_t *A[NSET], *C[NSET], *P[NSET], *Bw, *rowop = nullptr;
         float *bias, *ref = nullptr, *ref_pre = nullptr;
