@@ -314,7 +314,8 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     }
     // the half-tile phase 0 of the next K-tile would issue (see SEAM), behind the first row-operand loads so that their
     // wait does not include it; then the next tile's bias
-    g3_issue<3>(s, nxt, 1, nk);
+    if (HALF) g3_issue<2>(s, nxt, 1, nk);       // (a 128-row item's stream: phase 0 of a K-tile issues the NEXT one's B-Y)
+    else g3_issue<3>(s, nxt, 1, nk);
     const G3Bias nb = g3r_bias(brs, ntn, s.wave, lane);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (np == 1) { sb = nxt; kb = nkt0; kc = nkt0 + 1; }
                 g3_ktile<0, false, SEAM, HALF>(s, cur, 0, sb, kb);
                 G3R_STAMP(1)
-                g3_ktile<1, false, 0, HALF>(s, sb, kb, sb, kc);
+                g3_ktile<1, false, 0, HALF, HALF ? SEAM : 0>(s, sb, kb, sb, kc);
             }
             G3R_STAMP(2)
             if (dyn) {
@@ -639,15 +640,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     g3_epilogue<5>(p, s, m0, n0, lane, reinterpret_cast<float*>(p.C) + (int64_t)split * p.slab_stride, 0);
 }
 
-int g3_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    }
-    return n;
-}
 
 // The work counters of the resident kernel: every stream gets its own set (launches on a stream are serialised, and the
 // kernel leaves its counters at zero), handed out on the host from a per-device pool (keyed by the STREAM's device) that is

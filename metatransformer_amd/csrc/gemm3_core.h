@@ -177,11 +177,60 @@ __device__ __forceinline__ float g3_frag_sum(bf16x8 f) {
 // issue went out BEFORE the epilogue, and the counted wait of phase 3 lets the epilogue's SEAM memory operations (which
 // sit between that half-tile and this K-tile's own three in the in-order queue) stay in flight.  It is also the first K-tile
 // of an output tile: its MFMAs take s.binit as their C operand, so the accumulators need no initialisation pass.
-// HALF (resident NT kernel, a 128 x 256 item: the rows of A-X only): phases 2 and 3 keep their DMA issue, counted wait and
-// barriers -- the stream and both wave rows' barrier counts stay exactly those of a whole tile -- but read no A-Y fragments and
-// issue no MFMAs; phases 0 and 1 ARE the item's two quadrants (A-X x B-X, A-X x B-Y).
-template <int BUF, int P, bool TN = false, int SEAM = 0, bool HALF = false>
+// HALF (resident NT kernel, a 128 x 256 item: the rows of A-X only).  The item's two quadrants (A-X x B-X, A-X x B-Y) ARE phases 0
+// and 1; its K-tile has only these two phases (four barriers: both wave rows of a workgroup run the same item, so their one-barrier
+// stagger is untouched) and a three-half-tile stream with its own schedule -- keeping phases 2 / 3 as empty shells measured 1 680
+// clocks per K-tile against 2 270 for a whole tile (each shell waits out the partner row's MFMA block):
+//   phase 0 of K-tile t:  reads B-X(t), A-X(t);  issues B-Y(t+1) -> the other buffer   [skipped when SEAM: it went out ahead of the epilogue]
+//   phase 1 of K-tile t:  reads B-Y(t);          issues B-X(t+2), A-X(t+2) -> this buffer
+//   both: every fragment read of the phase RETIRES before the phase's first barrier (lgkmcnt(0) ahead of it), then
+//         s_waitcnt vmcnt(6 [+ SLACK, see below]) -- phase 1: B-X / A-X of t+1 have landed (behind them in the queue: B-Y(t+1) and the four
+//         instructions just issued); phase 0: B-Y(t) has landed (behind it: B-X / A-X(t+1) and the two just issued).
+//   WAR: a slot is overwritten one phase after its last read at the earliest, and that read retired before a barrier which the
+//        issuing wave row -- and, one barrier later, the other row -- has passed by then.
+//   RAW: every wave waits for its own share before the phase's first barrier; the data is read behind the phase's second one.
+// Seams: the K-tile ahead of an item's first and second one were issued by the previous item's last K-tiles / epilogue in either
+// item's pattern (a whole tile's tail issues A-Y too: out of range for a 128-row item, see g3_make_src_half); the first two K-tiles of an
+// item wait with SLACK = the epilogue's operation count more (they sit between those half-tiles and the K-tile's own in the queue).
+template <int BUF, int P, bool TN = false, int SEAM = 0, bool HALF = false, int SLACK = SEAM>
 __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1, bool cs_on = false) {
+    if (HALF) {
+        static_assert(!HALF || (!TN && P < 2), "128-row items: NT, phases 0 and 1");
+        if (P == 0) {
+            s.bx[0][0] = g3_frag<0 * G3_HALF + 0 * 2048>(s.rb[BUF][0]); s.bx[0][1] = g3_frag<0 * G3_HALF + 0 * 2048>(s.rb[BUF][1]);
+            s.bx[1][0] = g3_frag<0 * G3_HALF + 1 * 2048>(s.rb[BUF][0]); s.bx[1][1] = g3_frag<0 * G3_HALF + 1 * 2048>(s.rb[BUF][1]);
+            s.ax[0][0] = g3_frag<1 * G3_HALF + 0 * 2048>(s.ra[BUF][0]); s.ax[0][1] = g3_frag<1 * G3_HALF + 0 * 2048>(s.ra[BUF][1]);
+            s.ax[1][0] = g3_frag<1 * G3_HALF + 1 * 2048>(s.ra[BUF][0]); s.ax[1][1] = g3_frag<1 * G3_HALF + 1 * 2048>(s.ra[BUF][1]);
+            s.ax[2][0] = g3_frag<1 * G3_HALF + 2 * 2048>(s.ra[BUF][0]); s.ax[2][1] = g3_frag<1 * G3_HALF + 2 * 2048>(s.ra[BUF][1]);
+            s.ax[3][0] = g3_frag<1 * G3_HALF + 3 * 2048>(s.ra[BUF][0]); s.ax[3][1] = g3_frag<1 * G3_HALF + 3 * 2048>(s.ra[BUF][1]);
+        } else {
+            s.by[0][0] = g3_frag<2 * G3_HALF + 0 * 2048>(s.rb[BUF][0]); s.by[0][1] = g3_frag<2 * G3_HALF + 0 * 2048>(s.rb[BUF][1]);
+            s.by[1][0] = g3_frag<2 * G3_HALF + 1 * 2048>(s.rb[BUF][0]); s.by[1][1] = g3_frag<2 * G3_HALF + 1 * 2048>(s.rb[BUF][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (P == 0 && SEAM == 0) g3_issue<2>(s, s0, BUF ^ 1, k0);
+        if (P == 1) { g3_issue<0>(s, s1, BUF, k1); g3_issue<1>(s, s1, BUF, k1); }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (the slack covers half-tiles that were issued AHEAD of the epilogue: everything the item's first K-tile waits for, and the
+        // B-Y its second K-tile's phase 0 waits for -- not the B-X / A-X that phase 1 of the second K-tile waits for: those went
+        // out in phase 1 of the first K-tile, behind the epilogue's stores)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + ((P == 0 || SEAM) ? SLACK : 0)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if (P == 0) {
+            G3_MMA(0, 0, s.ax, s.bx) G3_MMA(0, 1, s.ax, s.bx) G3_MMA(1, 0, s.ax, s.bx) G3_MMA(1, 1, s.ax, s.bx)
+            G3_MMA(2, 0, s.ax, s.bx) G3_MMA(2, 1, s.ax, s.bx) G3_MMA(3, 0, s.ax, s.bx) G3_MMA(3, 1, s.ax, s.bx)
+        } else {
+            G3_MMA(0, 2, s.ax, s.by) G3_MMA(0, 3, s.ax, s.by) G3_MMA(1, 2, s.ax, s.by) G3_MMA(1, 3, s.ax, s.by)
+            G3_MMA(2, 2, s.ax, s.by) G3_MMA(2, 3, s.ax, s.by) G3_MMA(3, 2, s.ax, s.by) G3_MMA(3, 3, s.ax, s.by)
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
     if (TN && (P == 1 || P == 3) && cs_on) {      // (wave-uniform) fragments read one / two phases ago, waited for in that phase
         const int wcol = s.wave & 3;
         if (wcol == 0) s.cs[P >> 1] += g3_frag_sum((P == 1 ? s.ax : s.ay)[0][0]) + g3_frag_sum((P == 1 ? s.ax : s.ay)[0][1]);
@@ -200,7 +249,7 @@ __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, co
         s.ax[2][0] = G3_RD_A(1, 2, 0); s.ax[2][1] = G3_RD_A(1, 2, 1); s.ax[3][0] = G3_RD_A(1, 3, 0); s.ax[3][1] = G3_RD_A(1, 3, 1);
     } else if (P == 1) {
         s.by[0][0] = G3_RD_B(2, 0, 0); s.by[0][1] = G3_RD_B(2, 0, 1); s.by[1][0] = G3_RD_B(2, 1, 0); s.by[1][1] = G3_RD_B(2, 1, 1);
-    } else if (P == 2 && !HALF) {
+    } else if (P == 2) {
         s.ay[0][0] = G3_RD_A(3, 0, 0); s.ay[0][1] = G3_RD_A(3, 0, 1); s.ay[1][0] = G3_RD_A(3, 1, 0); s.ay[1][1] = G3_RD_A(3, 1, 1);
         s.ay[2][0] = G3_RD_A(3, 2, 0); s.ay[2][1] = G3_RD_A(3, 2, 1); s.ay[3][0] = G3_RD_A(3, 3, 0); s.ay[3][1] = G3_RD_A(3, 3, 1);
     }
@@ -225,10 +274,10 @@ __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, co
     } else if (P == 1) {
         G3_MMA(0, 2, s.ax, s.by) G3_MMA(0, 3, s.ax, s.by) G3_MMA(1, 2, s.ax, s.by) G3_MMA(1, 3, s.ax, s.by)
         G3_MMA(2, 2, s.ax, s.by) G3_MMA(2, 3, s.ax, s.by) G3_MMA(3, 2, s.ax, s.by) G3_MMA(3, 3, s.ax, s.by)
-    } else if (P == 2 && !HALF) {
+    } else if (P == 2) {
         G3_MMA(4, 2, s.ay, s.by) G3_MMA(4, 3, s.ay, s.by) G3_MMA(5, 2, s.ay, s.by) G3_MMA(5, 3, s.ay, s.by)
         G3_MMA(6, 2, s.ay, s.by) G3_MMA(6, 3, s.ay, s.by) G3_MMA(7, 2, s.ay, s.by) G3_MMA(7, 3, s.ay, s.by)
-    } else if (!HALF) {
+    } else {
         G3_MMA(4, 0, s.ay, s.bx) G3_MMA(4, 1, s.ay, s.bx) G3_MMA(5, 0, s.ay, s.bx) G3_MMA(5, 1, s.ay, s.bx)
         G3_MMA(6, 0, s.ay, s.bx) G3_MMA(6, 1, s.ay, s.bx) G3_MMA(7, 0, s.ay, s.bx) G3_MMA(7, 1, s.ay, s.bx)
     }
@@ -237,12 +286,13 @@ __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, co
     __builtin_amdgcn_s_barrier();
 }
 
-template <int BUF, bool TN = false, int SEAM = 0, bool HALF = false>
+template <int BUF, bool TN = false, int SEAM = 0, bool HALF = false, int SLACK = SEAM>
 __device__ __forceinline__ void g3_ktile(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1, bool cs_on = false) {
-    g3_phase<BUF, 0, TN, SEAM, HALF>(s, s0, k0, s1, k1, cs_on);
-    g3_phase<BUF, 1, TN, SEAM, HALF>(s, s0, k0, s1, k1, cs_on);
-    g3_phase<BUF, 2, TN, SEAM, HALF>(s, s0, k0, s1, k1, cs_on);
-    g3_phase<BUF, 3, TN, SEAM, HALF>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 0, TN, SEAM, HALF, SLACK>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 1, TN, SEAM, HALF, SLACK>(s, s0, k0, s1, k1, cs_on);
+    if (HALF) return;
+    g3_phase<BUF, 2, TN, SEAM, false, SLACK>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 3, TN, SEAM, false, SLACK>(s, s0, k0, s1, k1, cs_on);
 }
 
 __device__ __forceinline__ void g3_init_lane(G3State& s, const GemmParams& p, char* smem, int wave, int lane) {
@@ -438,6 +488,17 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
             if (ok) store8_from_f32(p.C, p.c_dtype, m * p.ldc + n[q], v0, v1);
         }
     }
+}
+
+// CUs of the current device (the resident / persistent forms launch one workgroup per CU)
+inline int g3_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
 }
 
 }  // namespace
