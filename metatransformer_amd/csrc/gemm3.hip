@@ -410,7 +410,10 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
 // row-operand loads); an under-count only makes the wait stricter
 template <int EPI, int PRE> constexpr int g3r_seam() { return (PRE == 1 || PRE == 2) ? 32 : EPI >= 2 ? 20 : 16; }
 
-template <int EPI, int PRE>
+// HI: this instantiation also carries the 128-row item form (run_item<HALF>): a second K-loop and epilogue in the kernel.  Only the
+// bias-only forms are built with it (launch3r): around the row-operand epilogues the extra scalar state pushed 16-27 VGPRs of
+// per-item spills into the seams (fc2 dgrad 244 -> 280 us in the training step), for items that buy next to nothing there.
+template <int EPI, int PRE, bool HI = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g3r_kernel(const GemmParams p) {
     constexpr int SEAM = g3r_seam<EPI, PRE>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -489,6 +492,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (kMeDev && trace && (wave & 3) == 0 && item < 16) {                                                      \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                             \
         if (lane == 0) trace[(((size_t)bid * 2 + wr) * 16 + item) * 8 + (i)] = t_;                              \
+        if ((i) == 0 || (i) == 5) {       /* the constant-rate counter next to the shader clock: effective clock under load */ \
+            const unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                                     \
+            if (lane == 0) trace[(((size_t)bid * 2 + wr) * 16 + item) * 8 + ((i) == 0 ? 6 : 7)] = r_;           \
+        }                                                                                                        \
     }
     // Which item comes next: static (slot + G8: every workgroup owns a fixed list) or, with p.g3_tickets, CLAIMED from the
     // XCD's counter -- a CU that is slow, or that could not take its workgroup for a while because a communication kernel
@@ -549,7 +556,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             g3_epilogue_r<EPI, PRE, HALF>(p, s, (int64_t)tm * G3_BM + (HALF ? part * 128 : 0), tn, 0, nxt, nkt0 + 1, brs, ntn, PRE == 3,
                                           has_next ? ctr : nullptr, nx, lds_tick);
         };
-        if (part >= 0) run_item(std::true_type{});
+        if (HI && part >= 0) run_item(std::true_type{});
         else run_item(std::false_type{});
         G3R_STAMP(5)
         if (kMeDev) ++item;
@@ -686,16 +693,17 @@ unsigned* g3r_tickets(hipStream_t stream) {
 }
 
 template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_t stream) {
+    constexpr bool HI = EPI == 0;              // which forms carry the 128-row items (see the kernel)
     static OncePerDevice once;
     if (once.need())
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS + 64);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE, HI>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS + 64);
     GemmParams q = q0;
     // Tile quantisation: T tiles on G resident workgroups take ceil(T / G) rounds, and the encoder's N = 768 outputs are 591 tiles =
     // 2.31 rounds (N = 3072: 9.23).  When at most half the CUs would work in the last round, its tiles run as two 128-row items
     // each -- same kernel, same epilogue, no slabs (g3_phase<.., HALF>): the last round then costs a little over half a round.
     const int tiles = q.tiles_m * q.tiles_n, rem = tiles % G;
     q.g3_full_tiles = tiles; q.g3_split = 1; q.g3_half = 0;
-    if (tiles >= G && rem > 0 && 2 * rem <= G && q.K >= 4 * G3_BK && gemm_dev().tail_split != 3) {
+    if (HI && tiles >= G && rem > 0 && 2 * rem <= G && q.K >= 4 * G3_BK && gemm_dev().tail_split != 3) {
         q.g3_full_tiles = tiles - rem;
         q.g3_half = 1;
     }
@@ -703,7 +711,7 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
     q.g3_tickets = (q.K >= 4 * G3_BK && gemm_dev().g3_persistent == 1) ? g3r_tickets(stream) : nullptr;
     if (kMeDev && gemm_dev().tail_split == 2) q.g3_tickets = nullptr;          // dev: "g3s" = static schedule
     ME_DEV_ONLY(q.colsum_ws = (q.debug & 8) ? reinterpret_cast<float*>(g_gemm_dev_trace) : nullptr;)
-    hipLaunchKernelGGL((gemm_g3r_kernel<EPI, PRE>), dim3((unsigned)G), dim3(512), G3_LDS + 64, stream, q);
+    hipLaunchKernelGGL((gemm_g3r_kernel<EPI, PRE, HI>), dim3((unsigned)G), dim3(512), G3_LDS + 64, stream, q);
     ME_CHECK_LAUNCH("me_gemm(g3 resident)");
     return ME_OK;
 }

@@ -145,7 +145,7 @@ class _WeightCache:
                 w32, g32, b32 = w.detach().float(), ln_w.detach().float(), ln_b.detach().float()
                 wf = (w32 * g32[None, :]).to(dtype).contiguous()
                 s_vec = wf.float().sum(dim=1).contiguous()
-                c_vec = (w32 @ b32)
+                c_vec = (w32 * b32[None, :]).sum(dim=1)        # (elementwise + reduce: no vendor BLAS call anywhere in the package)
                 if bias is not None:
                     c_vec = c_vec + bias.detach().float()
                 hit = (k, (wf, s_vec, c_vec.contiguous()))

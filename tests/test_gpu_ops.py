@@ -401,8 +401,9 @@ def test_attention_fp8_rejects_what_it_does_not_implement(dev):
 def test_gemm_resident_half_items_every_epilogue(dev, M, N, K):
     """Tile quantisation on the resident NT kernel: when the last round holds at most half the CUs' worth of tiles, those tiles
     run as two 128-row items each (gemm3.hip, g3_phase<.., HALF>).  Shapes chosen so that this happens (273 / 267 / 372 tiles on
-    256 CUs) with a ragged last tile row -- 77 rows: its second half is EMPTY; 200 rows: its second half is partial -- through
-    every epilogue form of the kernel, every output element checked."""
+    256 CUs) with a ragged last tile row -- 77 rows: its second half is EMPTY; 200 rows: its second half is partial.  The bias-only
+    and folded-LayerNorm forms carry the items (launch3r: HI); the other epilogues run the same shapes as whole tiles -- every form,
+    every output element checked."""
     dt = torch.bfloat16
     a, w, bias = rnd(M, K, seed=1).to(dt), (0.05 * rnd(N, K, seed=2)).to(dt), 0.1 * rnd(N, seed=3)
     lin = a.double() @ w.double().t() + bias.double()

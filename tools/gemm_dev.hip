@@ -379,6 +379,16 @@ int main(int argc, char** argv) {
                     mn = d < mn ? d : mn; mx = d > mx ? d : mx; sum += d; ++cnt;
                     xs[w & 7] += d; ++xc[w & 7];
                 }
+                {   // effective shader clock: s_memtime ticks per s_memrealtime tick (constant 100 MHz) over whole items
+                    double st_ = 0, rt_ = 0;
+                    for (int w = 0; w < 256; ++w)
+                        for (int it = 0; it < 16; ++it) {
+                            const unsigned long long* q = &h[(((size_t)w * 2) * 16 + it) * 8];
+                            if (!q[0] || !q[5] || !q[6] || !q[7]) continue;
+                            st_ += (double)(q[5] - q[0]); rt_ += (double)(q[7] - q[6]);
+                        }
+                    if (rt_ > 0) printf("  shader clock under this kernel: %.3f GHz (s_memtime ticks / s_memrealtime ticks x 100 MHz, summed over items)\n", st_ / rt_ * 0.1);
+                }
                 printf("  per-workgroup busy clocks: min %.0f  mean %.0f  max %.0f   per XCD mean:", mn, sum / cnt, mx);
                 for (int x = 0; x < 8; ++x) printf(" %.0f", xc[x] ? xs[x] / xc[x] : 0.0);
                 printf("\n");

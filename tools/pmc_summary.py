@@ -28,10 +28,9 @@ def main(mode):
             e["fetch_MB"] = round(2 * c["FETCH_SIZE"] / 1024, 1)
             e["write_MB"] = round(c.get("WRITE_SIZE", 0) / 1024, 1)
             e["hbm_traffic_MB"] = round(e["fetch_MB"] + e["write_MB"], 1)
-        if "GRBM_GUI_ACTIVE" in c and dur.get(k):
-            # effective shader clock under this kernel: busy cycles of the graphics block over the launch's wall time (the chip
-            # clocks to its power budget -- MI355X_MICROARCH.md "DVFS give-back"; profiled passes run a few per cent lower)
-            e["clock_GHz"] = round(c["GRBM_GUI_ACTIVE"] / (1e3 * sum(dur[k]) / len(dur[k])), 3)
+        # (GRBM_GUI_ACTIVE over the launch's wall time is NOT used as a clock estimate here: the counter is summed over the eight XCDs
+        # and over a different pass than the durations -- it gave 2.1 .. 2.7 "GHz".  The effective clock under a kernel is measured
+        # inside it instead: s_memtime against s_memrealtime, tools/gemm_dev debug bit 8 -> profiles/r03_gemm_dev_clock.txt.)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
             e["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 256 * 4), 4)
         if "SQ_WAVE_CYCLES" in c:
