@@ -645,8 +645,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
 // developer instrumentation (tools/attn_trace.hip defines ME_ATTN_TRACE and includes this file): per-workgroup
 // s_memtime stamps at the phase boundaries; compiled out of libmetaenc.so
 #ifdef ME_ATTN_TRACE
-__device__ long long g_trace[1 << 16];
-#define TRACE_STAMP(slot, k) do { if (threadIdx.x == 0 && (slot) < (1 << 12)) g_trace[(slot) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+__device__ long long g_trace[1 << 19];      // [item slot < 4096][wave < 16][stamp < 8]
+#define TRACE_STAMP(slot, k) do { if ((threadIdx.x & 63) == 0 && (slot) < (1 << 12)) g_trace[((slot) * 16 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define TRACE_STAMP(slot, k) do { } while (0)
 #endif
@@ -661,8 +661,9 @@ template <int HD, int NARR, int MAXN = SM_MAXN, int NTHR = SM_THREADS> struct Sm
     static constexpr int CPR = HD / 8;
     static constexpr int ITEMS = (MAXN * CPR) / NTHR;
     u32x4 v[NARR][ITEMS];
-    // branch-free: out-of-range rows / chunks read a clamped (valid) address and are zeroed afterwards, so every load
-    // of every array is in flight before the first use
+    // branch-free: out-of-range rows / chunks read a clamped (valid) address; they are zeroed when the values are WRITTEN to
+    // LDS (store), not here -- a select on a loaded value right behind the load makes the wave wait for the data, which
+    // is exactly what a prefetch must not do (measured: ~4 k of 15.7 k clocks per item in the persistent forward)
     __device__ __forceinline__ void load(const bf16_t* const (&base)[NARR], const int64_t (&ld)[NARR], int N, int hd, int tid) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -672,19 +673,19 @@ template <int HD, int NARR, int MAXN = SM_MAXN, int NTHR = SM_THREADS> struct Sm
             const int rc = ok ? row : 0, cc = ok ? chunk : 0;
 #pragma unroll
             for (int a = 0; a < NARR; ++a) v[a][i] = *reinterpret_cast<const u32x4*>(base[a] + (int64_t)rc * ld[a] + cc * 8);
-#pragma unroll
-            for (int a = 0; a < NARR; ++a) v[a][i] = ok ? v[a][i] : zero4();
         }
     }
-    __device__ __forceinline__ void store(char* const (&lds)[NARR], int NR, int tid) const {
+    // N / hd: the bounds the matching load() was given (rows >= N and chunks past hd are written as zeros)
+    __device__ __forceinline__ void store(char* const (&lds)[NARR], int NR, int tid, int N, int hd) const {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const int it = tid + NTHR * i;
             const int chunk = it % CPR, row = it / CPR;
+            const bool ok = (row < N) && (chunk * 8 < hd);
             if (row < NR) {
 #pragma unroll
                 for (int a = 0; a < NARR; ++a)
-                    *reinterpret_cast<u32x4*>(lds[a] + row * Cfg<bf16_t, HD>::RROW + chunk * 16) = v[a][i];
+                    *reinterpret_cast<u32x4*>(lds[a] + row * Cfg<bf16_t, HD>::RROW + chunk * 16) = ok ? v[a][i] : zero4();
             }
         }
     }
@@ -804,18 +805,27 @@ __global__ __launch_bounds__(SM_THREADS) void attn_fwd_small_kernel(const bf16_t
         for (int kk = 0; kk < C::NKK; ++kk) {
             const int d = (2 * kk + h) * 8;
             const bool ok = d < hd;
-            u32x4 raw = *reinterpret_cast<const u32x4*>(qptr + (int64_t)qrow * ld + (ok ? d : 0));
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(qptr + (int64_t)qrow * ld + (ok ? d : 0));
+            qdst[kk] = *reinterpret_cast<const bf16x8*>(&raw);      // (chunks past hd are zeroed by q_take, when the value is first needed)
+        }
+    };
+    auto q_take = [&](const bf16x8 (&src)[C::NKK]) {
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            const bool ok = (2 * kk + h) * 8 < hd;
+            u32x4 raw = *reinterpret_cast<const u32x4*>(&src[kk]);
             raw = ok ? raw : zero4();
-            qdst[kk] = *reinterpret_cast<bf16x8*>(&raw);
+            qf[kk] = *reinterpret_cast<bf16x8*>(&raw);
         }
     };
     auto park = [&]() {
         char* const tiles[2] = {Ks, Vs};
-        st.store(tiles, NR, fresh_tid());
+        st.store(tiles, NR, fresh_tid(), N, hd);
     };
     int it = blockIdx.x;
-    issue(it, qf);
+    issue(it, qn);
     park();
+    q_take(qn);
     __syncthreads();
     for (; it < items; it += gridDim.x) {
         const int nxt = (it + (int)gridDim.x < items) ? it + (int)gridDim.x : it;
@@ -848,10 +858,539 @@ __global__ __launch_bounds__(SM_THREADS) void attn_fwd_small_kernel(const bf16_t
         TRACE_STAMP(it, 3);
         park();
         TRACE_STAMP(it, 4);
-#pragma unroll
-        for (int kk = 0; kk < C::NKK; ++kk) qf[kk] = qn[kk];
+        q_take(qn);
         __syncthreads();
         TRACE_STAMP(it, 5);
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Resident-sequence forward, ring form (SM_MINN < N <= RS_MAXN = 224: every Base / Large image, window and point-cloud
+// shape).  What the per-wave time stamps of the kernel above showed (tools/attn_trace, N = 197: 15.3 k clocks per item):
+// ~4 k clocks in which every wave sits in the ISSUE of its prefetch loads (the CU's vector-memory path takes ~32 B/clk, a
+// whole item's 100 KB asked for at once backs the queue up and an in-order wave cannot get past a load it cannot issue),
+// ~1 k parking the prefetched rows in LDS between two barriers, and a step loop in which one wave's MFMAs and its SIMD
+// partner's softmax arithmetic hardly overlap (each 64-key step is 16 MFMAs + ~180 VALU slots, strictly alternating, both
+// waves in the same phase).  This form:
+//   * K / V of the NEXT item go global -> LDS by DMA (buffer_load ... lds) into the other half of a two-item ring, one
+//     instruction (1 KiB) per 32-key sub-tile of the current item's QK^T pass: nothing queues, no staging registers, no
+//     park phase, ONE barrier per item.  Rows are unpadded; the 16-byte chunks are XOR-swizzled on the SOURCE side (a DMA
+//     lane chooses which global chunk lands in its fixed LDS slot) so that both the 16-byte row reads and the transposing
+//     ds_read_b64_tr_b16 reads stay bank-conflict free.  Rows >= N and chunks >= hd arrive as zeros through the buffer
+//     descriptor's bounds check.
+//   * two-pass softmax: N <= 224 keeps the whole S^T row block (7 x 16 accumulator registers per lane) in registers, so
+//     there is no running maximum, no rescale of O and no per-step shuffle -- and the pass structure (28 MFMAs | softmax
+//     VALU | 28 MFMAs) lets the two waves of a SIMD run out of phase, one on the matrix pipe while the other does VALU.
+//   * the output of item i is stored AFTER the item barrier, i.e. under the next item's QK^T pass.
+typedef __attribute__((address_space(3))) void lds_dma_t;
+constexpr int RS_MAXN = 224;
+constexpr int RS_MAXS = RS_MAXN / 32;
+template <int HD> struct RCfg {
+    static constexpr int RB = HD * 2;                          // bytes per (unpadded) row
+    static constexpr int CPR = HD / 8;                         // 16-byte chunks per row
+    static constexpr int RPI = 1024 / RB;                      // rows one DMA instruction fills (64 lanes x 16 B)
+    static constexpr int SCR = 32 * Cfg<bf16_t, HD>::RROW;     // per-wave output transposition scratch (padded rows)
+};
+// chunk c of row r lives in 16-byte slot c ^ rs_swz(r).  The LDS services a ds_read_b128 in four groups of 16 lanes --
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- over 64 banks = one 256-byte bank row per cycle
+// (MI355X_MICROARCH.md, LDS), and a ds_read_b64_tr_b16 in two groups of 32 lanes.  HD = 64 (two rows per bank row):
+// the QK^T operand read (lane = row, one chunk) needs 16 distinct (row parity, slot) pairs over the rows of a lane group,
+// i.e. the swizzle must take 8 values over rows {0,2,12,14,20,22,24,26} and over {4,6,8,10,16,18,28,30}: any bijection of
+// row bits 1..3 does; the transposing PV read (4 consecutive rows x 4 consecutive chunks per group) additionally needs rows
+// r and r + 2 to land in different halves of the bank row -> row bit 1 goes to slot bit 2.  HD = 32 (four rows per bank
+// row): row bits 2..3.
+template <int CPR> __device__ __forceinline__ int rs_swz(int r) {
+    return CPR == 8 ? ((((r >> 1) & 1) << 2) | ((r >> 2) & 3)) : ((r >> 2) & 3);
+}
+
+// NS = number of 32-key sub-tiles = ceil(N / 32), a template parameter: every loop below is straight-line code, so the
+// s_waitcnt counts the compiler derives are exact (with run-time guards it must assume the shortest path at every join).
+// Waves 0 .. NS-1 (NS <= 7) own 32 queries each; WAVE 7 IS THE LOADER: it issues every DMA instruction of the next item
+// (an LDS-DMA piece costs its issuer 60-180 clocks -- MI355X_MICROARCH.md -- which the compute waves do not have) and
+// otherwise only keeps the barrier count.
+template <int HD, int NS>
+__global__ __launch_bounds__(SM_THREADS) void attn_fwd_ring_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                   bf16_t* __restrict__ out, int64_t ldo,
+                                                                   float* __restrict__ lse, int N, int H, int hd,
+                                                                   float scale, int items) {
+    typedef Cfg<bf16_t, HD> C;
+    typedef RCfg<HD> R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NR = NS * 32;
+    constexpr int arr_bytes = NR * R::RB;             // one array (K or V) of one item
+    constexpr int NRI = NR / R::RPI;                  // DMA instructions per array
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    char* scr = smem + 4 * arr_bytes + wave * R::SCR;
+    const int Cdim = H * hd;
+    const int q = 32 * wave + l31;
+    const int qrow = (q < N) ? q : N - 1;
+    const bool active = 32 * wave < N;                // wave-uniform
+    const bool loader = wave == 7;
+    const float sl = scale * LOG2E;
+    const int G = (int)gridDim.x;
+
+    if (loader) {
+        // ---- the loader wave: lane l fills LDS bytes [16 l, 16 l + 16) of an instruction's 1 KiB = slot `pos` of row `rg` of
+        // the row group; it fetches the chunk that belongs there (HD = 64: the swizzle of row 8 g + rg depends on g's parity)
+        const int rg = (lane * 16) / R::RB, pos = ((lane * 16) % R::RB) / 16;
+        int dma_voff[2];
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int csrc = pos ^ rs_swz<R::CPR>(rg + (R::RPI == 8 ? 8 * par : 0));
+            dma_voff[par] = (csrc * 8 < hd) ? rg * (int)ld * 2 + csrc * 16 : 0x7f000000;      // (out of range -> zeros)
+        }
+        const int dma_gstep = R::RPI * (int)ld * 2;
+        const int rec_bytes = (int)(((int64_t)(N - 1) * ld + hd) * 2);
+        // PACED: in the steady state one (K, V) pair of pieces every ~200 clocks.  Asked for all at once, an item's 56 KiB backs
+        // up the CU's vector-memory path and the compute waves' own few loads and stores queue behind it (time stamps: 2-3 k
+        // clocks lost at the head of every item).
+        auto fill = [&](int it, char* half, bool paced) {
+            const bf16_t* base = qkv + (int64_t)(it / H) * N * ld + (it % H) * hd + Cdim;
+            const __amdgpu_buffer_rsrc_t kd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, rec_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t vd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base + Cdim), 0, rec_bytes, 0x00020000);
+#pragma unroll
+            for (int g = 0; g < NRI; ++g) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(kd, (lds_dma_t*)(half + g * 1024), 16, dma_voff[g & 1] + g * dma_gstep, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vd, (lds_dma_t*)(half + arr_bytes + g * 1024), 16, dma_voff[g & 1] + g * dma_gstep, 0, 0, 0);
+                if (paced) __builtin_amdgcn_s_sleep(2);
+            }
+        };
+        int it = blockIdx.x, cur = 0;
+        fill(it, smem, false);
+        __syncthreads();
+        for (; it < items; it += G) {
+            if (it + G < items) fill(it + G, smem + (cur ^ 1) * 2 * arr_bytes, true);
+            __syncthreads();                          // (vmcnt(0) first: the fill has landed)
+            cur ^= 1;
+        }
+        return;
+    }
+
+    // ---- compute waves: per-lane constants
+    // QK^T operand: row 32 u + l31, chunk 2 kk + h
+    int koff[C::NKK];
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk) koff[kk] = l31 * R::RB + 16 * ((2 * kk + h) ^ rs_swz<R::CPR>(l31));
+    // PV operand (transposing read, see tr_chunk): rows 16 c + 8 r + rr, 8 bytes at column 32 db + 16 (g & 1) + 4 (p & 3)
+    int voff[C::NDB][2];
+    {
+        const int g = lane >> 4, p = lane & 15, rr = 4 * (g >> 1) + (p >> 2), low = 2 * (g & 1) + ((p >> 1) & 1);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                voff[db][r] = (8 * r + rr) * R::RB + 16 * ((4 * db + low) ^ rs_swz<R::CPR>(8 * r + rr)) + 8 * (p & 1);
+    }
+
+    bf16x8 qf[C::NKK], qn[C::NKK];
+    auto q_issue = [&](int it) {
+        const bf16_t* qptr = qkv + (int64_t)(it / H) * N * ld + (it % H) * hd;
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            const int d = (2 * kk + h) * 8;
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(qptr + (int64_t)qrow * ld + (d < hd ? d : 0));
+            qn[kk] = *reinterpret_cast<const bf16x8*>(&raw);
+        }
+    };
+    auto q_take = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < C::NKK; ++kk) {
+            const bool ok = (2 * kk + h) * 8 < hd;
+            u32x4 raw = *reinterpret_cast<const u32x4*>(&qn[kk]);
+            raw = ok ? raw : zero4();
+            qf[kk] = *reinterpret_cast<bf16x8*>(&raw);
+        }
+    };
+
+    // the finished item whose output is still in registers (stored under the next item's QK^T pass)
+    f32x16 o[C::NDB];
+    float m2 = 0.f, l_tot = 1.f;
+    int it_out = -1;
+    auto flush = [&]() {
+        const float inv = 1.0f / l_tot;
+        const int b = it_out / H, head = it_out % H;
+        store_rows_via_lds<HD>(scr, o, inv, out + ((int64_t)b * N + 32 * wave) * ldo + head * hd, ldo, N - 32 * wave, hd, lane);
+        if (lse && h == 0 && q < N) lse[((int64_t)b * H + head) * N + q] = (m2 + __builtin_amdgcn_logf(l_tot)) * LN2;
+    };
+
+    int it = blockIdx.x;
+    q_issue(it);
+    int cur = 0;
+    __syncthreads();
+    for (; it < items; it += G) {
+        const int nxt = (it + G < items) ? it + G : it;
+        TRACE_STAMP(it, 0);
+        q_take();
+        TRACE_STAMP(it, 1);
+        const char* Kb = smem + cur * 2 * arr_bytes;
+        const char* Vb = Kb + arr_bytes;
+        if (active) {
+            // ---- pass 1: S^T[kv][q] for every 32-key sub-tile.  Software-pipelined by hand (left alone hipcc emits read ->
+            // wait -> MFMA one fragment at a time): the four operand chunks of sub-tile u + 1 are in flight while the four MFMAs
+            // of sub-tile u run; the previous item's output leaves behind the first MFMA group.
+            f32x16 s[NS];
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            bf16x8 ka[C::NKK], kb[C::NKK];
+            auto kread = [&](int u, bf16x8 (&dst)[C::NKK]) {
+#pragma unroll
+                for (int kk = 0; kk < C::NKK; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(Kb + 32 * u * R::RB + koff[kk]);
+            };
+            auto kmma = [&](int u, const bf16x8 (&src)[C::NKK]) {
+                s[u] = mma_chunk(src[0], qf[0], zero16);
+#pragma unroll
+                for (int kk = 1; kk < C::NKK; ++kk) s[u] = mma_chunk(src[kk], qf[kk], s[u]);
+            };
+            // (priority: a wave in a matrix pass outranks its SIMD partner's softmax arithmetic -- an MFMA needs one issue slot per 32
+            //  clocks, which the arbiter otherwise hands to the older wave's unbroken VALU stream)
+            __builtin_amdgcn_s_setprio(1);
+            kread(0, ka);
+#pragma unroll
+            for (int u = 0; u < NS; u += 2) {
+                if (u + 1 < NS) kread(u + 1, kb);
+                __builtin_amdgcn_sched_barrier(0);
+                kmma(u, ka);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u == 0) { TRACE_STAMP(it, 2); if (it_out >= 0) flush(); TRACE_STAMP(it, 3); }
+                if (u + 1 < NS) {
+                    if (u + 2 < NS) kread(u + 2, ka);
+                    __builtin_amdgcn_sched_barrier(0);
+                    kmma(u + 1, kb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            TRACE_STAMP(it, 4);
+            q_issue(nxt);                             // (here, not at the head of the item: the memory path is quiet now)
+            // ---- softmax over the whole row (registers only)
+            if (N & 31) {
+                // (the bound is made opaque per item: left visible, hipcc hoists the lane masks out of the item loop into SGPRs)
+                int nkeys = N - 4 * h;
+                asm volatile("" : "+v"(nkeys));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[NS - 1][r] = (32 * (NS - 1) + acc_row(r, 0) < nkeys) ? s[NS - 1][r] : -INFINITY;
+            }
+            float mt = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < NS; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[u][r]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            m2 = mt * sl;
+            float ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < NS; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pe = __builtin_amdgcn_exp2f(s[u][r] * sl - m2);
+                    s[u][r] = pe;
+                    ps += pe;
+                }
+            l_tot = ps + __shfl_xor(ps, 32, 64);
+            TRACE_STAMP(it, 5);
+            // ---- pass 2: O^T[d][q] = V^T P^T, 16 keys (one P chunk) at a time; the V^T operand of chunk c + 1 is in flight
+            // while chunk c's MFMAs run
+            bf16x8 va[C::NDB], vb[C::NDB];
+            auto vread = [&](int c, bf16x8 (&dst)[C::NDB]) {
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) {
+                    union { bf16x4 q4[2]; bf16x8 v; } a;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+                        a.q4[r] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (lds_bf16x4_t*)((uint32_t)(uintptr_t)Vb + 16 * c * R::RB + voff[db][r]));
+                    dst[db] = a.v;
+                }
+            };
+            auto vmma = [&](int c, const bf16x8 (&src)[C::NDB], bool first) {
+                bf16x8 pb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[e] = (bf16_t)s[c >> 1][8 * (c & 1) + e];
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) o[db] = mma_chunk(src[db], pb, first ? zero16 : o[db]);
+            };
+            __builtin_amdgcn_s_setprio(1);
+            vread(0, va);
+#pragma unroll
+            for (int c = 0; c < 2 * NS; c += 2) {
+                vread(c + 1, vb);
+                __builtin_amdgcn_sched_barrier(0);
+                vmma(c, va, c == 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 2 < 2 * NS) vread(c + 2, va);
+                __builtin_amdgcn_sched_barrier(0);
+                vmma(c + 1, vb, false);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            it_out = it;
+            TRACE_STAMP(it, 6);
+        }
+        __syncthreads();      // the loader's fill of the other half has landed and every wave is done with `cur`
+        TRACE_STAMP(it, 7);
+        cur ^= 1;
+    }
+    if (active && it_out >= 0) flush();
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Ring form with 16-query waves.  tools/probe_valu: ONE wave issues a VALU instruction every ~5 clocks whatever it is, but a SIMD
+// retires one per ~1.9 (add / fma), ~2.8 (max3, cvt_pk, packed) or ~5.3 (exp) clocks once three or four waves feed it -- the
+// softmax arithmetic of this kernel is bound by how many waves issue it, not by the VALU itself, and two 250-register waves per
+// SIMD leave more than half of it idle.  So: 16 waves per workgroup (four per SIMD, <= 128 registers each), a wave owns 16
+// queries and uses the 16 x 16 x 32 MFMA:
+//   S^T tile (16 keys x 16 queries) = K rows (A: lane = key l & 15, d = 8 (l >> 4) ..) x Q^T (B: lane = query l & 15, same d)
+//       -> lane (query l & 15, g = l >> 4) holds keys 16 t + 4 g + j, j = 0..3;
+//   O^T tile (16 d x 16 queries) += V^T (A, transposing read) x P^T (B): a lane's 8 reduction slots of a 32-key step are
+//       exactly the 2 x 4 accumulator registers it already holds (keys 32 kk + 4 g + j and 32 kk + 16 + 4 g + j), and the
+//       transposing read fetches V^T in the same order -- no cross-lane movement between the two products.
+// Waves 14 and 15 are the loaders (paced LDS-DMA of the next item's K and V into the other ring half), other waves >= ceil(N / 16)
+// only keep the barrier.
+constexpr int R16_THREADS = 1024;
+// slot of chunk c in row r: c ^ r16_swz(r).  HD = 64: the b128 operand read has lanes {0-3, 12-15} on rows r, chunk c and lanes
+// {20-27} on rows 4-11, chunk c + 1 in one LDS cycle, the transposing read 8 consecutive rows x one aligned chunk pair: row bits
+// 1..2 -> slot bits 1..2 separates both.  HD = 32 (four rows per 256-byte bank row): per 4-row block the values 0, 2, 3, 1.
+template <int CPR> __device__ __forceinline__ int r16_swz(int r) {
+    return CPR == 8 ? (((r >> 1) & 3) << 1) : ((0x78 >> (2 * ((r >> 2) & 3))) & 3);
+}
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+template <int HD, int NS>
+__global__ __launch_bounds__(R16_THREADS) void attn_fwd_ring16_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                      bf16_t* __restrict__ out, int64_t ldo,
+                                                                      float* __restrict__ lse, int N, int H, int hd,
+                                                                      float scale, int items) {
+    typedef Cfg<bf16_t, HD> C;
+    typedef RCfg<HD> R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NR = NS * 32;
+    constexpr int arr_bytes = NR * R::RB;             // one array (K or V) of one item
+    constexpr int NRI = NR / R::RPI;                  // DMA instructions per array
+    constexpr int NT = 2 * NS;                        // 16-key tiles
+    constexpr int NKS = HD / 32;                      // 32-wide d steps of QK^T
+    constexpr int NDT = HD / 16;                      // 16-wide d tiles of O^T
+    constexpr int SCR = 16 * C::RROW;                 // per-wave output transposition scratch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int Cdim = H * hd;
+    const int G = (int)gridDim.x;
+    const bool active = 16 * wave < N;                // wave-uniform
+
+    if (!active) {
+        if (wave < 14) {                              // spare waves: the barrier count only
+            __syncthreads();
+            for (int it = blockIdx.x; it < items; it += G) __syncthreads();
+            return;
+        }
+        // ---- the two loader waves (14: K, 15: V): lane l fills LDS bytes [16 l, 16 l + 16) of an instruction's 1 KiB = slot `pos` of row `rg` of the
+        // row group, with the chunk that belongs there; rows >= N / chunks >= hd are out of the descriptor's range -> zeros
+        const int rg = (lane * 16) / R::RB, pos = ((lane * 16) % R::RB) / 16;
+        const int csrc = pos ^ r16_swz<R::CPR>(rg);
+        const int dma_voff = (csrc * 8 < hd) ? rg * (int)ld * 2 + csrc * 16 : 0x7f000000;
+        const int dma_gstep = R::RPI * (int)ld * 2;
+        const int rec_bytes = (int)(((int64_t)(N - 1) * ld + hd) * 2);
+        // PACED in the steady state (one piece per ~150 clocks and loader): asked for all at once, an item's 56 KiB backs up the
+        // CU's vector-memory path and the compute waves' own loads and stores queue behind it
+        const int which = wave - 14;                  // 0: K, 1: V
+        auto fill = [&](int it, char* half, bool paced) {
+            const bf16_t* base = qkv + (int64_t)(it / H) * N * ld + (it % H) * hd + (1 + which) * Cdim;
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, rec_bytes, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NRI; ++i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(half + which * arr_bytes + i * 1024), 16, dma_voff + i * dma_gstep, 0, 0, 0);
+                if (paced) __builtin_amdgcn_s_sleep(1);
+            }
+        };
+        int it = blockIdx.x, cur = 0;
+        fill(it, smem, false);
+        __syncthreads();
+        for (; it < items; it += G) {
+            if (it + G < items) fill(it + G, smem + (cur ^ 1) * 2 * arr_bytes, true);
+            __syncthreads();                          // (vmcnt(0) first: the fill has landed)
+            cur ^= 1;
+        }
+        return;
+    }
+
+    // ---- compute waves
+    char* scr = smem + 4 * arr_bytes + wave * SCR;
+    const int q = 16 * wave + l15;
+    const int qrow = (q < N) ? q : N - 1;
+    const float sl = scale * LOG2E;
+    int koff[NKS];                                    // QK^T operand: row 16 t + l15, chunk 4 ks + g
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) koff[ks] = l15 * R::RB + 16 * ((4 * ks + g) ^ r16_swz<R::CPR>(l15));
+    int voff[NDT];                                    // PV operand: rows 32 kk + 16 r + 4 g + (l15 >> 2), 8 bytes at d = 16 dt + 4 (l15 & 3)
+    {
+        const int rr = 4 * g + (l15 >> 2);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+            voff[dt] = rr * R::RB + 16 * ((2 * dt + ((l15 & 3) >> 1)) ^ r16_swz<R::CPR>(rr)) + 8 * (l15 & 1);
+    }
+
+    bf16x8 qf[NKS], qn[NKS];
+    auto q_issue = [&](int it) {
+        const bf16_t* qptr = qkv + (int64_t)(it / H) * N * ld + (it % H) * hd;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = 32 * ks + 8 * g;
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(qptr + (int64_t)qrow * ld + (d < hd ? d : 0));
+            qn[ks] = *reinterpret_cast<const bf16x8*>(&raw);
+        }
+    };
+    auto q_take = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bool ok = 32 * ks + 8 * g < hd;
+            u32x4 raw = *reinterpret_cast<const u32x4*>(&qn[ks]);
+            raw = ok ? raw : zero4();
+            qf[ks] = *reinterpret_cast<bf16x8*>(&raw);
+        }
+    };
+
+    f32x4 o[NDT];
+    float m2 = 0.f, l_tot = 1.f;
+    int it_out = -1;
+    auto flush = [&]() {
+        const float inv = 1.0f / l_tot;
+        const int b = it_out / H, head = it_out % H;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            bf16x4 v4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(o[dt][e] * inv);
+            *reinterpret_cast<bf16x4*>(scr + l15 * C::RROW + (16 * dt + 4 * g) * 2) = v4;
+        }
+        __builtin_amdgcn_wave_barrier();
+        bf16_t* grow0 = out + ((int64_t)b * N + 16 * wave) * ldo + head * hd;
+        constexpr int RPI = 64 / C::CPR;              // rows per store instruction
+        const int chunk = lane % C::CPR, r0 = lane / C::CPR;
+#pragma unroll
+        for (int k = 0; k < 16 / RPI; ++k) {
+            const int r = r0 + RPI * k;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(scr + r * C::RROW + chunk * 16);
+            if (16 * wave + r < N && chunk * 8 < hd) *reinterpret_cast<u32x4*>(grow0 + (int64_t)r * ldo + chunk * 8) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lse && g == 0 && q < N) lse[((int64_t)b * H + head) * N + q] = (m2 + __builtin_amdgcn_logf(l_tot)) * LN2;
+    };
+
+    int it = blockIdx.x;
+    q_issue(it);
+    int cur = 0;
+    __syncthreads();
+    for (; it < items; it += G) {
+        const int nxt = (it + G < items) ? it + G : it;
+        TRACE_STAMP(it, 0);
+        q_take();
+        const char* Kb = smem + cur * 2 * arr_bytes;
+        const char* Vb = Kb + arr_bytes;
+        // ---- pass 1: S^T, two 16-key tiles at a time; the operand chunks of the next pair are in flight while this pair's
+        // MFMAs run (software-pipelined by hand: left alone hipcc emits read -> wait -> MFMA one fragment at a time)
+        f32x4 s[NT];
+        const f32x4 zero4f = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 ka[2][NKS], kb[2][NKS];
+        auto kread = [&](int t, bf16x8 (&dst)[2][NKS]) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) dst[tt][ks] = *reinterpret_cast<const bf16x8*>(Kb + 16 * (t + tt) * R::RB + koff[ks]);
+        };
+        auto kmma = [&](int t, const bf16x8 (&src)[2][NKS]) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) s[t + tt] = mma16(src[tt][0], qf[0], zero4f);
+#pragma unroll
+            for (int ks = 1; ks < NKS; ++ks)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) s[t + tt] = mma16(src[tt][ks], qf[ks], s[t + tt]);
+        };
+        kread(0, ka);
+#pragma unroll
+        for (int t = 0; t < NT; t += 4) {
+            if (t + 2 < NT) kread(t + 2, kb);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(t, ka);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == 0) { TRACE_STAMP(it, 1); }
+            if (t + 2 < NT) {
+                if (t + 4 < NT) kread(t + 4, ka);
+                __builtin_amdgcn_sched_barrier(0);
+                kmma(t + 2, kb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        TRACE_STAMP(it, 3);
+        q_issue(nxt);                                 // (here, not at the head of the item: the memory path is quiet now)
+        // ---- softmax over the whole row (registers only); keys >= N sit in the last two tiles
+        if (N & 31) {
+            int nkeys = N - 4 * g;                    // (opaque per item: hipcc would hoist the lane masks into SGPRs)
+            asm volatile("" : "+v"(nkeys));
+#pragma unroll
+            for (int t = NT - 2; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[t][e] = (16 * t + e < nkeys) ? s[t][e] : -INFINITY;
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[t][e]);
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        m2 = mt * sl;
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(s[t][e] * sl - m2);
+                s[t][e] = pe;
+                ps += pe;
+            }
+        ps += __shfl_xor(ps, 16, 64);
+        l_tot = ps + __shfl_xor(ps, 32, 64);
+        TRACE_STAMP(it, 4);
+        // ---- pass 2: O^T += V^T P^T, 32 keys at a time, the d tiles in two halves: the V^T operand of the next half is in flight
+        // while this half's MFMAs run (half-steps keep the operand buffers at 2 x NDT / 2 fragments: the kernel has to fit 128 registers)
+        constexpr int NH = NDT / 2;
+        bf16x8 va[NH], vb[NH];
+        auto vread = [&](int kk, int half, bf16x8 (&dst)[NH]) {
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                union { bf16x4 q4[2]; bf16x8 v; } a;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    a.q4[r] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4_t*)((uint32_t)(uintptr_t)Vb + (32 * kk + 16 * r) * R::RB + voff[NH * half + i]));
+                dst[i] = a.v;
+            }
+        };
+        vread(0, 0, va);
+#pragma unroll
+        for (int kk = 0; kk < NS; ++kk) {
+            vread(kk, 1, vb);
+            bf16x8 pb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pb[e] = (bf16_t)s[2 * kk][e]; pb[4 + e] = (bf16_t)s[2 * kk + 1][e]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NH; ++i) o[i] = mma16(va[i], pb, kk == 0 ? zero4f : o[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < NS) vread(kk + 1, 0, va);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NH; ++i) o[NH + i] = mma16(vb[i], pb, kk == 0 ? zero4f : o[NH + i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        it_out = it;
+        TRACE_STAMP(it, 5);
+        flush();
+        TRACE_STAMP(it, 2);
+        __syncthreads();      // the loader's fill of the other half has landed and every wave is done with `cur`
+        TRACE_STAMP(it, 6);
+        cur ^= 1;
     }
 }
 
@@ -994,7 +1533,7 @@ __global__ __launch_bounds__(SM_THREADS) void attn_bwd_small_kernel(const bf16_t
     const float lse_mine = (tid < N && tid < SM_MAXN) ? lse[bh + tid] * LOG2E : INFINITY;
     {
         char* const tiles[4] = {Qs, Ks, Vs, dOs};
-        st.store(tiles, NR, tid);
+        st.store(tiles, NR, tid, N, hd);
     }
     if (tid < SM_MAXN) lse_s[tid] = lse_mine;
     __syncthreads();
@@ -1101,7 +1640,7 @@ __global__ __launch_bounds__(NTHR) void attn_fwd_mid_kernel(const bf16_t* __rest
         const int64_t ldv[2] = {ld, ld};
         st.load(bases, ldv, N, hd, tid);
         char* const tiles[2] = {Ks, Vs};
-        st.store(tiles, NR, tid);
+        st.store(tiles, NR, tid, N, hd);
     }
     __syncthreads();
     const float sl = scale * LOG2E;
@@ -1178,7 +1717,7 @@ __global__ __launch_bounds__(NTHR) void attn_bwd_mid_kernel(const bf16_t* __rest
         const int64_t ldv[2] = {ld, ld};
         st.load(bases, ldv, N, hd, tid);
         char* const tiles[2] = {T0, T1};
-        st.store(tiles, NR, tid);
+        st.store(tiles, NR, tid, N, hd);
     }
     for (int i = tid; i < MAXN; i += NTHR) lse_s[i] = i < N ? lse[bh + i] * LOG2E : INFINITY;
     __syncthreads();
@@ -1258,7 +1797,7 @@ __global__ __launch_bounds__(NTHR) void attn_bwd_mid_kernel(const bf16_t* __rest
         const int64_t ldv[2] = {ld, lddo};
         st.load(bases, ldv, N, hd, tid);
         char* const tiles[2] = {T0, T1};
-        st.store(tiles, NR, tid);
+        st.store(tiles, NR, tid, N, hd);
     }
     __syncthreads();
     // ---- pass B (Q / dO resident): dK, dV, a wave walks its 32-key groups
@@ -1348,7 +1887,7 @@ __global__ __launch_bounds__(SM_THREADS) void attn_fwd_chunk_kernel(const bf16_t
             const int64_t ldv[2] = {ld, ld};
             st.load(bases, ldv, rows, hd, tid);
             char* const tiles[2] = {Ks, Vs};
-            st.store(tiles, NSc * 32, tid);
+            st.store(tiles, NSc * 32, tid, rows, hd);
         }
         __syncthreads();
         if (!active) continue;
@@ -1440,7 +1979,7 @@ __global__ __launch_bounds__(SM_THREADS) void attn_bwd_dq_chunk_kernel(const bf1
             const int64_t ldv[2] = {ld, ld};
             st.load(bases, ldv, rows, hd, tid);
             char* const tiles[2] = {Ks, Vs};
-            st.store(tiles, NSc * 32, tid);
+            st.store(tiles, NSc * 32, tid, rows, hd);
         }
         __syncthreads();
         if (!active) continue;
@@ -1518,7 +2057,7 @@ __global__ __launch_bounds__(SM_THREADS) void attn_bwd_dkdv_chunk_kernel(const b
             const int64_t ldv[2] = {ld, lddo};
             st.load(bases, ldv, rows, hd, tid);
             char* const tiles[2] = {Qs, dOs};
-            st.store(tiles, NSc * 32, tid);
+            st.store(tiles, NSc * 32, tid, rows, hd);
         }
         if (tid < CH_ROWS) {
             const bool ok = tid < rows;
@@ -1581,6 +2120,60 @@ int launch_fwd_small(const void* qkv, int64_t ld, void* out, int64_t ldo, float*
                        (int)items);
     ME_CHECK_LAUNCH("me_attention_fwd(small)");
     return ME_OK;
+}
+template <int HD, int NS>
+int launch_fwd_ring_ns(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
+                       hipStream_t stream) {
+    typedef RCfg<HD> R;
+    constexpr size_t smem = (size_t)4 * NS * 32 * R::RB + (SM_THREADS / 64) * R::SCR;      // two items of {K, V} + per-wave scratch
+    static OncePerDevice once;
+    if (once.need()) { set_smem(attn_fwd_ring_kernel<HD, NS>, smem); }
+    const int64_t items = (int64_t)B * H;
+    const int64_t slots = device_cus();
+    const unsigned grid = (unsigned)(items < slots ? items : slots);
+    hipLaunchKernelGGL((attn_fwd_ring_kernel<HD, NS>), dim3(grid), dim3(SM_THREADS), smem, stream,
+                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale,
+                       (int)items);
+    ME_CHECK_LAUNCH("me_attention_fwd(ring)");
+    return ME_OK;
+}
+template <int HD, int NS>
+int launch_fwd_ring16_ns(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
+                         hipStream_t stream) {
+    typedef RCfg<HD> R;
+    constexpr size_t smem = (size_t)4 * NS * 32 * R::RB + (R16_THREADS / 64) * 16 * Cfg<bf16_t, HD>::RROW;
+    static OncePerDevice once;
+    if (once.need()) { set_smem(attn_fwd_ring16_kernel<HD, NS>, smem); }
+    const int64_t items = (int64_t)B * H;
+    const int64_t slots = device_cus();
+    const unsigned grid = (unsigned)(items < slots ? items : slots);
+    hipLaunchKernelGGL((attn_fwd_ring16_kernel<HD, NS>), dim3(grid), dim3(R16_THREADS), smem, stream,
+                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale,
+                       (int)items);
+    ME_CHECK_LAUNCH("me_attention_fwd(ring16)");
+    return ME_OK;
+}
+template <int HD>
+int launch_fwd_ring16(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
+                      hipStream_t stream) {
+    switch ((N + 31) / 32) {
+        case 3: return launch_fwd_ring16_ns<HD, 3>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
+        case 4: return launch_fwd_ring16_ns<HD, 4>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
+        case 5: return launch_fwd_ring16_ns<HD, 5>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
+        case 6: return launch_fwd_ring16_ns<HD, 6>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
+        default: return launch_fwd_ring16_ns<HD, 7>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
+    }
+}
+template <int HD>
+int launch_fwd_ring(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
+                    hipStream_t stream) {
+    switch ((N + 31) / 32) {
+        case 3: return launch_fwd_ring_ns<HD, 3>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
+        case 4: return launch_fwd_ring_ns<HD, 4>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
+        case 5: return launch_fwd_ring_ns<HD, 5>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
+        case 6: return launch_fwd_ring_ns<HD, 6>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
+        default: return launch_fwd_ring_ns<HD, 7>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
+    }
 }
 template <int HD>
 int launch_bwd_small(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
@@ -1732,6 +2325,10 @@ extern "C" int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int6
     ME_CHECK_ARG(ld_out % 4 == 0, "me_attention_fwd: ld_out must be a multiple of 4");
     ME_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "me_attention_fwd: p_drop must be in [0, 1)");
     if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN) {
+        if (N <= RS_MAXN && (int64_t)N * ld_qkv * 2 < (int64_t)0x7e000000) {
+            if (head_dim <= 32) return launch_fwd_ring16<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+            return launch_fwd_ring16<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+        }
         if (head_dim <= 32) return launch_fwd_small<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
         return launch_fwd_small<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
     }

@@ -19,27 +19,33 @@ int main(int argc, char** argv) {
     hipMemcpy(qkv, hq.data(), hq.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(dout, hdo.data(), hdo.size() * 2, hipMemcpyHostToDevice);
     const int nslots = 4096;
-    std::vector<long long> tr(nslots * 16);
+    std::vector<long long> tr((size_t)nslots * 128);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int pass = 0; pass < 2; ++pass) {
-        for (int rep = 0; rep < 3; ++rep) {
+        float ms = 0.f;
+        for (int rep = 0; rep < 6; ++rep) {
+            if (rep == 1) hipEventRecord(e0, nullptr);
             int rc = pass == 0 ? me_attention_fwd(qkv, 3 * C, out, C, lse, B, N, H, hd, 0.125f, ME_BF16, 0.f, 0, nullptr)
                                : me_attention_bwd(qkv, 3 * C, out, C, dout, C, lse, delta, dqkv, 3 * C, B, N, H, hd, 0.125f, ME_BF16, 0.f, 0, nullptr);
             if (rc) { printf("error: %s\n", me_last_error()); return 1; }
-            hipDeviceSynchronize();
         }
+        hipEventRecord(e1, nullptr); hipDeviceSynchronize(); hipEventElapsedTime(&ms, e0, e1);
         hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_trace), tr.size() * 8);
-        const int nst = pass == 0 ? 6 : 7;
+        const int nst = pass == 0 ? 8 : 7;
         const int items = std::min(B * H, nslots);
-        long long t0 = tr[0];
-        for (int i = 0; i < items; ++i) t0 = std::min(t0, tr[i * 16]);
-        printf("%s: per-workgroup/item phase durations (cycles of the 100 MHz-class s_memtime counter), mean over %d items\n", pass == 0 ? "fwd" : "bwd", items);
-        for (int k = 1; k < nst; ++k) {
-            double sum = 0; for (int i = 0; i < items; ++i) sum += (double)(tr[i * 16 + k] - tr[i * 16 + k - 1]);
-            printf("  stamp %d -> %d : %10.1f\n", k - 1, k, sum / items);
+        printf("%s: %.1f us per launch (stamps compiled in); per-wave timeline, mean shader clocks since the item's first stamp of wave 0, over %d items\n",
+               pass == 0 ? "fwd" : "bwd", ms * 1000.f / 5, items);
+        for (int w = 0; w < 16; ++w) {
+            printf("  wave %d:", w);
+            for (int k = 0; k < nst; ++k) {
+                double sum = 0; int cnt = 0;
+                for (int i = 0; i < items; ++i) { long long v = tr[((size_t)i * 16 + w) * 8 + k], b = tr[(size_t)i * 128]; if (v) { sum += (double)(v - b); ++cnt; } }
+                if (cnt) printf(" %9.0f", sum / cnt); else printf("         -");
+            }
+            printf("\n");
         }
-        double tot = 0; for (int i = 0; i < items; ++i) tot += (double)(tr[i * 16 + nst - 1] - tr[i * 16]);
-        long long tend = 0; for (int i = 0; i < items; ++i) tend = std::max(tend, tr[i * 16 + nst - 1]);
-        printf("  total per item %10.1f ; kernel span %lld\n", tot / items, tend - t0);
+        std::fill(tr.begin(), tr.end(), 0);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_trace), tr.data(), tr.size() * 8);
     }
     return 0;
 }
