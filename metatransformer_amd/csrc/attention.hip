@@ -1148,6 +1148,12 @@ __global__ __launch_bounds__(SM_THREADS) void attn_fwd_ring_kernel(const bf16_t*
 // Waves 14 and 15 are the loaders (paced LDS-DMA of the next item's K and V into the other ring half), other waves >= ceil(N / 16)
 // only keep the barrier.
 constexpr int R16_THREADS = 1024;
+#ifndef ME_R16_SLEEP
+#define ME_R16_SLEEP 1      // loader pacing: s_sleep units (64 clocks) behind every DMA piece
+#endif
+#ifndef ME_R16_PRIO
+#define ME_R16_PRIO 0       // (dev experiment) 1: the younger compute waves (>= 8) run at s_setprio 1
+#endif
 // slot of chunk c in row r: c ^ r16_swz(r).  HD = 64: the b128 operand read has lanes {0-3, 12-15} on rows r, chunk c and lanes
 // {20-27} on rows 4-11, chunk c + 1 in one LDS cycle, the transposing read 8 consecutive rows x one aligned chunk pair: row bits
 // 1..2 -> slot bits 1..2 separates both.  HD = 32 (four rows per 256-byte bank row): per 4-row block the values 0, 2, 3, 1.
@@ -1200,7 +1206,7 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_ring16_kernel(const bf16
 #pragma unroll
             for (int i = 0; i < NRI; ++i) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(half + which * arr_bytes + i * 1024), 16, dma_voff + i * dma_gstep, 0, 0, 0);
-                if (paced) __builtin_amdgcn_s_sleep(1);
+                if (paced && ME_R16_SLEEP) __builtin_amdgcn_s_sleep(ME_R16_SLEEP);
             }
         };
         int it = blockIdx.x, cur = 0;
@@ -1215,6 +1221,7 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_ring16_kernel(const bf16
     }
 
     // ---- compute waves
+    if (ME_R16_PRIO && wave >= 8) __builtin_amdgcn_s_setprio(1);
     char* scr = smem + 4 * arr_bytes + wave * SCR;
     const int q = 16 * wave + l15;
     const int qrow = (q < N) ? q : N - 1;
@@ -1254,7 +1261,7 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_ring16_kernel(const bf16
     float m2 = 0.f, l_tot = 1.f;
     int it_out = -1;
     auto flush = [&]() {
-        const float inv = 1.0f / l_tot;
+        const float inv = __builtin_amdgcn_rcpf(l_tot);      // (1 ulp; the result is rounded to bf16)
         const int b = it_out / H, head = it_out % H;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
@@ -1607,6 +1614,289 @@ __global__ __launch_bounds__(SM_THREADS) void attn_bwd_small_kernel(const bf16_t
     store_rows_via_lds<HD>(scr0, dk, scale, grow0 + Cdim, lddq, N - 32 * wave, hd, lane);
     store_rows_via_lds<HD>(scr1, dv, 1.0f, grow0 + 2 * Cdim, lddq, N - 32 * wave, hd, lane);
     TRACE_STAMP(trace_slot, 6);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Backward in the ring form (SM_MINN < N <= RS_MAXN), 16 waves, 16 rows per wave (see attn_fwd_ring16_kernel for why).
+// LDS holds two 2-array regions, KV = {K, V} and QD = {Q, dO}, unpadded and swizzled (r16_swz).  Per item:
+//   phase A (wave = 16 queries):  S^T, dP^T from the KV region + the wave's own Q / dO rows (registers, prefetched from global),
+//                                 dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T;  delta = rowsum(dO o O) on the way in;
+//                                 at the end the wave lifts its own 16 K / V rows (phase B's register operands)       -- barrier 1
+//   phase B (wave = 16 keys):     S, dP from the QD region + those rows, dV^T += dO^T P, dK^T += Q^T dS                  -- barrier 2
+// The KV region is dead during phase B and the QD region during phase A: the two loader waves (14: K then Q, 15: V then dO)
+// refill each region by LDS-DMA while the OTHER phase computes -- the whole item's 100 KB arrives under compute, which the
+// one-workgroup-per-item kernel above exposes completely (13 k of 40 k clocks per item).  S and dP are computed twice (7 MFMA
+// products instead of 5) so that no gradient needs a cross-wave reduction; results are deterministic.
+// 16 accumulator rows (lane (row l & 15, g = l >> 4) holds d = 16 dt + 4 g + j) -> bf16 rows of `grow0`, transposed through the
+// wave's LDS scratch into whole 128-byte row stores.  The stores are BUFFER stores behind a descriptor that ends with the last
+// valid row (rows past it and chunks past hd are dropped by the bounds check, never branched over): the number of memory
+// operations is fixed, so a later wait for loads issued BEFORE these stores can be a counted vmcnt instead of vmcnt(0).
+template <int HD>
+__device__ __forceinline__ void r16_store_rows(char* scr, const f32x4 (&acc)[HD / 16], float mul, bf16_t* __restrict__ grow0,
+                                               int64_t ldg, int rows_valid, int hd, int lane) {
+    typedef Cfg<bf16_t, HD> C;
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+        bf16x4 v4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(acc[dt][e] * mul);
+        *reinterpret_cast<bf16x4*>(scr + l15 * C::RROW + (16 * dt + 4 * g) * 2) = v4;
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int RPI = 64 / C::CPR;              // rows per store instruction
+    const int chunk = lane % C::CPR, r0 = lane / C::CPR;
+    const int nrec = rows_valid > 0 ? (int)(((int64_t)(rows_valid - 1) * ldg + hd) * 2) : 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(grow0, 0, nrec, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 16 / RPI; ++k) {
+        const int r = r0 + RPI * k;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(scr + r * C::RROW + chunk * 16);
+        const int off = chunk * 8 < hd ? (int)(r * ldg * 2) + chunk * 16 : 0x7f000000;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int HD, int NS>
+__global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                      const bf16_t* __restrict__ out, int64_t ldo,
+                                                                      const bf16_t* __restrict__ dout, int64_t lddo,
+                                                                      const float* __restrict__ lse, float* __restrict__ delta,
+                                                                      bf16_t* __restrict__ dqkv, int64_t lddq, int N, int H, int hd,
+                                                                      float scale, int items) {
+    typedef Cfg<bf16_t, HD> C;
+    typedef RCfg<HD> R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NR = NS * 32;
+    constexpr int arr_bytes = NR * R::RB;
+    constexpr int NRI = NR / R::RPI;
+    constexpr int NKS = HD / 32;
+    constexpr int NDT = HD / 16;
+    constexpr int SCR = 16 * C::RROW;
+    char* const KVr = smem;                           // {K, V}
+    char* const QDr = smem + 2 * arr_bytes;           // {Q, dO}
+    float* const lse_s = reinterpret_cast<float*>(smem + 4 * arr_bytes);      // [NR] lse * log2(e), +inf on padded queries
+    float* const del_s = lse_s + NR;                                          // [NR]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int Cdim = H * hd;
+    const int G = (int)gridDim.x;
+    const bool active = 16 * wave < N;                // wave-uniform
+
+    if (!active) {
+        if (wave < 14) {                              // spare waves: the barrier count only
+            __syncthreads();
+            for (int it = blockIdx.x; it < items; it += G) { __syncthreads(); __syncthreads(); }
+            return;
+        }
+        // ---- loader waves: 14 fills the first array of a region (K, Q), 15 the second (V, dO)
+        const int which = wave - 14;
+        const int rg = (lane * 16) / R::RB, pos = ((lane * 16) % R::RB) / 16;
+        const int csrc = pos ^ r16_swz<R::CPR>(rg);
+        const bool cok = csrc * 8 < hd;
+        const int voff_a = cok ? rg * (int)ld * 2 + csrc * 16 : 0x7f000000;              // rows of qkv
+        const int voff_d = cok ? rg * (int)(which ? lddo : ld) * 2 + csrc * 16 : 0x7f000000;      // rows of the QD array of this loader
+        const int gstep_a = R::RPI * (int)ld * 2, gstep_d = R::RPI * (int)(which ? lddo : ld) * 2;
+        const int rec_a = (int)(((int64_t)(N - 1) * ld + hd) * 2);
+        const int rec_d = (int)(((int64_t)(N - 1) * (which ? lddo : ld) + hd) * 2);
+        auto fill = [&](const bf16_t* base, int rec, int voff, int gstep, char* dst, int paced) {
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, rec, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NRI; ++i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(dst + i * 1024), 16, voff + i * gstep, 0, 0, 0);
+                if (paced == 1) __builtin_amdgcn_s_sleep(1);
+                if (paced == 2) __builtin_amdgcn_s_sleep(3);
+            }
+        };
+        auto kv_base = [&](int it) { return qkv + (int64_t)(it / H) * N * ld + (it % H) * hd + (1 + which) * Cdim; };
+        auto qd_base = [&](int it) {
+            return which ? dout + (int64_t)(it / H) * N * lddo + (it % H) * hd : qkv + (int64_t)(it / H) * N * ld + (it % H) * hd;
+        };
+        int it = blockIdx.x;
+        fill(kv_base(it), rec_a, voff_a, gstep_a, KVr + which * arr_bytes, 0);
+        __syncthreads();
+        for (; it < items; it += G) {
+            fill(qd_base(it), rec_d, voff_d, gstep_d, QDr + which * arr_bytes, 1);
+            __syncthreads();                          // barrier 1 (vmcnt(0) first: the fill has landed)
+            if (it + G < items) fill(kv_base(it + G), rec_a, voff_a, gstep_a, KVr + which * arr_bytes, 2);
+            __syncthreads();                          // barrier 2
+        }
+        return;
+    }
+
+    // ---- compute waves
+    char* scr = smem + 4 * arr_bytes + 2 * NR * (int)sizeof(float) + wave * SCR;
+    const int row = 16 * wave + l15;                  // the query (phase A) / key (phase B) of this lane
+    const bool row_ok = row < N;
+    const int rowc = row_ok ? row : N - 1;
+    const float sl = scale * LOG2E;
+    int koff[NKS];                                    // row-operand read: row 16 t + l15, chunk 4 ks + g
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) koff[ks] = l15 * R::RB + 16 * ((4 * ks + g) ^ r16_swz<R::CPR>(l15));
+    int troff[NDT];                                   // transposing read: rows 32 kk + 16 r + 4 g + (l15 >> 2), 8 bytes at d = 16 dt + 4 (l15 & 3)
+    {
+        const int rr = 4 * g + (l15 >> 2);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+            troff[dt] = rr * R::RB + 16 * ((2 * dt + ((l15 & 3) >> 1)) ^ r16_swz<R::CPR>(rr)) + 8 * (l15 & 1);
+    }
+    for (int i = tid; i < NR; i += 64 * ((N + 15) / 16)) { lse_s[i] = INFINITY; del_s[i] = 0.f; }      // rows no wave owns stay this way
+
+    // own-row operands of the NEXT item's phase A, in flight across this item's phase B
+    u32x4 qn[NKS], don[NKS], on[NKS];
+    float lse_n = 0.f;
+    // piece i of 3 NKS + 1: issued one per phase-B step -- asked for at once (13 waves x 7 loads on top of the loaders' DMA and the
+    // dQ stores) the CU's vector-memory path backs up and every wave sits in the issue of its loads for thousands of clocks
+    constexpr int NPF = 3 * NKS + 1;
+    auto prefetch = [&](int it, int i) {
+        const int b = it / H, head = it % H;
+        const int ks = i % NKS, arr = i / NKS;
+        const int d = 32 * ks + 8 * g, dc = d < hd ? d : 0;
+        if (arr == 0) qn[ks] = *reinterpret_cast<const u32x4*>(qkv + ((int64_t)b * N + rowc) * ld + head * hd + dc);
+        else if (arr == 1) don[ks] = *reinterpret_cast<const u32x4*>(dout + ((int64_t)b * N + rowc) * lddo + head * hd + dc);
+        else if (arr == 2) on[ks] = *reinterpret_cast<const u32x4*>(out + ((int64_t)b * N + rowc) * ldo + head * hd + dc);
+        else lse_n = lse[((int64_t)b * H + head) * N + rowc];
+    };
+    auto rowread = [&](const char* arr, int t, bf16x8 (&dst)[NKS]) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) dst[ks] = *reinterpret_cast<const bf16x8*>(arr + 16 * t * R::RB + koff[ks]);
+    };
+    auto trread = [&](const char* arr, int kk, int dt) {
+        union { bf16x4 q4[2]; bf16x8 v; } a;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            a.q4[r] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)((uint32_t)(uintptr_t)arr + (32 * kk + 16 * r) * R::RB + troff[dt]));
+        return a.v;
+    };
+    const f32x4 zero4f = {0.f, 0.f, 0.f, 0.f};
+
+    int it = blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) prefetch(it, i);
+    __syncthreads();
+    for (; it < items; it += G) {
+        const int nxt = (it + G < items) ? it + G : it;
+        const int b = it / H, head = it % H;
+        const int64_t bh = ((int64_t)b * H + head) * N;
+        TRACE_STAMP(it, 0);
+        // ---- phase A: this wave's 16 queries.  Own rows: chunks past hd are zeros; delta from the O / dO fragments
+        bf16x8 qf[NKS], dof[NKS];
+        float del = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bool ok = 32 * ks + 8 * g < hd;
+            const u32x4 qv = ok ? qn[ks] : zero4(), dv4 = ok ? don[ks] : zero4(), ov = ok ? on[ks] : zero4();
+            qf[ks] = *reinterpret_cast<const bf16x8*>(&qv);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(&dv4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                del += __uint_as_float(ov[e] << 16) * __uint_as_float(dv4[e] << 16) +
+                       __uint_as_float(ov[e] & 0xffff0000u) * __uint_as_float(dv4[e] & 0xffff0000u);
+        }
+        del += __shfl_xor(del, 16, 64);
+        del += __shfl_xor(del, 32, 64);
+        const float lse2 = row_ok ? lse_n * LOG2E : INFINITY;      // +inf on padded queries -> P = 0
+        if (g == 0) {
+            lse_s[row] = lse2;
+            del_s[row] = del;
+            if (row_ok && delta) delta[bh + row] = del;
+        }
+        TRACE_STAMP(it, 1);
+        f32x4 dq[NDT];
+#pragma unroll
+        for (int kk = 0; kk < NS; ++kk) {
+            bf16x8 ka[2][NKS], va[2][NKS];
+            rowread(KVr, 2 * kk, ka[0]); rowread(KVr, 2 * kk + 1, ka[1]);
+            rowread(KVr + arr_bytes, 2 * kk, va[0]); rowread(KVr + arr_bytes, 2 * kk + 1, va[1]);
+            f32x4 s[2], dp[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) { s[tt] = mma16(ka[tt][0], qf[0], zero4f); dp[tt] = mma16(va[tt][0], dof[0], zero4f); }
+#pragma unroll
+            for (int ks = 1; ks < NKS; ++ks)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) { s[tt] = mma16(ka[tt][ks], qf[ks], s[tt]); dp[tt] = mma16(va[tt][ks], dof[ks], dp[tt]); }
+            bf16x8 kt[NDT];
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) kt[dt] = trread(KVr, kk, dt);
+            // keys >= N: their K rows are zeros, so whatever dS holds there adds nothing to dQ -- no mask
+            bf16x8 dsb;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(s[tt][e] * sl - lse2);
+                    dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - del));      // dS^T / scale (scale applied to dQ once)
+                }
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) dq[dt] = mma16(kt[dt], dsb, kk == 0 ? zero4f : dq[dt]);
+        }
+        // this wave's own K / V rows = phase B's register operands (the loaders overwrite the region behind barrier 1)
+        bf16x8 kf[NKS], vf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(KVr + 16 * wave * R::RB + koff[ks]);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(KVr + arr_bytes + 16 * wave * R::RB + koff[ks]);
+        }
+        TRACE_STAMP(it, 2);
+        __syncthreads();      // barrier 1: KV region dead; {Q, dO} of this item landed; lse_s / del_s complete
+        TRACE_STAMP(it, 3);
+        bf16_t* grow0 = dqkv + ((int64_t)b * N + 16 * wave) * lddq + head * hd;
+        r16_store_rows<HD>(scr, dq, scale, grow0, lddq, N - 16 * wave, hd, lane);
+        TRACE_STAMP(it, 4);
+        // ---- phase B: this wave's 16 keys.  Padded keys need no mask: a key is a lane (column) here, whatever it accumulates
+        // stays in its own dK / dV rows, which are never stored; padded queries have lse_s = +inf -> P = 0
+        f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+        for (int qq = 0; qq < NS; ++qq) {
+#pragma unroll
+            for (int i = qq * NPF / NS; i < (qq + 1) * NPF / NS; ++i) prefetch(nxt, i);
+            f32x4 s[2], dp[2];
+            {
+                bf16x8 qa[2][NKS];
+                rowread(QDr, 2 * qq, qa[0]); rowread(QDr, 2 * qq + 1, qa[1]);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) s[tt] = mma16(qa[tt][0], kf[0], zero4f);
+#pragma unroll
+                for (int ks = 1; ks < NKS; ++ks)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) s[tt] = mma16(qa[tt][ks], kf[ks], s[tt]);
+            }
+            {
+                bf16x8 da[2][NKS];
+                rowread(QDr + arr_bytes, 2 * qq, da[0]); rowread(QDr + arr_bytes, 2 * qq + 1, da[1]);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) dp[tt] = mma16(da[tt][0], vf[0], zero4f);
+#pragma unroll
+                for (int ks = 1; ks < NKS; ++ks)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) dp[tt] = mma16(da[tt][ks], vf[ks], dp[tt]);
+            }
+            bf16x8 pb, dsb;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const f32x4 L = *reinterpret_cast<const f32x4*>(lse_s + 16 * (2 * qq + tt) + 4 * g);
+                const f32x4 D = *reinterpret_cast<const f32x4*>(del_s + 16 * (2 * qq + tt) + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(s[tt][e] * sl - L[e]);
+                    pb[4 * tt + e] = (bf16_t)pe;
+                    dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - D[e]));      // dS / scale (scale applied to dK once)
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) dv[dt] = mma16(trread(QDr + arr_bytes, qq, dt), pb, qq == 0 ? zero4f : dv[dt]);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) dk[dt] = mma16(trread(QDr, qq, dt), dsb, qq == 0 ? zero4f : dk[dt]);
+        }
+        TRACE_STAMP(it, 5);
+        r16_store_rows<HD>(scr, dk, scale, grow0 + Cdim, lddq, N - 16 * wave, hd, lane);
+        r16_store_rows<HD>(scr, dv, 1.0f, grow0 + 2 * Cdim, lddq, N - 16 * wave, hd, lane);
+        TRACE_STAMP(it, 6);
+        __syncthreads();      // barrier 2: QD region dead; {K, V} of the next item landed
+        TRACE_STAMP(it, 7);
+    }
 }
 
 // =====================================================================================================
@@ -2190,6 +2480,34 @@ int launch_bwd_small(const void* qkv, int64_t ld, const void* out, int64_t ldo, 
     return ME_OK;
 }
 
+template <int HD, int NS>
+int launch_bwd_ring16_ns(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                         float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
+    typedef RCfg<HD> R;
+    constexpr size_t smem = (size_t)4 * NS * 32 * R::RB + 2 * NS * 32 * sizeof(float) + (R16_THREADS / 64) * 16 * Cfg<bf16_t, HD>::RROW;
+    static OncePerDevice once;
+    if (once.need()) { set_smem(attn_bwd_ring16_kernel<HD, NS>, smem); }
+    const int64_t items = (int64_t)B * H;
+    const int64_t slots = device_cus();
+    const unsigned grid = (unsigned)(items < slots ? items : slots);
+    hipLaunchKernelGGL((attn_bwd_ring16_kernel<HD, NS>), dim3(grid), dim3(R16_THREADS), smem, stream,
+                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<const bf16_t*>(out), ldo,
+                       reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd, scale,
+                       (int)items);
+    ME_CHECK_LAUNCH("me_attention_bwd(ring16)");
+    return ME_OK;
+}
+template <int HD>
+int launch_bwd_ring16(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                      float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
+    switch ((N + 31) / 32) {
+        case 3: return launch_bwd_ring16_ns<HD, 3>(qkv, ld, out, ldo, dout, lddo, lse, delta, dqkv, lddq, B, N, H, hd, scale, stream);
+        case 4: return launch_bwd_ring16_ns<HD, 4>(qkv, ld, out, ldo, dout, lddo, lse, delta, dqkv, lddq, B, N, H, hd, scale, stream);
+        case 5: return launch_bwd_ring16_ns<HD, 5>(qkv, ld, out, ldo, dout, lddo, lse, delta, dqkv, lddq, B, N, H, hd, scale, stream);
+        case 6: return launch_bwd_ring16_ns<HD, 6>(qkv, ld, out, ldo, dout, lddo, lse, delta, dqkv, lddq, B, N, H, hd, scale, stream);
+        default: return launch_bwd_ring16_ns<HD, 7>(qkv, ld, out, ldo, dout, lddo, lse, delta, dqkv, lddq, B, N, H, hd, scale, stream);
+    }
+}
 template <int HD, int NTHR, int MAXN>
 int launch_fwd_mid(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
                    hipStream_t stream) {
@@ -2356,6 +2674,11 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
     ME_CHECK_ARG(ld_dout % E == 0 && ld_dqkv % 4 == 0, "me_attention_bwd: bad strides");
     ME_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "me_attention_bwd: p_drop must be in [0, 1)");
     if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN && ld_out % 8 == 0) {
+        if (N <= RS_MAXN && (int64_t)N * ld_qkv * 2 < (int64_t)0x7e000000 && (int64_t)N * ld_dout * 2 < (int64_t)0x7e000000) {
+            if (head_dim <= 32)
+                return launch_bwd_ring16<32>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale, stream);
+            return launch_bwd_ring16<64>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale, stream);
+        }
         if (head_dim <= 32)
             return launch_bwd_small<32>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim,
                                         scale, stream);

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
         }
         hipEventRecord(e1, nullptr); hipDeviceSynchronize(); hipEventElapsedTime(&ms, e0, e1);
         hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_trace), tr.size() * 8);
-        const int nst = pass == 0 ? 8 : 7;
+        const int nst = 8;
         const int items = std::min(B * H, nslots);
         printf("%s: %.1f us per launch (stamps compiled in); per-wave timeline, mean shader clocks since the item's first stamp of wave 0, over %d items\n",
                pass == 0 ? "fwd" : "bwd", ms * 1000.f / 5, items);
