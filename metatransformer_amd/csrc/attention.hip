@@ -865,275 +865,29 @@ __global__ __launch_bounds__(SM_THREADS) void attn_fwd_small_kernel(const bf16_t
 }
 
 // -----------------------------------------------------------------------------------------------------
-// Resident-sequence forward, ring form (SM_MINN < N <= RS_MAXN = 224: every Base / Large image, window and point-cloud
-// shape).  What the per-wave time stamps of the kernel above showed (tools/attn_trace, N = 197: 15.3 k clocks per item):
-// ~4 k clocks in which every wave sits in the ISSUE of its prefetch loads (the CU's vector-memory path takes ~32 B/clk, a
+// Resident-sequence kernels, ring form (SM_MINN < N <= RS_MAXN = 224: every Base / Large image, window and point-cloud shape).
+// What per-wave time stamps of the kernels above showed (tools/attn_trace, N = 197, forward 15.3 k clocks per item):
+// ~4 k clocks in which every wave sits in the ISSUE of its prefetch loads (the CU's vector-memory path takes ~32 B/clk: a
 // whole item's 100 KB asked for at once backs the queue up and an in-order wave cannot get past a load it cannot issue),
-// ~1 k parking the prefetched rows in LDS between two barriers, and a step loop in which one wave's MFMAs and its SIMD
-// partner's softmax arithmetic hardly overlap (each 64-key step is 16 MFMAs + ~180 VALU slots, strictly alternating, both
-// waves in the same phase).  This form:
-//   * K / V of the NEXT item go global -> LDS by DMA (buffer_load ... lds) into the other half of a two-item ring, one
-//     instruction (1 KiB) per 32-key sub-tile of the current item's QK^T pass: nothing queues, no staging registers, no
-//     park phase, ONE barrier per item.  Rows are unpadded; the 16-byte chunks are XOR-swizzled on the SOURCE side (a DMA
-//     lane chooses which global chunk lands in its fixed LDS slot) so that both the 16-byte row reads and the transposing
+// ~1 k parking the prefetched rows in LDS between two barriers, a step loop hipcc schedules as read -> wait -> MFMA one
+// fragment at a time, and two 250-register waves per SIMD that cannot keep the VALU fed (tools/probe_valu).  The ring form:
+//   * the NEXT item's arrays go global -> LDS by DMA (buffer_load ... lds) from dedicated LOADER waves, paced, into the half
+//     of LDS the current phase does not read: nothing queues in front of the compute waves, no staging registers, no park
+//     phase, one barrier per phase.  Rows are unpadded; the 16-byte chunks are XOR-swizzled on the SOURCE side (a DMA lane
+//     chooses which global chunk lands in its fixed LDS slot) so that both the 16-byte row reads and the transposing
 //     ds_read_b64_tr_b16 reads stay bank-conflict free.  Rows >= N and chunks >= hd arrive as zeros through the buffer
 //     descriptor's bounds check.
-//   * two-pass softmax: N <= 224 keeps the whole S^T row block (7 x 16 accumulator registers per lane) in registers, so
-//     there is no running maximum, no rescale of O and no per-step shuffle -- and the pass structure (28 MFMAs | softmax
-//     VALU | 28 MFMAs) lets the two waves of a SIMD run out of phase, one on the matrix pipe while the other does VALU.
-//   * the output of item i is stored AFTER the item barrier, i.e. under the next item's QK^T pass.
+//   * 16 waves of 16 rows (16 x 16 x 32 MFMA), <= 128 registers, four waves per SIMD.
+//   * forward: two-pass softmax -- N <= 224 keeps the whole S^T row block in registers, so there is no running maximum, no
+//     rescale of O and no per-step shuffle; MFMA passes software-pipelined by hand (sched_barrier).
 typedef __attribute__((address_space(3))) void lds_dma_t;
 constexpr int RS_MAXN = 224;
-constexpr int RS_MAXS = RS_MAXN / 32;
 template <int HD> struct RCfg {
     static constexpr int RB = HD * 2;                          // bytes per (unpadded) row
     static constexpr int CPR = HD / 8;                         // 16-byte chunks per row
     static constexpr int RPI = 1024 / RB;                      // rows one DMA instruction fills (64 lanes x 16 B)
     static constexpr int SCR = 32 * Cfg<bf16_t, HD>::RROW;     // per-wave output transposition scratch (padded rows)
 };
-// chunk c of row r lives in 16-byte slot c ^ rs_swz(r).  The LDS services a ds_read_b128 in four groups of 16 lanes --
-// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- over 64 banks = one 256-byte bank row per cycle
-// (MI355X_MICROARCH.md, LDS), and a ds_read_b64_tr_b16 in two groups of 32 lanes.  HD = 64 (two rows per bank row):
-// the QK^T operand read (lane = row, one chunk) needs 16 distinct (row parity, slot) pairs over the rows of a lane group,
-// i.e. the swizzle must take 8 values over rows {0,2,12,14,20,22,24,26} and over {4,6,8,10,16,18,28,30}: any bijection of
-// row bits 1..3 does; the transposing PV read (4 consecutive rows x 4 consecutive chunks per group) additionally needs rows
-// r and r + 2 to land in different halves of the bank row -> row bit 1 goes to slot bit 2.  HD = 32 (four rows per bank
-// row): row bits 2..3.
-template <int CPR> __device__ __forceinline__ int rs_swz(int r) {
-    return CPR == 8 ? ((((r >> 1) & 1) << 2) | ((r >> 2) & 3)) : ((r >> 2) & 3);
-}
-
-// NS = number of 32-key sub-tiles = ceil(N / 32), a template parameter: every loop below is straight-line code, so the
-// s_waitcnt counts the compiler derives are exact (with run-time guards it must assume the shortest path at every join).
-// Waves 0 .. NS-1 (NS <= 7) own 32 queries each; WAVE 7 IS THE LOADER: it issues every DMA instruction of the next item
-// (an LDS-DMA piece costs its issuer 60-180 clocks -- MI355X_MICROARCH.md -- which the compute waves do not have) and
-// otherwise only keeps the barrier count.
-template <int HD, int NS>
-__global__ __launch_bounds__(SM_THREADS) void attn_fwd_ring_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
-                                                                   bf16_t* __restrict__ out, int64_t ldo,
-                                                                   float* __restrict__ lse, int N, int H, int hd,
-                                                                   float scale, int items) {
-    typedef Cfg<bf16_t, HD> C;
-    typedef RCfg<HD> R;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NR = NS * 32;
-    constexpr int arr_bytes = NR * R::RB;             // one array (K or V) of one item
-    constexpr int NRI = NR / R::RPI;                  // DMA instructions per array
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
-    char* scr = smem + 4 * arr_bytes + wave * R::SCR;
-    const int Cdim = H * hd;
-    const int q = 32 * wave + l31;
-    const int qrow = (q < N) ? q : N - 1;
-    const bool active = 32 * wave < N;                // wave-uniform
-    const bool loader = wave == 7;
-    const float sl = scale * LOG2E;
-    const int G = (int)gridDim.x;
-
-    if (loader) {
-        // ---- the loader wave: lane l fills LDS bytes [16 l, 16 l + 16) of an instruction's 1 KiB = slot `pos` of row `rg` of
-        // the row group; it fetches the chunk that belongs there (HD = 64: the swizzle of row 8 g + rg depends on g's parity)
-        const int rg = (lane * 16) / R::RB, pos = ((lane * 16) % R::RB) / 16;
-        int dma_voff[2];
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const int csrc = pos ^ rs_swz<R::CPR>(rg + (R::RPI == 8 ? 8 * par : 0));
-            dma_voff[par] = (csrc * 8 < hd) ? rg * (int)ld * 2 + csrc * 16 : 0x7f000000;      // (out of range -> zeros)
-        }
-        const int dma_gstep = R::RPI * (int)ld * 2;
-        const int rec_bytes = (int)(((int64_t)(N - 1) * ld + hd) * 2);
-        // PACED: in the steady state one (K, V) pair of pieces every ~200 clocks.  Asked for all at once, an item's 56 KiB backs
-        // up the CU's vector-memory path and the compute waves' own few loads and stores queue behind it (time stamps: 2-3 k
-        // clocks lost at the head of every item).
-        auto fill = [&](int it, char* half, bool paced) {
-            const bf16_t* base = qkv + (int64_t)(it / H) * N * ld + (it % H) * hd + Cdim;
-            const __amdgpu_buffer_rsrc_t kd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, rec_bytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t vd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base + Cdim), 0, rec_bytes, 0x00020000);
-#pragma unroll
-            for (int g = 0; g < NRI; ++g) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(kd, (lds_dma_t*)(half + g * 1024), 16, dma_voff[g & 1] + g * dma_gstep, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(vd, (lds_dma_t*)(half + arr_bytes + g * 1024), 16, dma_voff[g & 1] + g * dma_gstep, 0, 0, 0);
-                if (paced) __builtin_amdgcn_s_sleep(2);
-            }
-        };
-        int it = blockIdx.x, cur = 0;
-        fill(it, smem, false);
-        __syncthreads();
-        for (; it < items; it += G) {
-            if (it + G < items) fill(it + G, smem + (cur ^ 1) * 2 * arr_bytes, true);
-            __syncthreads();                          // (vmcnt(0) first: the fill has landed)
-            cur ^= 1;
-        }
-        return;
-    }
-
-    // ---- compute waves: per-lane constants
-    // QK^T operand: row 32 u + l31, chunk 2 kk + h
-    int koff[C::NKK];
-#pragma unroll
-    for (int kk = 0; kk < C::NKK; ++kk) koff[kk] = l31 * R::RB + 16 * ((2 * kk + h) ^ rs_swz<R::CPR>(l31));
-    // PV operand (transposing read, see tr_chunk): rows 16 c + 8 r + rr, 8 bytes at column 32 db + 16 (g & 1) + 4 (p & 3)
-    int voff[C::NDB][2];
-    {
-        const int g = lane >> 4, p = lane & 15, rr = 4 * (g >> 1) + (p >> 2), low = 2 * (g & 1) + ((p >> 1) & 1);
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-                voff[db][r] = (8 * r + rr) * R::RB + 16 * ((4 * db + low) ^ rs_swz<R::CPR>(8 * r + rr)) + 8 * (p & 1);
-    }
-
-    bf16x8 qf[C::NKK], qn[C::NKK];
-    auto q_issue = [&](int it) {
-        const bf16_t* qptr = qkv + (int64_t)(it / H) * N * ld + (it % H) * hd;
-#pragma unroll
-        for (int kk = 0; kk < C::NKK; ++kk) {
-            const int d = (2 * kk + h) * 8;
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(qptr + (int64_t)qrow * ld + (d < hd ? d : 0));
-            qn[kk] = *reinterpret_cast<const bf16x8*>(&raw);
-        }
-    };
-    auto q_take = [&]() {
-#pragma unroll
-        for (int kk = 0; kk < C::NKK; ++kk) {
-            const bool ok = (2 * kk + h) * 8 < hd;
-            u32x4 raw = *reinterpret_cast<const u32x4*>(&qn[kk]);
-            raw = ok ? raw : zero4();
-            qf[kk] = *reinterpret_cast<bf16x8*>(&raw);
-        }
-    };
-
-    // the finished item whose output is still in registers (stored under the next item's QK^T pass)
-    f32x16 o[C::NDB];
-    float m2 = 0.f, l_tot = 1.f;
-    int it_out = -1;
-    auto flush = [&]() {
-        const float inv = 1.0f / l_tot;
-        const int b = it_out / H, head = it_out % H;
-        store_rows_via_lds<HD>(scr, o, inv, out + ((int64_t)b * N + 32 * wave) * ldo + head * hd, ldo, N - 32 * wave, hd, lane);
-        if (lse && h == 0 && q < N) lse[((int64_t)b * H + head) * N + q] = (m2 + __builtin_amdgcn_logf(l_tot)) * LN2;
-    };
-
-    int it = blockIdx.x;
-    q_issue(it);
-    int cur = 0;
-    __syncthreads();
-    for (; it < items; it += G) {
-        const int nxt = (it + G < items) ? it + G : it;
-        TRACE_STAMP(it, 0);
-        q_take();
-        TRACE_STAMP(it, 1);
-        const char* Kb = smem + cur * 2 * arr_bytes;
-        const char* Vb = Kb + arr_bytes;
-        if (active) {
-            // ---- pass 1: S^T[kv][q] for every 32-key sub-tile.  Software-pipelined by hand (left alone hipcc emits read ->
-            // wait -> MFMA one fragment at a time): the four operand chunks of sub-tile u + 1 are in flight while the four MFMAs
-            // of sub-tile u run; the previous item's output leaves behind the first MFMA group.
-            f32x16 s[NS];
-            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            bf16x8 ka[C::NKK], kb[C::NKK];
-            auto kread = [&](int u, bf16x8 (&dst)[C::NKK]) {
-#pragma unroll
-                for (int kk = 0; kk < C::NKK; ++kk) dst[kk] = *reinterpret_cast<const bf16x8*>(Kb + 32 * u * R::RB + koff[kk]);
-            };
-            auto kmma = [&](int u, const bf16x8 (&src)[C::NKK]) {
-                s[u] = mma_chunk(src[0], qf[0], zero16);
-#pragma unroll
-                for (int kk = 1; kk < C::NKK; ++kk) s[u] = mma_chunk(src[kk], qf[kk], s[u]);
-            };
-            // (priority: a wave in a matrix pass outranks its SIMD partner's softmax arithmetic -- an MFMA needs one issue slot per 32
-            //  clocks, which the arbiter otherwise hands to the older wave's unbroken VALU stream)
-            __builtin_amdgcn_s_setprio(1);
-            kread(0, ka);
-#pragma unroll
-            for (int u = 0; u < NS; u += 2) {
-                if (u + 1 < NS) kread(u + 1, kb);
-                __builtin_amdgcn_sched_barrier(0);
-                kmma(u, ka);
-                __builtin_amdgcn_sched_barrier(0);
-                if (u == 0) { TRACE_STAMP(it, 2); if (it_out >= 0) flush(); TRACE_STAMP(it, 3); }
-                if (u + 1 < NS) {
-                    if (u + 2 < NS) kread(u + 2, ka);
-                    __builtin_amdgcn_sched_barrier(0);
-                    kmma(u + 1, kb);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-            TRACE_STAMP(it, 4);
-            q_issue(nxt);                             // (here, not at the head of the item: the memory path is quiet now)
-            // ---- softmax over the whole row (registers only)
-            if (N & 31) {
-                // (the bound is made opaque per item: left visible, hipcc hoists the lane masks out of the item loop into SGPRs)
-                int nkeys = N - 4 * h;
-                asm volatile("" : "+v"(nkeys));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[NS - 1][r] = (32 * (NS - 1) + acc_row(r, 0) < nkeys) ? s[NS - 1][r] : -INFINITY;
-            }
-            float mt = -INFINITY;
-#pragma unroll
-            for (int u = 0; u < NS; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[u][r]);
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            m2 = mt * sl;
-            float ps = 0.f;
-#pragma unroll
-            for (int u = 0; u < NS; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pe = __builtin_amdgcn_exp2f(s[u][r] * sl - m2);
-                    s[u][r] = pe;
-                    ps += pe;
-                }
-            l_tot = ps + __shfl_xor(ps, 32, 64);
-            TRACE_STAMP(it, 5);
-            // ---- pass 2: O^T[d][q] = V^T P^T, 16 keys (one P chunk) at a time; the V^T operand of chunk c + 1 is in flight
-            // while chunk c's MFMAs run
-            bf16x8 va[C::NDB], vb[C::NDB];
-            auto vread = [&](int c, bf16x8 (&dst)[C::NDB]) {
-#pragma unroll
-                for (int db = 0; db < C::NDB; ++db) {
-                    union { bf16x4 q4[2]; bf16x8 v; } a;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-                        a.q4[r] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (lds_bf16x4_t*)((uint32_t)(uintptr_t)Vb + 16 * c * R::RB + voff[db][r]));
-                    dst[db] = a.v;
-                }
-            };
-            auto vmma = [&](int c, const bf16x8 (&src)[C::NDB], bool first) {
-                bf16x8 pb;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pb[e] = (bf16_t)s[c >> 1][8 * (c & 1) + e];
-#pragma unroll
-                for (int db = 0; db < C::NDB; ++db) o[db] = mma_chunk(src[db], pb, first ? zero16 : o[db]);
-            };
-            __builtin_amdgcn_s_setprio(1);
-            vread(0, va);
-#pragma unroll
-            for (int c = 0; c < 2 * NS; c += 2) {
-                vread(c + 1, vb);
-                __builtin_amdgcn_sched_barrier(0);
-                vmma(c, va, c == 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (c + 2 < 2 * NS) vread(c + 2, va);
-                __builtin_amdgcn_sched_barrier(0);
-                vmma(c + 1, vb, false);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            it_out = it;
-            TRACE_STAMP(it, 6);
-        }
-        __syncthreads();      // the loader's fill of the other half has landed and every wave is done with `cur`
-        TRACE_STAMP(it, 7);
-        cur ^= 1;
-    }
-    if (active && it_out >= 0) flush();
-}
-
 // -----------------------------------------------------------------------------------------------------
 // Ring form with 16-query waves.  tools/probe_valu: ONE wave issues a VALU instruction every ~5 clocks whatever it is, but a SIMD
 // retires one per ~1.9 (add / fma), ~2.8 (max3, cvt_pk, packed) or ~5.3 (exp) clocks once three or four waves feed it -- the
@@ -1150,9 +904,6 @@ __global__ __launch_bounds__(SM_THREADS) void attn_fwd_ring_kernel(const bf16_t*
 constexpr int R16_THREADS = 1024;
 #ifndef ME_R16_SLEEP
 #define ME_R16_SLEEP 1      // loader pacing: s_sleep units (64 clocks) behind every DMA piece
-#endif
-#ifndef ME_R16_PRIO
-#define ME_R16_PRIO 0       // (dev experiment) 1: the younger compute waves (>= 8) run at s_setprio 1
 #endif
 // slot of chunk c in row r: c ^ r16_swz(r).  HD = 64: the b128 operand read has lanes {0-3, 12-15} on rows r, chunk c and lanes
 // {20-27} on rows 4-11, chunk c + 1 in one LDS cycle, the transposing read 8 consecutive rows x one aligned chunk pair: row bits
@@ -1221,7 +972,6 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_ring16_kernel(const bf16
     }
 
     // ---- compute waves
-    if (ME_R16_PRIO && wave >= 8) __builtin_amdgcn_s_setprio(1);
     char* scr = smem + 4 * arr_bytes + wave * SCR;
     const int q = 16 * wave + l15;
     const int qrow = (q < N) ? q : N - 1;
@@ -2409,22 +2159,6 @@ int launch_fwd_small(const void* qkv, int64_t ld, void* out, int64_t ldo, float*
                        reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale,
                        (int)items);
     ME_CHECK_LAUNCH("me_attention_fwd(small)");
-    return ME_OK;
-}
-template <int HD, int NS>
-int launch_fwd_ring_ns(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
-                       hipStream_t stream) {
-    typedef RCfg<HD> R;
-    constexpr size_t smem = (size_t)4 * NS * 32 * R::RB + (SM_THREADS / 64) * R::SCR;      // two items of {K, V} + per-wave scratch
-    static OncePerDevice once;
-    if (once.need()) { set_smem(attn_fwd_ring_kernel<HD, NS>, smem); }
-    const int64_t items = (int64_t)B * H;
-    const int64_t slots = device_cus();
-    const unsigned grid = (unsigned)(items < slots ? items : slots);
-    hipLaunchKernelGGL((attn_fwd_ring_kernel<HD, NS>), dim3(grid), dim3(SM_THREADS), smem, stream,
-                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale,
-                       (int)items);
-    ME_CHECK_LAUNCH("me_attention_fwd(ring)");
     return ME_OK;
 }
 template <int HD, int NS>
