@@ -1366,17 +1366,6 @@ __global__ __launch_bounds__(SM_THREADS) void attn_bwd_small_kernel(const bf16_t
     TRACE_STAMP(trace_slot, 6);
 }
 
-// -----------------------------------------------------------------------------------------------------
-// Backward in the ring form (SM_MINN < N <= RS_MAXN), 16 waves, 16 rows per wave (see attn_fwd_ring16_kernel for why).
-// LDS holds two 2-array regions, KV = {K, V} and QD = {Q, dO}, unpadded and swizzled (r16_swz).  Per item:
-//   phase A (wave = 16 queries):  S^T, dP^T from the KV region + the wave's own Q / dO rows (registers, prefetched from global),
-//                                 dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T;  delta = rowsum(dO o O) on the way in;
-//                                 at the end the wave lifts its own 16 K / V rows (phase B's register operands)       -- barrier 1
-//   phase B (wave = 16 keys):     S, dP from the QD region + those rows, dV^T += dO^T P, dK^T += Q^T dS                  -- barrier 2
-// The KV region is dead during phase B and the QD region during phase A: the two loader waves (14: K then Q, 15: V then dO)
-// refill each region by LDS-DMA while the OTHER phase computes -- the whole item's 100 KB arrives under compute, which the
-// one-workgroup-per-item kernel above exposes completely (13 k of 40 k clocks per item).  S and dP are computed twice (7 MFMA
-// products instead of 5) so that no gradient needs a cross-wave reduction; results are deterministic.
 // 16 accumulator rows (lane (row l & 15, g = l >> 4) holds d = 16 dt + 4 g + j) -> bf16 rows of `grow0`, transposed through the
 // wave's LDS scratch into whole 128-byte row stores.  The stores are BUFFER stores behind a descriptor that ends with the last
 // valid row (rows past it and chunks past hd are dropped by the bounds check, never branched over): the number of memory
@@ -1408,6 +1397,237 @@ __device__ __forceinline__ void r16_store_rows(char* scr, const f32x4 (&acc)[HD 
     __builtin_amdgcn_wave_barrier();
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Long sequences (N > SM_MAXN), forward: the ring form with K / V STREAMED.  A workgroup (16 waves: up to 14 compute waves of 16
+// queries + the two loader waves) owns a block of queries of one (batch, head) and walks the keys in chunks of 128; the loaders
+// keep a three-slot LDS ring of {K, V} chunks two chunks ahead of the compute waves (one barrier per chunk: "chunk k has landed
+// and everybody is done with chunk k - 1", whose slot the loaders then refill with chunk k + 2).  Online softmax per chunk (the
+// row block no longer fits in registers); the same 16 x 16 x 32 products, operand swizzle and hand pipelining as the ring form.
+// Replaces the one-workgroup-per-(batch, head) "mid" kernel and the 256-row "chunk" kernel in the forward: those ran 8 waves of
+// 32 rows (two per SIMD) with register-staged loads.  Workgroups of one XCD take neighbouring query blocks of the same heads,
+// so a head's K / V comes out of HBM once and is re-read from that XCD's L2.
+// (Measured and dropped: 64-key chunks with the NEXT chunk's QK^T MFMAs issued ahead of this chunk's softmax arithmetic in every
+// wave -- 511 us against 444 at N = 1568: twice the barriers, and the chunk barrier keeps all waves of a SIMD in the same phase;
+// skipping the 64-key groups of the last chunk that lie past N with wave-uniform branches -- slower, 502 against 472 us: the joins
+// cost the straight-line schedule more than the skipped MFMAs save.)
+constexpr int ST_KC = 128;                            // keys per chunk
+constexpr int ST_RING = 3;
+template <int HD>
+__global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                        bf16_t* __restrict__ out, int64_t ldo,
+                                                                        float* __restrict__ lse, int N, int H, int hd, float scale,
+                                                                        int QB, int nqb, int items) {
+    typedef Cfg<bf16_t, HD> C;
+    typedef RCfg<HD> R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int arr_bytes = ST_KC * R::RB;          // one array (K or V) of one chunk
+    constexpr int slot_bytes = 2 * arr_bytes;
+    constexpr int NPC = ST_KC / R::RPI;               // DMA pieces per array and chunk
+    constexpr int NTC = ST_KC / 16;                   // 16-key tiles per chunk
+    constexpr int NKS = HD / 32, NDT = HD / 16, NH = NDT / 2;
+    constexpr int SCR = 16 * C::RROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int Cdim = H * hd;
+    const int G = (int)gridDim.x;
+    const int NCH = (N + ST_KC - 1) / ST_KC;
+    // XCD-major virtual id: the workgroups of one XCD (blockIdx & 7) take consecutive items = neighbouring query blocks of a head
+    const int vid = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int my_items = vid < items ? (items - vid + G - 1) / G : 0;      // items vid, vid + G, ...
+    const bool compute = 16 * wave < QB;              // wave-uniform
+
+    if (!compute) {
+        if (wave < 14) {                              // spare waves: the barrier count only
+            for (int k = 0; k < my_items * NCH; ++k) __builtin_amdgcn_s_barrier();
+            return;
+        }
+        // ---- loader waves (14: K, 15: V): chunk j of the workgroup's stream = chunk j % NCH of its (j / NCH)-th item
+        const int which = wave - 14;
+        const int rg = (lane * 16) / R::RB, pos = ((lane * 16) % R::RB) / 16;
+        const int csrc = pos ^ r16_swz<R::CPR>(rg);
+        const int dma_voff = (csrc * 8 < hd) ? rg * (int)ld * 2 + csrc * 16 : 0x7f000000;
+        const int dma_gstep = R::RPI * (int)ld * 2;
+        const int rec_bytes = (int)(((int64_t)(N - 1) * ld + hd) * 2);
+        const int total = my_items * NCH;
+        auto fill = [&](int j) {
+            if (j >= total) return;
+            const int it = vid + (j / NCH) * G, c = j % NCH;
+            const int bh = it / nqb;
+            const bf16_t* base = qkv + (int64_t)(bh / H) * N * ld + (bh % H) * hd + (1 + which) * Cdim;
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, rec_bytes, 0x00020000);
+            char* dst = smem + (j % ST_RING) * slot_bytes + which * arr_bytes;
+            const int voff = dma_voff + c * NPC * dma_gstep;
+#pragma unroll
+            for (int i = 0; i < NPC; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(dst + i * 1024), 16, voff + i * dma_gstep, 0, 0, 0);
+        };
+        fill(0);
+        fill(1);
+        for (int k = 0; k < total; ++k) {
+            // chunk k has landed once at most chunk k + 1's pieces are outstanding (in-order retirement)
+            if (k + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // chunk k ready; everybody is done with chunk k - 1
+            fill(k + 2);                              // ... whose slot takes chunk k + 2
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---- compute waves
+    char* scr = smem + ST_RING * slot_bytes + wave * SCR;
+    const float sl = scale * LOG2E;
+    int koff[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) koff[ks] = l15 * R::RB + 16 * ((4 * ks + g) ^ r16_swz<R::CPR>(l15));
+    int voff[NDT];
+    {
+        const int rr = 4 * g + (l15 >> 2);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+            voff[dt] = rr * R::RB + 16 * ((2 * dt + ((l15 & 3) >> 1)) ^ r16_swz<R::CPR>(rr)) + 8 * (l15 & 1);
+    }
+    const f32x4 zero4f = {0.f, 0.f, 0.f, 0.f};
+    int j = 0;                                        // chunk index in the workgroup's stream
+    for (int ii = 0; ii < my_items; ++ii) {
+        const int it = vid + ii * G;
+        const int bh = it / nqb, qb = it % nqb;
+        const int b = bh / H, head = bh % H;
+        const int q0 = qb * QB + 16 * wave;           // first query of this wave
+        const int q = q0 + l15;
+        const int qrow = q < N ? q : N - 1;
+        bf16x8 qf[NKS];
+        {
+            const bf16_t* qptr = qkv + ((int64_t)b * N + qrow) * ld + head * hd;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int d = 32 * ks + 8 * g;
+                u32x4 raw = *reinterpret_cast<const u32x4*>(qptr + (d < hd ? d : 0));
+                raw = d < hd ? raw : zero4();
+                qf[ks] = *reinterpret_cast<bf16x8*>(&raw);
+            }
+        }
+        f32x4 o[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[dt] = zero4f;
+        float m_run = -INFINITY, l_run = 0.f;         // l_run: this lane's own keys only (summed over the four key groups at the end)
+        for (int c = 0; c < NCH; ++c, ++j) {
+            __syncthreads();                          // chunk j has landed (the loaders waited for it); see the loader loop
+            const char* Kb = smem + (j % ST_RING) * slot_bytes;
+            const char* Vb = Kb + arr_bytes;
+            const int nkeys = N - c * ST_KC;          // valid keys of this chunk (>= 1); wave-uniform
+            // ---- S^T for the chunk's 16-key tiles, two at a time, operands one pair ahead
+            f32x4 s[NTC];
+            bf16x8 ka[2][NKS], kb[2][NKS];
+            auto kread = [&](int t, bf16x8 (&dst)[2][NKS]) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) dst[tt][ks] = *reinterpret_cast<const bf16x8*>(Kb + 16 * (t + tt) * R::RB + koff[ks]);
+            };
+            auto kmma = [&](int t, const bf16x8 (&src)[2][NKS]) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) s[t + tt] = mma16(src[tt][0], qf[0], zero4f);
+#pragma unroll
+                for (int ks = 1; ks < NKS; ++ks)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) s[t + tt] = mma16(src[tt][ks], qf[ks], s[t + tt]);
+            };
+            kread(0, ka);
+#pragma unroll
+            for (int t = 0; t < NTC; t += 4) {
+                kread(t + 2, kb);
+                __builtin_amdgcn_sched_barrier(0);
+                kmma(t, ka);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 4 < NTC) kread(t + 4, ka);
+                __builtin_amdgcn_sched_barrier(0);
+                kmma(t + 2, kb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- online softmax
+            if (nkeys < ST_KC) {
+                int nk = nkeys - 4 * g;               // (opaque: hipcc would hoist the lane masks out of the loops into SGPRs)
+                asm volatile("" : "+v"(nk));
+#pragma unroll
+                for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[t][e] = (16 * t + e < nk) ? s[t][e] : -INFINITY;
+            }
+            float mt = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[t][e]);
+            mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float m_new = fmaxf(m_run, mt * sl);     // every chunk holds a valid key: finite from the first chunk on
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(s[t][e] * sl - m_new);
+                    s[t][e] = pe;
+                    ps += pe;
+                }
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+            // ---- O^T += V^T P^T, 32 keys at a time, d tiles in two halves (operands one half ahead)
+            bf16x8 va[NH], vb[NH];
+            auto vread = [&](int kk, int half, bf16x8 (&dst)[NH]) {
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    union { bf16x4 q4[2]; bf16x8 v; } a;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+                        a.q4[r] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (lds_bf16x4_t*)((uint32_t)(uintptr_t)Vb + (32 * kk + 16 * r) * R::RB + voff[NH * half + i]));
+                    dst[i] = a.v;
+                }
+            };
+            vread(0, 0, va);
+#pragma unroll
+            for (int kk = 0; kk < ST_KC / 32; ++kk) {
+                vread(kk, 1, vb);
+                bf16x8 pb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pb[e] = (bf16_t)s[2 * kk][e]; pb[4 + e] = (bf16_t)s[2 * kk + 1][e]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NH; ++i) o[i] = mma16(va[i], pb, o[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < ST_KC / 32) vread(kk + 1, 0, va);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NH; ++i) o[NH + i] = mma16(vb[i], pb, o[NH + i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- finish the item: row sums over the four key groups, normalise, store
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
+        const float inv = __builtin_amdgcn_rcpf(l_run);
+        r16_store_rows<HD>(scr, o, inv, out + ((int64_t)b * N + q0) * ldo + head * hd, ldo, N - q0, hd, lane);
+        if (lse && g == 0 && q < N) lse[((int64_t)b * H + head) * N + q] = (m_run + __builtin_amdgcn_logf(l_run)) * LN2;
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Backward in the ring form (SM_MINN < N <= RS_MAXN), 16 waves, 16 rows per wave (see attn_fwd_ring16_kernel for why).
+// LDS holds two 2-array regions, KV = {K, V} and QD = {Q, dO}, unpadded and swizzled (r16_swz).  Per item:
+//   phase A (wave = 16 queries):  S^T, dP^T from the KV region + the wave's own Q / dO rows (registers, prefetched from global),
+//                                 dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T;  delta = rowsum(dO o O) on the way in;
+//                                 at the end the wave lifts its own 16 K / V rows (phase B's register operands)       -- barrier 1
+//   phase B (wave = 16 keys):     S, dP from the QD region + those rows, dV^T += dO^T P, dK^T += Q^T dS                  -- barrier 2
+// The KV region is dead during phase B and the QD region during phase A: the two loader waves (14: K then Q, 15: V then dO)
+// refill each region by LDS-DMA while the OTHER phase computes -- the whole item's 100 KB arrives under compute, which the
+// one-workgroup-per-item kernel above exposes completely (13 k of 40 k clocks per item).  S and dP are computed twice (7 MFMA
+// products instead of 5) so that no gradient needs a cross-wave reduction; results are deterministic.
 template <int HD, int NS>
 __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
                                                                       const bf16_t* __restrict__ out, int64_t ldo,
@@ -2214,6 +2434,25 @@ int launch_bwd_small(const void* qkv, int64_t ld, const void* out, int64_t ldo, 
     return ME_OK;
 }
 
+template <int HD>
+int launch_fwd_stream16(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
+                        hipStream_t stream) {
+    typedef RCfg<HD> R;
+    constexpr size_t smem = (size_t)ST_RING * 2 * ST_KC * R::RB + (R16_THREADS / 64) * 16 * Cfg<bf16_t, HD>::RROW;
+    static OncePerDevice once;
+    if (once.need()) { set_smem(attn_fwd_stream16_kernel<HD>, smem); }
+    // query blocks of (at most) 14 x 16 rows, evened out over the sequence
+    const int nqb = (N + 223) / 224;
+    const int QB = ((N + nqb - 1) / nqb + 15) / 16 * 16;
+    const int64_t items = (int64_t)B * H * nqb;
+    const int64_t slots = device_cus();
+    const unsigned grid = (unsigned)(items < slots ? items : slots);
+    hipLaunchKernelGGL((attn_fwd_stream16_kernel<HD>), dim3(grid), dim3(R16_THREADS), smem, stream,
+                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale, QB, nqb,
+                       (int)items);
+    ME_CHECK_LAUNCH("me_attention_fwd(stream16)");
+    return ME_OK;
+}
 template <int HD, int NS>
 int launch_bwd_ring16_ns(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
                          float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
@@ -2383,6 +2622,11 @@ extern "C" int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int6
         }
         if (head_dim <= 32) return launch_fwd_small<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
         return launch_fwd_small<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+    }
+    // (head_dim <= 32: half the MFMA work per key for the same softmax arithmetic -- the 32-row kernels below measured faster there)
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim > 32 && head_dim <= 64 && N > SM_MAXN && (int64_t)N * ld_qkv * 2 < (int64_t)0x7e000000 &&
+        (int64_t)B * H * ((N + 223) / 224) < (int64_t)0x7fffffff && ld_out % 8 == 0) {
+        return launch_fwd_stream16<64>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
     }
     if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MAXN && N <= MD_MAXN) {
         if (head_dim <= 32) return launch_fwd_mid<32, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);

@@ -6,7 +6,7 @@
 #include <algorithm>
 
 int main(int argc, char** argv) {
-    const int B = 256, N = argc > 1 ? atoi(argv[1]) : 197, H = 12, hd = 64, C = H * hd;
+    const int N = argc > 1 ? atoi(argv[1]) : 197, B = argc > 2 ? atoi(argv[2]) : 256, H = argc > 3 ? atoi(argv[3]) : 12, hd = 64, C = H * hd;
     const size_t rows = (size_t)B * N;
     std::vector<uint16_t> hq(rows * 3 * C), hdo(rows * C);
     uint32_t s = 12345;
