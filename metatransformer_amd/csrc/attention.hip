@@ -1438,18 +1438,24 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf
     const bool compute = 16 * wave < QB;              // wave-uniform
 
     if (!compute) {
-        if (wave < 14) {                              // spare waves: the barrier count only
+        // ---- loader waves: the last two (QB = 224) or four (fewer compute waves) waves; the others only keep the barrier count.
+        // With four, each array of a chunk is split between two loaders -- an LDS-DMA piece costs its issuer 60-180 clocks, and 16 of
+        // them per 128-key chunk is about what the compute waves of a short query block need for the chunk.
+        const int NL = QB <= 12 * 16 ? 4 : 2;
+        if (wave < 16 - NL) {
             for (int k = 0; k < my_items * NCH; ++k) __builtin_amdgcn_s_barrier();
             return;
         }
-        // ---- loader waves (14: K, 15: V): chunk j of the workgroup's stream = chunk j % NCH of its (j / NCH)-th item
-        const int which = wave - 14;
+        const int lw = wave - (16 - NL);              // loader index
+        const int which = lw & 1;                     // 0: K, 1: V
+        const int part = lw >> 1, nparts = NL >> 1;   // which pieces of the array
         const int rg = (lane * 16) / R::RB, pos = ((lane * 16) % R::RB) / 16;
         const int csrc = pos ^ r16_swz<R::CPR>(rg);
         const int dma_voff = (csrc * 8 < hd) ? rg * (int)ld * 2 + csrc * 16 : 0x7f000000;
         const int dma_gstep = R::RPI * (int)ld * 2;
         const int rec_bytes = (int)(((int64_t)(N - 1) * ld + hd) * 2);
         const int total = my_items * NCH;
+        // chunk j of the workgroup's stream = chunk j % NCH of its (j / NCH)-th item
         auto fill = [&](int j) {
             if (j >= total) return;
             const int it = vid + (j / NCH) * G, c = j % NCH;
@@ -1458,16 +1464,25 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf
             const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, rec_bytes, 0x00020000);
             char* dst = smem + (j % ST_RING) * slot_bytes + which * arr_bytes;
             const int voff = dma_voff + c * NPC * dma_gstep;
+            if (nparts == 1) {
 #pragma unroll
-            for (int i = 0; i < NPC; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(dst + i * 1024), 16, voff + i * dma_gstep, 0, 0, 0);
+                for (int i = 0; i < NPC; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(dst + i * 1024), 16, voff + i * dma_gstep, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPC / 2; ++i) {
+                    const int p = 2 * i + part;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(dst + p * 1024), 16, voff + p * dma_gstep, 0, 0, 0);
+                }
+            }
         };
         fill(0);
         fill(1);
         for (int k = 0; k < total; ++k) {
-            // chunk k has landed once at most chunk k + 1's pieces are outstanding (in-order retirement)
-            if (k + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // chunk k has landed once at most chunk k + 1's pieces (of this loader) are outstanding (in-order retirement)
+            if (k + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (nparts == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC / 2) : "memory");
             __builtin_amdgcn_s_barrier();             // chunk k ready; everybody is done with chunk k - 1
             fill(k + 2);                              // ... whose slot takes chunk k + 2
         }
@@ -1489,6 +1504,19 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf
             voff[dt] = rr * R::RB + 16 * ((2 * dt + ((l15 & 3) >> 1)) ^ r16_swz<R::CPR>(rr)) + 8 * (l15 & 1);
     }
     const f32x4 zero4f = {0.f, 0.f, 0.f, 0.f};
+    // the wave's own query rows: item ii + 1's are fetched under item ii's last chunk
+    u32x4 qn[NKS];
+    auto q_issue = [&](int it) {
+        const int bh = it / nqb, qb = it % nqb;
+        const int q = qb * QB + 16 * wave + l15;
+        const bf16_t* qptr = qkv + ((int64_t)(bh / H) * N + (q < N ? q : N - 1)) * ld + (bh % H) * hd;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = 32 * ks + 8 * g;
+            qn[ks] = *reinterpret_cast<const u32x4*>(qptr + (d < hd ? d : 0));
+        }
+    };
+    if (my_items > 0) q_issue(vid);
     int j = 0;                                        // chunk index in the workgroup's stream
     for (int ii = 0; ii < my_items; ++ii) {
         const int it = vid + ii * G;
@@ -1496,17 +1524,11 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf
         const int b = bh / H, head = bh % H;
         const int q0 = qb * QB + 16 * wave;           // first query of this wave
         const int q = q0 + l15;
-        const int qrow = q < N ? q : N - 1;
         bf16x8 qf[NKS];
-        {
-            const bf16_t* qptr = qkv + ((int64_t)b * N + qrow) * ld + head * hd;
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const int d = 32 * ks + 8 * g;
-                u32x4 raw = *reinterpret_cast<const u32x4*>(qptr + (d < hd ? d : 0));
-                raw = d < hd ? raw : zero4();
-                qf[ks] = *reinterpret_cast<bf16x8*>(&raw);
-            }
+        for (int ks = 0; ks < NKS; ++ks) {
+            const u32x4 raw = 32 * ks + 8 * g < hd ? qn[ks] : zero4();      // chunks of d past hd are zeros
+            qf[ks] = *reinterpret_cast<const bf16x8*>(&raw);
         }
         f32x4 o[NDT];
 #pragma unroll
@@ -1514,6 +1536,7 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf
         float m_run = -INFINITY, l_run = 0.f;         // l_run: this lane's own keys only (summed over the four key groups at the end)
         for (int c = 0; c < NCH; ++c, ++j) {
             __syncthreads();                          // chunk j has landed (the loaders waited for it); see the loader loop
+            if (c == NCH - 1) q_issue(ii + 1 < my_items ? it + G : it);
             const char* Kb = smem + (j % ST_RING) * slot_bytes;
             const char* Vb = Kb + arr_bytes;
             const int nkeys = N - c * ST_KC;          // valid keys of this chunk (>= 1); wave-uniform

@@ -235,6 +235,39 @@ def test_attention_bwd(dev, B, N, H, hd, dt):
     assert rel_err(dqkv.float(), qr.grad) < (5e-5 if dt == torch.float32 else 3e-2)
 
 
+# the persistent ring / streaming kernels: more (batch, head[, query block]) items than CUs (a workgroup walks several items: ring
+# swap, prefetch chain, loader stream across item boundaries), head_dim below the template width (zero chunks through the DMA
+# descriptor), every sub-tile count of the ring form, 13 / 14 compute waves, sequence lengths around the chunk size of the stream
+RING_SHAPES = [(40, 197, 12, 64), (30, 100, 12, 48), (2, 209, 3, 64), (3, 224, 2, 64), (2, 96, 2, 64), (2, 129, 2, 40),
+               (2, 161, 3, 64), (40, 300, 12, 64), (3, 1000, 2, 48), (2, 225, 2, 64), (2, 384, 2, 64), (2, 385, 3, 64),
+               (9, 640, 4, 64), (300, 66, 2, 32)]
+
+
+@pytest.mark.parametrize("B,N,H,hd", RING_SHAPES)
+def test_attention_persistent_kernels_fwd_bwd(dev, B, N, H, hd):
+    dt = torch.bfloat16
+    qkv = rnd(B * N, 3 * H * hd, seed=B * 100 + N).to(dt)
+    do = rnd(B * N, H * hd, seed=78).to(dt)
+    scale = hd ** -0.5
+    qr = qkv.double().requires_grad_(True)
+    ref, lse_ref = attn_ref(qr, B, N, H, hd, scale)
+    ref.backward(do.double())
+    out, lse = ops.attention_fwd(qkv.to(dev), B, N, H, hd, scale, True)
+    assert rel_err(out.float(), ref.detach()) < 1.5e-2
+    assert rel_err(lse, lse_ref.detach()) < 5e-3
+    # every item on its own (an item that took another item's K / V, or a stale ring half, is far off while the global error stays small)
+    per_item = (out.float().cpu().view(B, N, H * hd) - ref.detach().float().view(B, N, H * hd)).abs().amax(dim=(1, 2))
+    assert float(per_item.max()) < 0.05 * float(ref.detach().abs().max()), int(per_item.argmax())
+    dqkv = ops.attention_bwd(qkv.to(dev), out, do.to(dev), lse, B, N, H, hd, scale)
+    assert rel_err(dqkv.float(), qr.grad) < 3e-2
+    per_item = (dqkv.float().cpu().view(B, N, -1) - qr.grad.float().view(B, N, -1)).abs().amax(dim=(1, 2))
+    assert float(per_item.max()) < 0.08 * float(qr.grad.abs().max()), int(per_item.argmax())
+    # run to run identical (no atomics, fixed reduction order)
+    out2, _ = ops.attention_fwd(qkv.to(dev), B, N, H, hd, scale, True)
+    assert torch.equal(out, out2)
+    assert torch.equal(dqkv, ops.attention_bwd(qkv.to(dev), out, do.to(dev), lse, B, N, H, hd, scale))
+
+
 @pytest.mark.parametrize("B,N,H,hd", [(4, 130, 8, 32), (2, 40, 32, 24), (1, 300, 2, 64)])
 @pytest.mark.parametrize("dt", DTYPES)
 def test_attention_dropout(dev, B, N, H, hd, dt):
