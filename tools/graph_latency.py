@@ -5,6 +5,8 @@ dev = torch.device('cuda:0')
 torch.manual_seed(0)
 enc = M.build_encoder(12, 768, 12).to(dev).eval()
 for b in enc: b.compute_dtype = torch.bfloat16
+if 'nofold' in sys.argv:
+    for b in enc: b.fold_norm = False      # LayerNorm as its own kernel instead of folded into qkv / fc1
 for B in (1, 8, 32):
     x = torch.randn(B, 197, 768, device=dev).bfloat16()
     with torch.no_grad():
