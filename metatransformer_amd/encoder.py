@@ -279,7 +279,10 @@ class _BlockFn(torch.autograd.Function):
                    fc2_b=f(fc2b), gamma1=f(g1), gamma2=f(g2))
         d = ops.block_desc(B, N, C, H, fc1w.shape[0], blk.eps, blk.attn.scale, cdt, rdt, w, wt, vec)
         folded = None
-        if fold and cdt == torch.bfloat16 and rdt == torch.bfloat16:
+        # (only when every CU gets 256 x 256 tiles of qkv: the fold's row-affine epilogue lives in the resident GEMM kernel; below
+        #  that the generic epilogue it would fall back to measured slower than LayerNorm + GEMM -- B = 32: 2.95 vs 2.75 ms)
+        big = ((B * N + 255) // 256) * ((3 * C + 255) // 256) >= 256
+        if fold and (big or fold == "always") and cdt == torch.bfloat16 and rdt == torch.bfloat16:
             folded = (cache.folded("qkv", qkvw, n1w, n1b, qkvb, cdt), cache.folded("fc1", fc1w, n2w, n2b, fc1b, cdt))
             (d.qkv_wf, d.qkv_s, d.qkv_c), (d.fc1_wf, d.fc1_s, d.fc1_c) = [tuple(ops.ptr(t) for t in trip) for trip in folded]
         return d, (w, wt, vec, folded)
@@ -474,7 +477,7 @@ class Block(nn.Module):
         self.compute_dtype: Optional[torch.dtype] = None     # override; None = infer (autocast / param dtype)
         self.c_side = True          # plain blocks run as one me_block_fwd / me_block_bwd call; False = op-by-op composition
         self.attn_fp8 = False       # True: e4m3 attention forward (me_attention_fwd_fp8; bf16 compute, head_dim 64) -- config 5
-        self.fold_norm = True       # inference (no gradient wanted), bf16 compute on a bf16 token stream: norm1 / norm2 folded into
+        self.fold_norm = True       # (True: when it pays, see _desc; "always": whenever it is legal; False: never)  inference (no gradient wanted), bf16 compute on a bf16 token stream: norm1 / norm2 folded into
                                     # qkv / fc1 (me_row_stats + row_affine GEMM epilogue instead of me_layernorm_fwd + GEMM)
         self._wcache = _WeightCache()
 
