@@ -242,9 +242,6 @@ def block_bwd(d, x2: torch.Tensor, dy2: torch.Tensor, saved: torch.Tensor, grads
 
 # ----------------------------------------------------------------------------- attention
 
-_FP8_WS = {}        # (device, bytes) -> scratch for the quantised Q / K / V^T of the fp8 attention forward
-
-
 def attention_fwd(qkv: torch.Tensor, B: int, N: int, H: int, hd: int, scale: float, need_lse: bool,
                   p_drop: float = 0.0, seed: int = 0, fp8: bool = False):
     """p_drop > 0: dropout on the attention probabilities (training-mode attn_drop); same p_drop / seed in attention_bwd.
@@ -258,11 +255,10 @@ def attention_fwd(qkv: torch.Tensor, B: int, N: int, H: int, hd: int, scale: flo
         if qkv.dtype != torch.bfloat16 or hd != 64 or p_drop > 0:
             raise MetaEncError("fp8 attention: bf16 qkv, head_dim 64 and no attention dropout are required")
         nbytes = lib.me_attention_fp8_workspace(B, N, H, hd)
-        key = (qkv.device, nbytes)
-        ws = _FP8_WS.get(key)
-        if ws is None:
-            _FP8_WS.clear()
-            ws = _FP8_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+        # scratch for the quantised Q / K / V^T: taken from torch's caching allocator per call -- a block freed here goes back to
+        # the pool of the stream it was allocated on, so a second stream (or a graph capture) never sees it while this call's
+        # kernels may still be running (a module-level buffer shared by every stream did not have that property)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
         check(lib.me_attention_fwd_fp8(ptr(qkv), 3 * C, ptr(out), C, ptr(lse), B, N, H, hd, float(scale), ptr(ws), nbytes,
                                        stream_ptr()), "me_attention_fwd_fp8")
         return out, lse
