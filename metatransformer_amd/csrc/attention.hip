@@ -1790,7 +1790,9 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
         }
         del += __shfl_xor(del, 16, 64);
         del += __shfl_xor(del, 32, 64);
-        const float lse2 = row_ok ? lse_n * LOG2E : INFINITY;      // +inf on padded queries -> P = 0
+        // +inf on padded queries -> P = 0; bounded below so that exp2(-lse2), what a padded key (zero K row, s = 0) evaluates to, stays
+        // finite (it only ever multiplies zeros)
+        const float lse2 = row_ok ? fmaxf(lse_n * LOG2E, -120.f) : INFINITY;
         if (g == 0) {
             lse_s[row] = lse2;
             del_s[row] = del;
