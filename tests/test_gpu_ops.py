@@ -464,3 +464,28 @@ def test_gemm_resident_half_items_every_epilogue(dev, M, N, K):
     y1 = ops.gemm(ad, wd, bias=bd, residual=res.to(dev))
     for _ in range(3):
         assert torch.equal(ops.gemm(ad, wd, bias=bd, residual=res.to(dev)), y1)
+    # claimed against STATIC schedule (the ticket of the claimed schedule travels through a hand-counted wait): a launch
+    # captured into a hipGraph always runs the static one -- same bits, every form that has a resident kernel
+    resd, facd, csd, outs = res.to(dev), fac.to(dev), w.float().sum(1).to(dev), {}
+    forms = {"bias": lambda o: ops.gemm(ad, wd, bias=bd, out=o), "gelu": lambda o: ops.gemm(ad, wd, bias=bd, act=_capi.ME_ACT_GELU, out=o),
+             "residual": lambda o: ops.gemm(ad, wd, bias=bd, residual=resd, out=o),
+             "factor": lambda o: ops.gemm(ad, wd, aux=facd, flags=_capi.ME_GEMM_AUX_IS_FACTOR, out=o),
+             "folded": lambda o: ops.gemm(ad, wd, bias=bd, row_affine=st, col_shift=csd, out=o)}
+    eager = {k: f(torch.empty(M, N, dtype=dt, device=dev)).clone() for k, f in forms.items()}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for k, f in forms.items():
+            outs[k] = torch.empty(M, N, dtype=dt, device=dev)
+            f(outs[k])                                 # (first launch on this stream outside the capture)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for k, f in forms.items():
+            f(outs[k])
+    for o in outs.values():
+        o.fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    for k in forms:
+        assert torch.equal(outs[k], eager[k]), k
