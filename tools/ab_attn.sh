@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B: bench with the current library, then with tools/_build_base/libmetaenc_prevattn.so (previous attention kernels)
+# same-box A/B: bench with the current library, then with tools/_build_base/libmetaenc_prevattn.so (previous attention kernels) -- built by tools/build_prevattn.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out/ab
 cp metatransformer_amd/libmetaenc.so /tmp/cur.so

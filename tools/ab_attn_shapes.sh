@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of the attention entry points alone over a list of shapes: current library vs tools/_build_base/libmetaenc_prevattn.so
+# same-box A/B of the attention entry points alone over a list of shapes: current library vs tools/_build_base/libmetaenc_prevattn.so -- built by tools/build_prevattn.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 cp metatransformer_amd/libmetaenc.so /tmp/cur.so
