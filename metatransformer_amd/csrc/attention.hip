@@ -1657,7 +1657,7 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
                                                                       const bf16_t* __restrict__ dout, int64_t lddo,
                                                                       const float* __restrict__ lse, float* __restrict__ delta,
                                                                       bf16_t* __restrict__ dqkv, int64_t lddq, int N, int H, int hd,
-                                                                      float scale, int items) {
+                                                                      float scale, int items, unsigned* __restrict__ ctr) {
     typedef Cfg<bf16_t, HD> C;
     typedef RCfg<HD> R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1677,11 +1677,44 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
     const int Cdim = H * hd;
     const int G = (int)gridDim.x;
     const bool active = 16 * wave < N;                // wave-uniform
-
+    // ---- items are CLAIMED (ctr != null; null under hipGraph capture = the static schedule it, it + G, ...): a workgroup's first item
+    // is its block index, every further one a draw from a counter -- a workgroup that starts late, because its CU was held by a
+    // communication kernel when this one was launched, then simply gets fewer items instead of making the whole launch wait for its
+    // full static share (the resident GEMM does the same: gemm3.hip).  Wave 0 draws the next item's id during phase A and leaves it in
+    // an LDS word ahead of barrier 1; everybody reads it behind that barrier.  Draws of one launch: (items - G) hits + one miss per
+    // workgroup = items; whoever draws the last one zeroes the counter for the next launch on this stream.
+    volatile int* const nextw = reinterpret_cast<volatile int*>(smem + 4 * arr_bytes + 2 * NR * (int)sizeof(float) + 16 * SCR);
+    // The draw is issued at the head of phase A and its result picked up at the end of it (a returning atomic takes a couple of
+    // microseconds; consumed where it is issued, wave 0 would sit on it and hold barrier 1 back -- measured +5 %): the atomic goes out
+    // through inline asm with only lane 0 enabled, so that the compiler sees no pending result to wait for; the explicit vmcnt(0)
+    // in draw_take() is the wait.
+    auto draw_issue = [&]() -> unsigned {            // (wave 0 only)
+        unsigned old = 0, one = 1;
+        if (ctr) {
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                         : "=&v"(old), "=&s"(saved) : "v"(0u), "v"(one), "s"(ctr) : "memory");
+        }
+        return old;                                  // valid in lane 0 once the operation has retired
+    };
+    auto draw_take = [&](unsigned drawn, int it) {   // (wave 0 only)
+        int nx = it + G;
+        if (ctr) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn) : : "memory");
+            const unsigned t = __builtin_amdgcn_readfirstlane(drawn);
+            if (t == (unsigned)(items > G ? items : G) - 1u && lane == 0) atomicExch(ctr, 0u);
+            nx = G + (int)t;
+        }
+        if (lane == 0) *nextw = nx;
+    };
     if (!active) {
         if (wave < 14) {                              // spare waves: the barrier count only
             __syncthreads();
-            for (int it = blockIdx.x; it < items; it += G) { __syncthreads(); __syncthreads(); }
+            for (int it = blockIdx.x; it < items;) {
+                __syncthreads();
+                it = __builtin_amdgcn_readfirstlane(*nextw);
+                __syncthreads();
+            }
             return;
         }
         // ---- loader waves: 14 fills the first array of a region (K, Q), 15 the second (V, dO)
@@ -1710,10 +1743,11 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
         int it = blockIdx.x;
         fill(kv_base(it), rec_a, voff_a, gstep_a, KVr + which * arr_bytes, 0);
         __syncthreads();
-        for (; it < items; it += G) {
+        while (it < items) {
             fill(qd_base(it), rec_d, voff_d, gstep_d, QDr + which * arr_bytes, 1);
             __syncthreads();                          // barrier 1 (vmcnt(0) first: the fill has landed)
-            if (it + G < items) fill(kv_base(it + G), rec_a, voff_a, gstep_a, KVr + which * arr_bytes, 2);
+            it = __builtin_amdgcn_readfirstlane(*nextw);      // the next item of this workgroup (>= items: none)
+            if (it < items) fill(kv_base(it), rec_a, voff_a, gstep_a, KVr + which * arr_bytes, 2);
             __syncthreads();                          // barrier 2
         }
         return;
@@ -1769,11 +1803,12 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
 #pragma unroll
     for (int i = 0; i < NPF; ++i) prefetch(it, i);
     __syncthreads();
-    for (; it < items; it += G) {
-        const int nxt = (it + G < items) ? it + G : it;
+    while (it < items) {
         const int b = it / H, head = it % H;
         const int64_t bh = ((int64_t)b * H + head) * N;
         TRACE_STAMP(it, 0);
+        unsigned drawn = 0;
+        if (wave == 0) drawn = draw_issue();
         // ---- phase A: this wave's 16 queries.  Own rows: chunks past hd are zeros; delta from the O / dO fragments
         bf16x8 qf[NKS], dof[NKS];
         float del = 0.f;
@@ -1835,8 +1870,11 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
             vf[ks] = *reinterpret_cast<const bf16x8*>(KVr + arr_bytes + 16 * wave * R::RB + koff[ks]);
         }
         TRACE_STAMP(it, 2);
-        __syncthreads();      // barrier 1: KV region dead; {Q, dO} of this item landed; lse_s / del_s complete
+        if (wave == 0) draw_take(drawn, it);
+        __syncthreads();      // barrier 1: KV region dead; {Q, dO} of this item landed; lse_s / del_s complete; next item's id published
         TRACE_STAMP(it, 3);
+        const int nid = __builtin_amdgcn_readfirstlane(*nextw);      // (wave-uniform: keep the address arithmetic that follows scalar)
+        const int nxt = nid < items ? nid : it;      // (own rows of the next item, or a harmless re-read of this one's)
         bf16_t* grow0 = dqkv + ((int64_t)b * N + 16 * wave) * lddq + head * hd;
         r16_store_rows<HD>(scr, dq, scale, grow0, lddq, N - 16 * wave, hd, lane);
         TRACE_STAMP(it, 4);
@@ -1891,6 +1929,7 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
         TRACE_STAMP(it, 6);
         __syncthreads();      // barrier 2: QD region dead; {K, V} of the next item landed
         TRACE_STAMP(it, 7);
+        it = nid;
     }
 }
 
@@ -2482,16 +2521,18 @@ template <int HD, int NS>
 int launch_bwd_ring16_ns(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
                          float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
     typedef RCfg<HD> R;
-    constexpr size_t smem = (size_t)4 * NS * 32 * R::RB + 2 * NS * 32 * sizeof(float) + (R16_THREADS / 64) * 16 * Cfg<bf16_t, HD>::RROW;
+    constexpr size_t smem = (size_t)4 * NS * 32 * R::RB + 2 * NS * 32 * sizeof(float) + (R16_THREADS / 64) * 16 * Cfg<bf16_t, HD>::RROW + 16;
     static OncePerDevice once;
     if (once.need()) { set_smem(attn_bwd_ring16_kernel<HD, NS>, smem); }
+    unsigned* ctr = me_work_counters(stream);      // (null while capturing: static schedule)
+    if (ctr) ctr += 1;                              // word 1 of the stream's set (word 0: the resident GEMM, XCD 0)
     const int64_t items = (int64_t)B * H;
     const int64_t slots = device_cus();
     const unsigned grid = (unsigned)(items < slots ? items : slots);
     hipLaunchKernelGGL((attn_bwd_ring16_kernel<HD, NS>), dim3(grid), dim3(R16_THREADS), smem, stream,
                        reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<const bf16_t*>(out), ldo,
                        reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd, scale,
-                       (int)items);
+                       (int)items, ctr);
     ME_CHECK_LAUNCH("me_attention_bwd(ring16)");
     return ME_OK;
 }

@@ -249,3 +249,6 @@ __device__ __forceinline__ f32x16 mma_chunk(f32x4 a, f32x4 b, f32x16 c) {
 }
 // row index inside a 32x32 accumulator tile for register r of half h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// per-stream work counters for persistent kernels that CLAIM their items (gemm3.hip): zero between launches, null under hipGraph capture
+unsigned* me_work_counters(hipStream_t stream);

@@ -765,6 +765,10 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
 
 }  // namespace
 
+// the same per-stream counter sets for the other persistent kernels of the library (attention): words 1..15 of a set are free (the
+// resident GEMM uses words 0, 16, 32, ...); null while the stream is capturing -> static schedule
+unsigned* me_work_counters(hipStream_t stream) { return g3r_tickets(stream); }
+
 // TN: p.split_k slabs of p.ksteps_per_split K-tiles (of 64) each into p.C = [split_k][M][N] fp32
 int launch_g3_tn(const GemmParams& p, hipStream_t stream) {
     static OncePerDevice once;
