@@ -335,7 +335,8 @@ int me_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
  *     Image/segmentation/mmcv_custom/layer_decay_optimizer_constructor.py:17-41 -> a table of contiguous segments of the flat
  *     bucket, each with its lr scale and weight decay (me_adamw_segment, device memory, sorted, the last end == n);
  *   * NativeScalerWithGradNormCount (Video/utils.py:376-404) = GradScaler.unscale_ + clip_grad_norm_ + "skip the step when
- *     a gradient is non-finite": me_grad_stats reduces the bucket to {sum of squares, number of non-finite values} (device),
+ *     a gradient is non-finite": me_grad_stats reduces the bucket to {L2 norm of the finite values (squares summed in double: a loss-scaled gradient whose
+ *     square leaves the fp32 range is NOT reported as non-finite), number of non-finite values} (device),
  *     me_adamw_prepare turns that into the control block -- gradient multiplier = grad_scale / *loss_scale * min(1, max_norm /
  *     (norm + 1e-6)), skip flag, step counter (advanced only when the step is taken) and its bias corrections -- and
  *     me_adamw_step_segments applies (or skips) the step.  total_norm / found_inf stay readable in the control block (the

@@ -1640,6 +1640,9 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf
     }
 }
 
+// a softmax probability from its log2-domain argument: v_exp_f32 with the clamp output modifier (hipcc folds the med3 into it)
+__device__ __forceinline__ float r16_p(float arg) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(arg), 0.f, 1.f); }
+
 // -----------------------------------------------------------------------------------------------------
 // Backward in the ring form (SM_MINN < N <= RS_MAXN), 16 waves, 16 rows per wave (see attn_fwd_ring16_kernel for why).
 // LDS holds two 2-array regions, KV = {K, V} and QD = {Q, dO}, unpadded and swizzled (r16_swz).  Per item:
@@ -1825,9 +1828,11 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
         }
         del += __shfl_xor(del, 16, 64);
         del += __shfl_xor(del, 32, 64);
-        // +inf on padded queries -> P = 0; bounded below so that exp2(-lse2), what a padded key (zero K row, s = 0) evaluates to, stays
-        // finite (it only ever multiplies zeros)
-        const float lse2 = row_ok ? fmaxf(lse_n * LOG2E, -120.f) : INFINITY;
+        // +inf on padded queries -> P = 0.  Valid rows keep their exact lse; a padded key (zero K row, s = 0) evaluates to
+        // exp2(-lse2), which overflows for a row whose scores are all very negative -- and it only ever multiplies zeros.  Every P is
+        // therefore taken through r16_p(): exp2 with the result clamped to [0, 1] (the output modifier of v_exp_f32, no extra
+        // instruction), exact for real entries (P <= 1 by construction of lse) and finite for padded ones
+        const float lse2 = row_ok ? lse_n * LOG2E : INFINITY;
         if (g == 0) {
             lse_s[row] = lse2;
             del_s[row] = del;
@@ -1856,7 +1861,7 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pe = __builtin_amdgcn_exp2f(s[tt][e] * sl - lse2);
+                    const float pe = r16_p(s[tt][e] * sl - lse2);
                     dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - del));      // dS^T / scale (scale applied to dQ once)
                 }
 #pragma unroll
@@ -1913,7 +1918,7 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
                 const f32x4 D = *reinterpret_cast<const f32x4*>(del_s + 16 * (2 * qq + tt) + 4 * g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pe = __builtin_amdgcn_exp2f(s[tt][e] * sl - L[e]);
+                    const float pe = r16_p(s[tt][e] * sl - L[e]);
                     pb[4 * tt + e] = (bf16_t)pe;
                     dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - D[e]));      // dS / scale (scale applied to dK once)
                 }

@@ -374,27 +374,35 @@ __global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p
 // Image/segmentation/mmcv_custom/layer_decay_optimizer_constructor.py:17-41), GradScaler.unscale_ + clip_grad_norm_ and the
 // skipped step on a non-finite gradient (Video/utils.py:376-404) -- on the flat bucket, with the decisions taken ON THE
 // DEVICE: no host round trip between backward and the optimizer step.
-//   grad_stats_kernel + grad_stats_fold_kernel : sum of squares and number of non-finite values of the bucket (deterministic
-//                                                two-level sum, fp32 partials of <= 4 K elements folded in double)
+//   grad_stats_kernel + grad_stats_fold_kernel : L2 norm and number of non-finite values of the bucket (deterministic
+//                                                two-level sum of squares in double)
 //   adamw_prepare_kernel                       : one thread: total norm, clip coefficient, found-inf, the step counter and its
 //                                                bias corrections -> me_adamw_ctl
 //   adamw_seg_kernel                           : the AdamW pass with a per-segment (lr scale, weight decay) table in LDS
 constexpr int GS_BLOCKS = 1024;
 __global__ __launch_bounds__(EW_THREADS) void grad_stats_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ part) {
-    float ss = 0.f, bad = 0.f;
+    // the squares are formed and summed in DOUBLE: the gradients are still multiplied by the loss scale here (the unscale is
+    // part of adamw_prepare), and a finite gradient whose scaled square leaves the fp32 range must not read as non-finite --
+    // GradScaler.unscale_ divides first and only then looks for inf (Video/utils.py:388-392).  HBM-bound either way.
+    double ss = 0.0;
+    float bad = 0.f;
     const int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(g + i * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            ss = __builtin_fmaf(v[e], v[e], ss);
-            bad += (__float_as_uint(v[e]) & 0x7f800000u) == 0x7f800000u ? 1.f : 0.f;       // inf or nan
+            const bool nf = (__float_as_uint(v[e]) & 0x7f800000u) == 0x7f800000u;            // inf or nan
+            const double d = nf ? 0.0 : (double)v[e];                                        // (counted, not summed)
+            ss = __builtin_fma(d, d, ss);
+            bad += nf ? 1.f : 0.f;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
         const float v = g[n4 * 4 + threadIdx.x];
-        ss = __builtin_fmaf(v, v, ss);
-        bad += (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u ? 1.f : 0.f;
+        const bool nf = (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u;
+        const double d = nf ? 0.0 : (double)v;
+        ss = __builtin_fma(d, d, ss);
+        bad += nf ? 1.f : 0.f;
     }
     __shared__ double sh[2][EW_THREADS / 64];
     double dss = ss, dbad = bad;
@@ -414,7 +422,8 @@ __global__ __launch_bounds__(64) void grad_stats_fold_kernel(const double* __res
     for (int i = threadIdx.x; i < nb; i += 64) { a += part[i * 2]; b += part[i * 2 + 1]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-    if (threadIdx.x == 0) { stats[0] = (float)a; stats[1] = (float)b; }
+    // stats[0] is the L2 NORM (not its square): representable in fp32 for any finite fp32 gradient buffer of < 2^64 elements
+    if (threadIdx.x == 0) { stats[0] = (float)sqrt(a); stats[1] = (float)b; }
 }
 __global__ void adamw_prepare_kernel(me_adamw_ctl* __restrict__ ctl, const float* __restrict__ stats, const float* __restrict__ loss_scale,
                                      float grad_scale, float max_norm, float b1, float b2) {
@@ -423,7 +432,7 @@ __global__ void adamw_prepare_kernel(me_adamw_ctl* __restrict__ ctl, const float
     if (loss_scale) mul /= *loss_scale;                               // GradScaler.unscale_: grads were computed on loss * scale
     float norm = 0.f, bad = 0.f;
     if (stats) {
-        norm = sqrtf(stats[0]) * fabsf(mul);                          // norm of the UNSCALED, averaged gradient
+        norm = stats[0] * fabsf(mul);                                 // norm of the UNSCALED, averaged gradient
         bad = (stats[1] > 0.f || !(norm == norm) || norm > 3.0e38f) ? 1.f : 0.f;
         if (max_norm > 0.f) {
             // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped at 1

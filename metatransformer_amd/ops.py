@@ -453,8 +453,8 @@ def adamw_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
 
 
 def grad_stats(grad: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """{sum of squares, number of non-finite values} of a flat fp32 gradient buffer as a 2-element DEVICE tensor
-    (me_grad_stats: deterministic two-level sum; nothing is synchronised)."""
+    """{L2 norm of the finite values, number of non-finite values} of a flat fp32 gradient buffer as a 2-element DEVICE
+    tensor (me_grad_stats: deterministic two-level sum of squares in double; nothing is synchronised)."""
     _req(grad, "grad")
     if grad.dtype != torch.float32 or grad.dim() != 1:
         raise MetaEncError("grad_stats: a flat float32 buffer is required")

@@ -505,7 +505,10 @@ class FusedAdamW:
         f = self.flat
         f.check()
         if self.bf16_mirror and f.flat_bf16 is None:
+            # filled from the CURRENT parameters: a first step that the device skips (found_inf) writes nothing, and the
+            # mirror is handed to every Block as its forward weights from here on
             f.flat_bf16 = torch.empty(f.numel, dtype=torch.bfloat16, device=f.flat_param.device)
+            ops.cast(f.flat_param, torch.bfloat16, out=f.flat_bf16)
         out = None
         if self.fine_tune:
             need_stats = self.max_norm > 0 or self.loss_scale is not None

@@ -148,3 +148,16 @@ def test_resident_gemm_isa_has_no_inner_loop_spills_and_keeps_its_ticket_registe
         asm = mod.compile_asm(d)
     report, findings = mod.check(asm)
     assert len(report) >= 7 and not findings, findings
+
+
+def test_attention_backward_isa_keeps_its_ticket_register():
+    """The same check on the claimed-item draw of attn_bwd_ring16_kernel (attention.hip): the returning atomic is issued at the head
+    of phase A and consumed at its end; nothing may write, spill or copy its result register in between."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_g3r_isa", os.path.join(ROOT, "tools", "check_g3r_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with tempfile.TemporaryDirectory() as d:
+        asm = mod.compile_asm(d, mod.SRC_ATTN)
+    report, findings = mod.check(asm, kernel="attn_bwd_ring16_kernel", check_loops=False)
+    assert len(report) >= 8 and not findings, findings

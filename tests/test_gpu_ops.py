@@ -235,6 +235,75 @@ def test_attention_bwd(dev, B, N, H, hd, dt):
     assert rel_err(dqkv.float(), qr.grad) < (5e-5 if dt == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("B,N,H,hd", [(96, 197, 12, 64), (70, 100, 12, 48)])
+def test_attention_bwd_claimed_items_match_the_static_schedule(dev, B, N, H, hd):
+    """the persistent ring backward CLAIMS its items (a returning atomic retired by a hand-counted wait, ~400
+    instructions after it was issued).  A launch captured into a hipGraph runs the static schedule: same bits; and the claimed
+    form stays bit-identical over many launches next to unrelated traffic on a second stream (workgroups then start unevenly and
+    really do end up with different item lists)."""
+    dt = torch.bfloat16
+    qkv = rnd(B * N, 3 * H * hd, seed=B + N).to(dt).to(dev)
+    do = rnd(B * N, H * hd, seed=81).to(dt).to(dev)
+    scale = hd ** -0.5
+    out, lse = ops.attention_fwd(qkv, B, N, H, hd, scale, True)
+    eager = ops.attention_bwd(qkv, out, do, lse, B, N, H, hd, scale).clone()
+    assert B * H > 256                                   # more items than CUs: every workgroup draws
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = ops.attention_bwd(qkv, out, do, lse, B, N, H, hd, scale)      # (first launch on this stream outside the capture)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        got = ops.attention_bwd(qkv, out, do, lse, B, N, H, hd, scale)
+    got.fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, eager)
+    noise = torch.empty(32 << 20, device=dev)
+    bad = 0
+    for i in range(40):
+        if i % 2 == 0:
+            with torch.cuda.stream(side):
+                noise.add_(1.0)
+        bad += int(not torch.equal(ops.attention_bwd(qkv, out, do, lse, B, N, H, hd, scale), eager))
+    torch.cuda.synchronize()
+    assert bad == 0
+
+
+@pytest.mark.parametrize("N", [197, 250, 400, 600])
+def test_attention_bwd_rows_with_very_negative_lse(dev, N):
+    """Query rows whose scaled scores are ALL far below zero (lse < -100): P = exp(s - lse) must still use the exact lse (no
+    lower bound on it), and the padded keys of the last key group (zero K rows, s = 0 -> exp(-lse) overflows) must stay harmless.
+    Covers the ring (N <= 224), resident, mid and chunked backward kernels."""
+    B, H, hd = 2, 2, 64
+    dt = torch.bfloat16
+    qkv = rnd(B * N, 3 * H * hd, seed=4000 + N)
+    q = qkv.view(B, N, 3, H, hd)
+    # every key of head 0 gets a common component c; queries 5, 60 and N - 1 point along -c with a large norm: all their scores ~ -180
+    c = torch.ones(hd) / hd ** 0.5
+    q[:, :, 1, 0, :] = 0.2 * q[:, :, 1, 0, :] + 6.0 * c
+    for r in (5, 60, N - 1):
+        q[:, r, 0, 0, :] = -240.0 * c + q[:, r, 0, 0, :]
+    qkv = qkv.to(dt)
+    do = rnd(B * N, H * hd, seed=79).to(dt)
+    scale = hd ** -0.5
+    qr = qkv.double().requires_grad_(True)
+    ref, lse_ref = attn_ref(qr, B, N, H, hd, scale)
+    ref.backward(do.double())
+    assert float(lse_ref[:, 0, 5].max()) < -100.0
+    out, lse = ops.attention_fwd(qkv.to(dev), B, N, H, hd, scale, True)
+    assert rel_err(lse, lse_ref.detach()) < 5e-3
+    dqkv = ops.attention_bwd(qkv.to(dev), out, do.to(dev), lse, B, N, H, hd, scale)
+    assert torch.isfinite(dqkv.float()).all()
+    assert rel_err(dqkv.float(), qr.grad) < 3e-2
+    # the rows in question on their own (dq of a row with a wrong P is off by O(1) of ITS scale, invisible in the global maximum)
+    got = dqkv.float().cpu().view(B, N, 3, H, hd)
+    want = qr.grad.float().view(B, N, 3, H, hd)
+    for r in (5, 60, N - 1):
+        assert rel_err(got[:, r, 0, 0], want[:, r, 0, 0]) < 5e-2, r
+
+
 # the persistent ring / streaming kernels: more (batch, head[, query block]) items than CUs (a workgroup walks several items: ring
 # swap, prefetch chain, loader stream across item boundaries), head_dim below the template width (zero chunks through the DMA
 # descriptor), every sub-tile count of the ring form, 13 / 14 compute waves, sequence lengths around the chunk size of the stream

@@ -32,12 +32,15 @@ def _torch_groups(named, lr, wd, scales):
     return list(groups.values())
 
 
-def test_grad_stats_sum_of_squares_and_nonfinite_count(dev):
+def test_grad_stats_norm_and_nonfinite_count(dev):
     g = torch.randn(1_000_003, generator=torch.Generator().manual_seed(1)).to(dev)
     buf = torch.zeros(1_000_064, device=dev)[:1_000_003]
     buf.copy_(g)
     st = ops.grad_stats(buf)
-    assert abs(float(st[0]) - float(g.double().pow(2).sum())) < 1e-5 * float(g.double().pow(2).sum()) and float(st[1]) == 0.0
+    want = float(g.double().pow(2).sum().sqrt())
+    assert abs(float(st[0]) - want) < 1e-6 * want and float(st[1]) == 0.0
+    big = ops.grad_stats(buf * 1e25)                                # squares far outside fp32: still a finite norm, nothing "bad"
+    assert abs(float(big[0]) / 1e25 - want) < 1e-5 * want and float(big[1]) == 0.0
     buf[12345] = float("inf"); buf[999_999] = float("nan"); buf[1_000_002] = float("-inf")
     assert float(ops.grad_stats(buf)[1]) == 3.0
 
@@ -103,5 +106,54 @@ def test_found_inf_skips_the_step_and_the_scale_backs_off(dev):
     assert float(scaler.scale_t) == 512.0
     assert one_step(False) == 0.0                                    # the step counter did not advance on the skipped step
     topt.step()
+    for (n, p), (_, q) in zip(named, ref):
+        assert rel_err(p, q) < 2e-6, n
+
+
+def test_first_step_skipped_leaves_a_valid_bf16_mirror(dev):
+    """A found-inf skip on the very FIRST step writes nothing -- the bf16 mirror the Blocks then read as their forward weights
+    must already hold the current parameters (it is filled when it is allocated), not uninitialised memory."""
+    named = _named_params(dev, seed=11)
+    flat = parallel.FlatParams(named, no_decay=parallel.no_decay_rule)
+    scaler = parallel.DynamicLossScale(dev, init_scale=256.0, growth_interval=1000)
+    opt = parallel.FusedAdamW(flat, lr=1e-2, weight_decay=0.1, bf16_mirror=True, loss_scale=scaler.scale_t)
+    flat.zero_grad()
+    for _, p in named:
+        p.grad.fill_(1.0)
+    named[2][1].grad.view(-1)[0] = float("nan")
+    before = flat.flat_param.detach().clone()
+    _, found = opt.step()
+    assert float(found) == 1.0 and torch.equal(before, flat.flat_param.detach())
+    assert flat.flat_bf16 is not None and torch.equal(flat.flat_bf16, before.to(torch.bfloat16))
+    # a step that IS taken then rewrites it from the updated parameters
+    flat.zero_grad()
+    for _, p in named:
+        p.grad.fill_(256.0)
+    _, found = opt.step()
+    assert float(found) == 0.0 and not torch.equal(before, flat.flat_param.detach())
+    assert torch.equal(flat.flat_bf16, flat.flat_param.detach().to(torch.bfloat16))
+
+
+def test_large_loss_scale_does_not_fake_a_nonfinite_gradient(dev):
+    """GradScaler.unscale_ divides first and only then looks for inf: finite gradients whose SCALED sum of squares leaves the
+    fp32 range (|g * scale| ~ 1e19 and up) must still take the step, with the unscaled norm reported."""
+    named = _named_params(dev, seed=13)
+    ref = [(n, torch.nn.Parameter(p.detach().clone())) for n, p in named]
+    topt = torch.optim.AdamW([{"params": [q for n, q in ref if q.dim() == 1 or n.endswith(".bias")], "weight_decay": 0.0},
+                              {"params": [q for n, q in ref if not (q.dim() == 1 or n.endswith(".bias"))], "weight_decay": 0.1}], lr=1e-2)
+    flat = parallel.FlatParams(named, no_decay=parallel.no_decay_rule)
+    scale = torch.full((1,), 2.0 ** 70, device=dev)
+    opt = parallel.FusedAdamW(flat, lr=1e-2, weight_decay=0.1, bf16_mirror=False, loss_scale=scale, max_norm=1e9)
+    g = torch.Generator().manual_seed(17)
+    flat.zero_grad()
+    for (n, p), (_, q) in zip(named, ref):
+        gr = torch.randn(p.shape, generator=g).to(dev)
+        p.grad.copy_(gr * scale)                                    # ~1e21 per element: squares overflow fp32, the values do not
+        q.grad = gr.clone()
+    want = torch.nn.utils.clip_grad_norm_([q for _, q in ref], 1e9)
+    topt.step()
+    norm, found = opt.step()
+    assert float(found) == 0.0
+    assert abs(float(norm) - float(want)) < 1e-4 * float(want)
     for (n, p), (_, q) in zip(named, ref):
         assert rel_err(p, q) < 2e-6, n

@@ -7,6 +7,11 @@ for metatransformer_amd/csrc/gemm3.hip -- no GPU needed:
      hand-counted s_waitcnt) is neither overwritten nor spilled between the atomic and the v_readfirstlane that consumes it --
      the compiler cannot see that the value is still in flight.
 
+The persistent attention backward (attn_bwd_ring16_kernel, attention.hip) draws its items the same way -- issued at the head of
+phase A, consumed at its end, ~300-600 instructions apart in a 1024-thread kernel at ~128 VGPRs -- and gets check 2 as well
+(ADVICE r3): between the atomic and the v_readfirstlane the ticket register must not be written, spilled, or COPIED (a v_mov /
+v_accvgpr_write of it would read the register before the atomic has returned).
+
     python tools/check_g3r_isa.py            # compiles to a temporary directory, prints one line per kernel, exit 1 on a finding
 """
 import os
@@ -17,6 +22,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "metatransformer_amd", "csrc", "gemm3.hip")
+SRC_ATTN = os.path.join(ROOT, "metatransformer_amd", "csrc", "attention.hip")
 
 
 def _regs(tok):
@@ -28,17 +34,18 @@ def _regs(tok):
     return out
 
 
-def compile_asm(workdir):
+def compile_asm(workdir, src=SRC):
     from metatransformer_amd import build as me_build
-    out = os.path.join(workdir, "gemm3.s")
-    cmd = [me_build._hipcc()] + me_build.FLAGS + ["-S", "--cuda-device-only", SRC, "-o", out]
+    out = os.path.join(workdir, os.path.basename(src)[:-4] + ".s")
+    cmd = [me_build._hipcc()] + me_build.FLAGS + ["-S", "--cuda-device-only", src, "-o", out]
     subprocess.run(cmd, check=True, capture_output=True)
     return open(out).read()
 
 
-def check(asm):
+def check(asm, kernel="gemm_g3r_kernel", check_loops=True):
+    """kernel: substring of the mangled names to check; check_loops: also run check 1 (inner MFMA loops free of spills)"""
     findings, report = [], []
-    names = [m.group(1) for m in re.finditer(r"^(_Z\w*gemm_g3r_kernel\w*):", asm, re.M)]
+    names = [m.group(1) for m in re.finditer(r"^(_Z\w*" + kernel + r"\w*):", asm, re.M)]
     for nm in names:
         pos = asm.index("\n" + nm + ":")
         lines = asm[pos:asm.find(".end_amdhsa_kernel", pos)].splitlines()
@@ -51,7 +58,7 @@ def check(asm):
         inner = [lp for lp in loops if lp[1] - lp[0] < 1500 and any("v_mfma" in x for x in lines[lp[0]:lp[1]])]
         spills = [i for i, l in enumerate(lines) if ("scratch_" in l or "v_readlane_b32" in l or "v_writelane_b32" in l)
                   and any(a <= i <= b for a, b in inner)]
-        if spills:
+        if spills and check_loops:
             findings.append(f"{nm}: {len(spills)} spill operations inside an inner K-loop (first at line {spills[0]})")
         draws = 0
         for i, l in enumerate(lines):
@@ -74,6 +81,9 @@ def check(asm):
                 if ops[0].startswith("scratch_store") and reg in _regs(ops[1]):
                     status = f"spilled {j - i} instructions behind the atomic"
                     break
+                if ops[0].startswith(("v_mov_b32", "v_accvgpr_write", "v_mov_b64")) and reg in _regs(",".join(args[1:])):
+                    status = f"copied {j - i} instructions behind the atomic (reads the register before the result is back): {t[:60]}"
+                    break
                 is_store = ops[0].startswith(("buffer_store", "global_store", "ds_write", "s_"))
                 if not is_store and "v_permlane" not in ops[0] and reg in _regs(args[0]):
                     status = f"overwritten {j - i} instructions behind the atomic: {t[:60]}"
@@ -81,9 +91,14 @@ def check(asm):
             if status != "ok":
                 findings.append(f"{nm}: ticket register v{reg}: {status}")
         scratch = sum("scratch_" in l for l in lines)
-        report.append(f"{nm}: {len(inner)} inner K-loops clean, {draws} ticket draws intact, {scratch} scratch operations outside the loops")
+        if check_loops:
+            report.append(f"{nm}: {len(inner)} inner K-loops clean, {draws} ticket draws intact, {scratch} scratch operations outside the loops")
+        else:
+            if draws == 0:
+                findings.append(f"{nm}: no ticket draw found")
+            report.append(f"{nm}: {draws} ticket draws intact, {scratch} scratch operations in the kernel")
     if not names:
-        findings.append("no gemm_g3r_kernel instantiation found in the assembly")
+        findings.append(f"no {kernel} instantiation found in the assembly")
     return report, findings
 
 
@@ -91,7 +106,10 @@ def main():
     sys.path.insert(0, ROOT)
     with tempfile.TemporaryDirectory() as d:
         asm = compile_asm(d)
+        asm_attn = compile_asm(d, SRC_ATTN)
     report, findings = check(asm)
+    r2, f2 = check(asm_attn, kernel="attn_bwd_ring16_kernel", check_loops=False)
+    report, findings = report + r2, findings + f2
     print("\n".join(report))
     for f in findings:
         print("FINDING:", f)
