@@ -49,10 +49,13 @@ DEV_DIR = os.path.join(os.path.dirname(HERE), "tools", "_build")
 DEV_OUT = os.path.join(DEV_DIR, "libmetaenc_dev.so")
 
 
-def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
-    out = DEV_OUT if dev else OUT
-    obj_dir = os.path.join(DEV_DIR, "_obj") if dev else OBJ_DIR
-    flags = FLAGS + (["-DME_DEV"] if dev else [])
+def build(force: bool = False, verbose: bool = True, dev: bool = False, variant: str = "", defines=()) -> str:
+    """variant / defines (dev builds only): a further copy of the dev library, tools/_build_<variant>/, compiled with the extra
+    -D switches (compile-time A/B arms such as the resident GEMM's cache policies: tools/r4_policy_builds.sh)"""
+    dev_dir = DEV_DIR + ("_" + variant if variant else "")
+    out = os.path.join(dev_dir, "libmetaenc_dev.so") if dev else OUT
+    obj_dir = os.path.join(dev_dir, "_obj") if dev else OBJ_DIR
+    flags = FLAGS + (["-DME_DEV"] + ["-D" + d for d in defines] if dev else [])
     if not dev and not force and not needs_build():
         return OUT
     hipcc = _hipcc()
@@ -80,9 +83,9 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
     subprocess.run(cmd, check=True)
     os.replace(out + ".tmp", out)
     if dev:
-        exe = os.path.join(DEV_DIR, "gemm_dev")
+        exe = os.path.join(dev_dir, "gemm_dev")
         cmd = [hipcc, "-O2", "-std=c++17", f"--offload-arch={ARCH}", os.path.join(os.path.dirname(HERE), "tools", "gemm_dev.hip"),
-               "-o", exe, "-L" + DEV_DIR, "-lmetaenc_dev", "-Wl,-rpath,$ORIGIN"]
+               "-o", exe, "-L" + dev_dir, "-lmetaenc_dev", "-Wl,-rpath,$ORIGIN", "-lpthread"]
         if verbose:
             print("[metaenc build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -90,4 +93,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv))
+    # python -m metatransformer_amd.build [--force] [--dev [--variant NAME -DX=1 -DY=2 ...]]
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    _defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv, variant=_variant, defines=_defs))

@@ -280,7 +280,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     const int to_reg = 4 * (8 * (r & 7) + 4 * (r >> 3) + 2 * (g & 1) + (g >> 1));
     auto fetch = [&](const int mt, u32x4 (&raw)[2]) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) raw[h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(roff + (2 * mt + h) * rstep), 0, 0);
+        for (int h = 0; h < 2; ++h) raw[h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(roff + (2 * mt + h) * rstep), 0, G3_POL_R);
     };
     auto unpack = [](const u32x4& rw, f32x4& a, f32x4& b) {
         a[0] = __uint_as_float(rw[0] << 16); a[1] = __uint_as_float(rw[0] & 0xffff0000u);
@@ -351,8 +351,8 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
             }
             u32x4 o0 = pack(v[0][0], v[0][1]), o1 = pack(v[1][0], v[1][1]);
             g3r_rows8_packed(o0, o1);
-            __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(o0, to_mem), crs, (int)(coff + (2 * mt) * cstep), 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(o1, to_mem), crs, (int)(coff + (2 * mt + 1) * cstep), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(o0, to_mem), crs, (int)(coff + (2 * mt) * cstep), 0, G3_POL_C);
+            __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(o1, to_mem), crs, (int)(coff + (2 * mt + 1) * cstep), 0, G3_POL_C);
             continue;
         }
         g3r_rows8(v[0][0], v[0][1], v[1][0], v[1][1]);
@@ -368,11 +368,11 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                     phi_parts4(v0, ph0, ga0);
                     phi_parts4(v1, ph1, ga1);
                     const f32x4 d0 = ph0 + v0 * ga0 * 0.3989422804014327f, d1 = ph1 + v1 * ga1 * 0.3989422804014327f;
-                    __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(d0, d1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(d0, d1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, G3_POL_P);
                     v0 *= ph0;
                     v1 *= ph1;
                 } else {
-                    if (SAVE) __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, 0);
+                    if (SAVE) __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, G3_POL_P);
                     v0 = gelu_bf16_4(v0);
                     v1 = gelu_bf16_4(v1);
                 }
@@ -383,7 +383,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                 v1 *= gelu_bf16_grad4(ro[h][1]);
             }
             if (EPI == 2) { v0 += ro[h][0]; v1 += ro[h][1]; }
-            __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), crs, (int)(coff + (2 * mt + h) * cstep), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), crs, (int)(coff + (2 * mt + h) * cstep), 0, G3_POL_C);
         }
     }
     if (HALF) {

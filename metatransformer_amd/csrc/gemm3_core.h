@@ -46,6 +46,24 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void3;
 
 constexpr int G3_BM = 256, G3_BN = 256, G3_BK = 64;
+// Cache policy (the `aux` operand of the buffer instructions: 1 = sc0, 2 = nt, 16 = sc1) of the resident kernel's five streams.
+// Compile-time so that an A/B is one more build of the dev library (tools/r4_policy_builds.sh), never a branch around a
+// memory operation: A = token rows (DMA), B = weight rows (DMA), C = output stores, R = row-operand loads, P = saved-tensor stores.
+#ifndef G3_POL_A
+#define G3_POL_A 0
+#endif
+#ifndef G3_POL_B
+#define G3_POL_B 0
+#endif
+#ifndef G3_POL_C
+#define G3_POL_C 0
+#endif
+#ifndef G3_POL_R
+#define G3_POL_R 0
+#endif
+#ifndef G3_POL_P
+#define G3_POL_P 0
+#endif
 constexpr int G3_HALF = 128 * 128;              // bytes in a half-tile
 constexpr int G3_BUF = 4 * G3_HALF;             // 64 KiB
 constexpr int G3_LDS = 2 * G3_BUF;              // 128 KiB
@@ -120,8 +138,9 @@ template <int J> __device__ __forceinline__ void g3_issue(const G3State& s, cons
     char* dst = s.smem + buf * G3_BUF + J * G3_HALF + s.wave * 2048;
     const __amdgpu_buffer_rsrc_t r = (J & 1) ? src.a : src.b;
     const int koff = kt * ((J & 1) ? s.kstep_a : s.kstep_b);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)dst, 16, (int)s.src[J][0], koff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)(dst + 1024), 16, (int)s.src[J][1], koff, 0, 0);
+    constexpr int pol = (J & 1) ? G3_POL_A : G3_POL_B;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)dst, 16, (int)s.src[J][0], koff, 0, pol);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)(dst + 1024), 16, (int)s.src[J][1], koff, 0, pol);
 }
 
 // NT fragment: one 16-byte read at (lane part + buffer) + an IMMEDIATE (half-tile slot, tile).  Inline asm for the same

@@ -15,7 +15,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <chrono>
+#include <glob.h>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../include/metaenc.h"
 
@@ -116,6 +120,52 @@ __global__ void cmp_kernel(const uint16_t* got, const float* ref, size_t n, floa
     atomicMax(reinterpret_cast<unsigned int*>(maxerr), __float_as_uint(me));
 }
 
+// ---- socket power / shader clock next to a timed loop (--power SECONDS): the amdgpu hwmon files of the visible device, sampled
+// every 20 ms by a host thread while the launches run ("the power-bound claim is half-instrumented").  Energy per
+// flop = mean power x time / flops of the loop.  Files that do not exist on a box simply report nothing.
+struct PowerProbe {
+    std::vector<std::string> pw, fq;
+    std::atomic<bool> stop{false};
+    std::thread th;
+    double sum_w = 0, sum_mhz = 0, max_w = 0;
+    int n_w = 0, n_f = 0;
+    static std::vector<std::string> find(const char* pat) {
+        std::vector<std::string> out;
+        glob_t g;
+        if (glob(pat, 0, nullptr, &g) == 0) for (size_t i = 0; i < g.gl_pathc; ++i) out.push_back(g.gl_pathv[i]);
+        globfree(&g);
+        return out;
+    }
+    static bool read_ll(const std::string& f, long long& v) {
+        FILE* fp = fopen(f.c_str(), "r");
+        if (!fp) return false;
+        const bool ok = fscanf(fp, "%lld", &v) == 1;
+        fclose(fp);
+        return ok;
+    }
+    PowerProbe() {
+        pw = find("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average");
+        if (pw.empty()) pw = find("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input");
+        fq = find("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input");
+    }
+    void start() {
+        stop = false; sum_w = sum_mhz = max_w = 0; n_w = n_f = 0;
+        th = std::thread([this] {
+            while (!stop) {
+                long long v;
+                double w = 0; bool any = false;
+                for (auto& f : pw) if (read_ll(f, v) && v > 0) { w = v * 1e-6 > w ? v * 1e-6 : w; any = true; }    // the busiest visible socket
+                if (any) { sum_w += w; ++n_w; max_w = w > max_w ? w : max_w; }
+                double mhz = 0; any = false;
+                for (auto& f : fq) if (read_ll(f, v) && v > 0) { mhz = v * 1e-6 > mhz ? v * 1e-6 : mhz; any = true; }
+                if (any) { sum_mhz += mhz; ++n_f; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+        });
+    }
+    void finish() { stop = true; if (th.joinable()) th.join(); }
+};
+
 static int family_code(const std::string& f) {
     if (f == "auto") return -1;
     if (f == "g128") return 0;
@@ -129,10 +179,12 @@ static int family_code(const std::string& f) {
 int main(int argc, char** argv) {
     int iters = 20;
     bool check = false;
+    double power_secs = 0;
     std::vector<std::string> cases;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--iters")) iters = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--check")) check = true;
+        else if (!strcmp(argv[i], "--power")) power_secs = atof(argv[++i]);
         else cases.push_back(argv[i]);
     }
     constexpr int NSET = 3;
@@ -325,6 +377,32 @@ int main(int argc, char** argv) {
         const double us = 1e3 * ms / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
         printf("%-34s %8.1f us  %7.1f TF/s  %s\n", c.c_str(), us, tf, verdict.c_str());
         fflush(stdout);
+        if (power_secs > 0) {
+            // a sustained loop (the DVFS loop settles within a few hundred ms; the first 0.3 s are not sampled)
+            const int n_warm = (int)(0.3e6 / us) + 1, n_loop = (int)(power_secs * 1e6 / us) + 1;
+            for (int i = 0; i < n_warm; ++i) run(i % NSET);
+            CK(hipStreamSynchronize(st));
+            PowerProbe pp;
+            pp.start();
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < n_loop; ++i) run(i % NSET);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            pp.finish();
+            float ms2 = 0.f;
+            CK(hipEventElapsedTime(&ms2, e0, e1));
+            const double us2 = 1e3 * ms2 / n_loop, flop = 2.0 * M * N * K;
+            if (pp.n_w) {
+                const double w = pp.sum_w / pp.n_w;
+                printf("  power: %6.1f us/launch over %.1f s  %7.1f TF/s  mean %6.1f W (max %6.1f, %d samples)  %.3f pJ/flop", us2, ms2 * 1e-3,
+                       flop / (us2 * 1e-6) / 1e12, w, pp.max_w, pp.n_w, w * us2 * 1e-6 / flop * 1e12);
+            } else {
+                printf("  power: %6.1f us/launch over %.1f s  %7.1f TF/s  (no hwmon power file readable)", us2, ms2 * 1e-3, flop / (us2 * 1e-6) / 1e12);
+            }
+            if (pp.n_f) printf("  hwmon sclk %.0f MHz", pp.sum_mhz / pp.n_f);
+            printf("\n");
+            fflush(stdout);
+        }
         if (debug & 8) {
             // time stamps of the resident kernel (debug bit 8): [256 workgroups][2 wave rows][16 items][4] shader clocks
             const size_t n = 256 * 2 * 16 * 8;
