@@ -153,3 +153,100 @@ def test_multirank_reducer_sums_over_every_visible_gpu():
     for p in procs:
         p.join(timeout=120)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def test_bf16_wire_reducer_round_trip_on_the_gpu():
+    """OverlappedGradReducer(wire_dtype=bfloat16) through me_allreduce_bucket(ME_BF16) with a world of one: fp32 bucket -> me_cast
+    -> bf16 all-reduce (identity) -> me_cast back behind the join.  The result is the fp32 gradient rounded to bf16 once (relative
+    error <= 2^-9 per element, exactly representable values untouched), and the optimizer stream sees it only after the join."""
+    import metatransformer_amd as M
+    from metatransformer_amd import parallel
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    enc = M.build_encoder(2, 128, 4).to(dev)
+    flat = parallel.FlatParams(enc.named_parameters(), no_decay=parallel.no_decay_rule)
+    comm = parallel.Comm(parallel.Comm.new_unique_id(), 0, 1)
+    red = parallel.OverlappedGradReducer(flat, comm=comm, force=True, bucket_bytes=256 << 10, wire_dtype=torch.bfloat16)
+    x = torch.randn(4, 33, 128, device=dev, requires_grad=True)
+    with red.no_sync():
+        flat.zero_grad()
+        enc(x).square().mean().backward()
+        want32 = flat.flat_grad.clone()
+    for it in range(2):
+        flat.zero_grad()
+        enc(x).square().mean().backward()
+        red.finish()
+        got = flat.flat_grad.clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want32.bfloat16().float()), it          # one bf16 rounding of every element, nothing else
+        assert float((got - want32).abs().max()) <= 2.0 ** -8 * float(want32.abs().max())
+    assert comm.info()["buckets_reduced"] == 2 * len(red.bucket_slices)
+    red.remove()
+    comm.destroy()
+
+
+def _ddp_worker(port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        import metatransformer_amd as M
+        torch.manual_seed(0)
+        enc = M.build_encoder(2, 128, 4).to(dev)
+        ref = M.build_encoder(2, 128, 4).to(dev)
+        ref.load_state_dict(enc.state_dict())
+        # the wrapper the reference's fine-tune scripts put around the model (Video/run_class_finetuning.py:739-742,
+        # PointCloud/examples/classification/train.py:83-87): its reducer hooks the .grad of ordinary nn.Parameters that a custom
+        # autograd.Function fills
+        ddp = torch.nn.parallel.DistributedDataParallel(enc, device_ids=[0])
+        x = torch.randn(4, 33, 128, generator=torch.Generator().manual_seed(5)).to(dev)
+        res = {}
+        for name, model in (("ddp", ddp), ("plain", ref)):
+            for amp in (False, True):
+                model.zero_grad(set_to_none=True)
+                xr = x.clone().requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                    y = model(xr)
+                y.float().square().mean().backward()
+                mod = model.module if name == "ddp" else model
+                res[(name, amp)] = (y.detach().clone(), xr.grad.clone(), {k: p.grad.clone() for k, p in mod.named_parameters()})
+        for amp in (False, True):
+            (ya, dxa, ga), (yb, dxb, gb) = res[("ddp", amp)], res[("plain", amp)]
+            assert torch.equal(ya, yb) and torch.equal(dxa, dxb), amp
+            for k in ga:
+                assert torch.equal(ga[k], gb[k]), (k, amp)       # world 1: averaged over one rank == the local gradient, bit for bit
+        # a frozen encoder under DDP with a trainable tokenizer in front (the common reference set-up): only dL/dx flows
+        for p in enc.parameters():
+            p.requires_grad_(False)
+        tok = torch.nn.Linear(16, 128).to(dev)
+        stack = torch.nn.parallel.DistributedDataParallel(torch.nn.Sequential(tok, enc), device_ids=[0])
+        stack(torch.randn(4, 33, 16, device=dev)).square().mean().backward()
+        assert tok.weight.grad is not None and all(p.grad is None for p in enc.parameters())
+        q.put("ok")
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put(traceback.format_exc()[-2500:] or repr(e))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:       # noqa: BLE001
+            pass
+
+
+def test_blocks_inside_distributed_data_parallel_world1():
+    """SURVEY 8b lists DistributedDataParallel among the wrappers the drop-in must survive: a 2-block encoder wrapped in DDP on a
+    world-1 nccl (= RCCL) group gives the same outputs and gradients as the unwrapped encoder, fp32 and under bf16 autocast."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_ddp_worker, args=(29000 + os.getpid() % 2000, q))
+    p.start()
+    try:
+        msg = q.get(timeout=300)
+    finally:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert msg == "ok", msg

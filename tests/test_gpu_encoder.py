@@ -80,6 +80,8 @@ def test_backward_fp32_matches_reference_golden(dev, name):
         assert abs(p.grad.double().abs().sum().item() - stats[1]) < 1e-3 * max(stats[1], 1e-6), k
         head = p.grad.flatten()[:16].cpu().numpy()
         assert np.allclose(head, z["dparam_head/" + k], rtol=5e-3, atol=1e-3 * stats[1] / p.numel() + 1e-6), k
+        if c.get("grad_stride"):      # the reference's OWN gradient values, element for element (whole, or every 5th of the Base block)
+            check_close(p.grad.flatten()[::c["grad_stride"]], torch.from_numpy(z["dparam_s/" + k]), TOL_F32, f"{name} d{k} vs reference values")
     # EVERY element of every gradient (the fixture keeps sums and heads only: a wrong tail column of a 3072-wide weight
     # gradient would pass those): against the CPU restatement on the fixture's inputs, which tests/test_oracle.py pins to the
     # same reference-generated statistics
@@ -105,7 +107,7 @@ def test_backward_full_parity_vs_oracle(dev):
         (y * go.to(dev)).sum().backward()
         assert rel_err(y, y_ref) < t and rel_err(xr.grad, dx_ref) < t
         for k, p in enc.named_parameters():
-            assert rel_err(p.grad, dp_ref[k]) < t, (k, dt)
+            check_close(p.grad, dp_ref[k], t, f"d{k} {dt}")      # (max-abs AND per element)
 
 
 def test_flat_params_fused_gradient_accumulation(dev):
@@ -827,7 +829,7 @@ def test_large_config3_backward_vs_oracle(dev):
         check_close(y.float(), y_ref, tf, f"config 3 y {dt}")
         check_close(xr.grad.float(), dx_ref, tg, f"config 3 dx {dt}")
         for k, p in enc.named_parameters():
-            assert rel_err(p.grad, dp_ref[k]) < tg, (k, dt)
+            check_close(p.grad, dp_ref[k], tg, f"config 3 d{k} {dt}")
 
 
 def test_block_with_fp8_attention_config5_shape(dev):
@@ -847,7 +849,7 @@ def test_block_with_fp8_attention_config5_shape(dev):
     (y * go.to(dev)).sum().backward()
     assert rel_err(y, y_ref) < 1e-2 and rel_err(xr.grad, dx_ref) < 3e-2
     for k, p in enc.named_parameters():
-        assert rel_err(p.grad, dp_ref[k]) < 3e-2, k
+        check_close(p.grad, dp_ref[k], 3e-2, f"config 5 block d{k} (fp8 attention forward)")
     enc[0].attn_fp8 = False
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         y16 = enc(x.to(dev))
@@ -904,7 +906,12 @@ def test_inference_with_folded_layernorm_matches_reference_golden(dev, name):
     check_close(y_fold[:, ::s].float(), ref, tol, name + " folded")
     check_close(y_plain[:, ::s].float(), ref, tol, name + " unfolded")
     assert torch.equal(y_one, y_fold)
-    assert rel_err(y_fold.float(), y_plain.float()) < tol
+    # folded against unfolded: two bf16 paths of the same arithmetic -- bf16 noise of ONE rounding per block output for a block or
+    # two; through 12 blocks the two streams drift apart like any two bf16 evaluations do (measured 7.6e-3 .. 1.0e-2), still well
+    # under the 3e-2 either holds against the fp32 reference, so a fold-specific error of 1e-2 cannot hide
+    ff = rel_err(y_fold.float(), y_plain.float())
+    print(f"folded vs unfolded ({name}): {ff:.2e}")
+    assert ff < (TOL_BF16 if c["depth"] <= 2 else 1.5e-2)
     assert not torch.equal(y_fold, y_plain)            # (they are different kernels: identical bits would mean the fold is off)
     # a weight update invalidates the folded copies
     with torch.no_grad():
