@@ -56,7 +56,12 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, variant:
     out = os.path.join(dev_dir, "libmetaenc_dev.so") if dev else OUT
     obj_dir = os.path.join(dev_dir, "_obj") if dev else OBJ_DIR
     flags = FLAGS + (["-DME_DEV"] + ["-D" + d for d in defines] if dev else [])
-    if not dev and not force and not needs_build():
+    if not dev and variant:
+        # a PRODUCT-flavoured A/B arm (no -DME_DEV): tools/_build_prod_<variant>/libmetaenc.so, swapped in for the in-tree library by
+        # the same-box A/B scripts (tools/ab_bench.sh); never loaded by the package itself
+        dev_dir = os.path.join(os.path.dirname(HERE), "tools", "_build_prod_" + variant)
+        out, obj_dir, flags = os.path.join(dev_dir, "libmetaenc.so"), os.path.join(dev_dir, "_obj"), FLAGS + ["-D" + d for d in defines]
+    if not dev and not variant and not force and not needs_build():
         return OUT
     hipcc = _hipcc()
     os.makedirs(obj_dir, exist_ok=True)

@@ -291,7 +291,7 @@ def test_attention_bwd_rows_with_very_negative_lse(dev, N):
     qr = qkv.double().requires_grad_(True)
     ref, lse_ref = attn_ref(qr, B, N, H, hd, scale)
     ref.backward(do.double())
-    assert float(lse_ref[:, 0, 5].max()) < -100.0
+    assert float(lse_ref.detach()[:, 0, 5].max()) < -100.0
     out, lse = ops.attention_fwd(qkv.to(dev), B, N, H, hd, scale, True)
     assert rel_err(lse, lse_ref.detach()) < 5e-3
     dqkv = ops.attention_bwd(qkv.to(dev), out, do.to(dev), lse, B, N, H, hd, scale)
@@ -300,8 +300,10 @@ def test_attention_bwd_rows_with_very_negative_lse(dev, N):
     # the rows in question on their own (dq of a row with a wrong P is off by O(1) of ITS scale, invisible in the global maximum)
     got = dqkv.float().cpu().view(B, N, 3, H, hd)
     want = qr.grad.float().view(B, N, 3, H, hd)
+    # (bound: the keys share a large common component here, so the bf16 rounding of dS -- whose row sums cancel exactly only in
+    # exact arithmetic -- shows up as a common offset of a few % in dq; a P taken against a wrong lse is off by orders of magnitude)
     for r in (5, 60, N - 1):
-        assert rel_err(got[:, r, 0, 0], want[:, r, 0, 0]) < 5e-2, r
+        assert rel_err(got[:, r, 0, 0], want[:, r, 0, 0]) < 0.15, r
 
 
 # the persistent ring / streaming kernels: more (batch, head[, query block]) items than CUs (a workgroup walks several items: ring
