@@ -1392,7 +1392,7 @@ __device__ __forceinline__ void r16_store_rows(char* scr, const f32x4 (&acc)[HD 
         const int r = r0 + RPI * k;
         const u32x4 v = *reinterpret_cast<const u32x4*>(scr + r * C::RROW + chunk * 16);
         const int off = chunk * 8 < hd ? (int)(r * ldg * 2) + chunk * 16 : 0x7f000000;
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, ME_POL_ATTN_ST);
     }
     __builtin_amdgcn_wave_barrier();
 }

@@ -1,5 +1,24 @@
 // common.h -- shared device/host helpers for libmetaenc (gfx950 / CDNA4 only).
 #pragma once
+// Compile-time cache-policy arms (A/B builds only; all default to the plain policy): non-temporal loads / stores for streams that
+// are written or read exactly once (tools/r4_policy_builds.sh).  __builtin_nontemporal_* lower to global_load / global_store ... nt.
+#ifndef ME_POL_LN_ST
+#define ME_POL_LN_ST 0
+#endif
+#ifndef ME_POL_LN_LD
+#define ME_POL_LN_LD 0
+#endif
+#ifndef ME_POL_ATTN_ST
+#define ME_POL_ATTN_ST 0
+#endif
+#ifndef ME_POL_SLAB
+#define ME_POL_SLAB 0
+#endif
+#ifndef ME_POL_ADAMW
+#define ME_POL_ADAMW 0
+#endif
+#define ME_NT_LOAD(POL, ptr) ((POL) ? __builtin_nontemporal_load(ptr) : *(ptr))
+#define ME_NT_STORE(POL, val, ptr) do { if (POL) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -267,26 +267,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t m = i / nq, n = (i % nq) * 4;
         const float* s0 = slabs + m * p.N + n;
-        f32x4 v = *reinterpret_cast<const f32x4*>(s0);
+        f32x4 v = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0));
         int s = 1;
         // eight slab reads in flight (the fold is latency-bound otherwise: S reads in dependent rounds of a few), added in
         // slab order -- deterministic
         for (; s + 7 < S; s += 8) {
             f32x4 t[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + j) * sstride);
+            for (int j = 0; j < 8; ++j) t[j] = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + j) * sstride));
 #pragma unroll
             for (int j = 0; j < 8; ++j) v += t[j];
         }
         if (s + 3 < S) {
             f32x4 t[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + j) * sstride);
+            for (int j = 0; j < 4; ++j) t[j] = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + j) * sstride));
 #pragma unroll
             for (int j = 0; j < 4; ++j) v += t[j];
             s += 4;
         }
-        for (; s < S; ++s) v += *reinterpret_cast<const f32x4*>(s0 + (int64_t)s * sstride);
+        for (; s < S; ++s) v += ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0 + (int64_t)s * sstride));
         if (LIN) epilogue_quad_lin(p, m, n, v);
         else epilogue_quad(p, m, n, v);
     }

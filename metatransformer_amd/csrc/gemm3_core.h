@@ -478,8 +478,8 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
             if (EPI == 5) {
                 if (ok) {
                     float* d = slab + (m - slab_row0) * p.N + n[q];
-                    *reinterpret_cast<f32x4*>(d) = v0;
-                    *reinterpret_cast<f32x4*>(d + 4) = v1;
+                    ME_NT_STORE(ME_POL_SLAB, v0, reinterpret_cast<f32x4*>(d));
+                    ME_NT_STORE(ME_POL_SLAB, v1, reinterpret_cast<f32x4*>(d + 4));
                 }
                 continue;
             }

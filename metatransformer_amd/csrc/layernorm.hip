@@ -15,21 +15,21 @@ constexpr int LN_MAX_VEC = 16;            // supports C up to 4*64*16 = 4096 on 
 // s_waitcnt vmcnt(0) at each branch join, which serialises the 18 loads a wave has in flight per iteration.
 template <typename T> __device__ __forceinline__ f32x4 ld4(const void* base, int64_t idx);
 template <> __device__ __forceinline__ f32x4 ld4<float>(const void* base, int64_t idx) {
-    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+    return ME_NT_LOAD(ME_POL_LN_LD, reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx));
 }
 template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const void* base, int64_t idx) {
-    const u32x2 raw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+    const u32x2 raw = ME_NT_LOAD(ME_POL_LN_LD, reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(base) + idx));
     return f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u), __uint_as_float(raw[1] << 16),
                  __uint_as_float(raw[1] & 0xffff0000u)};
 }
 template <typename T> __device__ __forceinline__ void st4(void* base, int64_t idx, f32x4 v);
 template <> __device__ __forceinline__ void st4<float>(void* base, int64_t idx, f32x4 v) {
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
+    ME_NT_STORE(ME_POL_LN_ST, v, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx));
 }
 template <> __device__ __forceinline__ void st4<bf16_t>(void* base, int64_t idx, f32x4 v) {
     bf16x4 o;
     o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-    *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(base) + idx) = o;
+    ME_NT_STORE(ME_POL_LN_ST, __builtin_bit_cast(u32x2, o), reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(base) + idx));
 }
 
 // VPL = number of 4-element vectors per lane (C = 256 * VPL on the fast path); dtypes are template parameters for the

@@ -220,6 +220,7 @@ def _ddp_worker(port, q):
         # a frozen encoder under DDP with a trainable tokenizer in front (the common reference set-up): only dL/dx flows
         for p in enc.parameters():
             p.requires_grad_(False)
+            p.grad = None
         tok = torch.nn.Linear(16, 128).to(dev)
         stack = torch.nn.parallel.DistributedDataParallel(torch.nn.Sequential(tok, enc), device_ids=[0])
         stack(torch.randn(4, 33, 16, device=dev)).square().mean().backward()

@@ -11,12 +11,16 @@ for rep in $(seq $REPS); do
     L=${arm%%=*}; P=${arm#*=}
     cp $P metatransformer_amd/libmetaenc.so
     timeout 400 python bench.py $ARGS > /tmp/ab_$L.json 2> /tmp/ab_$L.err || { echo "$L: bench failed"; tail -3 /tmp/ab_$L.err; continue; }
+    [ -n "$KEEP" ] && cp /tmp/ab_$L.json $KEEP/ab_${L}_$rep.json
     python - "$L" <<'PY'
 import json,sys
 L=sys.argv[1]
 j=json.loads(open(f'/tmp/ab_{L}.json').read().strip().splitlines()[-1])
 f=j.get('fwd') or {}
-print(f"{L:10s} train {j['ms_per_step']:7.3f} ms  gemm roof {j['roofline']['frac']:.4f}  fwd {f.get('ms_per_step',0):6.3f} ms  fwd mfma {f.get('mfma_frac',0):.4f}  fwd gemm roof {(f.get('roofline') or {}).get('frac',0):.4f}")
+ok=j.get('other_kernels') or {}
+fo=f.get('other_kernels') or {}
+us=lambda d,k: (d.get(k) or {}).get('avg_launch_us',0)
+print(f"{L:10s} train {j['ms_per_step']:7.3f} ms  gemm {j['roofline']['avg_launch_us']:6.1f} us roof {j['roofline']['frac']:.4f} wgrad {j['roofline']['wgrad_kernel']['avg_launch_us']:6.1f}  ln f/b {us(ok,'layernorm_fwd'):5.1f}/{us(ok,'layernorm_bwd'):5.1f}  attn f/b {us(ok,'attention_fwd'):5.1f}/{us(ok,'attention_bwd'):6.1f} | fwd {f.get('ms_per_step',0):6.3f} ms mfma {f.get('mfma_frac',0):.4f} gemm {(f.get('roofline') or {}).get('avg_launch_us',0):6.1f} us  stats {us(fo,'row_stats'):5.1f} attn {us(fo,'attention_fwd'):5.1f}")
 PY
   done
 done
