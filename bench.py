@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--model", choices=["base", "large"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-leg", action="store_true")
+    ap.add_argument("--no-chain-stats", action="store_true",
+                    help="A/B: folded inference reads every LayerNorm input once more (me_row_stats) instead of taking the statistics from the residual GEMMs' epilogues")
     ap.add_argument("--attn-dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: e4m3 attention forward on the block-scaled MFMA (config 5; head_dim 64)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
@@ -136,6 +138,7 @@ def main():
     for blk in enc:
         blk.compute_dtype = torch.bfloat16       # fp32 master weights, bf16 MFMA compute, bf16 token stream
         blk.attn_fp8 = args.attn_dtype == "fp8"
+        blk.chain_stats = not args.no_chain_stats
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)        # per-rank data (Video/run_class_finetuning.py:417)
     tok_note = None
     if args.workload == "mixed":

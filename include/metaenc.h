@@ -53,6 +53,11 @@ int me_device_info(int dev, int* num_cus, int* lds_bytes, int* clock_mhz, char* 
 /* me_row_stats: per row of [rows, cols] the pair (rstd, -rstd * mean) -> out [rows][2] fp32: the statistics of the same
  * LayerNorm for a Linear that has the normalisation folded in (me_gemm_desc.row_affine).  One read of x, no write of x. */
 int me_row_stats(const void* x, int x_dtype, float* out, int64_t rows, int cols, float eps, void* stream);
+/* The same pairs from per-row PARTIAL statistics that a producing kernel left behind (me_gemm_desc.row_stats: [cols / 64][rows]
+ * pairs (mean, M2) over 64-column groups): Chan's parallel combination -- mean = average of the group means, M2 = sum of the
+ * group M2 + 64 * sum (group mean - mean)^2 -- then rstd = (M2 / cols + eps)^-1/2.  cols % 64 == 0. */
+size_t me_row_stats_partial_bytes(int64_t rows, int cols);
+int me_row_stats_combine(const float* partials, int64_t rows, int cols, float eps, float* out, void* stream);
 int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
                      void* y, int y_dtype, float* mean, float* rstd,
                      int64_t rows, int cols, float eps, void* stream);
@@ -122,6 +127,13 @@ typedef struct me_gemm_desc {
      * me_row_stats, col_shift = s [N] fp32.  Applied ahead of bias / activation: v = ra[m][0] * acc + ra[m][1] * s[n]. */
     const float* row_affine;
     const float* col_shift;
+    /* optional, ME_GEMM_NT with a bf16 residual epilogue (the proj / fc2 launches of a block): the per-row statistics of the
+     * OUTPUT rows on the side, so that the LayerNorm reading this residual stream next (norm2 behind proj, the next block's
+     * norm1 behind fc2) needs no pass of its own over it.  row_stats receives [N / 64][M] fp32 pairs (mean, M2 = sum of squared
+     * deviations from that mean) over 64-column groups -- me_row_stats_partial_bytes(M, N) bytes -- which
+     * me_row_stats_combine folds into the (rstd, -rstd * mean) pairs of me_row_stats.  Only when me_gemm_emits_row_stats(d)
+     * != 0 (whole 256 x 256 tiles on every CU, N % 64 == 0, plain residual epilogue); otherwise me_gemm rejects it. */
+    float* row_stats;
 } me_gemm_desc;
 
 /* Scratch the kernel selected for this problem can use (0 = none).  wgrad-shaped problems (tiny output, very long
@@ -130,6 +142,8 @@ typedef struct me_gemm_desc {
 size_t me_gemm_workspace_bytes(const me_gemm_desc* d);
 /* 1 if me_gemm(d) with d->colsum_a set (and a workspace of me_gemm_workspace_bytes(d)) will produce the column sums */
 int me_gemm_fuses_colsum(const me_gemm_desc* d);
+/* 1 if me_gemm(d) can serve d->row_stats (evaluated as if it were set) */
+int me_gemm_emits_row_stats(const me_gemm_desc* d);
 int me_gemm(const me_gemm_desc* d, void* stream);
 
 /* Per-launch timing for roofline accounting (bench.py): while enabled, every me_gemm call -- including those made from
@@ -215,6 +229,13 @@ typedef struct me_block_desc {
      * GEMMs instead of me_layernorm_fwd + GEMMs (the normalised tokens are neither written nor re-read); any NULL -> as before. */
     const void *qkv_wf, *fc1_wf;
     const float *qkv_s, *qkv_c, *fc1_s, *fc1_c;
+    /* optional, folded inference only: LayerNorm statistics handed from block to block.  x_stats = the [B*N][2] pairs of
+     * me_row_stats(x, eps) for THIS block's norm1 (saves its pass over x); y_stats = where to leave the same pairs for y (taken
+     * from the fc2 epilogue: me_gemm_desc.row_stats + me_row_stats_combine), for the next block's x_stats.  y_stats is written
+     * only when the block's shapes let the GEMMs emit statistics -- me_block_emits_stats(d) -- and is left untouched otherwise.
+     * me_encoder_fwd chains them by itself. */
+    const float* x_stats;
+    float* y_stats;
 } me_block_desc;
 
 /* Gradient destinations of me_block_bwd; any pointer may be NULL (that gradient is skipped -- frozen encoder).
@@ -231,6 +252,8 @@ typedef struct me_block_grads {
 /* bytes of the activation stash forward writes for backward (xn1, qkv, o, x1, xn2, fc1 pre-activation, gelu output,
  * LayerNorm statistics, attention LSE), and of the scratch either call needs (intermediates, split-K slabs) */
 size_t me_block_saved_bytes(const me_block_desc* d);
+/* 1 if me_block_fwd(d, ..., saved = NULL) takes the folded route AND its residual GEMMs emit row statistics (y_stats is served) */
+int me_block_emits_stats(const me_block_desc* d);
 size_t me_block_workspace_bytes(const me_block_desc* d, int backward);
 /* saved == NULL: inference (nothing kept; intermediates live in the workspace) */
 int me_block_fwd(const me_block_desc* d, const void* x, void* y, void* saved, void* workspace, size_t workspace_bytes,

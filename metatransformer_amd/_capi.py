@@ -54,6 +54,7 @@ class GemmDesc(ctypes.Structure):
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
         ("colsum_a", c_void_p),
         ("row_affine", c_void_p), ("col_shift", c_void_p),
+        ("row_stats", c_void_p),
     ]
 
 
@@ -82,7 +83,8 @@ class BlockDesc(ctypes.Structure):
                  ("heads", c_int32), ("hidden", c_int32), ("eps", c_float), ("scale", c_float)]
                 + [(n, c_void_p) for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_wt", "proj_wt", "fc1_wt", "fc2_wt",
                                            "ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_b", "proj_b", "fc1_b", "fc2_b",
-                                           "gamma1", "gamma2", "qkv_wf", "fc1_wf", "qkv_s", "qkv_c", "fc1_s", "fc1_c")])
+                                           "gamma1", "gamma2", "qkv_wf", "fc1_wf", "qkv_s", "qkv_c", "fc1_s", "fc1_c",
+                                           "x_stats", "y_stats")])
 
 
 class BlockGrads(ctypes.Structure):
@@ -111,6 +113,8 @@ SIGNATURES = {
     "me_build_arch": (c_char_p, []),
     "me_device_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
     "me_row_stats": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "me_row_stats_partial_bytes": (c_size_t, [c_int64, c_int]),
+    "me_row_stats_combine": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "me_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                  c_int64, c_int, c_float, c_void_p]),
     "me_layernorm_bwd_workspace": (c_size_t, [c_int]),
@@ -119,6 +123,7 @@ SIGNATURES = {
                                  c_int64, c_int, c_void_p, c_void_p]),
     "me_gemm_workspace_bytes": (c_size_t, [POINTER(GemmDesc)]),
     "me_gemm_fuses_colsum": (c_int, [POINTER(GemmDesc)]),
+    "me_gemm_emits_row_stats": (c_int, [POINTER(GemmDesc)]),
     "me_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
     "me_gemm_profile_enable": (c_int, [c_int]),
     "me_gemm_profile_read": (c_int, [POINTER(GemmProfileRec), c_int]),
@@ -135,6 +140,7 @@ SIGNATURES = {
     "me_attention_fwd_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                      c_void_p, c_size_t, c_void_p]),
     "me_block_saved_bytes": (c_size_t, [POINTER(BlockDesc)]),
+    "me_block_emits_stats": (c_int, [POINTER(BlockDesc)]),
     "me_block_workspace_bytes": (c_size_t, [POINTER(BlockDesc), c_int]),
     "me_block_fwd": (c_int, [POINTER(BlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "me_encoder_fwd": (c_int, [POINTER(BlockDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

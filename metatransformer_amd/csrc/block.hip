@@ -91,6 +91,28 @@ size_t aux_scratch(const Dims& s) {      // LayerNorm-backward and column-sum sc
     return align256(a > b ? a : b);
 }
 
+// ---- folded inference: LayerNorm statistics taken from the residual GEMMs' epilogues (me_gemm_desc.row_stats)
+bool wants_fold(const me_block_desc* d) {
+    return d->qkv_wf && d->fc1_wf && d->qkv_s && d->qkv_c && d->fc1_s && d->fc1_c && d->res_dtype == d->dtype;
+}
+// scratch behind the inference intermediates: the [C / 64][M] partials (shared by proj and fc2) + two [M][2] pair buffers that
+// me_encoder_fwd hands from block to block
+size_t stats_scratch(const Dims& s) { return align256(me_row_stats_partial_bytes(s.M, s.C)) + 2 * align256((size_t)s.M * 8); }
+// can the proj / fc2 launches of this block emit statistics?  (both have the same M, N = C; K differs -- ask for each)
+bool emits_stats(const me_block_desc* d, const Dims& s) {
+    if (!wants_fold(d) || d->gamma1 || d->gamma2 || s.C % 64) return false;
+    static char dummy_mem[64] __attribute__((aligned(64)));
+    me_gemm_desc g;
+    for (int64_t K : {(int64_t)s.C, (int64_t)s.Hd}) {
+        gemm_desc(g, ME_GEMM_NT, d->dtype, s.M, s.C, K, dummy_mem, K, dummy_mem, K, dummy_mem, s.C, d->res_dtype);
+        g.bias = reinterpret_cast<const float*>(dummy_mem);
+        g.residual = dummy_mem; g.ldres = s.C; g.res_dtype = d->res_dtype;
+        g.workspace = dummy_mem; g.workspace_bytes = (int64_t)1 << 40;      // (as me_block_fwd calls it: with a workspace)
+        if (!me_gemm_emits_row_stats(&g)) return false;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" size_t me_block_saved_bytes(const me_block_desc* d) {
@@ -99,11 +121,17 @@ extern "C" size_t me_block_saved_bytes(const me_block_desc* d) {
     return carve_saved(d, s, nullptr).bytes;
 }
 
+extern "C" int me_block_emits_stats(const me_block_desc* d) {
+    Dims s;
+    if (get_dims(d, s, "me_block_emits_stats") != ME_OK) return 0;
+    return emits_stats(d, s) ? 1 : 0;
+}
+
 extern "C" size_t me_block_workspace_bytes(const me_block_desc* d, int backward) {
     Dims s;
     if (get_dims(d, s, "me_block_workspace_bytes") != ME_OK) return 0;
     size_t w = gemm_scratch(d, s, backward != 0) + aux_scratch(s);
-    if (!backward) return w + carve_saved(d, s, nullptr).bytes;      // inference keeps the intermediates here
+    if (!backward) return w + carve_saved(d, s, nullptr).bytes + stats_scratch(s);      // inference keeps the intermediates here
     // dy_c, dh, dxn (shared by dxn2 / dxn1), dx1, dx1_c, do, dqkv, delta
     w += align256(s.M * s.C * s.esz) * 4 + align256(s.M * s.Hd * s.esz) + align256(s.M * s.C * s.rsz) +
          align256(s.M * s.C3 * s.esz) + align256((size_t)d->B * d->heads * d->N * 4);
@@ -132,11 +160,19 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     // the GEMM's A operand (it must already be in the compute dtype), the statistics come from one read-only pass, and the
     // epilogue applies rstd * acc - rstd * mean * s + c -- the normalised tokens are neither written nor read back.  The pair
     // buffer [M][2] takes the place of the (adjacent) mean / rstd arrays of the activation stash.
-    const bool fold = !keep && d->qkv_wf && d->fc1_wf && d->qkv_s && d->qkv_c && d->fc1_s && d->fc1_c && rdt == dt;
+    const bool fold = !keep && wants_fold(d);
+    // ... and, where the residual GEMMs can emit them, the statistics come out of the proj / fc2 epilogues (one tiny combine pass
+    // each) instead of a pass over the token stream: norm2's from proj, the NEXT block's norm1's from fc2 (d->y_stats)
+    const bool stats = fold && emits_stats(d, s);
+    float* partials = reinterpret_cast<float*>(ws + gsz + aux_scratch(s) + v.bytes);
     if (fold) {
-        if ((rc = me_row_stats(x, rdt, v.mean1, s.M, s.C, d->eps, stream))) return rc;
+        const float* st1 = d->x_stats;
+        if (!st1) {
+            if ((rc = me_row_stats(x, rdt, v.mean1, s.M, s.C, d->eps, stream))) return rc;
+            st1 = v.mean1;
+        }
         gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C3, s.C, x, s.C, d->qkv_wf, s.C, v.qkv, s.C3, dt);
-        g.bias = d->qkv_c; g.row_affine = v.mean1; g.col_shift = d->qkv_s;
+        g.bias = d->qkv_c; g.row_affine = st1; g.col_shift = d->qkv_s;
     } else {
         rc = me_layernorm_fwd(x, rdt, d->ln1_g, d->ln1_b, v.xn1, dt, keep ? v.mean1 : nullptr, keep ? v.rstd1 : nullptr, s.M, s.C, d->eps, stream);
         if (rc) return rc;
@@ -150,9 +186,12 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C, s.C, v.o, s.C, d->proj_w, s.C, v.x1, s.C, rdt);
     g.bias = d->proj_b; g.colscale = d->gamma1; g.residual = x; g.ldres = s.C; g.res_dtype = rdt;
     g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+    if (stats) g.row_stats = partials;
     if ((rc = me_gemm(&g, stream))) return rc;
     if (fold) {
-        if ((rc = me_row_stats(v.x1, rdt, v.mean2, s.M, s.C, d->eps, stream))) return rc;
+        if (stats) rc = me_row_stats_combine(partials, s.M, s.C, d->eps, v.mean2, stream);
+        else rc = me_row_stats(v.x1, rdt, v.mean2, s.M, s.C, d->eps, stream);
+        if (rc) return rc;
         gemm_desc(g, ME_GEMM_NT, dt, s.M, s.Hd, s.C, v.x1, s.C, d->fc1_wf, s.C, v.a, s.Hd, dt);
         g.bias = d->fc1_c; g.row_affine = v.mean2; g.col_shift = d->fc1_s;
     } else {
@@ -169,7 +208,10 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C, s.Hd, v.a, s.Hd, d->fc2_w, s.Hd, y, s.C, rdt);
     g.bias = d->fc2_b; g.colscale = d->gamma2; g.residual = v.x1; g.ldres = s.C; g.res_dtype = rdt;
     g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
-    return me_gemm(&g, stream);
+    if (stats && d->y_stats) g.row_stats = partials;
+    if ((rc = me_gemm(&g, stream))) return rc;
+    if (stats && d->y_stats) return me_row_stats_combine(partials, s.M, s.C, d->eps, d->y_stats, stream);
+    return ME_OK;
 }
 
 extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* dy, const void* saved, void* dx,
@@ -257,11 +299,28 @@ extern "C" int me_encoder_fwd(const me_block_desc* blocks, int n_blocks, const v
     ME_CHECK_ARG(n_blocks == 1 || pingpong, "me_encoder_fwd: more than one block needs the ping-pong token buffer");
     // block i writes y when (n_blocks - 1 - i) is even, the ping-pong buffer otherwise: the last block lands in y and no
     // block reads the buffer it writes
+    // LayerNorm statistics travel with the tokens: block i leaves the pairs of its output in one of the two pair buffers at the
+    // end of the workspace, block i + 1 (same width, same eps) starts from them instead of reading its input once more
     const void* in = x;
+    const float* st_in = nullptr;
     for (int i = 0; i < n_blocks; ++i) {
         void* out = ((n_blocks - 1 - i) % 2 == 0) ? y : pingpong;
-        int rc = me_block_fwd(&blocks[i], in, out, nullptr, workspace, workspace_bytes, stream);
+        me_block_desc d = blocks[i];
+        Dims s;
+        int rc = get_dims(&d, s, "me_encoder_fwd");
         if (rc) return rc;
+        d.x_stats = st_in;
+        d.y_stats = nullptr;
+        const bool chain = i + 1 < n_blocks && emits_stats(&d, s) && wants_fold(&blocks[i + 1]) && blocks[i + 1].C == d.C &&
+                           blocks[i + 1].B == d.B && blocks[i + 1].N == d.N && blocks[i + 1].eps == d.eps &&
+                           workspace_bytes >= me_block_workspace_bytes(&d, 0);
+        if (chain) {
+            char* tail = reinterpret_cast<char*>(workspace) + me_block_workspace_bytes(&d, 0) - 2 * align256((size_t)s.M * 8);
+            d.y_stats = reinterpret_cast<float*>(tail + (i & 1) * align256((size_t)s.M * 8));
+        }
+        rc = me_block_fwd(&d, in, out, nullptr, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        st_in = d.y_stats;
         in = out;
     }
     return ME_OK;

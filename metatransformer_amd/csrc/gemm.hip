@@ -487,6 +487,9 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     ME_CHECK_ARG((d->row_affine == nullptr) == (d->col_shift == nullptr), "me_gemm: row_affine and col_shift go together");
     ME_CHECK_ARG(!d->row_affine || d->op == ME_GEMM_NT, "me_gemm: row_affine (folded LayerNorm) is defined for ME_GEMM_NT");
     p.row_affine = d->row_affine; p.col_shift = d->col_shift;
+    ME_CHECK_ARG(!d->row_stats || (d->op == ME_GEMM_NT && d->residual && (uintptr_t)d->row_stats % 8 == 0),
+                 "me_gemm: row_stats goes with ME_GEMM_NT and a residual operand (8-byte aligned)");
+    p.row_stats = d->row_stats;
     p.g3_full_tiles = 0; p.g3_split = 0; p.g3_ktp = 0; p.g3_slabs = nullptr; p.slab_stride = 0; p.g3_tickets = nullptr; p.g3_half = 0;
     if (d->colsum_a) ME_CHECK_ARG(d->op == ME_GEMM_TN, "me_gemm: colsum_a is defined for ME_GEMM_TN only");
     p.debug = gemm_dev().debug;
@@ -511,6 +514,19 @@ extern "C" int me_gemm_fuses_colsum(const me_gemm_desc* d) {
     return (pl.family == 2 && pl.split_k > 1) || pl.family == 4;
 }
 
+extern "C" int me_gemm_emits_row_stats(const me_gemm_desc* d) {
+    GemmParams p;
+    if (!d || d->op != ME_GEMM_NT || d->ab_dtype != ME_BF16 || !d->residual) return 0;
+    me_gemm_desc e = *d;
+    e.row_stats = nullptr;
+    if (fill_params(&e, p) != ME_OK) return 0;
+    const GemmPlan pl = plan_gemm(&e, p);
+    if (pl.family != 4 || pl.tail_rows > 0) return 0;
+    p.tiles_m = (int)((d->M + 255) / 256);
+    p.tiles_n = (int)((d->N + 255) / 256);
+    return g3_emits_row_stats(p) ? 1 : 0;
+}
+
 namespace {
 int gemm_impl(const me_gemm_desc* d, hipStream_t stream);
 }
@@ -530,6 +546,8 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
     if (d->colsum_a)
         ME_CHECK_ARG(((pl.family == 2 && pl.split_k > 1) || pl.family == 4) && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes,
                      "me_gemm: colsum_a needs the split-K wgrad kernel and its workspace (see me_gemm_fuses_colsum)");
+    if (d->row_stats)
+        ME_CHECK_ARG(pl.family == 4 && d->op == ME_GEMM_NT && pl.tail_rows == 0, "me_gemm: row_stats is not available for this problem (see me_gemm_emits_row_stats)");
     if (pl.family >= 1) {
         if (pl.family == 4 && d->op == ME_GEMM_TN) {
             ME_CHECK_ARG(d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes,

@@ -231,6 +231,16 @@ __device__ __forceinline__ u32x4 g3r_lanes(const u32x4& v, int addr) {
 // PRE 3 (EPI 0 / 1): a LayerNorm folded into this Linear (GemmParams::row_affine / col_shift): the accumulators start at zero
 // and the epilogue applies v = rstd_m * acc + (-rstd_m mean_m) * s[n] + c[n] in the accumulator layout (one row per lane and
 // 16-row slab, four consecutive columns per register quad), ahead of the activation; nothing is saved.
+// PRE 4 (EPI 2): the per-row statistics of the OUTPUT rows on the side (GemmParams::row_stats) -- the LayerNorm that reads this
+// residual stream next then needs no pass of its own over it (me_row_stats_combine folds the partials).  After the row re-deal
+// eight lanes hold one row's 64 columns of this wave: per half slab every lane forms (S, Q) = sum (v - P), sum (v - P)^2 of its
+// eight values against a pivot P = the row's first value in this wave column (shifted sums: no cancellation however far the row
+// mean is from zero; P reaches the eight lanes through one DPP move and two lane-row swaps), and the sixteen (half slab) pairs of
+// a wave are summed over the eight lanes as a REDUCE-SCATTER -- DPP row_ror:8, v_permlane16_swap, v_permlane32_swap, each step
+// halving the number of live values -- so that every lane ends up with two finished rows: (mean, M2) over n = 64 columns,
+// one 8-byte store each into [N / 64][M].  Whole tiles only.  The statistics are those of the values AS STORED (rounded to
+// bf16 and converted back: eight more operations per half slab) -- for a row whose mean dwarfs its spread the rounding IS the
+// spread, and the reference's LayerNorm sees the rounded stream too.
 // HALF: a 128 x 256 item (g3_make_src_half): accumulator slabs 0..3 only, this wave row's rows are m0 + 64 wr + ..; the
 // epilogue is padded with stores no descriptor admits up to the whole tile's operation count, so that the counted waits behind it
 // (g3_phase<.., SEAM>, the ticket wait) are the same for both item kinds.
@@ -238,7 +248,8 @@ template <int EPI, int PRE, bool HALF = false>
 __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int64_t m0, int tn, int lane, const G3Src& nxt, int nk,
                                               const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero, unsigned* ctr, int nx,
                                               uint32_t lds_tick) {
-    constexpr bool SAVE = PRE == 1 || PRE == 2, LNF = PRE == 3;
+    constexpr bool SAVE = PRE == 1 || PRE == 2, LNF = PRE == 3, STATS = PRE == 4;
+    static_assert(!STATS || (EPI == 2 && !HALF), "row statistics: the residual epilogue, whole tiles");
     constexpr int NMT = HALF ? 4 : 8, WROWS = HALF ? 64 : 128;      // 16-row slabs per wave, rows per wave row
     // (claimed schedule: wave 0 draws the ticket for the item after next FIRST, ahead of every store of this epilogue)
     unsigned drawn = 0;
@@ -294,7 +305,16 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
         o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
         return __builtin_bit_cast(u32x4, o);
     };
-    constexpr int AHEAD = HALF ? 4 : EPI == 3 ? 4 : 6;      // row-operand slabs in flight ahead of their use (more spills: into the K-loop for gelu', onto the ticket register otherwise)
+    // (STATS) destination of this wave column's partials: [part = 4 tn + wc][M] pairs; a part past the last column, or an item past
+    // the last row, gets a descriptor that admits nothing (the operation count stays what it is)
+    float st_a[2][3], st_b[2][3];
+    __amdgpu_buffer_rsrc_t srs = crs;
+    if (STATS) {
+        const int64_t part = (int64_t)tn * 4 + wc;
+        const bool part_ok = item_ok && (part + 1) * 64 <= p.N;
+        srs = __builtin_amdgcn_make_buffer_rsrc(p.row_stats + (part_ok ? (part * p.M + m0) * 2 : 0), 0, part_ok ? (int)(rows * 8) : 0, 0x00020000);
+    }
+    constexpr int AHEAD = HALF ? 4 : (EPI == 3 || STATS) ? 4 : 6;      // row-operand slabs in flight ahead of their use (more spills: into the K-loop for gelu', onto the ticket register otherwise)
     u32x4 rowop[8][2];
     if (EPI == 2 || EPI == 3 || EPI == 6) {
 #pragma unroll
@@ -356,6 +376,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
             continue;
         }
         g3r_rows8(v[0][0], v[0][1], v[1][0], v[1][1]);
+        float st_s[2], st_q[2], st_p[2];        // (STATS) this slab's two half slabs
 #pragma unroll
         for (int h = 0; h < 2; ++h) {           // half A: rows 0..7 of the slab, half B: rows 8..15
             f32x4 v0 = v[h][0], v1 = v[h][1];
@@ -383,7 +404,56 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                 v1 *= gelu_bf16_grad4(ro[h][1]);
             }
             if (EPI == 2) { v0 += ro[h][0]; v1 += ro[h][1]; }
+            if (STATS) {
+                // the values AS STORED (rounded to bf16): what the LayerNorm behind this launch reads
+                const u32x4 pk = pack(v0, v1);
+                unpack(pk, v0, v1);
+                // pivot: chunk 0 of the row lives in lane (r & 7) of lane row 0
+                unsigned pu = __float_as_uint(v0[0]);
+                pu = __builtin_amdgcn_update_dpp(pu, pu, 0x128, 0xf, 0xc, false);                    // lanes 8..15 <- lanes 0..7
+                pu = __builtin_amdgcn_permlane16_swap(pu, pu, false, false)[0];                       // lane rows 1, 3 <- rows 0, 2
+                pu = __builtin_amdgcn_permlane32_swap(pu, pu, false, false)[0];                       // lane rows 2, 3 <- rows 0, 1
+                const float P = __uint_as_float(pu);
+                const f32x4 d0 = v0 - P, d1 = v1 - P;
+                const f32x4 sd = d0 + d1, qd = d0 * d0 + d1 * d1;
+                st_s[h] = (sd[0] + sd[1]) + (sd[2] + sd[3]);
+                st_q[h] = (qd[0] + qd[1]) + (qd[2] + qd[3]);
+                st_p[h] = P;
+            }
             __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), crs, (int)(coff + (2 * mt + h) * cstep), 0, G3_POL_C);
+        }
+        if (STATS) {
+            // reduce-scatter over the eight lanes of a row: lane bit 3 (DPP) picks the half slab, bit 4 (permlane16) the slab of
+            // a pair, bit 5 (permlane32) the pair of a quadruple; after slab 3 / 7 one finished value per lane and quantity
+            auto ror8 = [](float x) { return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x128, 0xf, 0xf, true)); };
+            const bool b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+            const float a_s0 = ror8(st_s[0]), a_s1 = ror8(st_s[1]), a_q0 = ror8(st_q[0]), a_q1 = ror8(st_q[1]);
+            st_a[mt & 1][0] = b3 ? a_s1 : a_s0;
+            st_a[mt & 1][1] = b3 ? a_q1 : a_q0;
+            st_a[mt & 1][2] = b3 ? st_p[1] : st_p[0];
+            if (mt & 1) {
+                auto fold16 = [](float x, float y) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+                    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                };
+                const int k = (mt >> 1) & 1;
+                st_b[k][0] = fold16(st_a[0][0], st_a[1][0]);
+                st_b[k][1] = fold16(st_a[0][1], st_a[1][1]);
+                st_b[k][2] = b4 ? st_a[1][2] : st_a[0][2];
+                if ((mt & 3) == 3) {
+                    auto fold32 = [](float x, float y) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+                        return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                    };
+                    const float S = fold32(st_b[0][0], st_b[1][0]), Q = fold32(st_b[0][1], st_b[1][1]);
+                    const float P = b5 ? st_b[1][2] : st_b[0][2];
+                    // this lane's row of slabs mt - 3 .. mt: slab 4 (mt >> 2) + 2 b5 + b4, half b3, row r & 7
+                    const float ds = S * (1.0f / 64.0f);
+                    const u32x2 out = {__float_as_uint(P + ds), __float_as_uint(Q - S * ds)};
+                    const int srow = wr * WROWS + 16 * (4 * (mt >> 2) + 2 * (int)b5 + (int)b4) + 8 * (int)b3 + (lane & 7);
+                    __builtin_amdgcn_raw_buffer_store_b64(out, srs, srow * 8, 0, 0);
+                }
+            }
         }
     }
     if (HALF) {
@@ -556,8 +626,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             g3_epilogue_r<EPI, PRE, HALF>(p, s, (int64_t)tm * G3_BM + (HALF ? part * 128 : 0), tn, 0, nxt, nkt0 + 1, brs, ntn, PRE == 3,
                                           has_next ? ctr : nullptr, nx, lds_tick);
         };
-        if (HI && part >= 0) run_item(std::true_type{});
-        else run_item(std::false_type{});
+        if constexpr (HI) {
+            if (part >= 0) run_item(std::true_type{});
+            else run_item(std::false_type{});
+        } else {
+            run_item(std::false_type{});
+        }
         G3R_STAMP(5)
         if (kMeDev) ++item;
         if (!has_next) break;
@@ -720,7 +794,7 @@ int launch3r_any(int epi, int pre, const GemmParams& q, int G, hipStream_t strea
     switch (epi) {
         case 0: return pre == 3 ? launch3r<0, 3>(q, G, stream) : launch3r<0, 0>(q, G, stream);
         case 1: return pre == 3 ? launch3r<1, 3>(q, G, stream) : pre == 2 ? launch3r<1, 2>(q, G, stream) : pre ? launch3r<1, 1>(q, G, stream) : launch3r<1, 0>(q, G, stream);
-        case 2: return launch3r<2, 0>(q, G, stream);
+        case 2: return pre == 4 ? launch3r<2, 4>(q, G, stream) : launch3r<2, 0>(q, G, stream);
         case 3: return launch3r<3, 0>(q, G, stream);
         default: return launch3r<6, 0>(q, G, stream);
     }
@@ -752,11 +826,16 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
             if (plain && p.flags == ME_GEMM_SAVE_GELU_GRAD && p.act == ME_ACT_GELU && p.preact && !p.aux) { repi = 1; pre = 2; }
             if (plain && p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_BF16 && !p.preact) repi = 6;
         }
+        if (EPI == 2 && p.row_stats) pre = 4;
         const int G = g3_cus() & ~7;
         const int64_t ldmax = std::max(std::max(p.ldc, p.preact ? p.ldpre : 0), std::max(p.residual ? p.ldres : 0, p.aux ? p.ldaux : 0));
         if (repi >= 0 && G >= 8 && nwg >= G && q.g3_split <= 1 && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!(pre == 1 || pre == 2) || p.preact_dtype == ME_BF16) &&
             256 * ldmax * 2 < (1ll << 31))
             return launch3r_any(repi, pre, q, G, stream);
+    }
+    if (p.row_stats) {
+        me_set_error("me_gemm: row_stats needs the resident residual kernel (see me_gemm_emits_row_stats)");
+        return ME_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL((gemm_g3_kernel<EPI>), dim3((unsigned)nwg), dim3(512), G3_LDS, stream, q);
     ME_CHECK_LAUNCH("me_gemm(g3)");
@@ -792,6 +871,17 @@ bool g3_supported(const GemmParams& p, int op) {
     // per-tile buffer descriptors and lane offsets are 32-bit
     if (256 * p.lda * 2 >= (1ll << 31) || 256 * p.ldb * 2 >= (1ll << 31)) return false;
     return true;
+}
+
+// Will launch_g3(p, 2, ..) run the resident residual kernel, i.e. can p.row_stats be served?  (the conditions of launch3e, restated
+// for a descriptor that has not been planned yet: whole tiles, every CU gets one, bf16 output and residual, plain epilogue)
+bool g3_emits_row_stats(const GemmParams& p) {
+    if (!g3_supported(p, ME_GEMM_NT) || gemm_dev().g3_persistent != 1 || pick_epi(p) != 2 || p.colscale) return false;
+    const int G = g3_cus() & ~7;
+    const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int64_t ldmax = std::max(p.ldc, p.ldres);
+    return G >= 8 && tiles >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && p.res_dtype == ME_BF16 && p.N % 64 == 0 &&
+           256 * ldmax * 2 < (1ll << 31) && p.M * 8 < (1ll << 31);
 }
 
 // scratch of the persistent stream-K form (dev build): one fp32 partial tile per workgroup + the hand-over flags (+ 1

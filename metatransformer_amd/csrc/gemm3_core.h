@@ -47,8 +47,14 @@ typedef __attribute__((address_space(3))) void lds_void3;
 
 constexpr int G3_BM = 256, G3_BN = 256, G3_BK = 64;
 // Cache policy (the `aux` operand of the buffer instructions: 1 = sc0, 2 = nt, 16 = sc1) of the resident kernel's five streams.
-// Compile-time so that an A/B is one more build of the dev library (tools/r4_policy_builds.sh), never a branch around a
+// Compile-time so that an A/B is one more build of the library (tools/r4_policy_builds.sh), never a branch around a
 // memory operation: A = token rows (DMA), B = weight rows (DMA), C = output stores, R = row-operand loads, P = saved-tensor stores.
+// Defaults (round 4, profiles/r04_policy_ab.txt): the outputs, the saved tensor and the row operands are NON-TEMPORAL -- a
+// launch writes 77 .. 620 MB that nothing re-reads before it has left the 4 MB L2s anyway, and kept out of them it stops evicting
+// the operand panels the other CUs of the XCD are about to re-read.  Kernel level (sustained loops, rotating buffers): qkv 186 ->
+// 154 us, fc1 + GELU 284 -> 247 us, fc1 + saved gelu' 295 -> 274 us, proj 80 -> 76 us at the same 1.39 kW socket power; whole
+// step, same box: train 33.2 -> 32.0 ms, forward 9.64 -> 9.51 ms.  sc1 (write-through) stores: no gain; nt on the token rows (A)
+// gives most of it back (the 9 .. 12 column tiles of a tile row share them through the L2).
 #ifndef G3_POL_A
 #define G3_POL_A 0
 #endif
@@ -56,13 +62,13 @@ constexpr int G3_BM = 256, G3_BN = 256, G3_BK = 64;
 #define G3_POL_B 0
 #endif
 #ifndef G3_POL_C
-#define G3_POL_C 0
+#define G3_POL_C 2
 #endif
 #ifndef G3_POL_R
-#define G3_POL_R 0
+#define G3_POL_R 2
 #endif
 #ifndef G3_POL_P
-#define G3_POL_P 0
+#define G3_POL_P 2
 #endif
 constexpr int G3_HALF = 128 * 128;              // bytes in a half-tile
 constexpr int G3_BUF = 4 * G3_HALF;             // 64 KiB

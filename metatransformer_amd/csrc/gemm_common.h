@@ -26,6 +26,8 @@ struct GemmParams {
     int64_t slab_stride;                    // g3 wgrad: floats between the split-K slabs in C (>= M * N, padded: see g3_tn_slab_stride)
     const float* row_affine;                // folded LayerNorm (me_gemm_desc.row_affine): [M][2] = (rstd, -rstd * mean), or null
     const float* col_shift;                 // ... and s[n] = sum_k W'[n, k]
+    float* row_stats;                       // resident EPI 2 kernel only (me_gemm_desc.row_stats): per-row partial statistics of the OUTPUT,
+                                            // [N / 64][M] pairs (mean, M2) over 64-column groups, or null
 };
 
 
@@ -163,6 +165,7 @@ int launch_g2b(const GemmParams& p, int op, int bm, int bn, hipStream_t stream);
 bool g2b_supported(const GemmParams& p, int op);
 int launch_g3(const GemmParams& p, int epi, void* ws, hipStream_t stream);      // ws = nullptr: one tile per workgroup
 bool g3_supported(const GemmParams& p, int op);
+bool g3_emits_row_stats(const GemmParams& p);          // will launch_g3 run the resident residual kernel that can emit p.row_stats?
 size_t g3_workspace_bytes();
 int launch_g3_tn(const GemmParams& p, hipStream_t stream);      // p.split_k slabs into p.C, p.ksteps_per_split K-tiles of 64 each
 bool g3_tn_supported(const GemmParams& p);

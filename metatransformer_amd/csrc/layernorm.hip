@@ -119,6 +119,30 @@ __global__ __launch_bounds__(LN_THREADS) void ln_stats_generic_kernel(const void
     if (lane == 0) *reinterpret_cast<float2*>(out + row * 2) = float2{rstd, -rstd * mean};
 }
 
+// ---- the pairs of ln_stats_kernel from 64-column partials (mean_i, M2_i) a GEMM epilogue left behind ([nparts][rows] pairs,
+// me_gemm_desc.row_stats): one thread per row, the partials of consecutive rows are consecutive in memory.  Chan et al.'s
+// combination for equal group sizes; exact in the sense that no large numbers are subtracted anywhere (the group M2 are sums of
+// squared deviations already).
+__global__ __launch_bounds__(256) void row_stats_combine_kernel(const float2* __restrict__ part, int nparts, int64_t rows, float inv_cols,
+                                                                float eps, float* __restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float ms = 0.f, m2 = 0.f;
+    for (int i = 0; i < nparts; ++i) {
+        const float2 v = part[(int64_t)i * rows + row];
+        ms += v.x;
+        m2 += v.y;
+    }
+    const float mean = ms / (float)nparts;
+    float dev = 0.f;
+    for (int i = 0; i < nparts; ++i) {
+        const float d = part[(int64_t)i * rows + row].x - mean;      // (second read: L2)
+        dev += d * d;
+    }
+    const float rstd = rsqrtf((m2 + 64.0f * dev) * inv_cols + eps);
+    *reinterpret_cast<float2*>(out + row * 2) = float2{rstd, -rstd * mean};
+}
+
 // generic fallback: any C, scalar accesses, row re-read from cache instead of registers
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_generic_kernel(const void* __restrict__ x, int x_dt,
                                                                     const float* __restrict__ gamma,
@@ -410,6 +434,22 @@ extern "C" int me_row_stats(const void* x, int x_dtype, float* out, int64_t rows
     }
 #undef LN_ST_CASE
     ME_CHECK_LAUNCH("me_row_stats");
+    return ME_OK;
+}
+
+extern "C" size_t me_row_stats_partial_bytes(int64_t rows, int cols) {
+    return rows > 0 && cols > 0 ? (size_t)(cols / 64) * (size_t)rows * 2 * sizeof(float) : 0;
+}
+
+extern "C" int me_row_stats_combine(const float* partials, int64_t rows, int cols, float eps, float* out, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(partials && out, "me_row_stats_combine: null pointer");
+    ME_CHECK_ARG(rows >= 0 && cols > 0 && cols % 64 == 0, "me_row_stats_combine: cols must be a positive multiple of 64");
+    ME_CHECK_ARG((uintptr_t)partials % 8 == 0 && (uintptr_t)out % 8 == 0, "me_row_stats_combine: 8-byte aligned buffers");
+    if (rows == 0) return ME_OK;
+    hipLaunchKernelGGL(row_stats_combine_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float2*>(partials), cols / 64, rows, 1.0f / (float)cols, eps, out);
+    ME_CHECK_LAUNCH("me_row_stats_combine");
     return ME_OK;
 }
 

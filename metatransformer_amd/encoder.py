@@ -210,7 +210,13 @@ class _BlockFn(torch.autograd.Function):
             d, keep = _BlockFn._desc(blk, cache, cdt, rdt, B, N, C, H, (n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb,
                                                                         fc1w, fc1b, fc2w, fc2b, g1, g2), False,
                                      fold=not need_grad and blk.fold_norm)
-            y, saved = ops.block_fwd(d, x2, keep=need_grad)
+            # LayerNorm statistics handed from block to block (folded inference): the caller (Block.forward) passes the pairs the
+            # previous block left on this very tensor, and gets this block's own back through blk._stats_out
+            xs = getattr(blk, "_stats_in", None)
+            blk._stats_in = None
+            want = keep[3] is not None and blk.chain_stats       # (the folded route is taken)
+            y, saved, ys = ops.block_fwd(d, x2, keep=need_grad, x_stats=xs if want else None, want_stats=want)
+            blk._stats_out = ys if in_dtype == rdt else None      # (an fp16 caller gets a converted copy: other values)
             del keep
             if need_grad:
                 ctx.save_for_backward(x2, saved, n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb, fc1w, fc1b, fc2w, fc2b)
@@ -480,6 +486,8 @@ class Block(nn.Module):
         self.fold_norm = True       # (True: when it pays, see _desc; "always": whenever it is legal; False: never)  inference (no gradient wanted), bf16 compute on a bf16 token stream: norm1 / norm2 folded into
                                     # qkv / fc1 (me_row_stats + row_affine GEMM epilogue instead of me_layernorm_fwd + GEMM)
         self._wcache = _WeightCache()
+        self.chain_stats = True     # folded inference: LayerNorm statistics from the proj / fc2 epilogues, handed from block to block
+        self._stats_in = self._stats_out = None      # (per-call hand-over between forward() and the autograd Function)
 
     def _compute_dtype(self, x: torch.Tensor) -> torch.dtype:
         if self.compute_dtype is not None:
@@ -520,9 +528,24 @@ class Block(nn.Module):
         a, m = self.attn, self.mlp
         g1 = self.gamma1 if self.layer_scale else None
         g2 = self.gamma2 if self.layer_scale else None
-        return _BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
-                              a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
-                              m.fc2.weight, m.fc2.bias, g1, g2, self, cdt, stoch, torch.is_grad_enabled(), win)
+        # folded inference: the LayerNorm statistics of a block's output come out of its fc2 epilogue and ride on the output
+        # TENSOR OBJECT (attribute _me_ln_stats = (pairs, eps, version)) to whichever Block is handed that same object next --
+        # nn.Sequential, a `for blk in blocks` loop.  Anything else (a new tensor from x + pos, an in-place edit: the version
+        # moves) simply finds no statistics and reads its input once more (me_row_stats).
+        tag = getattr(x, "_me_ln_stats", None)
+        self._stats_in = None
+        if (tag is not None and self.chain_stats and tag[1] == self.eps and tag[2] == x._version
+                and tag[0].shape[0] == x.shape[0] * x.shape[1]):
+            self._stats_in = tag[0]
+        self._stats_out = None
+        y = _BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
+                           a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
+                           m.fc2.weight, m.fc2.bias, g1, g2, self, cdt, stoch, torch.is_grad_enabled(), win)
+        self._stats_in = None
+        if self._stats_out is not None:
+            y._me_ln_stats = (self._stats_out, self.eps, y._version)
+            self._stats_out = None
+        return y
 
 
 def resize_pos_embed(pos_embed: torch.Tensor, input_shape, pos_shape, mode: str = "bicubic") -> torch.Tensor:

@@ -101,12 +101,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
          aux: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, alpha: float = 1.0,
          beta: float = 0.0, out_rows: Optional[int] = None, out_group: Tuple[int, int, int] = (0, 0, 0),
          want_colsum_a: bool = False, colsum_out: Optional[torch.Tensor] = None, flags: int = 0,
-         row_affine: Optional[torch.Tensor] = None, col_shift: Optional[torch.Tensor] = None):
+         row_affine: Optional[torch.Tensor] = None, col_shift: Optional[torch.Tensor] = None, want_row_stats: bool = False):
     """NT: out[M,N] = a[M,K] @ b[N,K]^T ;  TN: out[M,N] = a[K,M]^T @ b[K,N]; fused epilogue per include/metaenc.h.
     want_colsum_a (TN): also return sum_k a[k, :] (fp32 [M]) -- the bias gradient that goes with a weight gradient --
     from the same kernel when the library can fuse it, else from me_colsum; the result is then (out, colsum).
     colsum_out: fp32 [M] buffer for it, accumulated with the same beta as out (only used when the kernel fuses it).
-    flags: ME_GEMM_SAVE_GELU_GRAD (preact receives gelu'(pre-activation)) / ME_GEMM_AUX_IS_FACTOR (multiply by aux itself)."""
+    flags: ME_GEMM_SAVE_GELU_GRAD (preact receives gelu'(pre-activation)) / ME_GEMM_AUX_IS_FACTOR (multiply by aux itself).
+    want_row_stats (NT + residual): also return the per-row partial statistics of the OUTPUT, [N / 64, M, 2] fp32 (mean, M2) over
+    64-column groups (me_gemm_desc.row_stats; fold with row_stats_combine) -- None when the kernel for this problem cannot emit
+    them (me_gemm_emits_row_stats); the result is then (out, partials or None)."""
     lib = _capi.load()
     _req(a, "a"); _req(b, "b")
     if a.dtype != b.dtype:
@@ -168,7 +171,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
     if ws_bytes:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device); keep.append(ws)
         d.workspace, d.workspace_bytes = ptr(ws), ws_bytes
+    partials = None
+    if want_row_stats and lib.me_gemm_emits_row_stats(ctypes.byref(d)):
+        partials = torch.empty((N // 64, M, 2), dtype=torch.float32, device=a.device)
+        d.row_stats = ptr(partials)
     check(lib.me_gemm(ctypes.byref(d), stream_ptr()), "me_gemm")
+    if want_row_stats:
+        return out, partials
     if want_colsum_a:
         if cs is None:      # not fusable for this problem: separate pass over a
             cs = colsum(a2, out=colsum_out, accumulate=beta != 0.0)
@@ -206,14 +215,27 @@ def block_desc(B, N, C, heads, hidden, eps, scale, cdt, rdt, w, wt, vec) -> "_ca
     return d
 
 
-def block_fwd(d, x2: torch.Tensor, keep: bool):
-    """-> (y, saved or None)"""
+def block_fwd(d, x2: torch.Tensor, keep: bool, x_stats: Optional[torch.Tensor] = None, want_stats: bool = False):
+    """-> (y, saved or None[, y_stats or None]).  x_stats: the [M, 2] LayerNorm pairs of x for this block's norm1 (folded inference;
+    me_block_desc.x_stats); want_stats: also return the pairs of y, taken from the fc2 epilogue, when the block can emit them
+    (me_block_emits_stats) -- for the next block's x_stats."""
     lib = _capi.load()
     y = torch.empty_like(x2)
     saved = torch.empty(lib.me_block_saved_bytes(ctypes.byref(d)), dtype=torch.uint8, device=x2.device) if keep else None
     wsb = lib.me_block_workspace_bytes(ctypes.byref(d), 0)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x2.device)
+    y_stats = None
+    if not keep:
+        if x_stats is not None:
+            if x_stats.dtype != torch.float32 or x_stats.shape != (x2.shape[0], 2) or not x_stats.is_contiguous() or x_stats.device != x2.device:
+                raise MetaEncError("block_fwd: x_stats must be a contiguous [M, 2] float32 tensor on the tokens' device")
+            d.x_stats = ptr(x_stats)
+        if want_stats and lib.me_block_emits_stats(ctypes.byref(d)):
+            y_stats = torch.empty((x2.shape[0], 2), dtype=torch.float32, device=x2.device)
+            d.y_stats = ptr(y_stats)
     check(lib.me_block_fwd(ctypes.byref(d), ptr(x2), ptr(y), ptr(saved), ptr(ws), wsb, stream_ptr()), "me_block_fwd")
+    if want_stats:
+        return y, saved, y_stats
     return y, saved
 
 
@@ -495,6 +517,18 @@ def adamw_step_segments(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.
 def ctypes_sizeof_ctl() -> int:
     import ctypes
     return ctypes.sizeof(_capi.AdamwCtl)
+
+
+def row_stats_combine(partials: torch.Tensor, eps: float) -> torch.Tensor:
+    """[C / 64, rows, 2] partial statistics (gemm(..., want_row_stats=True)) -> [rows, 2] pairs (rstd, -rstd * mean) of
+    LayerNorm(C, eps): the same pairs as row_stats(x, eps) on the tensor the GEMM wrote (me_row_stats_combine)."""
+    _req(partials, "partials")
+    if partials.dtype != torch.float32 or partials.dim() != 3 or partials.shape[2] != 2:
+        raise MetaEncError("row_stats_combine: [C / 64, rows, 2] float32 partials required")
+    nparts, rows, _ = partials.shape
+    out = torch.empty(rows, 2, dtype=torch.float32, device=partials.device)
+    check(_capi.load().me_row_stats_combine(ptr(partials), rows, nparts * 64, float(eps), ptr(out), stream_ptr()), "me_row_stats_combine")
+    return out
 
 
 def row_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
