@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_F32_TFLOPS = 157.3        # f32-input MFMA (v_mfma_f32_32x32x2_f32): the f32 vector rate, 1/16 of bf16 (same guide)
 PEAK_HBM_TBPS = 8.0            # HBM3E (same guide)
 
 WORKLOADS = {       # name: (model, per-GPU batch, tokens)
@@ -54,6 +55,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling); 0 = the workload's")
     ap.add_argument("--tokens", type=int, default=0)
     ap.add_argument("--model", choices=["base", "large"], default=None)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16",
+                    help="fp32: the reference's default arithmetic (no autocast: README.md:113-150) -- fp32 tokens, exact-fp32 MFMA GEMMs "
+                         "and attention; roofline against the 157 TF f32-input MFMA peak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-leg", action="store_true")
     ap.add_argument("--no-chain-stats", action="store_true",
@@ -135,8 +139,10 @@ def main():
     for p in enc.parameters():                   # N(0, 0.02) weights in the checkpoint layout (no .pth available)
         if p.dim() == 2:
             torch.nn.init.normal_(p, std=0.02)
+    f32 = args.dtype == "fp32"
+    tdt = torch.float32 if f32 else torch.bfloat16
     for blk in enc:
-        blk.compute_dtype = torch.bfloat16       # fp32 master weights, bf16 MFMA compute, bf16 token stream
+        blk.compute_dtype = tdt                  # fp32 master weights; bf16 MFMA compute on a bf16 token stream, or fp32 throughout
         blk.attn_fp8 = args.attn_dtype == "fp8"
         blk.chain_stats = not args.no_chain_stats
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)        # per-rank data (Video/run_class_finetuning.py:417)
@@ -154,16 +160,16 @@ def main():
             if args.mixed_per_rank:
                 # every rank feeds the shared encoder from a different tokenizer (sequence lengths differ per rank; nothing in
                 # forward / backward depends on another rank, the gradient buckets have the same shape everywhere)
-                x = (xi, xt, xa)[rank % 3].bfloat16().contiguous()
+                x = (xi, xt, xa)[rank % 3].to(tdt).contiguous()
             else:
-                x = torch.cat([xi, xt, xa], dim=1).bfloat16().contiguous()
+                x = torch.cat([xi, xt, xa], dim=1).to(tdt).contiguous()
         N = x.shape[1]
         tok_note = (f"Image 224/16 -> {xi.shape[1]} + Time-Series L96/c7 -> {xt.shape[1]} + Audio 128x256 k16/s10 -> {xa.shape[1]} tokens"
                     + ("; per-rank modality (rank r: modality r % 3), tokens = rank 0's" if args.mixed_per_rank else ""))
     else:
         N = args.tokens or N0
-        x = torch.randn(B, N, C, generator=g).to(dev).bfloat16()
-    gy = (torch.randn(B, N, C, generator=g) / (B * N)).to(dev).bfloat16()
+        x = torch.randn(B, N, C, generator=g).to(dev).to(tdt)
+    gy = (torch.randn(B, N, C, generator=g) / (B * N)).to(dev).to(tdt)
 
     train = args.mode == "train"
     flat = opt = reducer = None
@@ -268,28 +274,33 @@ def main():
 
     def gemm_roofline(recs, wall_s, nsteps, with_wgrad):
         train_now[0] = bool(with_wgrad)
-        nt = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_NT and dt == _capi.ME_BF16]
-        tn = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_TN and dt == _capi.ME_BF16]
+        cdt_code = _capi.ME_F32 if f32 else _capi.ME_BF16
+        peak = PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS
+        nt = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_NT and dt == cdt_code]
+        tn = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_TN and dt == cdt_code]
         if not nt:
             return None
         flops = sum(2.0 * m * n * k for m, n, k, _ in nt)
         ms = sum(t for *_, t in nt)
         ach = flops / (ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic("train" if with_wgrad else "fwd") if args.workload == "base" and B == 256 else (None, None)
+        traffic, traffic_src = pmc_traffic("train" if with_wgrad else "fwd") if args.workload == "base" and B == 256 and not f32 else (None, None)
+        esz = 4.0 if f32 else 2.0
         roof = {"bound": "mfma",
-                "kernel": "gemm_g3r_kernel<EPI> (bf16 NT MFMA GEMM, resident 256x256x64-tile workgroups: every forward + dgrad launch)",
-                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "kernel": ("gemm_g128_kernel<float> (exact-fp32 NT GEMM on v_mfma_f32_32x32x2_f32, 128x128 tiles: every forward + dgrad launch)" if f32 else
+                           "gemm_g3r_kernel<EPI> (bf16 NT MFMA GEMM, resident 256x256x64-tile workgroups: every forward + dgrad launch)"),
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": len(nt) // nsteps, "avg_launch_us": round(1e3 * ms / len(nt), 2),
                 "avg_launch_gflop": round(flops / len(nt) / 1e9, 2),
                 # operands + output, 2 bytes each, plus the second [M, N] array the fused epilogues move: the residual read by
                 # proj / fc2 (N = C), the saved gelu' written by fc1 in a training step and read by the fc2 dgrad (N or K = 4C)
-                "algorithmic_bytes_per_launch": round(sum(2.0 * (m * k + n * k + m * n) + 2.0 * m * n * aux_arrays(m, n, k) for m, n, k, _ in nt) / len(nt)),
+                "algorithmic_bytes_per_launch": round(sum(esz * (m * k + n * k + m * n) + esz * m * n * aux_arrays(m, n, k) for m, n, k, _ in nt) / len(nt)),
                 "share_of_step_time": round(ms * 1e-3 / nsteps / wall_s, 4)}
         if with_wgrad and tn:
             f2 = sum(2.0 * m * n * k for m, n, k, _ in tn)
             ms2 = sum(t for *_, t in tn)
-            roof["wgrad_kernel"] = {"kernel": "gemm_g3tn_kernel + splitk_reduce_kernel (wgrad dW = dY^T X with the bias-gradient column sums fused; 256x256x64 tiles, split-K folded in fixed order)",
+            roof["wgrad_kernel"] = {"kernel": ("gemm_g128_kernel<float, TN> (exact-fp32 wgrad)" if f32 else
+                                               "gemm_g3tn_kernel + splitk_reduce_kernel (wgrad dW = dY^T X with the bias-gradient column sums fused; 256x256x64 tiles, split-K folded in fixed order)"),
                                     "achieved": round(f2 / (ms2 * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                                     "avg_launch_us": round(1e3 * ms2 / len(tn), 2),
                                     "share_of_step_time": round(ms2 * 1e-3 / nsteps / wall_s, 4)}
@@ -310,7 +321,7 @@ def main():
             if work_fn is not None:
                 o["TFLOPs"] = round(sum(work_fn(m, n, k) for m, n, k, _ in rs) / (ms * 1e-3) / 1e12, 1)
             return o
-        es = 2      # bf16 token stream
+        es = 4 if f32 else 2      # token stream
         d = {"row_stats": _class(_capi.ME_PROF_ROW_STATS, None, lambda m, n, k: 1.0 * m * n * es),
              "layernorm_fwd": _class(_capi.ME_PROF_LN_FWD, None, lambda m, n, k: 2.0 * m * n * es),
              "layernorm_bwd": _class(_capi.ME_PROF_LN_BWD, None, lambda m, n, k: 4.0 * m * n * es),
@@ -339,17 +350,17 @@ def main():
     value = world * B * args.steps / elapsed
     fwd_flops = M.encoder_flops_per_sample(N, C, L)
     model_flops = (3.0 if train else 1.0) * fwd_flops
-    is_metric = args.workload == "base" and B == 256 and N == 197 and model == "base"
+    is_metric = args.workload == "base" and B == 256 and N == 197 and model == "base" and not f32
     what = "forward+backward+AdamW" if train else "encoder forward (no_grad)"
     out = {
-        "metric": "encoder samples/sec at B=256,N=197,C=768 (Base)" if is_metric else f"encoder samples/sec at B={B},N={N},C={C}",
+        "metric": "encoder samples/sec at B=256,N=197,C=768 (Base)" if is_metric else f"encoder samples/sec at B={B},N={N},C={C}" + (" (fp32 arithmetic)" if f32 else ""),
         "value": round(value, 2), "unit": "samples/s", "n_gpus": comm_info["world"] if comm_info else world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * step_s, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if args.attn_dtype == "bf16" else "bf16 (attention forward in fp8 e4m3, fp32 softmax statistics)",
+        "dtype": "f32" if f32 else ("bf16" if args.attn_dtype == "bf16" else "bf16 (attention forward in fp8 e4m3, fp32 softmax statistics)"),
         "data": "synthetic",
         "config": {"workload": ("BASELINE config 2: " if is_metric else ("BASELINE config 4 (sequence-concat): " if args.workload == "mixed" else ""))
-                               + f"Meta-Transformer-{model.capitalize()} {what}, tokens [{B},{N},{C}] bf16 per GPU, "
+                               + f"Meta-Transformer-{model.capitalize()} {what}, tokens [{B},{N},{C}] {'fp32' if f32 else 'bf16'} per GPU, "
                                f"{L}L/{C}d/{H}h, fp32 master weights, random init N(0,0.02)" + (f"; {tok_note}" if tok_note else ""),
                    "mode": args.mode, "per_gpu_batch": B, "global_batch": B * world, "tokens": N,
                    "parallelism": f"dp{world}" if world > 1 else "single",
@@ -359,7 +370,7 @@ def main():
                                       f"RCCL world {comm_info['world']}") if (comm_info and train) else
                                      (f"{comm_fallback}: one all_reduce(sum) per 64 MiB flat fp32 bucket from grad hooks" if (comm_fallback and train) else None)},
         "model_tflops_per_s": round(value * model_flops / 1e12, 2),
-        "mfma_frac_end_to_end": round(value * model_flops / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+        "mfma_frac_end_to_end": round(value * model_flops / 1e12 / ((PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS) * world), 4),
         "per_rank_gemm": per_rank,
         "roofline": gemm_roofline(prof, step_s, psteps, train),
         "other_kernels": other_kernels(prof, step_s, psteps),
@@ -371,7 +382,7 @@ def main():
         out["fwd"] = {"what": "encoder forward alone (torch.no_grad), same tokens and weights, same K steps",
                       "ms_per_step": round(1e3 * fs, 3), "samples_per_s": round(fv, 2),
                       "model_tflops_per_s": round(fv * fwd_flops / 1e12, 2),
-                      "mfma_frac": round(fv * fwd_flops / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+                      "mfma_frac": round(fv * fwd_flops / 1e12 / ((PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS) * world), 4),
                       "roofline": gemm_roofline(fwd_prof, fs, psteps, False),
                       "other_kernels": other_kernels(fwd_prof, fs, psteps)}
     if not args.no_cpu_baseline and world == 1:

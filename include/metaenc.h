@@ -157,7 +157,9 @@ typedef struct me_gemm_profile_rec {
     int32_t op, ab_dtype;
     int64_t M, N, K;
     float ms;          /* start of the (first) GEMM kernel to end of its last kernel (split-K fold included) */
-    int32_t reserved;
+    int32_t plan;      /* GEMM records: which kernel plan ran -- bits 0-3 the family (0 = exact-fp32 / generic 128 x 128 "g128", 2 = "g2b"
+                        * 128 x 256 two workgroups per CU, 3 = "g2w" 256 x 256 K-step 32, 4 = "g3" 256 x 256 K-tile 64, resident when every
+                        * CU gets a tile), bit 4 = a split-K tail / whole-problem split ran with a fold, bits 8-15 = split-K parts; else 0 */
 } me_gemm_profile_rec;
 int me_gemm_profile_enable(int on);
 int me_gemm_profile_read(me_gemm_profile_rec* out, int max);

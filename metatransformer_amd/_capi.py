@@ -61,7 +61,7 @@ class GemmDesc(ctypes.Structure):
 class GemmProfileRec(ctypes.Structure):
     """Mirror of ``struct me_gemm_profile_rec``."""
     _fields_ = [("op", c_int32), ("ab_dtype", c_int32), ("M", c_int64), ("N", c_int64), ("K", c_int64), ("ms", c_float),
-                ("reserved", c_int32)]
+                ("plan", c_int32)]
 
 
 ME_TC_BATCH = 48

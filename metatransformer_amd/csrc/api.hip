@@ -36,7 +36,7 @@ extern "C" int me_device_info(int dev, int* num_cus, int* lds_bytes, int* clock_
 
 // ---- optional per-launch timing
 namespace {
-struct ProfEntry { int op, dt; int64_t M, N, K; hipEvent_t e0, e1; };
+struct ProfEntry { int op, dt; int64_t M, N, K; hipEvent_t e0, e1; int plan; };
 std::mutex g_prof_mu;
 std::vector<ProfEntry> g_prof;
 bool g_prof_on = false;
@@ -53,7 +53,7 @@ ProfScope::~ProfScope() {
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; }
     (void)hipEventRecord(e1, stream);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.push_back(ProfEntry{op, dt, M, N, K, e0, e1});
+    g_prof.push_back(ProfEntry{op, dt, M, N, K, e0, e1, plan});
 }
 
 extern "C" int me_gemm_profile_enable(int on) {
@@ -71,7 +71,7 @@ extern "C" int me_gemm_profile_read(me_gemm_profile_rec* out, int max) {
         float ms = 0.f;
         (void)hipEventSynchronize(e.e1);
         (void)hipEventElapsedTime(&ms, e.e0, e.e1);
-        if (out && n < max) out[n] = me_gemm_profile_rec{e.op, e.dt, e.M, e.N, e.K, ms, 0};
+        if (out && n < max) out[n] = me_gemm_profile_rec{e.op, e.dt, e.M, e.N, e.K, ms, e.plan};
         ++n;
         (void)hipEventDestroy(e.e0);
         (void)hipEventDestroy(e.e1);

@@ -74,6 +74,7 @@ struct ProfScope {
     hipStream_t stream;
     int op, dt;
     int64_t M, N, K;
+    int plan = 0;               // (GEMM records: me_gemm_profile_rec.plan, filled in by the planner)
     ProfScope(int op, int dt, int64_t M, int64_t N, int64_t K, hipStream_t stream);
     ~ProfScope();
 };

@@ -528,21 +528,26 @@ extern "C" int me_gemm_emits_row_stats(const me_gemm_desc* d) {
 }
 
 namespace {
-int gemm_impl(const me_gemm_desc* d, hipStream_t stream);
+int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out);
 }
 
 extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ProfScope prof(d ? d->op : 0, d ? d->ab_dtype : 0, d ? d->M : 0, d ? d->N : 0, d ? d->K : 0, stream);
-    return gemm_impl(d, stream);
+    return gemm_impl(d, stream, &prof.plan);
 }
 
 namespace {
-int gemm_impl(const me_gemm_desc* d, hipStream_t stream) {
+int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out) {
     GemmParams p;
     int rc = fill_params(d, p);
     if (rc) return rc;
     GemmPlan pl = plan_gemm(d, p);
+    {   // me_gemm_profile_rec.plan
+        const bool have_ws = pl.ws_bytes && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes;
+        const int parts = pl.split_k > 1 ? pl.split_k : (pl.tail_rows > 0 ? pl.tail_split : 1);
+        *plan_out = (pl.family & 15) | ((have_ws && parts > 1) ? 16 : 0) | ((have_ws ? parts : 1) << 8);
+    }
     if (d->colsum_a)
         ME_CHECK_ARG(((pl.family == 2 && pl.split_k > 1) || pl.family == 4) && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes,
                      "me_gemm: colsum_a needs the split-K wgrad kernel and its workspace (see me_gemm_fuses_colsum)");

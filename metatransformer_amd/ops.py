@@ -24,11 +24,14 @@ def gemm_profile(on: bool) -> None:
     check(_capi.load().me_gemm_profile_enable(1 if on else 0), "me_gemm_profile_enable")
 
 
-def gemm_profile_read(max_records: int = 1 << 16):
-    """-> [(op, ab_dtype, M, N, K, ms)] in call order since gemm_profile(True); waits for the recorded events"""
+def gemm_profile_read(max_records: int = 1 << 16, with_plan: bool = False):
+    """-> [(op, ab_dtype, M, N, K, ms[, plan])] in call order since gemm_profile(True); waits for the recorded events.
+    plan (with_plan=True): me_gemm_profile_rec.plan -- kernel family / split-K parts of a GEMM record."""
     lib = _capi.load()
     buf = (_capi.GemmProfileRec * max_records)()
     n = lib.me_gemm_profile_read(buf, max_records)
+    if with_plan:
+        return [(r.op, r.ab_dtype, r.M, r.N, r.K, r.ms, r.plan) for r in buf[:min(n, max_records)]]
     return [(r.op, r.ab_dtype, r.M, r.N, r.K, r.ms) for r in buf[:min(n, max_records)]]
 
 
@@ -216,7 +219,7 @@ def block_desc(B, N, C, heads, hidden, eps, scale, cdt, rdt, w, wt, vec) -> "_ca
 
 
 def block_fwd(d, x2: torch.Tensor, keep: bool, x_stats: Optional[torch.Tensor] = None, want_stats: bool = False):
-    """-> (y, saved or None[, y_stats or None]).  x_stats: the [M, 2] LayerNorm pairs of x for this block's norm1 (folded inference;
+    """-> (y, saved or None, y_stats or None).  x_stats: the [M, 2] LayerNorm pairs of x for this block's norm1 (folded inference;
     me_block_desc.x_stats); want_stats: also return the pairs of y, taken from the fc2 epilogue, when the block can emit them
     (me_block_emits_stats) -- for the next block's x_stats."""
     lib = _capi.load()
@@ -234,9 +237,7 @@ def block_fwd(d, x2: torch.Tensor, keep: bool, x_stats: Optional[torch.Tensor] =
             y_stats = torch.empty((x2.shape[0], 2), dtype=torch.float32, device=x2.device)
             d.y_stats = ptr(y_stats)
     check(lib.me_block_fwd(ctypes.byref(d), ptr(x2), ptr(y), ptr(saved), ptr(ws), wsb, stream_ptr()), "me_block_fwd")
-    if want_stats:
-        return y, saved, y_stats
-    return y, saved
+    return y, saved, y_stats
 
 
 def encoder_fwd(descs, x2: torch.Tensor) -> torch.Tensor:

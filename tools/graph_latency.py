@@ -1,6 +1,12 @@
-import torch, time, sys
-sys.path.insert(0, '/root/repo')
+"""Small-batch forward latency (Base, N = 197, bf16), eager and hipGraph replay:  python tools/graph_latency.py [nofold] [--pkg DIR]
+--pkg DIR: import metatransformer_amd from DIR instead of this repository (same-box A/B against an older snapshot: tools/_build_r1/
+holds the round-1 package + library, built from `git archive 26b68fd`)."""
+import os, sys, time
+import torch
+_pkg = sys.argv[sys.argv.index('--pkg') + 1] if '--pkg' in sys.argv else os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _pkg)
 import metatransformer_amd as M
+print("package:", os.path.dirname(M.__file__), flush=True)
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 enc = M.build_encoder(12, 768, 12).to(dev).eval()
