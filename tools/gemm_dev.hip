@@ -3,7 +3,8 @@
 //   python -m metatransformer_amd.build --dev      # builds tools/_build/libmetaenc_dev.so and tools/_build/gemm_dev
 //   tools/_build/gemm_dev [--iters N] [--check] case [case ...]
 //   case  = family:M:N:K:epi[:debug]      family in {auto, g128, g2b, g2w, g3, g3x, g3p, g3s, g3t, g3f}; epi 0 bias, 1 gelu(+preact), 2 residual,
-//           3 gelu'(aux), 6 * aux (ME_GEMM_AUX_IS_FACTOR), 7 gelu + saved gelu' (ME_GEMM_SAVE_GELU_GRAD); debug = GemmDev::debug bits
+//           3 gelu'(aux), 6 * aux (ME_GEMM_AUX_IS_FACTOR), 7 gelu + saved gelu' (ME_GEMM_SAVE_GELU_GRAD), 8 residual + row statistics
+//           (me_gemm_desc.row_stats); debug = GemmDev::debug bits
 //           tn-family:M:N:K               wgrad form C[M, N] = A[K, M]^T B[K, N] (fp32 output), family in {auto, g2b, g3}
 //
 // Every case is checked (all M x N outputs) against a straightforward fp32 kernel on the same bf16 operands, then timed
@@ -78,7 +79,7 @@ __global__ void ref_kernel(const uint16_t* A, const uint16_t* B, const float* bi
         v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
     } else if (epi == 6) {
         v *= bf2f(rowop[m * N + n]);
-    } else if (epi == 2) {
+    } else if (epi == 2 || epi == 8) {
         v += bf2f(rowop[m * N + n]);
     } else if (epi == 3) {
         const float x = bf2f(rowop[m * N + n]);
@@ -309,7 +310,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&bias, (size_t)N * 4));
         fill_kernel<<<2048, 256, 0, st>>>(Bw, (size_t)N * K, 99, 0.05f);
         fill_f32_kernel<<<64, 256, 0, st>>>(bias, (size_t)N, 5, 0.5f);
-        if (epi == 2 || epi == 3 || epi == 6) {
+        if (epi == 2 || epi == 3 || epi == 6 || epi == 8) {
             CK(hipMalloc(&rowop, (size_t)M * N * 2));
             fill_kernel<<<2048, 256, 0, st>>>(rowop, (size_t)M * N, 1234, 1.0f);
         }
@@ -321,7 +322,13 @@ int main(int argc, char** argv) {
         if (epi == 1 || epi == 7) { d.act = ME_ACT_GELU; d.ldpre = N; d.preact_dtype = ME_BF16; }
         if (epi == 7) d.flags = ME_GEMM_SAVE_GELU_GRAD;
         if (epi == 6) { d.aux = rowop; d.ldaux = N; d.aux_dtype = ME_BF16; d.flags = ME_GEMM_AUX_IS_FACTOR; }
-        if (epi == 2) { d.residual = rowop; d.ldres = N; d.res_dtype = ME_BF16; }
+        if (epi == 2 || epi == 8) { d.residual = rowop; d.ldres = N; d.res_dtype = ME_BF16; }
+        float* rstats = nullptr;
+        if (epi == 8) {           // residual + per-row statistics of the output on the side (me_gemm_desc.row_stats)
+            if (!me_gemm_emits_row_stats(&d)) { fprintf(stderr, "case %s: this shape does not emit row statistics\n", c.c_str()); return 2; }
+            CK(hipMalloc(&rstats, me_row_stats_partial_bytes(M, (int)N)));
+            d.row_stats = rstats;
+        }
         if (epi == 3) { d.aux = rowop; d.ldaux = N; d.aux_dtype = ME_BF16; }
         d.A = A[0]; d.C = C[0]; d.preact = P[0];
         const size_t wsb = me_gemm_workspace_bytes(&d);
@@ -484,6 +491,7 @@ int main(int argc, char** argv) {
         }
         CK(hipFree(Bw)); CK(hipFree(bias));
         if (rowop) CK(hipFree(rowop));
+        if (rstats) CK(hipFree(rstats));
         if (ws) CK(hipFree(ws));
     }
     return 0;

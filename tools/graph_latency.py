@@ -13,7 +13,8 @@ enc = M.build_encoder(12, 768, 12).to(dev).eval()
 for b in enc: b.compute_dtype = torch.bfloat16
 if 'nofold' in sys.argv:
     for b in enc: b.fold_norm = False      # LayerNorm as its own kernel instead of folded into qkv / fc1
-for B in (1, 8, 32):
+_bl = [int(v) for v in sys.argv[sys.argv.index('--batches') + 1].split(',')] if '--batches' in sys.argv else [1, 8, 32]
+for B in _bl:
     x = torch.randn(B, 197, 768, device=dev).bfloat16()
     with torch.no_grad():
         for _ in range(3): y = enc(x)
