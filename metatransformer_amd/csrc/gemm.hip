@@ -286,7 +286,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
             for (int j = 0; j < 4; ++j) v += t[j];
             s += 4;
         }
-        for (; s < S; ++s) v += ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0 + (int64_t)s * sstride));
+        if (s < S) {
+            // the last 1 .. 3 slabs: all three loads go out at once (slab index clamped: a redundant read of the last slab hits
+            // the cache line just fetched), the surplus is masked out of the sum.  Written as a dependent `for (; s < S; ++s)`
+            // this tail was S - 1 serial memory round trips for the S = 3 .. 7 folds of small-batch inference: 13 - 17 us per
+            // fold against 5 in round 1 (tools/graph_latency.py --pkg tools/_build_r1: B = 1 forward 0.91 -> 1.35 ms).
+            f32x4 t[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int sj = s + j < S ? s + j : S - 1;
+                t[j] = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0 + (int64_t)sj * sstride));
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                v += s + j < S ? t[j] : z;
+            }
+        }
         if (LIN) epilogue_quad_lin(p, m, n, v);
         else epilogue_quad(p, m, n, v);
     }

@@ -324,13 +324,13 @@ int main(int argc, char** argv) {
         if (epi == 6) { d.aux = rowop; d.ldaux = N; d.aux_dtype = ME_BF16; d.flags = ME_GEMM_AUX_IS_FACTOR; }
         if (epi == 2 || epi == 8) { d.residual = rowop; d.ldres = N; d.res_dtype = ME_BF16; }
         float* rstats = nullptr;
+        if (epi == 3) { d.aux = rowop; d.ldaux = N; d.aux_dtype = ME_BF16; }
+        d.A = A[0]; d.C = C[0]; d.preact = P[0];
         if (epi == 8) {           // residual + per-row statistics of the output on the side (me_gemm_desc.row_stats)
-            if (!me_gemm_emits_row_stats(&d)) { fprintf(stderr, "case %s: this shape does not emit row statistics\n", c.c_str()); return 2; }
+            if (!me_gemm_emits_row_stats(&d)) { fprintf(stderr, "case %s: this shape does not emit row statistics: %s\n", c.c_str(), me_last_error()); return 2; }
             CK(hipMalloc(&rstats, me_row_stats_partial_bytes(M, (int)N)));
             d.row_stats = rstats;
         }
-        if (epi == 3) { d.aux = rowop; d.ldaux = N; d.aux_dtype = ME_BF16; }
-        d.A = A[0]; d.C = C[0]; d.preact = P[0];
         const size_t wsb = me_gemm_workspace_bytes(&d);
         void* ws = nullptr;
         if (wsb) CK(hipMalloc(&ws, wsb));
