@@ -269,6 +269,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
         const float* s0 = slabs + m * p.N + n;
         f32x4 v = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0));
         int s = 1;
+#ifdef ME_FOLD_SIMPLE      // (A/B arm: round 1's loop)
+        for (; s < S; ++s) v += *reinterpret_cast<const f32x4*>(s0 + (int64_t)s * sstride);
+#endif
         // eight slab reads in flight (the fold is latency-bound otherwise: S reads in dependent rounds of a few), added in
         // slab order -- deterministic
         for (; s + 7 < S; s += 8) {
@@ -370,6 +373,7 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         pl.ws_bytes = (size_t)pl.split_k * (size_t)g3_tn_slab_stride(d->M, d->N) * sizeof(float);
         if (d->colsum_a)                  // partial column sums of A: one [M] row per (split, N-tile)
             pl.ws_bytes += (size_t)pl.split_k * (size_t)((d->N + 255) / 256) * (size_t)d->M * sizeof(float);
+        pl.ws_bytes += 256 + (size_t)((d->M + 255) / 256) * sizeof(unsigned);      // tile-row counters of the in-kernel fold (behind the rest, 256-byte aligned)
     } else if (d->op == ME_GEMM_TN) {
         pl.bn = fbn ? fbn : ((d->N % 256 == 0 || d->N > 512) ? 256 : 128);
         const int64_t tiles = pl.bn == 256 ? t256 : t128;
@@ -506,6 +510,7 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     ME_CHECK_ARG(!d->row_stats || (d->op == ME_GEMM_NT && d->residual && (uintptr_t)d->row_stats % 8 == 0),
                  "me_gemm: row_stats goes with ME_GEMM_NT and a residual operand (8-byte aligned)");
     p.row_stats = d->row_stats;
+    p.tn_colsum_out = nullptr;
     p.g3_full_tiles = 0; p.g3_split = 0; p.g3_ktp = 0; p.g3_slabs = nullptr; p.slab_stride = 0; p.g3_tickets = nullptr; p.g3_half = 0;
     if (d->colsum_a) ME_CHECK_ARG(d->op == ME_GEMM_TN, "me_gemm: colsum_a is defined for ME_GEMM_TN only");
     p.debug = gemm_dev().debug;
@@ -581,6 +586,23 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out) {
             ps.ksteps_per_split = pl.ksteps_per_split;
             ps.slab_stride = g3_tn_slab_stride(d->M, d->N);
             if (d->colsum_a) ps.colsum_ws = reinterpret_cast<float*>(d->workspace) + (size_t)pl.split_k * (size_t)ps.slab_stride;
+#ifndef G3_TN_FOLD
+#define G3_TN_FOLD 1      // (A/B arm: 0 = slabs + the separate fold launch)
+#endif
+            if (G3_TN_FOLD && g3_tn_fold_ok(p, pl.split_k) && gemm_dev().tail_split != 4) {
+                // the fold inside the launch: the kernel writes C itself (gemm3.hip, gemm_g3tn_kernel<true>)
+                GemmParams pf = p;
+                pf.split_k = pl.split_k;
+                pf.ksteps_per_split = pl.ksteps_per_split;
+                pf.slab_stride = ps.slab_stride;
+                pf.g3_slabs = reinterpret_cast<float*>(d->workspace);
+                pf.colsum_ws = ps.colsum_ws;
+                pf.tn_colsum_out = d->colsum_a;
+                const size_t used = (size_t)pl.split_k * (size_t)ps.slab_stride * sizeof(float) +
+                                    (d->colsum_a ? (size_t)pl.split_k * (size_t)p.tiles_n * (size_t)d->M * sizeof(float) : 0);
+                pf.g3_tickets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d->workspace) + ((used + 255) & ~(size_t)255));
+                return launch_g3_tn_fold(pf, stream);
+            }
             rc = launch_g3_tn(ps, stream);
             if (rc) return rc;
             p.split_k = 1;

@@ -646,6 +646,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // fold (splitk_reduce_kernel, gemm.hip) sums the slabs and applies the epilogue.  Work ids are split-major (id = split *
 // tiles + tile): the workgroups an XCD runs together read the SAME rows of dY and X at the same time, so every operand
 // row comes out of HBM once and is shared through that XCD's L2.
+// FOLD: the split-K fold runs INSIDE the launch (every workgroup is resident: tiles x splits <= CUs).  The S workgroups of an output
+// tile reduce-scatter their partial tiles: the tile is cut into 32 units (16 rows x the 32-column halves of the four wave columns),
+// unit u belongs to split (u S) >> 5; a workgroup writes the units it does not own into its slab (write-through stores: no
+// release fence), announces itself on the tile ROW's counter, waits for the S x tiles_n workgroups of that tile row, and then sums its
+// own units -- own registers first, the other splits in ascending order: deterministic -- and applies the real epilogue (alpha,
+// beta C, output dtype).  One workgroup of the tile row also folds the partial column sums (the bias gradient).  Replaces the
+// separate fold launch (48 per training step: ~25 us each + a kernel boundary) by ~1/S of its traffic per workgroup.  Hand-off
+// protocol: cdna_hip_programming.md, Guideline 16 (sc1 payload, every storing wave drains, one lane publishes / polls relaxed,
+// one agent-scope acquire, then plain loads); the counters are zeroed by a memset node ahead of every launch.
+template <bool FOLD>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g3tn_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -718,7 +728,108 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (keep == 1.2345e-30f) reinterpret_cast<float*>(p.C)[0] = keep;
         return;
     }
-    g3_epilogue<5>(p, s, m0, n0, lane, reinterpret_cast<float*>(p.C) + (int64_t)split * p.slab_stride, 0);
+    if (!FOLD) {
+        g3_epilogue<5>(p, s, m0, n0, lane, reinterpret_cast<float*>(p.C) + (int64_t)split * p.slab_stride, 0);
+        return;
+    }
+    // ---- in-kernel fold
+    const int S = p.split_k;
+    const int wc = wave & 3;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int64_t mrow = m0 + wr * 128 + lr;
+    int64_t ncol[2];
+    bool n_ok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        ncol[q] = n0 + wc * 64 + (2 * q + (lg & 1)) * 16 + 8 * (lg >> 1);
+        n_ok[q] = ncol[q] + 8 <= p.N;
+    }
+    const __amdgpu_buffer_rsrc_t mine = __builtin_amdgcn_make_buffer_rsrc(p.g3_slabs + (int64_t)split * p.slab_stride, 0, (int)(p.M * p.N * 4), 0x00020000);
+    // phase 1: re-deal every 16 x 16 pair into 8 consecutive columns per lane (kept in the accumulators), park the foreign units
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 v0 = s.acc[mt][2 * q], v1 = s.acc[mt][2 * q + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0[e]), __float_as_uint(v1[e]), false, false);
+                v0[e] = __uint_as_float(sw[0]);
+                v1[e] = __uint_as_float(sw[1]);
+            }
+            s.acc[mt][2 * q] = v0; s.acc[mt][2 * q + 1] = v1;
+            const int u = ((wr * 8 + mt) << 1) + q;
+            if (((u * S) >> 5) != split) {               // (wave-uniform)
+                const int64_t m = mrow + mt * 16;
+                const uint32_t off = (m < p.M && n_ok[q]) ? (uint32_t)((m * p.N + ncol[q]) * 4) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), mine, (int)off, 0, 16);        // sc1: write-through
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), mine, (int)(off + 16), 0, 16);
+            }
+        }
+    // publish / wait: every workgroup of this tile ROW (all N-tiles, all splits) -- the column sums need all of them anyway
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* ctr = p.g3_tickets + tm;
+        const unsigned want = (unsigned)(S * p.tiles_n);
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 26)) __builtin_trap();      // (seconds: a workgroup of the row never ran -- the launch was not resident)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    // phase 2: own units = own registers + the other splits' parked values, ascending; four splits' loads in flight at a time
+    const float* slab0 = p.g3_slabs;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int u = ((wr * 8 + mt) << 1) + q;
+            if (((u * S) >> 5) != split) continue;       // (wave-uniform)
+            const int64_t m = mrow + mt * 16;
+            const bool ok = m < p.M && n_ok[q];
+            f32x4 v0 = s.acc[mt][2 * q], v1 = s.acc[mt][2 * q + 1];
+            const float* src = slab0 + (ok ? m * p.N + ncol[q] : 0);
+            for (int sb = 0; sb < S; sb += 4) {
+                f32x4 t0[4], t1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sj = sb + j < S ? sb + j : S - 1;
+                    t0[j] = *reinterpret_cast<const f32x4*>(src + (int64_t)sj * p.slab_stride);
+                    t1[j] = *reinterpret_cast<const f32x4*>(src + (int64_t)sj * p.slab_stride + 4);
+                }
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool use = sb + j < S && sb + j != split;
+                    v0 += use ? t0[j] : z;
+                    v1 += use ? t1[j] : z;
+                }
+            }
+            if (ok) {
+                epilogue_quad_lin(p, m, ncol[q], v0);
+                epilogue_quad_lin(p, m, ncol[q] + 4, v1);
+            }
+        }
+    // the bias gradient: partial rows [split * tiles_n + tn][M] of this tile row, folded in row order by one workgroup
+    if (do_cs && p.tn_colsum_out && split == 0 && tn == 0 && tid < 256) {
+        const int64_t m = m0 + tid;
+        if (m < p.M) {
+            const int n_part = S * p.tiles_n;
+            float t = 0.f;
+            for (int j = 0; j < n_part; j += 4) {
+                float c[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c[e] = p.colsum_ws[(int64_t)(j + e < n_part ? j + e : n_part - 1) * p.M + m];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t += j + e < n_part ? c[e] : 0.f;
+            }
+            p.tn_colsum_out[m] = p.beta != 0.0f ? t + p.beta * p.tn_colsum_out[m] : t;
+        }
+    }
 }
 
 
@@ -855,10 +966,31 @@ unsigned* me_work_counters(hipStream_t stream) { return g3r_tickets(stream); }
 int launch_g3_tn(const GemmParams& p, hipStream_t stream) {
     static OncePerDevice once;
     if (once.need())
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3tn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
     const int nwg = p.tiles_m * p.tiles_n * p.split_k;
-    hipLaunchKernelGGL(gemm_g3tn_kernel, dim3((unsigned)nwg), dim3(512), G3_LDS, stream, p);
+    hipLaunchKernelGGL(gemm_g3tn_kernel<false>, dim3((unsigned)nwg), dim3(512), G3_LDS, stream, p);
     ME_CHECK_LAUNCH("me_gemm(g3 tn)");
+    return ME_OK;
+}
+
+// every workgroup of the launch must be resident at the same time (they wait for each other): one per CU, at most as many as CUs;
+// slab offsets are 32-bit; at most 32 splits (the ownership map has 32 units per tile)
+bool g3_tn_fold_ok(const GemmParams& p, int split_k) {
+    const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n * split_k;
+    return nwg <= g3_cus() && split_k <= 32 && p.M * p.N * 4 < (1ll << 31) && p.out_group_rows == 0 && p.res_row_mod == 0;
+}
+
+int launch_g3_tn_fold(const GemmParams& p, hipStream_t stream) {
+    static OncePerDevice once;
+    if (once.need())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3tn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+    const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+    if (hipMemsetAsync(p.g3_tickets, 0, (size_t)p.tiles_m * sizeof(unsigned), stream) != hipSuccess) {
+        me_set_error("me_gemm(g3 tn fold): hipMemsetAsync of the tile-row counters failed");
+        return ME_ERR_HIP;
+    }
+    hipLaunchKernelGGL(gemm_g3tn_kernel<true>, dim3((unsigned)nwg), dim3(512), G3_LDS, stream, p);
+    ME_CHECK_LAUNCH("me_gemm(g3 tn fold)");
     return ME_OK;
 }
 

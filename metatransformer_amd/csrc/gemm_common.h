@@ -26,6 +26,7 @@ struct GemmParams {
     int64_t slab_stride;                    // g3 wgrad: floats between the split-K slabs in C (>= M * N, padded: see g3_tn_slab_stride)
     const float* row_affine;                // folded LayerNorm (me_gemm_desc.row_affine): [M][2] = (rstd, -rstd * mean), or null
     const float* col_shift;                 // ... and s[n] = sum_k W'[n, k]
+    float* tn_colsum_out;                   // g3 wgrad with the in-kernel fold: where the folded column sums of A go (follows C's beta), or null
     float* row_stats;                       // resident EPI 2 kernel only (me_gemm_desc.row_stats): per-row partial statistics of the OUTPUT,
                                             // [N / 64][M] pairs (mean, M2) over 64-column groups, or null
 };
@@ -168,6 +169,10 @@ bool g3_supported(const GemmParams& p, int op);
 bool g3_emits_row_stats(const GemmParams& p);          // will launch_g3 run the resident residual kernel that can emit p.row_stats?
 size_t g3_workspace_bytes();
 int launch_g3_tn(const GemmParams& p, hipStream_t stream);      // p.split_k slabs into p.C, p.ksteps_per_split K-tiles of 64 each
+// the same with the split-K fold inside the launch (p.C = the real output, p.g3_slabs = p.split_k slabs, p.g3_tickets = one zeroed
+// counter per tile row); only when every workgroup of the launch is resident at once (g3_tn_fold_ok)
+int launch_g3_tn_fold(const GemmParams& p, hipStream_t stream);
+bool g3_tn_fold_ok(const GemmParams& p, int split_k);
 bool g3_tn_supported(const GemmParams& p);
 // floats between the split-K slabs of the g3 wgrad kernel.  (Padding the stride off the 256 KiB multiples the encoder's
 // shapes give was tried against HBM channel aliasing in the fold: 34 us against 23, i.e. worse -- the slabs stay dense.)
