@@ -310,8 +310,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
         else epilogue_quad(p, m, n, v);
     }
 }
+#ifdef ME_FOLD_R1      // (A/B arm: round 1's fold kernel, verbatim, for every fold without column sums and with dense slabs)
+__global__ __launch_bounds__(256) void splitk_reduce_r1_kernel(const GemmParams p, const float* __restrict__ slabs, int S) {
+    const int64_t nq = p.N / 4;
+    const int64_t total = p.M * nq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / nq, n = (i % nq) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slabs + m * p.N + n);
+        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(slabs + ((int64_t)s * p.M + m) * p.N + n);
+        epilogue_quad(p, m, n, v);
+    }
+}
+#endif
 static void launch_splitk_reduce(const GemmParams& p, unsigned nb, hipStream_t stream, const float* slabs, int S, const float* cs_part,
                                  int n_part, float* colsum_out, int64_t sstride = 0) {
+#ifdef ME_FOLD_R1
+    if (!colsum_out && (sstride == 0 || sstride == p.M * p.N)) {
+        hipLaunchKernelGGL(splitk_reduce_r1_kernel, dim3(nb), dim3(256), 0, stream, p, slabs, S);
+        return;
+    }
+#endif
     if (sstride == 0) sstride = p.M * p.N;
     if (p.act == ME_ACT_NONE && !p.preact && !p.aux && !p.row_affine)
         hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride);
@@ -586,10 +604,8 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out) {
             ps.ksteps_per_split = pl.ksteps_per_split;
             ps.slab_stride = g3_tn_slab_stride(d->M, d->N);
             if (d->colsum_a) ps.colsum_ws = reinterpret_cast<float*>(d->workspace) + (size_t)pl.split_k * (size_t)ps.slab_stride;
-#ifndef G3_TN_FOLD
-#define G3_TN_FOLD 1      // (A/B arm: 0 = slabs + the separate fold launch)
-#endif
-            if (G3_TN_FOLD && g3_tn_fold_ok(p, pl.split_k) && gemm_dev().tail_split != 4) {
+#if G3_TN_FOLD
+            if (g3_tn_fold_ok(p, pl.split_k)) {
                 // the fold inside the launch: the kernel writes C itself (gemm3.hip, gemm_g3tn_kernel<true>)
                 GemmParams pf = p;
                 pf.split_k = pl.split_k;
@@ -603,6 +619,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out) {
                 pf.g3_tickets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d->workspace) + ((used + 255) & ~(size_t)255));
                 return launch_g3_tn_fold(pf, stream);
             }
+#endif
             rc = launch_g3_tn(ps, stream);
             if (rc) return rc;
             p.split_k = 1;

@@ -404,9 +404,9 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                 v1 *= gelu_bf16_grad4(ro[h][1]);
             }
             if (EPI == 2) { v0 += ro[h][0]; v1 += ro[h][1]; }
+            const u32x4 pk = pack(v0, v1);
             if (STATS) {
                 // the values AS STORED (rounded to bf16): what the LayerNorm behind this launch reads
-                const u32x4 pk = pack(v0, v1);
                 unpack(pk, v0, v1);
                 // pivot: chunk 0 of the row lives in lane (r & 7) of lane row 0
                 unsigned pu = __float_as_uint(v0[0]);
@@ -420,7 +420,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                 st_q[h] = (qd[0] + qd[1]) + (qd[2] + qd[3]);
                 st_p[h] = P;
             }
-            __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), crs, (int)(coff + (2 * mt + h) * cstep), 0, G3_POL_C);
+            __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pk, to_mem), crs, (int)(coff + (2 * mt + h) * cstep), 0, EPI == 2 ? G3_POL_C_RES : G3_POL_C);
         }
         if (STATS) {
             // reduce-scatter over the eight lanes of a row: lane bit 3 (DPP) picks the half slab, bit 4 (permlane16) the slab of
@@ -973,6 +973,7 @@ int launch_g3_tn(const GemmParams& p, hipStream_t stream) {
     return ME_OK;
 }
 
+#if G3_TN_FOLD
 // every workgroup of the launch must be resident at the same time (they wait for each other): one per CU, at most as many as CUs;
 // slab offsets are 32-bit; at most 32 splits (the ownership map has 32 units per tile)
 bool g3_tn_fold_ok(const GemmParams& p, int split_k) {
@@ -993,6 +994,7 @@ int launch_g3_tn_fold(const GemmParams& p, hipStream_t stream) {
     ME_CHECK_LAUNCH("me_gemm(g3 tn fold)");
     return ME_OK;
 }
+#endif
 
 bool g3_tn_supported(const GemmParams& p) {
     // 16-byte chunks of 8 columns; lane offsets and per-K-tile steps are 32-bit; the bounds check spans the whole matrix

@@ -67,6 +67,9 @@ constexpr int G3_BM = 256, G3_BN = 256, G3_BK = 64;
 #ifndef G3_POL_R
 #define G3_POL_R 2
 #endif
+#ifndef G3_POL_C_RES
+#define G3_POL_C_RES G3_POL_C      // C policy of the residual epilogue (the 77 MB token stream the next kernel reads straight away)
+#endif
 #ifndef G3_POL_P
 #define G3_POL_P 2
 #endif

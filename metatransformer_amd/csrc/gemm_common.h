@@ -169,6 +169,14 @@ bool g3_supported(const GemmParams& p, int op);
 bool g3_emits_row_stats(const GemmParams& p);          // will launch_g3 run the resident residual kernel that can emit p.row_stats?
 size_t g3_workspace_bytes();
 int launch_g3_tn(const GemmParams& p, hipStream_t stream);      // p.split_k slabs into p.C, p.ksteps_per_split K-tiles of 64 each
+// A/B arm, measured and NOT shipped (round 4): -DG3_TN_FOLD=1 = the split-K fold of the wgrad kernel INSIDE its launch.  Same-box
+// result: wgrad 211 us per launch against 176 us for kernel + separate fold launch (train step 32.8 vs 31.35 ms): the S partial
+// tiles of a tile are 64 MB per launch either way, and inside the launch their write-through, the wait for the tile row and the
+// read-back are exposed one after the other on every CU, where the separate fold streams them at full-chip bandwidth while the
+// next kernel's launch overlaps the tail (the guide's "splitk-seam" verdict, reproduced at this size).
+#ifndef G3_TN_FOLD
+#define G3_TN_FOLD 0
+#endif
 // the same with the split-K fold inside the launch (p.C = the real output, p.g3_slabs = p.split_k slabs, p.g3_tickets = one zeroed
 // counter per tile row); only when every workgroup of the launch is resident at once (g3_tn_fold_ok)
 int launch_g3_tn_fold(const GemmParams& p, hipStream_t stream);
