@@ -879,9 +879,12 @@ unsigned* g3r_tickets(hipStream_t stream) {
 
 template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_t stream) {
 #ifndef G3_HI_EPI2
-#define G3_HI_EPI2 0                           // (A/B arm: 128-row items in the plain residual kernel too)
+#define G3_HI_EPI2 1                           // (A/B arm: 128-row items in the plain residual kernel too)
 #endif
-    constexpr bool HI = EPI == 0 || (G3_HI_EPI2 && EPI == 2 && PRE == 0);      // which forms carry the 128-row items (see the kernel)
+#ifndef G3_HI_EPI1
+#define G3_HI_EPI1 1                           // (A/B arm: ... and in the GELU kernels -- fc1's 2 364 tiles leave a last round of 60)
+#endif
+    constexpr bool HI = EPI == 0 || (G3_HI_EPI2 && EPI == 2 && PRE == 0) || (G3_HI_EPI1 && EPI == 1);      // which forms carry the 128-row items (see the kernel)
     static OncePerDevice once;
     if (once.need())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE, HI>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS + 64);
