@@ -235,9 +235,10 @@ int launch_g128(const GemmParams& p, hipStream_t stream) {
 __device__ __forceinline__ void fold_colsum(const GemmParams& p, const float* __restrict__ cs_part, int n_part, float* __restrict__ colsum_out) {
     __shared__ float red[8][32];
     const int nblk = (int)((p.M + 31) / 32);
-    const int b = (int)gridDim.x - 1 - (int)blockIdx.x;
-    if (b < nblk || gridDim.x < (unsigned)nblk) {
-        for (int cb = b; cb < nblk; cb += (int)gridDim.x) {
+    const int nwg = (int)(gridDim.x * gridDim.y);
+    const int b = nwg - 1 - (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    if (b < nblk || nwg < nblk) {
+        for (int cb = b; cb < nblk; cb += nwg) {
             const int64_t m = (int64_t)cb * 32 + (threadIdx.x & 31);
             const int jg = threadIdx.x >> 5;
             float s = 0.f;
@@ -256,24 +257,40 @@ __device__ __forceinline__ void fold_colsum(const GemmParams& p, const float* __
     }
 }
 
-// ---- split-K fold: sum the fp32 slabs [S][M][N] and apply the real epilogue (LIN: the descriptor has no GELU form)
+// ---- split-K fold: sum the fp32 slabs [S][M][N] and apply the real epilogue (LIN: the descriptor has no GELU form).
+// Indexing (round 4): a WAVE owns 256 consecutive columns of one row (64 lanes x one quad), blockIdx.x walks the column blocks,
+// blockIdx.y / the wave index the rows -- no division anywhere.  The flat form (i -> m = i / nq, n = i % nq in 64-bit) spent ~150
+// instructions per quad on that division: the fold of a weight gradient ran instruction-bound at 25 us for 85 MB that mostly sit
+// in the Infinity Cache.
 template <bool LIN>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ slabs, int S,
                                                             const float* __restrict__ cs_part, int n_part,
                                                             float* __restrict__ colsum_out, int64_t sstride) {
     if (colsum_out) fold_colsum(p, cs_part, n_part, colsum_out);
-    const int64_t nq = p.N / 4;
-    const int64_t total = p.M * nq;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t m = i / nq, n = (i % nq) * 4;
+    const int q = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63);
+    if (q >= (int)(p.N / 4)) return;
+    const int64_t n = (int64_t)q * 4;
+    // LIN: the operands of the epilogue (bias, residual row, the old C of an accumulating weight gradient) are loaded UNCONDITIONALLY,
+    // from the real address or -- operand absent -- from the slab itself, ahead of the slab reads: written as `if (p.bias) v += load`
+    // hipcc waits with vmcnt(0) at the join of every such branch, and the fold became four serial memory round trips (PMC: 5 080
+    // wait cycles per wave against 1 320 for round 1's kernel on the same problem -- the whole small-batch latency regression).
+    const bool res16 = LIN && p.residual && p.res_dtype == ME_BF16, res32 = LIN && p.residual && p.res_dtype != ME_BF16;
+    const bool c16 = LIN && p.beta != 0.0f && p.c_dtype == ME_BF16, c32 = LIN && p.beta != 0.0f && p.c_dtype != ME_BF16;
+    const bool plain_rows = p.res_row_mod == 0 && p.out_group_rows == 0;      // (otherwise: the generic epilogue below)
+    for (int64_t m = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); m < p.M; m += (int64_t)gridDim.y * 4) {
         const float* s0 = slabs + m * p.N + n;
         f32x4 v = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0));
+        f32x4 e_bias, e_r32, e_c32;
+        u32x2 e_r16, e_c16;
+        if (LIN && plain_rows) {
+            e_bias = *reinterpret_cast<const f32x4*>(p.bias ? p.bias + n : s0);
+            e_r16 = *reinterpret_cast<const u32x2*>(res16 ? reinterpret_cast<const char*>(p.residual) + (m * p.ldres + n) * 2 : reinterpret_cast<const char*>(s0));
+            e_r32 = *reinterpret_cast<const f32x4*>(res32 ? reinterpret_cast<const char*>(p.residual) + (m * p.ldres + n) * 4 : reinterpret_cast<const char*>(s0));
+            e_c16 = *reinterpret_cast<const u32x2*>(c16 ? reinterpret_cast<const char*>(p.C) + (m * p.ldc + n) * 2 : reinterpret_cast<const char*>(s0));
+            e_c32 = *reinterpret_cast<const f32x4*>(c32 ? reinterpret_cast<const char*>(p.C) + (m * p.ldc + n) * 4 : reinterpret_cast<const char*>(s0));
+        }
         int s = 1;
-#ifdef ME_FOLD_SIMPLE      // (A/B arm: round 1's loop)
-        for (; s < S; ++s) v += *reinterpret_cast<const f32x4*>(s0 + (int64_t)s * sstride);
-#endif
-        // eight slab reads in flight (the fold is latency-bound otherwise: S reads in dependent rounds of a few), added in
-        // slab order -- deterministic
+        // eight slab reads in flight, added in slab order -- deterministic
         for (; s + 7 < S; s += 8) {
             f32x4 t[8];
 #pragma unroll
@@ -290,10 +307,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
             s += 4;
         }
         if (s < S) {
-            // the last 1 .. 3 slabs: all three loads go out at once (slab index clamped: a redundant read of the last slab hits
-            // the cache line just fetched), the surplus is masked out of the sum.  Written as a dependent `for (; s < S; ++s)`
-            // this tail was S - 1 serial memory round trips for the S = 3 .. 7 folds of small-batch inference: 13 - 17 us per
-            // fold against 5 in round 1 (tools/graph_latency.py --pkg tools/_build_r1: B = 1 forward 0.91 -> 1.35 ms).
+            // the last 1 .. 3 slabs go out together (slab index clamped: a redundant read of the last slab hits the line just
+            // fetched), the surplus is masked out of the sum -- not S - 1 serial round trips for the S = 3 .. 7 folds of small batches
             f32x4 t[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -306,35 +321,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
                 v += s + j < S ? t[j] : z;
             }
         }
-        if (LIN) epilogue_quad_lin(p, m, n, v);
-        else epilogue_quad(p, m, n, v);
+        if (LIN && plain_rows) {
+            // epilogue_quad_lin with the operands already here (same order of operations)
+            auto up = [](u32x2 r) { return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)}; };
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            v *= p.alpha;
+            v += p.bias ? e_bias : z;
+            if (p.colscale) v *= *reinterpret_cast<const f32x4*>(p.colscale + n);
+            v += res16 ? up(e_r16) : (res32 ? e_r32 : z);
+            v += c16 ? p.beta * up(e_c16) : (c32 ? p.beta * e_c32 : z);
+            store4_from_f32(p.C, p.c_dtype, m * p.ldc + n, v);
+        } else if (LIN) {
+            epilogue_quad_lin(p, m, n, v);
+        } else {
+            epilogue_quad(p, m, n, v);
+        }
     }
 }
-#ifdef ME_FOLD_R1      // (A/B arm: round 1's fold kernel, verbatim, for every fold without column sums and with dense slabs)
-__global__ __launch_bounds__(256) void splitk_reduce_r1_kernel(const GemmParams p, const float* __restrict__ slabs, int S) {
-    const int64_t nq = p.N / 4;
-    const int64_t total = p.M * nq;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t m = i / nq, n = (i % nq) * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(slabs + m * p.N + n);
-        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(slabs + ((int64_t)s * p.M + m) * p.N + n);
-        epilogue_quad(p, m, n, v);
-    }
-}
-#endif
-static void launch_splitk_reduce(const GemmParams& p, unsigned nb, hipStream_t stream, const float* slabs, int S, const float* cs_part,
+static void launch_splitk_reduce(const GemmParams& p, unsigned /*nb*/, hipStream_t stream, const float* slabs, int S, const float* cs_part,
                                  int n_part, float* colsum_out, int64_t sstride = 0) {
-#ifdef ME_FOLD_R1
-    if (!colsum_out && (sstride == 0 || sstride == p.M * p.N)) {
-        hipLaunchKernelGGL(splitk_reduce_r1_kernel, dim3(nb), dim3(256), 0, stream, p, slabs, S);
-        return;
-    }
-#endif
     if (sstride == 0) sstride = p.M * p.N;
+    const unsigned gx = (unsigned)((p.N / 4 + 63) / 64);
+    int64_t gy = (p.M + 3) / 4;
+    const int64_t cap = 4096 / gx > 1 ? 4096 / gx : 1;          // ~16 blocks per CU at most; rows beyond that by stride
+    if (gy > cap) gy = cap;
+    const dim3 grid(gx, (unsigned)gy);
     if (p.act == ME_ACT_NONE && !p.preact && !p.aux && !p.row_affine)
-        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride);
+        hipLaunchKernelGGL(splitk_reduce_kernel<true>, grid, dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride);
     else
-        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride);
+        hipLaunchKernelGGL(splitk_reduce_kernel<false>, grid, dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride);
 }
 
 struct GemmPlan {

@@ -47,7 +47,7 @@ def _usable_cores() -> int:
         return os.cpu_count() or 1
 
 
-def time_encoder(depth=12, dim=768, heads=12, N=197, backward=True, budget_s=20.0, seed=0):
+def time_encoder(depth=12, dim=768, heads=12, N=197, backward=True, budget_s=20.0, seed=0, replicas=True):
     """Sweep (threads, batch) and report the best samples/s with the configuration that gave it.
 
     Threads ascend through {8, 16, 32, 64, all usable}; a leg that is SLOWER than the best so far ends the ascent (throughput
@@ -94,11 +94,12 @@ def time_encoder(depth=12, dim=768, heads=12, N=197, backward=True, budget_s=20.
         legs[(th, batch)] = (batch * it / el, it, el)
         return legs[(th, batch)][0]
 
-    best_th, best = cand[0], leg(cand[0], 8)
+    asc_s = max(1.5, 0.12 * budget_s)          # per leg of the ascent: the 8 / 16 / 32-thread legs all get their turn
+    best_th, best = cand[0], leg(cand[0], 8, max_s=asc_s)
     for th in cand[1:]:
-        if time.perf_counter() - t_start > 0.4 * budget_s:
+        if time.perf_counter() - t_start > 0.5 * budget_s:
             break
-        v = leg(th, 8)
+        v = leg(th, 8, max_s=asc_s)
         if v <= best:
             break                               # slower than the best so far: stop ascending
         best_th, best = th, v
@@ -116,14 +117,88 @@ def time_encoder(depth=12, dim=768, heads=12, N=197, backward=True, budget_s=20.
         if not improved:
             break
     (th_b, batch_b), (val, it, el) = max(legs.items(), key=lambda kv: kv[1][0])
+    sweep = ", ".join(f"{t}x{b}: {v[0]:.1f}" for (t, b), v in sorted(legs.items()))
+    # What the HOST can do: one process of this model stops scaling at 8 - 32 threads, so R = cores / threads independent replicas of
+    # the best single-process configuration run side by side, each pinned to its own cores (one 16-thread process uses
+    # 6 % of a 256-core box).  The aggregate is the reported value when it is the larger one.
+    rep = None
+    R = min(cores // th_b, 32)
+    left = budget_s - (time.perf_counter() - t_start)
+    if R >= 2 and replicas and left > 4.0:
+        rep = _run_replicas(R, th_b, batch_b, depth, dim, heads, N, backward, min(6.0, max(3.0, 0.6 * left)))
+    head = (f"reference Block formulation (fused ATen ops, oracle/cpu_baseline.py) torch-CPU fp32 {'fwd+bwd' if backward else 'fwd'} of the "
+            f"{depth}L/{dim}d encoder; host has {cores} usable cores")
+    if rep is not None and rep["value"] > val:
+        return {"value": rep["value"], "unit": "samples/s", "cores": R * th_b, "kind": "port",
+                "sample": (f"{head}; {R} independent replicas x {th_b} threads (pinned core sets) on [{batch_b},{N},{dim}] tokens each, "
+                           f"{rep['iters']} iterations in {rep['seconds']:.1f} s, aggregate of the replicas' own rates; best single process "
+                           f"{val:.1f} samples/s at {th_b} threads; sweep (threads x batch: samples/s): {sweep}; "
+                           f"{time.perf_counter() - t_start:.0f} s in all")}
     return {
         "value": val, "unit": "samples/s", "cores": th_b, "kind": "port",
-        "sample": (f"reference Block formulation (fused ATen ops, oracle/cpu_baseline.py) torch-CPU fp32 "
-                   f"{'fwd+bwd' if backward else 'fwd'} of the {depth}L/{dim}d encoder on [{batch_b},{N},{dim}] tokens, {it} timed "
-                   f"iterations ({el:.1f} s) at {th_b} threads; sweep (threads x batch: samples/s): "
-                   + ", ".join(f"{t}x{b}: {v[0]:.1f}" for (t, b), v in sorted(legs.items()))
-                   + f"; ascent stops at the first slower leg; host has {cores} usable cores; {time.perf_counter() - t_start:.0f} s in all"),
+        "sample": (f"{head}; one process on [{batch_b},{N},{dim}] tokens, {it} timed iterations ({el:.1f} s) at {th_b} of {cores} cores; "
+                   f"sweep (threads x batch: samples/s): {sweep}; ascent stops at the first slower leg"
+                   + (f"; {R} replicas x {th_b} threads gave {rep['value']:.1f} samples/s in aggregate" if rep is not None else "")
+                   + f"; {time.perf_counter() - t_start:.0f} s in all"),
     }
+
+
+def _replica_worker(th, batch, depth, dim, heads, N, backward, secs, cpus):
+    """one replica: pinned to `cpus`, `th` threads, steps for `secs` seconds after a warm-up; prints its own rate"""
+    import json
+    if cpus:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            pass
+    torch.set_num_threads(th)
+    sd = bo.make_encoder_state_dict(depth, dim, seed=0)
+    if backward:
+        sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(0)
+    x, go = torch.randn(batch, N, dim, generator=g), torch.randn(batch, N, dim, generator=g)
+
+    def step():
+        if backward:
+            xr = x.clone().requires_grad_(True)
+            y = encoder_forward_fused(xr, sd, heads)
+            torch.autograd.grad(y, [xr] + list(sd.values()), go)
+        else:
+            with torch.no_grad():
+                encoder_forward_fused(x, sd, heads)
+    step()
+    t0, it = time.perf_counter(), 0
+    while time.perf_counter() - t0 < secs:
+        step()
+        it += 1
+    el = time.perf_counter() - t0
+    print(json.dumps({"rate": batch * it / el, "iters": it, "seconds": el}), flush=True)
+
+
+def _run_replicas(R, th, batch, depth, dim, heads, N, backward, secs):
+    import json
+    import subprocess
+    import sys
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = list(range(os.cpu_count() or 1))
+    procs = []
+    for r in range(R):
+        cpus = avail[r * th:(r + 1) * th]
+        cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--worker", str(th), str(batch), str(secs), ",".join(map(str, cpus)),
+               "--depth", str(depth), "--dim", str(dim), "--heads", str(heads), "--tokens", str(N)] + ([] if backward else ["--forward-only"])
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                      cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    rate, iters, worst = 0.0, 0, 0.0
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=secs * 6 + 120)
+            j = json.loads(out.strip().splitlines()[-1])
+            rate += j["rate"]; iters += j["iters"]; worst = max(worst, j["seconds"])
+        except Exception:       # noqa: BLE001 -- a replica that failed simply does not count
+            pr.kill()
+    return {"value": rate, "iters": iters, "seconds": worst} if rate > 0 else None
 
 
 if __name__ == "__main__":
@@ -137,5 +212,11 @@ if __name__ == "__main__":
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--budget-s", type=float, default=20.0)
     ap.add_argument("--batch", type=int, default=0, help="(ignored: the batch is swept)")
+    ap.add_argument("--no-replicas", action="store_true")
+    ap.add_argument("--worker", nargs=4, default=None, metavar=("THREADS", "BATCH", "SECONDS", "CPUS"), help="(internal: one replica)")
     a = ap.parse_args()
-    print(json.dumps(time_encoder(a.depth, a.dim, a.heads, a.tokens, not a.forward_only, a.budget_s)))
+    if a.worker:
+        th, batch, secs, cpus = int(a.worker[0]), int(a.worker[1]), float(a.worker[2]), [int(c) for c in a.worker[3].split(",") if c]
+        _replica_worker(th, batch, a.depth, a.dim, a.heads, a.tokens, not a.forward_only, secs, cpus)
+    else:
+        print(json.dumps(time_encoder(a.depth, a.dim, a.heads, a.tokens, not a.forward_only, a.budget_s, replicas=not a.no_replicas)))
