@@ -247,18 +247,23 @@ def main():
         """HBM bytes per launch of the roofline kernel from the committed PMC passes of this same command (rocprofv3 --pmc
         cannot run inside the process: tools/pmc_bench.sh collects FETCH_SIZE / WRITE_SIZE in separate passes and
         tools/pmc_summary.py folds them, traffic = 2 * FETCH_SIZE + WRITE_SIZE).  None when the file is not there."""
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r03_pmc_{mode}.json")
-        try:
-            with open(path) as f:
-                pm = json.load(f)
-        except (OSError, ValueError):
+        pm, src = None, None
+        for rnd in ("r04", "r03"):            # the newest committed set
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{rnd}_pmc_{mode}.json")
+            try:
+                with open(path) as f:
+                    pm, src = json.load(f), f"profiles/{rnd}_pmc_{mode}.json"
+                break
+            except (OSError, ValueError):
+                continue
+        if pm is None:
             return None, None
         rows = [(v["launches"], v["hbm_traffic_MB"]) for k, v in pm.items()
                 if k.startswith("gemm_g3r_kernel") and isinstance(v, dict) and "hbm_traffic_MB" in v and v.get("launches")]
         if not rows:
             return None, None
         mib = sum(n * t for n, t in rows) / sum(n for n, _ in rows)        # (tools/pmc_summary.py reports MiB)
-        return round(mib * 1048576), (f"profiles/r03_pmc_{mode}.json: rocprofv3 --pmc passes of this command (separate runs, 2*FETCH_SIZE + "
+        return round(mib * 1048576), (f"{src}: rocprofv3 --pmc passes of this command (separate runs, 2*FETCH_SIZE + "
                                       f"WRITE_SIZE), launch-weighted mean over the gemm_g3r_kernel launches; not re-measured in this run")
 
     def aux_arrays(m, n, k):

@@ -257,11 +257,83 @@ __device__ __forceinline__ void fold_colsum(const GemmParams& p, const float* __
     }
 }
 
-// ---- split-K fold: sum the fp32 slabs [S][M][N] and apply the real epilogue (LIN: the descriptor has no GELU form).
-// Indexing (round 4): a WAVE owns 256 consecutive columns of one row (64 lanes x one quad), blockIdx.x walks the column blocks,
-// blockIdx.y / the wave index the rows -- no division anywhere.  The flat form (i -> m = i / nq, n = i % nq in 64-bit) spent ~150
-// instructions per quad on that division: the fold of a weight gradient ran instruction-bound at 25 us for 85 MB that mostly sit
-// in the Infinity Cache.
+// ---- split-K fold: sum the fp32 slabs [S][M][N] and apply the real epilogue.
+// A WAVE owns 256 consecutive columns of one row (64 lanes x one quad), blockIdx.x walks the column blocks, blockIdx.y / the
+// wave index the rows -- no division.  Slab reads go out in batches (8 / 4 / the last 1 .. 3 together, the surplus of the last
+// batch masked), added in slab order: deterministic.
+__device__ __forceinline__ f32x4 fold_slabs(const float* __restrict__ s0, int S, int64_t sstride) {
+    f32x4 v = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0));
+    int s = 1;
+    for (; s + 7 < S; s += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + j) * sstride));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += t[j];
+    }
+    if (s + 3 < S) {
+        f32x4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + j) * sstride));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += t[j];
+        s += 4;
+    }
+    if (s < S) {
+        f32x4 t[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int sj = s + j < S ? s + j : S - 1;
+            t[j] = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0 + (int64_t)sj * sstride));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            v += s + j < S ? t[j] : z;
+        }
+    }
+    return v;
+}
+
+// The folds the encoder actually runs, one instantiation each -- NO run-time conditions around the operand loads: every `if (p.bias)
+// v += load` of the generic epilogue costs a vmcnt(0) at its join (hipcc), i.e. one more serial memory round trip per operand, and
+// hipcc turns a "load from the selected pointer" back into those branches.  PMC, B = 1 forward: 5 080 wait cycles per wave in the
+// generic fold against 1 320 in round 1's (which had fewer operands to test for) -- 0.45 ms of a 0.9 ms forward.
+//   BIAS  bias[n] present            RES  0 none / 1 bf16 / 2 fp32 residual row operand (plain rows)
+//   CST   0 bf16 store / 1 fp32 store / 2 fp32 store + beta * C_old (accumulating weight gradient)
+//   ACT   GELU (bf16-mode form by the output dtype, as the GEMM epilogues)       CS  fold the partial column sums too (bias gradient)
+template <bool BIAS, int RES, int CST, bool ACT, bool CS>
+__global__ __launch_bounds__(256) void splitk_fold_kernel(const GemmParams p, const float* __restrict__ slabs, int S, const float* __restrict__ cs_part,
+                                                          int n_part, float* __restrict__ colsum_out, int64_t sstride) {
+    if (CS) fold_colsum(p, cs_part, n_part, colsum_out);
+    const int q = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63);
+    if (q >= (int)(p.N / 4)) return;
+    const int64_t n = (int64_t)q * 4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (BIAS) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    for (int64_t m = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); m < p.M; m += (int64_t)gridDim.y * 4) {
+        f32x4 r4 = {0.f, 0.f, 0.f, 0.f}, c4 = r4;
+        u32x2 r2 = {0u, 0u};
+        if (RES == 1) r2 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.residual) + m * p.ldres + n);
+        if (RES == 2) r4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + m * p.ldres + n);
+        if (CST == 2) c4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + m * p.ldc + n);
+        f32x4 v = fold_slabs(slabs + m * p.N + n, S, sstride);
+        v = v * p.alpha + bias4;
+        if (ACT) v = gelu_for4(v, CST == 0 ? ME_BF16 : ME_F32);
+        if (RES == 1) v += f32x4{__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u), __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
+        if (RES == 2) v += r4;
+        if (CST == 2) v += p.beta * c4;
+        if (CST == 0) {
+            bf16x4 o;
+            o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(p.C) + m * p.ldc + n) = o;
+        } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = v;
+        }
+    }
+}
+
+// ... and everything else the header allows (column scale, row remaps, saved pre-activation, gelu' operand, folded LayerNorm)
 template <bool LIN>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ slabs, int S,
                                                             const float* __restrict__ cs_part, int n_part,
@@ -270,74 +342,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     const int q = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63);
     if (q >= (int)(p.N / 4)) return;
     const int64_t n = (int64_t)q * 4;
-    // LIN: the operands of the epilogue (bias, residual row, the old C of an accumulating weight gradient) are loaded UNCONDITIONALLY,
-    // from the real address or -- operand absent -- from the slab itself, ahead of the slab reads: written as `if (p.bias) v += load`
-    // hipcc waits with vmcnt(0) at the join of every such branch, and the fold became four serial memory round trips (PMC: 5 080
-    // wait cycles per wave against 1 320 for round 1's kernel on the same problem -- the whole small-batch latency regression).
-    const bool res16 = LIN && p.residual && p.res_dtype == ME_BF16, res32 = LIN && p.residual && p.res_dtype != ME_BF16;
-    const bool c16 = LIN && p.beta != 0.0f && p.c_dtype == ME_BF16, c32 = LIN && p.beta != 0.0f && p.c_dtype != ME_BF16;
-    const bool plain_rows = p.res_row_mod == 0 && p.out_group_rows == 0;      // (otherwise: the generic epilogue below)
     for (int64_t m = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); m < p.M; m += (int64_t)gridDim.y * 4) {
-        const float* s0 = slabs + m * p.N + n;
-        f32x4 v = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0));
-        f32x4 e_bias, e_r32, e_c32;
-        u32x2 e_r16, e_c16;
-        if (LIN && plain_rows) {
-            e_bias = *reinterpret_cast<const f32x4*>(p.bias ? p.bias + n : s0);
-            e_r16 = *reinterpret_cast<const u32x2*>(res16 ? reinterpret_cast<const char*>(p.residual) + (m * p.ldres + n) * 2 : reinterpret_cast<const char*>(s0));
-            e_r32 = *reinterpret_cast<const f32x4*>(res32 ? reinterpret_cast<const char*>(p.residual) + (m * p.ldres + n) * 4 : reinterpret_cast<const char*>(s0));
-            e_c16 = *reinterpret_cast<const u32x2*>(c16 ? reinterpret_cast<const char*>(p.C) + (m * p.ldc + n) * 2 : reinterpret_cast<const char*>(s0));
-            e_c32 = *reinterpret_cast<const f32x4*>(c32 ? reinterpret_cast<const char*>(p.C) + (m * p.ldc + n) * 4 : reinterpret_cast<const char*>(s0));
-        }
-        int s = 1;
-        // eight slab reads in flight, added in slab order -- deterministic
-        for (; s + 7 < S; s += 8) {
-            f32x4 t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + j) * sstride));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v += t[j];
-        }
-        if (s + 3 < S) {
-            f32x4 t[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0 + (int64_t)(s + j) * sstride));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v += t[j];
-            s += 4;
-        }
-        if (s < S) {
-            // the last 1 .. 3 slabs go out together (slab index clamped: a redundant read of the last slab hits the line just
-            // fetched), the surplus is masked out of the sum -- not S - 1 serial round trips for the S = 3 .. 7 folds of small batches
-            f32x4 t[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int sj = s + j < S ? s + j : S - 1;
-                t[j] = ME_NT_LOAD(ME_POL_SLAB, reinterpret_cast<const f32x4*>(s0 + (int64_t)sj * sstride));
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                v += s + j < S ? t[j] : z;
-            }
-        }
-        if (LIN && plain_rows) {
-            // epilogue_quad_lin with the operands already here (same order of operations)
-            auto up = [](u32x2 r) { return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)}; };
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            v *= p.alpha;
-            v += p.bias ? e_bias : z;
-            if (p.colscale) v *= *reinterpret_cast<const f32x4*>(p.colscale + n);
-            v += res16 ? up(e_r16) : (res32 ? e_r32 : z);
-            v += c16 ? p.beta * up(e_c16) : (c32 ? p.beta * e_c32 : z);
-            store4_from_f32(p.C, p.c_dtype, m * p.ldc + n, v);
-        } else if (LIN) {
-            epilogue_quad_lin(p, m, n, v);
-        } else {
-            epilogue_quad(p, m, n, v);
-        }
+        const f32x4 v = fold_slabs(slabs + m * p.N + n, S, sstride);
+        if (LIN) epilogue_quad_lin(p, m, n, v);
+        else epilogue_quad(p, m, n, v);
     }
 }
+
 static void launch_splitk_reduce(const GemmParams& p, unsigned /*nb*/, hipStream_t stream, const float* slabs, int S, const float* cs_part,
                                  int n_part, float* colsum_out, int64_t sstride = 0) {
     if (sstride == 0) sstride = p.M * p.N;
@@ -346,6 +357,35 @@ static void launch_splitk_reduce(const GemmParams& p, unsigned /*nb*/, hipStream
     const int64_t cap = 4096 / gx > 1 ? 4096 / gx : 1;          // ~16 blocks per CU at most; rows beyond that by stride
     if (gy > cap) gy = cap;
     const dim3 grid(gx, (unsigned)gy);
+#define ME_FOLD(BIAS, RES, CST, ACT, CS) \
+    do { hipLaunchKernelGGL((splitk_fold_kernel<BIAS, RES, CST, ACT, CS>), grid, dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride); return; } while (0)
+    const bool simple = !p.preact && !p.aux && !p.row_affine && !p.colscale && !p.flags && p.res_row_mod == 0 && p.out_group_rows == 0;
+    const int res = !p.residual ? 0 : (p.res_dtype == ME_BF16 ? 1 : 2);
+    if (simple) {
+        const bool bias = p.bias != nullptr, gelu = p.act == ME_ACT_GELU;
+        if (p.c_dtype == ME_F32 && !gelu && res == 0 && !bias) {          // weight gradients
+            if (p.beta == 1.0f || p.beta == 0.0f) {
+                if (p.beta != 0.0f) { if (colsum_out) ME_FOLD(false, 0, 2, false, true); else ME_FOLD(false, 0, 2, false, false); }
+                else { if (colsum_out) ME_FOLD(false, 0, 1, false, true); else ME_FOLD(false, 0, 1, false, false); }
+            }
+        }
+        if (p.beta == 0.0f && !colsum_out && bias) {                      // forward / dgrad launches split over the reduction (small batches, tails)
+            if (p.c_dtype == ME_BF16) {
+                if (gelu && res == 0) ME_FOLD(true, 0, 0, true, false);
+                if (!gelu && res == 0) ME_FOLD(true, 0, 0, false, false);
+                if (!gelu && res == 1) ME_FOLD(true, 1, 0, false, false);
+            } else {
+                if (gelu && res == 0) ME_FOLD(true, 0, 1, true, false);
+                if (!gelu && res == 0) ME_FOLD(true, 0, 1, false, false);
+                if (!gelu && res == 2) ME_FOLD(true, 2, 1, false, false);
+            }
+        }
+        if (p.beta == 0.0f && !colsum_out && !bias && !gelu && res == 0) {   // dgrad (no bias)
+            if (p.c_dtype == ME_BF16) ME_FOLD(false, 0, 0, false, false);
+            else ME_FOLD(false, 0, 1, false, false);
+        }
+    }
+#undef ME_FOLD
     if (p.act == ME_ACT_NONE && !p.preact && !p.aux && !p.row_affine)
         hipLaunchKernelGGL(splitk_reduce_kernel<true>, grid, dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride);
     else

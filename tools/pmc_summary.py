@@ -7,7 +7,7 @@ def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     return re.sub(r"\(.*", "", name)
 
-ROUND = "r03"
+ROUND = "r04"
 
 
 def main(mode):

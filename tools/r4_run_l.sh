@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-4 GPU call K: the division-free fold with hoisted epilogue operands -- tests, small-batch latency vs round 1, train step vs the previous fold
+# round-4 GPU call L: the division-free fold with hoisted epilogue operands -- tests, small-batch latency vs round 1, train step vs the previous fold
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r4k
+O=$R/gpurun_out/r4l
 mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_encoder.py -m gpu -q -x -k "gemm or backward or flat_params or fold or tail or small" > $O/pytest_new.log 2>&1; echo "pytest(new) rc=$?"; tail -5 $O/pytest_new.log
