@@ -33,74 +33,110 @@ template <> __device__ __forceinline__ void st4<bf16_t>(void* base, int64_t idx,
 }
 
 // VPL = number of 4-element vectors per lane (C = 256 * VPL on the fast path); dtypes are template parameters for the
-// reason given above (a runtime switch around the row loads would serialise them)
+// reason given above (a runtime switch around the row loads would serialise them).
+// A wave takes LN_R = 2 rows per pass with EVERY load of the pass issued up front -- both rows and (forward) the affine vectors:
+// with one row per wave and gamma / beta fetched behind the reductions a row was two dependent memory latencies and 1.5 KB in
+// flight (round 3: 0.58 of the HBM peak).
+constexpr int ln_rows_per_wave(int vpl) { return vpl <= 4 ? 2 : 1; }       // (wider rows: the registers go to the row itself)
 template <int VPL, typename TX, typename TY>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, void* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             int64_t rows, int C, float eps) {
+    constexpr int LN_R = ln_rows_per_wave(VPL);
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    f32x4 v[VPL];
-    float s = 0.f;
+    const int64_t row0 = ((int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6)) * LN_R;
+    if (row0 >= rows) return;
+    f32x4 v[LN_R][VPL], g[VPL], b[VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) v[i] = ld4<TX>(x, row * C + (int64_t)(lane + 64 * i) * 4);
+    for (int r = 0; r < LN_R; ++r) {
+        const int64_t row = row0 + r < rows ? row0 + r : rows - 1;          // (a clamped re-read instead of a branch around loads)
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
+        for (int i = 0; i < VPL; ++i) v[r][i] = ld4<TX>(x, row * C + (int64_t)(lane + 64 * i) * 4);
+    }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
+        g[i] = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4);
+        b[i] = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * i) * 4);
+    }
+    float mean[LN_R], rstd[LN_R];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = v[i][e] - mean;
-            q += d * d;
+    for (int r = 0; r < LN_R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) s += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+        mean[r] = wave_sum(s) / (float)C;
+    }
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) {
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[r][i][e] - mean[r];
+                q += d * d;
+            }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    if (lane == 0) {
-        if (mean_out) mean_out[row] = mean;
-        if (rstd_out) rstd_out[row] = rstd;
+        rstd[r] = rsqrtf(wave_sum(q) / (float)C + eps);
     }
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
-        f32x4 o;
+    for (int r = 0; r < LN_R; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= rows) break;
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean[r];
+            if (rstd_out) rstd_out[row] = rstd[r];
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-        st4<TY>(y, row * C + c, o);
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mean[r]) * rstd[r] * g[i][e] + b[i][e];
+            st4<TY>(y, row * C + c, o);
+        }
     }
 }
 
 // ---- row statistics only (inference with the LayerNorm FOLDED into the next Linear, see me_row_stats in include/metaenc.h):
-// the same one-wave-per-row, row-in-registers two-pass statistics as ln_fwd_kernel, but nothing is normalised or written
-// back -- per row the pair (rstd, -rstd * mean) that the folded GEMM's epilogue applies.  Reads rows * C elements once.
+// the same rows-in-registers two-pass statistics as ln_fwd_kernel, but nothing is normalised or written back -- per row the
+// pair (rstd, -rstd * mean) that the folded GEMM's epilogue applies.  Reads rows * C elements once.
 template <int VPL, typename TX>
 __global__ __launch_bounds__(LN_THREADS) void ln_stats_kernel(const void* __restrict__ x, float* __restrict__ out, int64_t rows, int C, float eps) {
+    constexpr int LN_R = ln_rows_per_wave(VPL);
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    f32x4 v[VPL];
-    float s = 0.f;
+    const int64_t row0 = ((int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6)) * LN_R;
+    if (row0 >= rows) return;
+    f32x4 v[LN_R][VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) v[i] = ld4<TX>(x, row * C + (int64_t)(lane + 64 * i) * 4);
+    for (int r = 0; r < LN_R; ++r) {
+        const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = v[i][e] - mean;
-            q += d * d;
-        }
+        for (int i = 0; i < VPL; ++i) v[r][i] = ld4<TX>(x, row * C + (int64_t)(lane + 64 * i) * 4);
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    if (lane == 0) *reinterpret_cast<float2*>(out + row * 2) = float2{rstd, -rstd * mean};
+    float mean[LN_R];
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) s += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+        mean[r] = wave_sum(s) / (float)C;
+    }
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) {
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[r][i][e] - mean[r];
+                q += d * d;
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        if (lane == 0 && row0 + r < rows) *reinterpret_cast<float2*>(out + (row0 + r) * 2) = float2{rstd, -rstd * mean[r]};
+    }
 }
 __global__ __launch_bounds__(LN_THREADS) void ln_stats_generic_kernel(const void* __restrict__ x, int x_dt, float* __restrict__ out,
                                                                       int64_t rows, int C, float eps) {
@@ -182,7 +218,10 @@ constexpr int LNB_BLOCKS = 1024;
 constexpr int LNB_WAVES = LNB_BLOCKS * (LN_THREADS / 64);
 constexpr int LNB_FOLD = 16;              // second-stage row groups
 
-template <int VPL, typename TX, typename TDY>
+// RES (the residual gradient is added: every call of the encoder's backward) is a TEMPLATE parameter: as a run-time `if (dres)`
+// around its loads hipcc waited vmcnt(0) behind each of the VPL load groups -- three serial memory round trips per pair of rows
+// instead of one (ISA: L L L L b L L W1 W0 per group), 4.1 TB/s.
+template <int VPL, typename TX, typename TDY, bool RES>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restrict__ dy, int dy_dt,
                                                             const void* __restrict__ x, int x_dt,
                                                             const float* __restrict__ mean,
@@ -216,7 +255,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
             d0[i] = ld4<TDY>(dy, row0 * C + c);
             xh1[i] = ld4<TX>(x, r1 * C + c);
             d1[i] = ld4<TDY>(dy, r1 * C + c);
-            if (dres) {
+            if (RES) {
                 q0[i] = ld4<TX>(dres, row0 * C + c);
                 q1[i] = ld4<TX>(dres, r1 * C + c);
             } else {
@@ -389,7 +428,7 @@ extern "C" int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     ProfScope prof(ME_PROF_LN_FWD, x_dtype, rows, cols, 0, stream);
     const unsigned nblk = (unsigned)((rows + 3) / 4);
 #define LN_FWD_LAUNCH(V, TX, TY)                                                                               \
-    hipLaunchKernelGGL((ln_fwd_kernel<V, TX, TY>), dim3(nblk), dim3(LN_THREADS), 0, stream, x, gamma, beta, y, mean, rstd,  \
+    hipLaunchKernelGGL((ln_fwd_kernel<V, TX, TY>), dim3((unsigned)((rows + 4 * ln_rows_per_wave(V) - 1) / (4 * ln_rows_per_wave(V)))), dim3(LN_THREADS), 0, stream, x, gamma, beta, y, mean, rstd,  \
                        rows, cols, eps)
 #define LN_FWD_CASE(V)                                                                                         \
     case V:                                                                                                    \
@@ -424,8 +463,8 @@ extern "C" int me_row_stats(const void* x, int x_dtype, float* out, int64_t rows
     const unsigned nblk = (unsigned)((rows + 3) / 4);
 #define LN_ST_CASE(V)                                                                                                          \
     case V:                                                                                                                    \
-        if (x_dtype == ME_BF16) hipLaunchKernelGGL((ln_stats_kernel<V, bf16_t>), dim3(nblk), dim3(LN_THREADS), 0, stream, x, out, rows, cols, eps); \
-        else hipLaunchKernelGGL((ln_stats_kernel<V, float>), dim3(nblk), dim3(LN_THREADS), 0, stream, x, out, rows, cols, eps);   \
+        if (x_dtype == ME_BF16) hipLaunchKernelGGL((ln_stats_kernel<V, bf16_t>), dim3((unsigned)((rows + 4 * ln_rows_per_wave(V) - 1) / (4 * ln_rows_per_wave(V)))), dim3(LN_THREADS), 0, stream, x, out, rows, cols, eps); \
+        else hipLaunchKernelGGL((ln_stats_kernel<V, float>), dim3((unsigned)((rows + 4 * ln_rows_per_wave(V) - 1) / (4 * ln_rows_per_wave(V)))), dim3(LN_THREADS), 0, stream, x, out, rows, cols, eps);   \
         break;
     if (cols % 256 == 0 && cols / 256 <= 8) {
         switch (cols / 256) { LN_ST_CASE(1) LN_ST_CASE(2) LN_ST_CASE(3) LN_ST_CASE(4) LN_ST_CASE(5) LN_ST_CASE(6) LN_ST_CASE(7) LN_ST_CASE(8) }
@@ -484,8 +523,12 @@ extern "C" int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int
     float* partial = reinterpret_cast<float*>(workspace);
     const size_t lds_bytes = want_affine ? (size_t)4 * 2 * cols * sizeof(float) : 0;
 #define LN_BWD_LAUNCH(V, TX, TDY)                                                                                 \
-    hipLaunchKernelGGL((ln_bwd_kernel<V, TX, TDY>), dim3(LNB_BLOCKS), dim3(LN_THREADS), lds_bytes, stream, dy, dy_dtype, \
-                       x, x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, partial, want_affine, rows, cols)
+    do {                                                                                                          \
+        if (dres) hipLaunchKernelGGL((ln_bwd_kernel<V, TX, TDY, true>), dim3(LNB_BLOCKS), dim3(LN_THREADS), lds_bytes, stream, dy, dy_dtype, \
+                                     x, x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, partial, want_affine, rows, cols);       \
+        else hipLaunchKernelGGL((ln_bwd_kernel<V, TX, TDY, false>), dim3(LNB_BLOCKS), dim3(LN_THREADS), lds_bytes, stream, dy, dy_dtype,     \
+                                x, x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, partial, want_affine, rows, cols);            \
+    } while (0)
 #define LN_BWD_CASE(V)                                                                                            \
     case V:                                                                                                       \
         if (x_dtype == ME_BF16 && dy_dtype == ME_BF16) LN_BWD_LAUNCH(V, bf16_t, bf16_t);                          \
