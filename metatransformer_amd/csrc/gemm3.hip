@@ -238,7 +238,7 @@ __device__ __forceinline__ u32x4 g3r_lanes(const u32x4& v, int addr) {
 // mean is from zero; P reaches the eight lanes through one DPP move and two lane-row swaps), and the sixteen (half slab) pairs of
 // a wave are summed over the eight lanes as a REDUCE-SCATTER -- DPP row_ror:8, v_permlane16_swap, v_permlane32_swap, each step
 // halving the number of live values -- so that every lane ends up with two finished rows: (mean, M2) over n = 64 columns,
-// one 8-byte store each into [N / 64][M].  Whole tiles only.  The statistics are those of the values AS STORED (rounded to
+// one 8-byte store each into [N / 64][M] (a 128-row item: four slabs, one row per lane).  The statistics are those of the values AS STORED (rounded to
 // bf16 and converted back: eight more operations per half slab) -- for a row whose mean dwarfs its spread the rounding IS the
 // spread, and the reference's LayerNorm sees the rounded stream too.
 // HALF: a 128 x 256 item (g3_make_src_half): accumulator slabs 0..3 only, this wave row's rows are m0 + 64 wr + ..; the
@@ -249,7 +249,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                                               const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero, unsigned* ctr, int nx,
                                               uint32_t lds_tick) {
     constexpr bool SAVE = PRE == 1 || PRE == 2, LNF = PRE == 3, STATS = PRE == 4;
-    static_assert(!STATS || (EPI == 2 && !HALF), "row statistics: the residual epilogue, whole tiles");
+    static_assert(!STATS || EPI == 2, "row statistics: the residual epilogue");
     constexpr int NMT = HALF ? 4 : 8, WROWS = HALF ? 64 : 128;      // 16-row slabs per wave, rows per wave row
     // (claimed schedule: wave 0 draws the ticket for the item after next FIRST, ahead of every store of this epilogue)
     unsigned drawn = 0;
@@ -459,7 +459,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     if (HALF) {
         // as many memory operations as a whole tile's epilogue issues behind the A-Y half-tile (stores: half of them went out
         // above; late row-operand loads: a whole tile issues 2 (8 - AHEAD) of them, this one none)
-        constexpr int PAD = (SAVE ? 16 : 8) + ((EPI == 2 || EPI == 6) ? 4 : EPI == 3 ? 8 : 0);
+        constexpr int PAD = (SAVE ? 16 : 8) + ((EPI == 2 || EPI == 6) ? 4 : EPI == 3 ? 8 : 0) + (STATS ? 1 : 0);      // (a whole tile stores two statistics pairs per lane, a 128-row item one)
         const u32x4 z = {0u, 0u, 0u, 0u};
         const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000);
 #pragma unroll
@@ -884,7 +884,7 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
 #ifndef G3_HI_EPI1
 #define G3_HI_EPI1 1                           // (A/B arm: ... and in the GELU kernels -- fc1's 2 364 tiles leave a last round of 60)
 #endif
-    constexpr bool HI = EPI == 0 || (G3_HI_EPI2 && EPI == 2 && PRE == 0) || (G3_HI_EPI1 && EPI == 1);      // which forms carry the 128-row items (see the kernel)
+    constexpr bool HI = EPI == 0 || (G3_HI_EPI2 && EPI == 2) || (G3_HI_EPI1 && EPI == 1);      // which forms carry the 128-row items (see the kernel)
     static OncePerDevice once;
     if (once.need())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE, HI>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS + 64);

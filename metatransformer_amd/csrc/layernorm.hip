@@ -214,8 +214,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_generic_kernel(const void* 
 // live in registers and are written once per wave to the workspace [n_waves, 2, C]; a second kernel folds
 // them (deterministic, no atomics).
 
+// The grid IS the residency: every block walks rows / gridDim.x of the problem, so the launch takes exactly as many blocks as the
+// chip holds at once (occupancy query per instantiation: the bf16 C = 768 form needs 136 - 168 registers = three blocks per CU;
+// round 3's fixed 1024 blocks ran as 1 + 1/3 rounds there, the last 256 alone on a third of the chip's waves).  LNB_BLOCKS is the
+// upper bound the partial-sum workspace is sized for.
 constexpr int LNB_BLOCKS = 1024;
-constexpr int LNB_WAVES = LNB_BLOCKS * (LN_THREADS / 64);
 constexpr int LNB_FOLD = 16;              // second-stage row groups
 
 // RES (the residual gradient is added: every call of the encoder's backward) is a TEMPLATE parameter: as a run-time `if (dres)`
@@ -242,8 +245,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
         db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // two rows in flight per wave; every load of both rows (x, dy and the residual gradient) is issued up front
-    for (int64_t row0 = gw; row0 < rows; row0 += 2 * LNB_WAVES) {
-        const int64_t row1 = row0 + LNB_WAVES;
+    const int64_t nwaves = (int64_t)gridDim.x * (LN_THREADS / 64);
+    for (int64_t row0 = gw; row0 < rows; row0 += 2 * nwaves) {
+        const int64_t row1 = row0 + nwaves;
         const bool has1 = row1 < rows;
         const int64_t r1 = has1 ? row1 : row0;
         const float mu0 = mean[row0], rs0 = rstd[row0], mu1 = mean[r1], rs1 = rstd[r1];
@@ -492,6 +496,21 @@ extern "C" int me_row_stats_combine(const float* partials, int64_t rows, int col
     return ME_OK;
 }
 
+// blocks of one ln_bwd_kernel instantiation the device holds at once (cached per instantiation and LDS size class)
+template <auto KERNEL>
+static int ln_bwd_resident_blocks(size_t lds_bytes) {
+    static int cached[2] = {0, 0};
+    int& c = cached[lds_bytes ? 1 : 0];
+    if (!c) {
+        int per_cu = 0, dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, LN_THREADS, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        c = per_cu * cus < LNB_BLOCKS ? per_cu * cus : LNB_BLOCKS;
+    }
+    return c;
+}
+
 extern "C" size_t me_layernorm_bwd_workspace(int cols) {
     return (size_t)(LNB_BLOCKS + LNB_FOLD) * 2 * (size_t)cols * sizeof(float);
 }
@@ -522,12 +541,18 @@ extern "C" int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int
     }
     float* partial = reinterpret_cast<float*>(workspace);
     const size_t lds_bytes = want_affine ? (size_t)4 * 2 * cols * sizeof(float) : 0;
+    int nblocks = LNB_BLOCKS;
 #define LN_BWD_LAUNCH(V, TX, TDY)                                                                                 \
     do {                                                                                                          \
-        if (dres) hipLaunchKernelGGL((ln_bwd_kernel<V, TX, TDY, true>), dim3(LNB_BLOCKS), dim3(LN_THREADS), lds_bytes, stream, dy, dy_dtype, \
-                                     x, x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, partial, want_affine, rows, cols);       \
-        else hipLaunchKernelGGL((ln_bwd_kernel<V, TX, TDY, false>), dim3(LNB_BLOCKS), dim3(LN_THREADS), lds_bytes, stream, dy, dy_dtype,     \
-                                x, x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, partial, want_affine, rows, cols);            \
+        if (dres) {                                                                                               \
+            nblocks = ln_bwd_resident_blocks<&ln_bwd_kernel<V, TX, TDY, true>>(lds_bytes);                          \
+            hipLaunchKernelGGL((ln_bwd_kernel<V, TX, TDY, true>), dim3(nblocks), dim3(LN_THREADS), lds_bytes, stream, dy, dy_dtype, \
+                               x, x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, partial, want_affine, rows, cols);    \
+        } else {                                                                                                  \
+            nblocks = ln_bwd_resident_blocks<&ln_bwd_kernel<V, TX, TDY, false>>(lds_bytes);                         \
+            hipLaunchKernelGGL((ln_bwd_kernel<V, TX, TDY, false>), dim3(nblocks), dim3(LN_THREADS), lds_bytes, stream, dy, dy_dtype, \
+                               x, x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, partial, want_affine, rows, cols);    \
+        }                                                                                                         \
     } while (0)
 #define LN_BWD_CASE(V)                                                                                            \
     case V:                                                                                                       \
@@ -544,7 +569,7 @@ extern "C" int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int
     ME_CHECK_LAUNCH("me_layernorm_bwd");
     if (want_affine) {
         float* partial2 = partial + (size_t)LNB_BLOCKS * 2 * cols;
-        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((cols + 63) / 64, LNB_FOLD), dim3(256), 0, stream, partial, LNB_BLOCKS,
+        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((cols + 63) / 64, LNB_FOLD), dim3(256), 0, stream, partial, nblocks,
                            partial2, nullptr, nullptr, cols, 0);
         ME_CHECK_LAUNCH("me_layernorm_bwd(fold 1)");
         hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((cols + 63) / 64, 1), dim3(256), 0, stream, partial2, LNB_FOLD,
