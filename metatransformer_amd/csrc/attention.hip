@@ -1938,6 +1938,376 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Long sequences (N >= ST_BWD_MINN), backward: the two phases of the ring backward as two STREAMING kernels in the form of
+// attn_fwd_stream16_kernel (16-row waves, three-slot LDS ring of 128-row chunks kept two chunks ahead by loader waves, one barrier
+// per chunk, XCD-major items so that a head's streamed side comes out of HBM once):
+//   attn_bwd_dq_stream16_kernel:    a workgroup owns <= 224 queries of a (batch, head) -- own Q / dO / O rows in registers, delta on the
+//                                   way in (written out for the second kernel) -- and streams {K, V};       phase A of the ring form
+//   attn_bwd_dkdv_stream16_kernel:  a workgroup owns <= 224 keys -- own K / V rows in registers -- and streams {Q, dO} together with the
+//                                   chunk's lse / delta (dword LDS-DMA into a small float ring);               phase B of the ring form
+// No masks: rows past N arrive as zeros from the bounds-checked DMA (K = V = 0 -> dS meets a zero K row; Q = dO = 0, lse = delta =
+// 0 -> P = 1 meets a zero dO row and dS = 0), every P goes through r16_p() and stays finite, and rows a wave owns past N are
+// never stored.  Replaces the 8-wave / 32-row chunk kernels where a sequence is at least five chunks long (same box: N = 1568
+// 1 406 vs 1 521 us, 592: 404 vs 465 us; at 512 the mid kernel still wins, 647 vs 718 us).
+#ifndef ME_ST_BWD_MINN
+#define ME_ST_BWD_MINN 560
+#endif
+constexpr int ST_BWD_MINN = ME_ST_BWD_MINN;
+
+// loader waves of the streaming backward kernels: array 0 / 1 of a chunk from (a0, ld0) / (a1, ld1); FL: 128 floats of f0 / f1 per chunk
+template <int HD, bool FL>
+__device__ __forceinline__ void st16_bwd_loader(char* smem, char* fring, int wave, int lane, int QB, int total, int NCH, int vid, int G,
+                                                int nblk, int H, int N, int hd, const bf16_t* a0, int64_t ld0, int64_t hoff0,
+                                                const bf16_t* a1, int64_t ld1, int64_t hoff1, const float* f0, const float* f1) {
+    typedef RCfg<HD> R;
+    constexpr int arr_bytes = ST_KC * R::RB;
+    constexpr int slot_bytes = 2 * arr_bytes;
+    constexpr int NPC = ST_KC / R::RPI;
+    const int NL = QB <= 12 * 16 ? 4 : 2;
+    if (wave < 16 - NL) {                             // spare waves: the barrier count only
+        for (int k = 0; k < total; ++k) __builtin_amdgcn_s_barrier();
+        return;
+    }
+    const int lw = wave - (16 - NL);
+    const int which = lw & 1;
+    const int part = lw >> 1, nparts = NL >> 1;
+    const bf16_t* const arr = which ? a1 : a0;
+    const int64_t ldw = which ? ld1 : ld0, hoff = which ? hoff1 : hoff0;
+    const float* const farr = which ? f1 : f0;
+    const int rg = (lane * 16) / R::RB, pos = ((lane * 16) % R::RB) / 16;
+    const int csrc = pos ^ r16_swz<R::CPR>(rg);
+    const int dma_voff = (csrc * 8 < hd) ? rg * (int)ldw * 2 + csrc * 16 : 0x7f000000;
+    const int dma_gstep = R::RPI * (int)ldw * 2;
+    const int rec_bytes = (int)(((int64_t)(N - 1) * ldw + hd) * 2);
+    auto fill = [&](int j) {
+        if (j >= total) return;
+        const int it = vid + (j / NCH) * G, c = j % NCH;
+        const int bh = it / nblk;
+        const bf16_t* base = arr + (int64_t)(bh / H) * N * ldw + (bh % H) * hd + hoff;
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, rec_bytes, 0x00020000);
+        char* dst = smem + (j % ST_RING) * slot_bytes + which * arr_bytes;
+        const int voff = dma_voff + c * NPC * dma_gstep;
+        if (nparts == 1) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(dst + i * 1024), 16, voff + i * dma_gstep, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPC / 2; ++i) {
+                const int p = 2 * i + part;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(dst + p * 1024), 16, voff + p * dma_gstep, 0, 0, 0);
+            }
+        }
+        if (FL) {
+            // 128 floats of this loader's statistics array: two dword pieces of 64 (one each when two loaders share the array)
+            const __amdgpu_buffer_rsrc_t rf =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(farr + (int64_t)bh * N), 0, N * 4, 0x00020000);
+            char* fdst = fring + ((j % ST_RING) * 2 + which) * (ST_KC * 4);
+            const int fvoff = (c * ST_KC + lane) * 4;
+            if (nparts == 1) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_dma_t*)fdst, 4, fvoff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_dma_t*)(fdst + 256), 4, fvoff + 256, 0, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_dma_t*)(fdst + 256 * part), 4, fvoff + 256 * part, 0, 0, 0);
+            }
+        }
+    };
+    fill(0);
+    fill(1);
+    for (int k = 0; k < total; ++k) {
+        // chunk k has landed once at most chunk k + 1's pieces (of this loader) are outstanding (in-order retirement)
+        if (k + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nparts == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC + (FL ? 2 : 0)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC / 2 + (FL ? 1 : 0)) : "memory");
+        __builtin_amdgcn_s_barrier();                 // chunk k ready; everybody is done with chunk k - 1
+        fill(k + 2);                                  // ... whose slot takes chunk k + 2
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int HD>
+__global__ __launch_bounds__(R16_THREADS) void attn_bwd_dq_stream16_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                           const bf16_t* __restrict__ out, int64_t ldo,
+                                                                           const bf16_t* __restrict__ dout, int64_t lddo,
+                                                                           const float* __restrict__ lse, float* __restrict__ delta,
+                                                                           bf16_t* __restrict__ dqkv, int64_t lddq, int N, int H, int hd,
+                                                                           float scale, int QB, int nqb, int items) {
+    typedef Cfg<bf16_t, HD> C;
+    typedef RCfg<HD> R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int arr_bytes = ST_KC * R::RB;
+    constexpr int slot_bytes = 2 * arr_bytes;
+    constexpr int NKS = HD / 32, NDT = HD / 16;
+    constexpr int SCR = 16 * C::RROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int Cdim = H * hd;
+    const int G = (int)gridDim.x;
+    const int NCH = (N + ST_KC - 1) / ST_KC;
+    const int vid = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int my_items = vid < items ? (items - vid + G - 1) / G : 0;
+    if (16 * wave >= QB) {
+        st16_bwd_loader<HD, false>(smem, nullptr, wave, lane, QB, my_items * NCH, NCH, vid, G, nqb, H, N, hd, qkv, ld, Cdim, qkv, ld,
+                                   2 * Cdim, nullptr, nullptr);
+        return;
+    }
+    char* scr = smem + ST_RING * slot_bytes + wave * SCR;
+    const float sl = scale * LOG2E;
+    int koff[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) koff[ks] = l15 * R::RB + 16 * ((4 * ks + g) ^ r16_swz<R::CPR>(l15));
+    int troff[NDT];
+    {
+        const int rr = 4 * g + (l15 >> 2);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+            troff[dt] = rr * R::RB + 16 * ((2 * dt + ((l15 & 3) >> 1)) ^ r16_swz<R::CPR>(rr)) + 8 * (l15 & 1);
+    }
+    auto rowread = [&](const char* arr, int t, bf16x8 (&dst)[NKS]) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) dst[ks] = *reinterpret_cast<const bf16x8*>(arr + 16 * t * R::RB + koff[ks]);
+    };
+    auto trread = [&](const char* arr, int kk, int dt) {
+        union { bf16x4 q4[2]; bf16x8 v; } a;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            a.q4[r] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)((uint32_t)(uintptr_t)arr + (32 * kk + 16 * r) * R::RB + troff[dt]));
+        return a.v;
+    };
+    const f32x4 zero4f = {0.f, 0.f, 0.f, 0.f};
+    // the wave's own rows (Q, dO, O, lse): the next item's are fetched under this item's last chunk
+    u32x4 qn[NKS], don[NKS], on[NKS];
+    float lse_n = 0.f;
+    auto own_issue = [&](int it) {
+        const int bh = it / nqb, qb = it % nqb;
+        const int q = qb * QB + 16 * wave + l15;
+        const int qc = q < N ? q : N - 1;
+        const int b = bh / H, head = bh % H;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = 32 * ks + 8 * g, dc = d < hd ? d : 0;
+            qn[ks] = *reinterpret_cast<const u32x4*>(qkv + ((int64_t)b * N + qc) * ld + head * hd + dc);
+            don[ks] = *reinterpret_cast<const u32x4*>(dout + ((int64_t)b * N + qc) * lddo + head * hd + dc);
+            on[ks] = *reinterpret_cast<const u32x4*>(out + ((int64_t)b * N + qc) * ldo + head * hd + dc);
+        }
+        lse_n = lse[(int64_t)bh * N + qc];
+    };
+    if (my_items > 0) own_issue(vid);
+    int j = 0;
+    for (int ii = 0; ii < my_items; ++ii) {
+        const int it = vid + ii * G;
+        const int bh = it / nqb, qb = it % nqb;
+        const int b = bh / H, head = bh % H;
+        const int q0 = qb * QB + 16 * wave;
+        const int q = q0 + l15;
+        const bool row_ok = q < N;
+        bf16x8 qf[NKS], dof[NKS];
+        float del = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bool ok = 32 * ks + 8 * g < hd;
+            const u32x4 qv = ok ? qn[ks] : zero4(), dv4 = ok ? don[ks] : zero4(), ov = ok ? on[ks] : zero4();
+            qf[ks] = *reinterpret_cast<const bf16x8*>(&qv);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(&dv4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                del += __uint_as_float(ov[e] << 16) * __uint_as_float(dv4[e] << 16) +
+                       __uint_as_float(ov[e] & 0xffff0000u) * __uint_as_float(dv4[e] & 0xffff0000u);
+        }
+        del += __shfl_xor(del, 16, 64);
+        del += __shfl_xor(del, 32, 64);
+        const float lse2 = row_ok ? lse_n * LOG2E : INFINITY;      // +inf on padded queries -> P = 0
+        if (g == 0 && row_ok) delta[(int64_t)bh * N + q] = del;
+        f32x4 dq[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) dq[dt] = zero4f;
+        auto chunk = [&](int c) {
+            const char* Kb = smem + (j % ST_RING) * slot_bytes;
+            const char* Vb = Kb + arr_bytes;
+#pragma unroll
+            for (int kk = 0; kk < ST_KC / 32; ++kk) {
+                bf16x8 ka[2][NKS], va[2][NKS];
+                rowread(Kb, 2 * kk, ka[0]); rowread(Kb, 2 * kk + 1, ka[1]);
+                rowread(Vb, 2 * kk, va[0]); rowread(Vb, 2 * kk + 1, va[1]);
+                f32x4 s[2], dp[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) { s[tt] = mma16(ka[tt][0], qf[0], zero4f); dp[tt] = mma16(va[tt][0], dof[0], zero4f); }
+#pragma unroll
+                for (int ks = 1; ks < NKS; ++ks)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) { s[tt] = mma16(ka[tt][ks], qf[ks], s[tt]); dp[tt] = mma16(va[tt][ks], dof[ks], dp[tt]); }
+                bf16x8 kt[NDT];
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) kt[dt] = trread(Kb, kk, dt);
+                bf16x8 dsb;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = r16_p(s[tt][e] * sl - lse2);
+                        dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - del));      // dS^T / scale (scale applied to dQ once)
+                    }
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) dq[dt] = mma16(kt[dt], dsb, dq[dt]);
+            }
+        };
+        for (int c = 0; c + 1 < NCH; ++c, ++j) {
+            __syncthreads();                          // chunk j has landed (the loaders waited for it)
+            chunk(c);
+        }
+        __syncthreads();
+        own_issue(ii + 1 < my_items ? it + G : it);   // (the last chunk is peeled: the next item's rows are live only under it)
+        chunk(NCH - 1);
+        ++j;
+        r16_store_rows<HD>(scr, dq, scale, dqkv + ((int64_t)b * N + q0) * lddq + head * hd, lddq, N - q0, hd, lane);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(R16_THREADS) void attn_bwd_dkdv_stream16_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                             const bf16_t* __restrict__ dout, int64_t lddo,
+                                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                             bf16_t* __restrict__ dqkv, int64_t lddq, int N, int H, int hd,
+                                                                             float scale, int KB, int nkb, int items) {
+    typedef Cfg<bf16_t, HD> C;
+    typedef RCfg<HD> R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int arr_bytes = ST_KC * R::RB;
+    constexpr int slot_bytes = 2 * arr_bytes;
+    constexpr int NKS = HD / 32, NDT = HD / 16;
+    constexpr int SCR = 16 * C::RROW;
+    constexpr int FRING = ST_RING * 2 * ST_KC * 4;    // {lse, delta} of a chunk, per ring slot
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int Cdim = H * hd;
+    const int G = (int)gridDim.x;
+    const int NCH = (N + ST_KC - 1) / ST_KC;
+    const int vid = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int my_items = vid < items ? (items - vid + G - 1) / G : 0;
+    char* const fring = smem + ST_RING * slot_bytes;
+    if (16 * wave >= KB) {
+        st16_bwd_loader<HD, true>(smem, fring, wave, lane, KB, my_items * NCH, NCH, vid, G, nkb, H, N, hd, qkv, ld, 0, dout, lddo, 0, lse,
+                                  delta);
+        return;
+    }
+    char* scr = fring + FRING + wave * SCR;
+    const float sl = scale * LOG2E;
+    int koff[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) koff[ks] = l15 * R::RB + 16 * ((4 * ks + g) ^ r16_swz<R::CPR>(l15));
+    int troff[NDT];
+    {
+        const int rr = 4 * g + (l15 >> 2);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+            troff[dt] = rr * R::RB + 16 * ((2 * dt + ((l15 & 3) >> 1)) ^ r16_swz<R::CPR>(rr)) + 8 * (l15 & 1);
+    }
+    auto rowread = [&](const char* arr, int t, bf16x8 (&dst)[NKS]) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) dst[ks] = *reinterpret_cast<const bf16x8*>(arr + 16 * t * R::RB + koff[ks]);
+    };
+    auto trread = [&](const char* arr, int kk, int dt) {
+        union { bf16x4 q4[2]; bf16x8 v; } a;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            a.q4[r] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)((uint32_t)(uintptr_t)arr + (32 * kk + 16 * r) * R::RB + troff[dt]));
+        return a.v;
+    };
+    const f32x4 zero4f = {0.f, 0.f, 0.f, 0.f};
+    // the wave's own K / V rows: the next item's are fetched under this item's last chunk
+    u32x4 kn[NKS], vn[NKS];
+    auto own_issue = [&](int it) {
+        const int bh = it / nkb, kb = it % nkb;
+        const int k = kb * KB + 16 * wave + l15;
+        const bf16_t* kptr = qkv + ((int64_t)(bh / H) * N + (k < N ? k : N - 1)) * ld + (bh % H) * hd + Cdim;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = 32 * ks + 8 * g, dc = d < hd ? d : 0;
+            kn[ks] = *reinterpret_cast<const u32x4*>(kptr + dc);
+            vn[ks] = *reinterpret_cast<const u32x4*>(kptr + Cdim + dc);
+        }
+    };
+    if (my_items > 0) own_issue(vid);
+    int j = 0;
+    for (int ii = 0; ii < my_items; ++ii) {
+        const int it = vid + ii * G;
+        const int bh = it / nkb, kb = it % nkb;
+        const int b = bh / H, head = bh % H;
+        const int k0 = kb * KB + 16 * wave;
+        bf16x8 kf[NKS], vf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bool ok = 32 * ks + 8 * g < hd;
+            const u32x4 kv = ok ? kn[ks] : zero4(), vv = ok ? vn[ks] : zero4();
+            kf[ks] = *reinterpret_cast<const bf16x8*>(&kv);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(&vv);
+        }
+        f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) { dk[dt] = zero4f; dv[dt] = zero4f; }
+        auto chunk = [&](int c) {
+            const char* Qb = smem + (j % ST_RING) * slot_bytes;
+            const char* Db = Qb + arr_bytes;
+            const float* lsb = reinterpret_cast<const float*>(fring + (j % ST_RING) * 2 * (ST_KC * 4));
+            const float* deb = lsb + ST_KC;
+#pragma unroll
+            for (int qq = 0; qq < ST_KC / 32; ++qq) {
+                f32x4 s[2], dp[2];
+                {
+                    bf16x8 qa[2][NKS];
+                    rowread(Qb, 2 * qq, qa[0]); rowread(Qb, 2 * qq + 1, qa[1]);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) s[tt] = mma16(qa[tt][0], kf[0], zero4f);
+#pragma unroll
+                    for (int ks = 1; ks < NKS; ++ks)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) s[tt] = mma16(qa[tt][ks], kf[ks], s[tt]);
+                }
+                {
+                    bf16x8 da[2][NKS];
+                    rowread(Db, 2 * qq, da[0]); rowread(Db, 2 * qq + 1, da[1]);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) dp[tt] = mma16(da[tt][0], vf[0], zero4f);
+#pragma unroll
+                    for (int ks = 1; ks < NKS; ++ks)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) dp[tt] = mma16(da[tt][ks], vf[ks], dp[tt]);
+                }
+                bf16x8 pb, dsb;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const f32x4 L = *reinterpret_cast<const f32x4*>(lsb + 16 * (2 * qq + tt) + 4 * g);
+                    const f32x4 D = *reinterpret_cast<const f32x4*>(deb + 16 * (2 * qq + tt) + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = r16_p(s[tt][e] * sl - L[e] * LOG2E);
+                        pb[4 * tt + e] = (bf16_t)pe;
+                        dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - D[e]));      // dS / scale (scale applied to dK once)
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) dv[dt] = mma16(trread(Db, qq, dt), pb, dv[dt]);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) dk[dt] = mma16(trread(Qb, qq, dt), dsb, dk[dt]);
+            }
+        };
+        for (int c = 0; c + 1 < NCH; ++c, ++j) {
+            __syncthreads();
+            chunk(c);
+        }
+        __syncthreads();
+        own_issue(ii + 1 < my_items ? it + G : it);
+        chunk(NCH - 1);
+        ++j;
+        bf16_t* grow0 = dqkv + ((int64_t)b * N + k0) * lddq + head * hd;
+        r16_store_rows<HD>(scr, dk, scale, grow0 + Cdim, lddq, N - k0, hd, lane);
+        r16_store_rows<HD>(scr, dv, 1.0f, grow0 + 2 * Cdim, lddq, N - k0, hd, lane);
+    }
+}
+
 // =====================================================================================================
 // mid-size sequences (256 < N <= 512: audio spectrogram tokens, 512 x 512 segmentation crops at /32, BASELINE config 3).
 // The tiled kernels re-stream Q/dO (or K/V) once per 128-row block of the other side -- four times at N = 512 -- and pay
@@ -2522,6 +2892,34 @@ int launch_fwd_stream16(const void* qkv, int64_t ld, void* out, int64_t ldo, flo
     ME_CHECK_LAUNCH("me_attention_fwd(stream16)");
     return ME_OK;
 }
+template <int HD>
+int launch_bwd_stream16(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                        float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
+    typedef RCfg<HD> R;
+    constexpr size_t smem1 = (size_t)ST_RING * 2 * ST_KC * R::RB + (R16_THREADS / 64) * 16 * Cfg<bf16_t, HD>::RROW;
+    constexpr size_t smem2 = smem1 + (size_t)ST_RING * 2 * ST_KC * sizeof(float);
+    static OncePerDevice once;
+    if (once.need()) {
+        set_smem(attn_bwd_dq_stream16_kernel<HD>, smem1);
+        set_smem(attn_bwd_dkdv_stream16_kernel<HD>, smem2);
+    }
+    // row blocks of (at most) 14 x 16 rows, evened out over the sequence (queries in the first kernel, keys in the second)
+    const int nrb = (N + 223) / 224;
+    const int RBk = ((N + nrb - 1) / nrb + 15) / 16 * 16;
+    const int64_t items = (int64_t)B * H * nrb;
+    const int64_t slots = device_cus();
+    const unsigned grid = (unsigned)(items < slots ? items : slots);
+    hipLaunchKernelGGL((attn_bwd_dq_stream16_kernel<HD>), dim3(grid), dim3(R16_THREADS), smem1, stream,
+                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<const bf16_t*>(out), ldo,
+                       reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd, scale,
+                       RBk, nrb, (int)items);
+    ME_CHECK_LAUNCH("me_attention_bwd(dq stream16)");
+    hipLaunchKernelGGL((attn_bwd_dkdv_stream16_kernel<HD>), dim3(grid), dim3(R16_THREADS), smem2, stream,
+                       reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta,
+                       reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd, scale, RBk, nrb, (int)items);
+    ME_CHECK_LAUNCH("me_attention_bwd(dkdv stream16)");
+    return ME_OK;
+}
 template <int HD, int NS>
 int launch_bwd_ring16_ns(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
                          float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
@@ -2740,6 +3138,11 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
                                                     head_dim, scale, stream);
         return launch_bwd_mid<64, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H,
                                                 head_dim, scale, stream);
+    }
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim > 32 && head_dim <= 64 && N >= ST_BWD_MINN && ld_out % 8 == 0 && ld_dqkv % 8 == 0 &&
+        (int64_t)N * ld_qkv * 2 < (int64_t)0x7e000000 && (int64_t)N * ld_dout * 2 < (int64_t)0x7e000000 &&
+        (int64_t)B * H * ((N + 223) / 224) < (int64_t)0x7fffffff) {
+        return launch_bwd_stream16<64>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale, stream);
     }
     if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > MD_MAXN && ld_out % 8 == 0) {
         if (head_dim <= 32)

@@ -311,7 +311,10 @@ def test_attention_bwd_rows_with_very_negative_lse(dev, N):
 # descriptor), every sub-tile count of the ring form, 13 / 14 compute waves, sequence lengths around the chunk size of the stream
 RING_SHAPES = [(40, 197, 12, 64), (30, 100, 12, 48), (2, 209, 3, 64), (3, 224, 2, 64), (2, 96, 2, 64), (2, 129, 2, 40),
                (2, 161, 3, 64), (40, 300, 12, 64), (3, 1000, 2, 48), (2, 225, 2, 64), (2, 384, 2, 64), (2, 385, 3, 64),
-               (9, 640, 4, 64), (300, 66, 2, 32)]
+               (9, 640, 4, 64), (300, 66, 2, 32),
+               # streaming backward (N >= 560, 32 < hd <= 64): several items per workgroup, the shortest sequence it takes, four
+               # loader waves (176-row blocks), a ragged last block and chunk, head_dim below the template width
+               (12, 592, 12, 64), (2, 560, 2, 64), (2, 673, 3, 64), (1, 3136, 2, 64), (3, 577, 2, 40)]
 
 
 @pytest.mark.parametrize("B,N,H,hd", RING_SHAPES)

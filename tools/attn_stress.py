@@ -9,7 +9,7 @@ from metatransformer_amd import ops
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 dev = torch.device("cuda:0")
 bad = 0
-for (B, N, H, hd) in ((256, 197, 12, 64), (64, 100, 12, 48), (32, 1568, 16, 64), (200, 209, 3, 64), (128, 300, 12, 64)):
+for (B, N, H, hd) in ((256, 197, 12, 64), (64, 100, 12, 48), (32, 1568, 16, 64), (64, 592, 12, 64), (200, 209, 3, 64), (128, 300, 12, 64)):
     C = H * hd
     qkv = torch.randn(B * N, 3 * C, device=dev).bfloat16()
     do = torch.randn(B * N, C, device=dev).bfloat16()
