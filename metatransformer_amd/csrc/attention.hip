@@ -1948,10 +1948,10 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
 //                                   chunk's lse / delta (dword LDS-DMA into a small float ring);               phase B of the ring form
 // No masks: rows past N arrive as zeros from the bounds-checked DMA (K = V = 0 -> dS meets a zero K row; Q = dO = 0, lse = delta =
 // 0 -> P = 1 meets a zero dO row and dS = 0), every P goes through r16_p() and stays finite, and rows a wave owns past N are
-// never stored.  Replaces the 8-wave / 32-row chunk kernels where a sequence is at least five chunks long (same box: N = 1568
-// 1 406 vs 1 521 us, 592: 404 vs 465 us; at 512 the mid kernel still wins, 647 vs 718 us).
+// never stored.  Replaces the 8-wave / 32-row chunk kernels (same box, profiles/r04_attn_bwd_stream16_vs_chunk.txt: N = 1568 1 442 vs
+// 1 520 us, 1000: 657 vs 711, 592: 409 vs 477, 520: 634 vs 797; 3136: 2 672 vs 2 640).
 #ifndef ME_ST_BWD_MINN
-#define ME_ST_BWD_MINN 560
+#define ME_ST_BWD_MINN 513
 #endif
 constexpr int ST_BWD_MINN = ME_ST_BWD_MINN;
 
@@ -3132,17 +3132,17 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
         return launch_bwd_small<64>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale,
                                     stream);
     }
+    if (p_drop == 0.f && dtype == ME_BF16 && head_dim > 32 && head_dim <= 64 && N >= ST_BWD_MINN && ld_out % 8 == 0 && ld_dqkv % 8 == 0 &&
+        (int64_t)N * ld_qkv * 2 < (int64_t)0x7e000000 && (int64_t)N * ld_dout * 2 < (int64_t)0x7e000000 &&
+        (int64_t)B * H * ((N + 223) / 224) < (int64_t)0x7fffffff) {
+        return launch_bwd_stream16<64>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale, stream);
+    }
     if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MAXN && N <= MD_MAXN && ld_out % 8 == 0) {
         if (head_dim <= 32)
             return launch_bwd_mid<32, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H,
                                                     head_dim, scale, stream);
         return launch_bwd_mid<64, 512, MD_MAXN>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H,
                                                 head_dim, scale, stream);
-    }
-    if (p_drop == 0.f && dtype == ME_BF16 && head_dim > 32 && head_dim <= 64 && N >= ST_BWD_MINN && ld_out % 8 == 0 && ld_dqkv % 8 == 0 &&
-        (int64_t)N * ld_qkv * 2 < (int64_t)0x7e000000 && (int64_t)N * ld_dout * 2 < (int64_t)0x7e000000 &&
-        (int64_t)B * H * ((N + 223) / 224) < (int64_t)0x7fffffff) {
-        return launch_bwd_stream16<64>(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale, stream);
     }
     if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > MD_MAXN && ld_out % 8 == 0) {
         if (head_dim <= 32)
