@@ -2848,17 +2848,6 @@ int launch_fwd_ring16(const void* qkv, int64_t ld, void* out, int64_t ldo, float
     }
 }
 template <int HD>
-int launch_fwd_ring(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
-                    hipStream_t stream) {
-    switch ((N + 31) / 32) {
-        case 3: return launch_fwd_ring_ns<HD, 3>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
-        case 4: return launch_fwd_ring_ns<HD, 4>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
-        case 5: return launch_fwd_ring_ns<HD, 5>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
-        case 6: return launch_fwd_ring_ns<HD, 6>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
-        default: return launch_fwd_ring_ns<HD, 7>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream);
-    }
-}
-template <int HD>
 int launch_bwd_small(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
                      float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
     typedef Cfg<bf16_t, HD> C;

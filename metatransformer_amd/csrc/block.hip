@@ -135,7 +135,7 @@ extern "C" size_t me_block_workspace_bytes(const me_block_desc* d, int backward)
     // dy_c, dh, dxn (shared by dxn2 / dxn1), dx1, dx1_c, do, dqkv, delta
     w += align256(s.M * s.C * s.esz) * 4 + align256(s.M * s.Hd * s.esz) + align256(s.M * s.C * s.rsz) +
          align256(s.M * s.C3 * s.esz) + align256((size_t)d->B * d->heads * d->N * 4);
-    return w;
+    return w + align256(me_layernorm_bwd_workspace(s.C));      // norm2's dgamma / dbeta partials, folded with norm1's at the end
 }
 
 extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void* saved, void* workspace, size_t workspace_bytes,
@@ -240,6 +240,8 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
     char* dout = take(s.M * s.C * s.esz);
     char* dqkv = take(s.M * s.C3 * s.esz);
     float* delta = reinterpret_cast<float*>(take((size_t)d->B * d->heads * d->N * 4));
+    void* ln2_ws = take(me_layernorm_bwd_workspace(s.C));
+    me_ln_fold_set folds[2];
     const float beta = gr->accumulate ? 1.0f : 0.0f;
     me_gemm_desc g;
 
@@ -274,8 +276,8 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
     if ((rc = wgrad(dyc, s.C, v.a, s.Hd, gr->fc2_w, gr->fc2_b))) return rc;
     if ((rc = nt(dh, s.Hd, d->fc1_wt, dxn, s.C, nullptr))) return rc;
     if ((rc = wgrad(dh, s.Hd, v.xn2, s.C, gr->fc1_w, gr->fc1_b))) return rc;
-    rc = me_layernorm_bwd(dxn, dt, v.x1, rdt, v.mean2, v.rstd2, d->ln2_g, dy, rdt, dx1, rdt, gr->ln2_g, gr->ln2_b,
-                          gr->accumulate, s.M, s.C, aws, stream);
+    rc = me_ln_bwd_deferred(dxn, dt, v.x1, rdt, v.mean2, v.rstd2, d->ln2_g, dy, rdt, dx1, rdt, gr->ln2_g, gr->ln2_b, gr->accumulate, s.M,
+                            s.C, ln2_ws, stream, &folds[0]);
     if (rc) return rc;
     // ---- attention branch: x1 = x + proj(attn(qkv(LN1(x))))
     const void* dx1c = dx1;
@@ -289,8 +291,10 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
     if (rc) return rc;
     if ((rc = nt(dqkv, s.C3, d->qkv_wt, dxn, s.C, nullptr))) return rc;
     if ((rc = wgrad(dqkv, s.C3, v.xn1, s.C, gr->qkv_w, gr->qkv_b))) return rc;
-    return me_layernorm_bwd(dxn, dt, x, rdt, v.mean1, v.rstd1, d->ln1_g, dx1, rdt, dx, rdt, gr->ln1_g, gr->ln1_b, gr->accumulate,
-                            s.M, s.C, aws, stream);
+    rc = me_ln_bwd_deferred(dxn, dt, x, rdt, v.mean1, v.rstd1, d->ln1_g, dx1, rdt, dx, rdt, gr->ln1_g, gr->ln1_b, gr->accumulate, s.M, s.C,
+                            aws, stream, &folds[1]);
+    if (rc) return rc;
+    return me_ln_bwd_fold_sets(folds, 2, s.C, stream);      // dgamma / dbeta of both LayerNorms: one launch
 }
 
 extern "C" int me_encoder_fwd(const me_block_desc* blocks, int n_blocks, const void* x, void* y, void* pingpong, void* workspace,

@@ -83,6 +83,15 @@ static inline size_t me_dtype_size(int dt) { return dt == ME_F32 ? 4 : 2; }
 static inline bool me_dtype_ok(int dt) { return dt == ME_F32 || dt == ME_BF16; }                    // compute dtypes
 static inline bool me_storage_dtype_ok(int dt) { return me_dtype_ok(dt) || dt == ME_F16; }          // me_cast only
 
+// ---- LayerNorm backward with the dgamma / dbeta fold deferred (layernorm.hip; me_block_bwd folds both LayerNorms of a block in one launch)
+constexpr int LN_FOLD_SETS = 4;
+struct me_ln_fold_set { const float* partial; int nrows; float* dgamma; float* dbeta; int accumulate; };
+struct me_ln_fold_batch { me_ln_fold_set set[LN_FOLD_SETS]; int cols; };
+int me_ln_bwd_deferred(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd, const float* gamma,
+                       const void* dres, int dres_dtype, void* dx, int dx_dtype, float* dgamma, float* dbeta, int accumulate_affine,
+                       int64_t rows, int cols, void* workspace, void* stream, me_ln_fold_set* defer);
+int me_ln_bwd_fold_sets(const me_ln_fold_set* sets, int n, int cols, void* stream);      // n <= LN_FOLD_SETS
+
 // ---- device helpers
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
 

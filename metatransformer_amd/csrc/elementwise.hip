@@ -74,6 +74,28 @@ __global__ __launch_bounds__(256) void transpose_cast_batched_kernel(const me_tc
     void* dst = b.item[k].dst;
     const int64_t rows = b.item[k].rows, cols = b.item[k].cols;
     const int64_t r0 = (t / tx_tiles) * 64, c0 = (t % tx_tiles) * 64;
+    const int ssz = b.src_dtype == ME_F32 ? 4 : 2, dsz = b.dst_dtype == ME_F32 ? 4 : 2;
+    if (b.src_dtype != ME_F16 && b.dst_dtype != ME_F16 && rows % 4 == 0 && cols % 4 == 0 && (uintptr_t)src % (4 * ssz) == 0 && (uintptr_t)dst % (4 * dsz) == 0) {      // (block-uniform)
+        // four elements per lane on both sides: 16 lanes read 64 columns of a row (128 / 256 contiguous bytes), 16 lanes write 64 rows
+        // of a destination row; the 65-word tile rows keep both LDS passes conflict-free (bank = row + column)
+        const int q = threadIdx.x & 15, p = threadIdx.x >> 4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int i = p + 16 * pass;
+            const int64_t r = r0 + i, c = c0 + 4 * q;
+            const f32x4 v = (r < rows && c < cols) ? load4_as_f32(src, b.src_dtype, r * cols + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[i][4 * q + e] = v[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int i = p + 16 * pass;
+            const int64_t c = c0 + i, r = r0 + 4 * q;
+            if (c < cols && r < rows) store4_from_f32(dst, b.dst_dtype, c * rows + r, f32x4{tile[4 * q][i], tile[4 * q + 1][i], tile[4 * q + 2][i], tile[4 * q + 3][i]});
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int64_t r = r0 + i, c = c0 + tx;

@@ -219,7 +219,6 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_generic_kernel(const void* 
 // round 3's fixed 1024 blocks ran as 1 + 1/3 rounds there, the last 256 alone on a third of the chip's waves).  LNB_BLOCKS is the
 // upper bound the partial-sum workspace is sized for.
 constexpr int LNB_BLOCKS = 1024;
-constexpr int LNB_FOLD = 16;              // second-stage row groups
 
 // RES (the residual gradient is added: every call of the encoder's backward) is a TEMPLATE parameter: as a run-time `if (dres)`
 // around its loads hipcc waited vmcnt(0) behind each of the VPL load groups -- three serial memory round trips per pair of rows
@@ -319,39 +318,37 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
     }
 }
 
-// fold [nrows][2][C] partials: stage 1 (grid.y = LNB_FOLD row groups) -> [LNB_FOLD][2][C]; stage 2 (grid.y = 1) -> outputs
-__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restrict__ partial, int nrows,
-                                                          float* __restrict__ out_partial, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, int C, int accumulate) {
-    __shared__ float sh[2][4][64];
+// fold the [nrows][2][C] dgamma / dbeta partials of up to LN_FOLD_SETS LayerNorm backward launches in ONE launch (me_block_bwd folds
+// both LayerNorms of a block together at its end: round 3 ran two fold stages per LayerNorm = 4 tiny launches per block): grid (C / 64, sets), 16 waves per block, wave w takes rows w, w + 16, ... of its set's [nrows][2][C]
+// partials (64 columns x 2 per row: two coalesced 256-byte reads), fixed-order tree over the 16 waves in LDS.  Deterministic.
+__global__ __launch_bounds__(1024) void ln_bwd_fold_sets_kernel(const me_ln_fold_batch fb) {
+    __shared__ float sh[2][16][64];
+    const me_ln_fold_set st = fb.set[blockIdx.y];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    const int per = (nrows + gridDim.y - 1) / gridDim.y;
-    const int rb = blockIdx.y * per;
-    const int re = rb + per < nrows ? rb + per : nrows;
-    float a = 0.f, b = 0.f;
+    const int C = fb.cols, c = blockIdx.x * 64 + lane;
+    float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
     if (c < C) {
-        for (int r = rb + w; r < re; r += 4) {
-            a += partial[((int64_t)r * 2 + 0) * C + c];
-            b += partial[((int64_t)r * 2 + 1) * C + c];
+        int r = w;
+        for (; r + 16 < st.nrows; r += 32) {
+            a0 += st.partial[((int64_t)r * 2 + 0) * C + c];
+            b0 += st.partial[((int64_t)r * 2 + 1) * C + c];
+            a1 += st.partial[((int64_t)(r + 16) * 2 + 0) * C + c];
+            b1 += st.partial[((int64_t)(r + 16) * 2 + 1) * C + c];
+        }
+        if (r < st.nrows) {
+            a0 += st.partial[((int64_t)r * 2 + 0) * C + c];
+            b0 += st.partial[((int64_t)r * 2 + 1) * C + c];
         }
     }
-    sh[0][w][lane] = a;
-    sh[1][w][lane] = b;
+    sh[0][w][lane] = a0 + a1;
+    sh[1][w][lane] = b0 + b1;
     __syncthreads();
-    if (w == 0 && c < C) {
-        a = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
-        b = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
-        if (out_partial) {
-            out_partial[((int64_t)blockIdx.y * 2 + 0) * C + c] = a;
-            out_partial[((int64_t)blockIdx.y * 2 + 1) * C + c] = b;
-        } else if (accumulate) {
-            dgamma[c] += a;
-            dbeta[c] += b;
-        } else {
-            dgamma[c] = a;
-            dbeta[c] = b;
-        }
+    if (w < 2 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) t += (sh[w][i][lane] + sh[w][i + 1][lane]) + (sh[w][i + 2][lane] + sh[w][i + 3][lane]);
+        float* out = w ? st.dbeta : st.dgamma;
+        out[c] = st.accumulate ? out[c] + t : t;
     }
 }
 
@@ -512,14 +509,36 @@ static int ln_bwd_resident_blocks(size_t lds_bytes) {
 }
 
 extern "C" size_t me_layernorm_bwd_workspace(int cols) {
-    return (size_t)(LNB_BLOCKS + LNB_FOLD) * 2 * (size_t)cols * sizeof(float);
+    return (size_t)LNB_BLOCKS * 2 * (size_t)cols * sizeof(float);
+}
+
+int me_ln_bwd_fold_sets(const me_ln_fold_set* sets, int n, int cols, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    me_ln_fold_batch fb;
+    fb.cols = cols;
+    int k = 0;
+    for (int i = 0; i < n; ++i)
+        if (sets[i].partial) fb.set[k++] = sets[i];          // (a set without partials was folded by its own launch: generic path)
+    if (k == 0) return ME_OK;
+    hipLaunchKernelGGL(ln_bwd_fold_sets_kernel, dim3((cols + 63) / 64, k), dim3(1024), 0, stream, fb);
+    ME_CHECK_LAUNCH("me_layernorm_bwd(fold)");
+    return ME_OK;
 }
 
 extern "C" int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
                                 const float* rstd, const float* gamma, const void* dres, int dres_dtype, void* dx,
                                 int dx_dtype, float* dgamma, float* dbeta, int accumulate_affine, int64_t rows,
                                 int cols, void* workspace, void* stream_) {
+    return me_ln_bwd_deferred(dy, dy_dtype, x, x_dtype, mean, rstd, gamma, dres, dres_dtype, dx, dx_dtype, dgamma, dbeta, accumulate_affine,
+                              rows, cols, workspace, stream_, nullptr);
+}
+
+// defer != null: the dgamma / dbeta partials stay in `workspace` and *defer describes them for a later me_ln_bwd_fold_sets()
+int me_ln_bwd_deferred(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd, const float* gamma,
+                       const void* dres, int dres_dtype, void* dx, int dx_dtype, float* dgamma, float* dbeta, int accumulate_affine,
+                       int64_t rows, int cols, void* workspace, void* stream_, me_ln_fold_set* defer) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (defer) defer->partial = nullptr;
     ProfScope prof(ME_PROF_LN_BWD, x_dtype, rows, cols, 0, stream);
     ME_CHECK_ARG(dy && x && mean && rstd && gamma && dx, "me_layernorm_bwd: null pointer");
     ME_CHECK_ARG(me_dtype_ok(dy_dtype) && me_dtype_ok(x_dtype) && me_dtype_ok(dx_dtype), "me_layernorm_bwd: bad dtype");
@@ -568,13 +587,10 @@ extern "C" int me_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int
 #undef LN_BWD_CASE
     ME_CHECK_LAUNCH("me_layernorm_bwd");
     if (want_affine) {
-        float* partial2 = partial + (size_t)LNB_BLOCKS * 2 * cols;
-        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((cols + 63) / 64, LNB_FOLD), dim3(256), 0, stream, partial, nblocks,
-                           partial2, nullptr, nullptr, cols, 0);
-        ME_CHECK_LAUNCH("me_layernorm_bwd(fold 1)");
-        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((cols + 63) / 64, 1), dim3(256), 0, stream, partial2, LNB_FOLD,
-                           nullptr, dgamma, dbeta, cols, accumulate_affine);
-        ME_CHECK_LAUNCH("me_layernorm_bwd(fold 2)");
+        me_ln_fold_set st;
+        st.partial = partial; st.nrows = nblocks; st.dgamma = dgamma; st.dbeta = dbeta; st.accumulate = accumulate_affine;
+        if (defer) *defer = st;
+        else return me_ln_bwd_fold_sets(&st, 1, cols, stream_);
     }
     return ME_OK;
 }

@@ -177,6 +177,14 @@ def test_colsum_cast_transpose(dev, dt):
     wt = ops.transpose_cast(w.to(dev), dt)
     assert torch.equal(wt.cpu(), w.t().contiguous().to(dt))
     assert torch.equal(ops.cast(w.to(dev), dt).cpu(), w.to(dt))
+    # batched form: four-element lanes where rows / cols / alignment allow it, the element-wise form otherwise (ragged shapes, a
+    # source that starts 4 bytes into an allocation), fp32 and bf16 sources
+    for src_dt in DTYPES:
+        flat = rnd(3 + 768 * 3072, 1, seed=5).to(src_dt).to(dev).view(-1)
+        ws = [rnd(768, 3072, seed=6).to(src_dt).to(dev), rnd(300, 520, seed=7).to(src_dt).to(dev), rnd(130, 67, seed=8).to(src_dt).to(dev),
+              rnd(64, 4, seed=9).to(src_dt).to(dev), flat[1:1 + 768 * 3072].view(768, 3072), rnd(1000, 768, seed=10).to(src_dt).to(dev)]
+        for w2, got in zip(ws, ops.transpose_cast_many(ws, dt)):
+            assert torch.equal(got.cpu(), w2.cpu().t().contiguous().to(dt)), tuple(w2.shape)
     pos = rnd(7, 64, seed=3)
     xx = rnd(21, 64, seed=4)
     y = ops.add_rows(xx.to(dev), pos.to(dev))
