@@ -319,36 +319,38 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
 }
 
 // fold the [nrows][2][C] dgamma / dbeta partials of up to LN_FOLD_SETS LayerNorm backward launches in ONE launch (me_block_bwd folds
-// both LayerNorms of a block together at its end: round 3 ran two fold stages per LayerNorm = 4 tiny launches per block): grid (C / 64, sets), 16 waves per block, wave w takes rows w, w + 16, ... of its set's [nrows][2][C]
-// partials (64 columns x 2 per row: two coalesced 256-byte reads), fixed-order tree over the 16 waves in LDS.  Deterministic.
+// both LayerNorms of a block together at its end: round 3 ran two fold stages per LayerNorm = 4 tiny launches per block): grid (C / 64, sets), fixed-order sums.  Deterministic.  (C % 4 == 0: only the vector path of me_layernorm_bwd, C % 256 == 0, uses it.)
 __global__ __launch_bounds__(1024) void ln_bwd_fold_sets_kernel(const me_ln_fold_batch fb) {
-    __shared__ float sh[2][16][64];
+    __shared__ float sh[2][64][65];
     const me_ln_fold_set st = fb.set[blockIdx.y];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int C = fb.cols, c = blockIdx.x * 64 + lane;
-    float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+    const int C = fb.cols;
+    // 16 lanes x 4 columns = the block's 64 columns of one partial row (256 contiguous bytes); 64 row slots per block, slot s takes
+    // rows s, s + 64, ...: 12 x 2 sixteen-byte loads per thread at 768 partial rows, all independent
+    const int cq = threadIdx.x & 15, rs = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + 4 * cq;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        int r = w;
-        for (; r + 16 < st.nrows; r += 32) {
-            a0 += st.partial[((int64_t)r * 2 + 0) * C + c];
-            b0 += st.partial[((int64_t)r * 2 + 1) * C + c];
-            a1 += st.partial[((int64_t)(r + 16) * 2 + 0) * C + c];
-            b1 += st.partial[((int64_t)(r + 16) * 2 + 1) * C + c];
-        }
-        if (r < st.nrows) {
-            a0 += st.partial[((int64_t)r * 2 + 0) * C + c];
-            b0 += st.partial[((int64_t)r * 2 + 1) * C + c];
+        for (int r = rs; r < st.nrows; r += 64) {
+            a += *reinterpret_cast<const f32x4*>(st.partial + ((int64_t)r * 2 + 0) * C + c);
+            b += *reinterpret_cast<const f32x4*>(st.partial + ((int64_t)r * 2 + 1) * C + c);
         }
     }
-    sh[0][w][lane] = a0 + a1;
-    sh[1][w][lane] = b0 + b1;
-    __syncthreads();
-    if (w < 2 && c < C) {
-        float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; i += 4) t += (sh[w][i][lane] + sh[w][i + 1][lane]) + (sh[w][i + 2][lane] + sh[w][i + 3][lane]);
-        float* out = w ? st.dbeta : st.dgamma;
-        out[c] = st.accumulate ? out[c] + t : t;
+    for (int e = 0; e < 4; ++e) { sh[0][rs][4 * cq + e] = a[e]; sh[1][rs][4 * cq + e] = b[e]; }
+    __syncthreads();
+    // 128 threads finish: thread (which, column) adds the 64 row slots in a fixed order
+    if (threadIdx.x < 128) {
+        const int w = threadIdx.x >> 6, col = threadIdx.x & 63, cc = blockIdx.x * 64 + col;
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 64; i += 4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] += sh[w][i + e][col];
+        const float tot = (t[0] + t[1]) + (t[2] + t[3]);
+        if (cc < C) {
+            float* out = w ? st.dbeta : st.dgamma;
+            out[cc] = st.accumulate ? out[cc] + tot : tot;
+        }
     }
 }
 
