@@ -372,20 +372,57 @@ __global__ __launch_bounds__(EW_THREADS) void dropout_add_kernel(const void* __r
     }
 }
 
+__device__ __forceinline__ float adamw_update(float& pi, float gi, float& mi, float& vi, float lr, float b1, float b2, float eps, float wd,
+                                              float bc1, float bc2_sqrt) {
+    pi *= (1.0f - lr * wd);
+    mi = b1 * mi + (1.0f - b1) * gi;
+    vi = b2 * vi + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    return pi;
+}
+// VEC: four elements per lane (16-byte accesses on the four fp32 streams, 8 bytes on the bf16 mirror); the launcher takes it when the
+// slice's addresses allow it, the n % 4 tail goes through block 0's first lanes.  Same arithmetic per element either way.
+template <bool VEC>
 __global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
                                                            float gscale, bf16_t* __restrict__ mirror) {
+    if (VEC) {
+        const int64_t n4 = n / 4;
+        for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
+            f32x4 pv = *reinterpret_cast<const f32x4*>(p + i * 4), mv = *reinterpret_cast<const f32x4*>(m + i * 4),
+                  vv = *reinterpret_cast<const f32x4*>(v + i * 4);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pi = pv[e], mi = mv[e], vi = vv[e];
+                adamw_update(pi, gv[e] * gscale, mi, vi, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+                pv[e] = pi; mv[e] = mi; vv[e] = vi;
+            }
+            *reinterpret_cast<f32x4*>(m + i * 4) = mv;
+            *reinterpret_cast<f32x4*>(v + i * 4) = vv;
+            *reinterpret_cast<f32x4*>(p + i * 4) = pv;
+            if (mirror) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)pv[e];
+                *reinterpret_cast<bf16x4*>(mirror + i * 4) = o;
+            }
+        }
+        if (blockIdx.x != 0 || (int64_t)threadIdx.x >= n - n4 * 4) return;
+        const int64_t i = n4 * 4 + threadIdx.x;
+        float pi = p[i], mi = m[i], vi = v[i];
+        adamw_update(pi, g[i] * gscale, mi, vi, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        m[i] = mi; v[i] = vi; p[i] = pi;
+        if (mirror) mirror[i] = (bf16_t)pi;
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
-        const float gi = g[i] * gscale;
-        float pi = p[i];
-        pi *= (1.0f - lr * wd);
-        const float mi = b1 * m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        float pi = p[i], mi = m[i], vi = v[i];
+        adamw_update(pi, g[i] * gscale, mi, vi, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
         m[i] = mi;
         v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi -= (lr / bc1) * (mi / denom);
         p[i] = pi;
         if (mirror) mirror[i] = (bf16_t)pi;
     }
@@ -490,15 +527,10 @@ __global__ __launch_bounds__(EW_THREADS) void adamw_seg_kernel(float* __restrict
             if (i < s_end[mid]) hi = mid; else lo = mid + 1;
         }
         const float lri = s_lr[lo], wd = s_wd[lo];
-        const float gi = g[i] * gscale;
-        float pi = p[i];
-        pi *= (1.0f - lri * wd);
-        const float mi = b1 * m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        float pi = p[i], mi = m[i], vi = v[i];
+        adamw_update(pi, g[i] * gscale, mi, vi, lri, b1, b2, eps, wd, bc1, bc2_sqrt);
         m[i] = mi;
         v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi -= (lri / bc1) * (mi / denom);
         p[i] = pi;
         if (mirror) mirror[i] = (bf16_t)pi;
     }
@@ -1073,8 +1105,14 @@ extern "C" int me_adamw_step(float* param, const float* grad, float* exp_avg, fl
     if (n == 0) return ME_OK;
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, param, grad, exp_avg, exp_avg_sq, n, lr,
-                       beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale, reinterpret_cast<bf16_t*>(bf16_mirror));
+    const bool vec = n >= 4 && (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
+                     ((uintptr_t)bf16_mirror & 7) == 0;
+    if (vec)
+        hipLaunchKernelGGL(adamw_kernel<true>, dim3(ew_blocks(n / 4)), dim3(EW_THREADS), 0, stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                           beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale, reinterpret_cast<bf16_t*>(bf16_mirror));
+    else
+        hipLaunchKernelGGL(adamw_kernel<false>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                           beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale, reinterpret_cast<bf16_t*>(bf16_mirror));
     ME_CHECK_LAUNCH("me_adamw_step");
     return ME_OK;
 }

@@ -884,7 +884,11 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
 #ifndef G3_HI_EPI1
 #define G3_HI_EPI1 1                           // (A/B arm: ... and in the GELU kernels -- fc1's 2 364 tiles leave a last round of 60)
 #endif
-    constexpr bool HI = EPI == 0 || (G3_HI_EPI2 && EPI == 2) || (G3_HI_EPI1 && EPI == 1);      // which forms carry the 128-row items (see the kernel)
+#ifndef G3_HI_EPI6
+#define G3_HI_EPI6 0                           // (A/B arm: ... and in the x-row-operand kernel, fc2 dgrad, the same 2 364 tiles: 22 scratch
+                                               //  operations at the seam, train 31.2 -> 31.6 ms same box -- off)
+#endif
+    constexpr bool HI = EPI == 0 || (G3_HI_EPI2 && EPI == 2) || (G3_HI_EPI1 && EPI == 1) || (G3_HI_EPI6 && EPI == 6);      // which forms carry the 128-row items (see the kernel)
     static OncePerDevice once;
     if (once.need())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE, HI>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS + 64);
