@@ -37,6 +37,10 @@
 // (a compile-time false in libmetaenc.so); the dev-only stream-K kernel is in gemm3_dev.hip.
 #include "gemm3_core.h"
 
+#ifndef G3_ROWOP_AHEAD
+#define G3_ROWOP_AHEAD 4                       // row-operand slabs in flight ahead of their use in a whole tile's epilogue (6 until round 4: proj 84.6 -> 80.6 us,
+                                               // fc2 205.7 -> 201.7 us sustained, gpurun_out r4s / profiles/r04_rowop_ahead.txt: fewer spills at the seam)
+#endif
 namespace {
 
 // ---- one tile per workgroup
@@ -314,7 +318,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
         const bool part_ok = item_ok && (part + 1) * 64 <= p.N;
         srs = __builtin_amdgcn_make_buffer_rsrc(p.row_stats + (part_ok ? (part * p.M + m0) * 2 : 0), 0, part_ok ? (int)(rows * 8) : 0, 0x00020000);
     }
-    constexpr int AHEAD = HALF ? 4 : (EPI == 3 || STATS) ? 4 : 6;      // row-operand slabs in flight ahead of their use (more spills: into the K-loop for gelu', onto the ticket register otherwise)
+    constexpr int AHEAD = HALF ? 4 : (EPI == 3 || STATS) ? 4 : G3_ROWOP_AHEAD;      // row-operand slabs in flight ahead of their use (more spills: into the K-loop for gelu', onto the ticket register otherwise)
     u32x4 rowop[8][2];
     if (EPI == 2 || EPI == 3 || EPI == 6) {
 #pragma unroll
