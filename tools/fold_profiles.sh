@@ -1,0 +1,10 @@
+#!/bin/bash
+# fold gpurun_out/prof_r04 (tools/prof_round.sh) into profiles/r04_*
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+P=gpurun_out/prof_r04; T=$(find $P/train -name "*kernel_trace.csv" | head -1); F=$(find $P/fwd -name "*kernel_trace.csv" | head -1)
+python tools/prof_summary.py $T 28 > profiles/r04_train_summary.txt; python tools/prof_summary.py $F 16 > profiles/r04_fwd_summary.txt
+cp $(find $P/train -name "*kernel_stats.csv" | head -1) profiles/r04_train_kernel_stats.csv; cp $(find $P/fwd -name "*kernel_stats.csv" | head -1) profiles/r04_fwd_kernel_stats.csv
+python tools/pmc_summary.py > /dev/null 2>&1
+for f in base large512_fwd large512_train large1568_fwd large1568_fwd_fp8attn large1568_train mixed fp32; do tail -1 $P/bench_$f.json > profiles/r04_bench_$f.json; done
+tail -1 $P/train.json > profiles/r04_bench_train_under_rocprof.json; tail -1 $P/fwd.json > profiles/r04_bench_fwd_under_rocprof.json
+cp $P/refshapes.json profiles/r04_refshapes.json; cp $P/refshapes.txt profiles/r04_refshapes.txt
