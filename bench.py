@@ -60,6 +60,8 @@ def parse():
                          "and attention; roofline against the 157 TF f32-input MFMA peak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-leg", action="store_true")
+    ap.add_argument("--no-wgrad-overlap", action="store_true",
+                    help="train: keep the weight-gradient GEMMs in program order on the one stream (me_block_bwd_overlap(0))")
     ap.add_argument("--no-chain-stats", action="store_true",
                     help="A/B: folded inference reads every LayerNorm input once more (me_row_stats) instead of taking the statistics from the residual GEMMs' epilogues")
     ap.add_argument("--attn-dtype", choices=["bf16", "fp8"], default="bf16",
@@ -232,9 +234,23 @@ def main():
         ops.gemm_profile(False)
         return recs
 
+    # The timed steps run the product's default schedule: me_block_bwd puts the weight-gradient GEMMs on its side stream, where they
+    # fill the CUs the LayerNorm / attention backward kernels and the tails of the dY -> dX chain leave idle.  Kernels that share the
+    # chip have no launch duration of their own, so the per-kernel records (roofline, other_kernels) come from a SERIAL pass of the
+    # same step (me_block_bwd_overlap(0): every kernel alone on the chip, in program order) -- that pass is also timed, as
+    # schedule.serial_ms_per_step.  `ME_WGRAD_OVERLAP=0 rocprofv3 ... bench.py` reproduces the serial durations, the plain command the
+    # overlapped ones (profiles/r04_train_serial_summary.txt / r04_train_summary.txt).
+    overlap = bool(train and not args.no_wgrad_overlap and os.environ.get("ME_WGRAD_OVERLAP", "1") != "0")
+    ops.block_bwd_overlap(overlap)
     elapsed = timed(step, args.steps, args.warmup)
     psteps = max(1, min(args.steps, 5))
+    serial_el = None
+    if train:
+        ops.block_bwd_overlap(False)
+        if overlap:
+            serial_el = timed(step, psteps, 1) / psteps
     prof = profiled(step, psteps)
+    ops.block_bwd_overlap(overlap)
     fwd = None
     if train and not args.no_fwd_leg:
         enc.eval()
@@ -377,9 +393,15 @@ def main():
         "model_tflops_per_s": round(value * model_flops / 1e12, 2),
         "mfma_frac_end_to_end": round(value * model_flops / 1e12 / ((PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS) * world), 4),
         "per_rank_gemm": per_rank,
-        "roofline": gemm_roofline(prof, step_s, psteps, train),
-        "other_kernels": other_kernels(prof, step_s, psteps),
+        "roofline": gemm_roofline(prof, serial_el or step_s, psteps, train),
+        "other_kernels": other_kernels(prof, serial_el or step_s, psteps),
     }
+    if train:
+        out["schedule"] = {"wgrad_side_stream": overlap,
+                           "serial_ms_per_step": round(1e3 * serial_el, 3) if serial_el else None,
+                           "note": ("timed steps: weight-gradient GEMMs on me_block_bwd's side stream beside the dY -> dX chain; roofline / "
+                                    "other_kernels: per-kernel HIP-event durations from a serial pass of the same step (shares are of the "
+                                    "serial step)") if overlap else "one stream, program order (timed steps and per-kernel records alike)"}
     if fwd is not None:
         fwd_el, fwd_prof = fwd
         fs = fwd_el / args.steps

@@ -263,6 +263,11 @@ int me_block_fwd(const me_block_desc* d, const void* x, void* y, void* saved, vo
 /* dx may be NULL (input does not need a gradient only if nothing upstream does -- rarely useful; kept for symmetry) */
 int me_block_bwd(const me_block_desc* d, const void* x, const void* dy, const void* saved, void* dx,
                  const me_block_grads* g, void* workspace, size_t workspace_bytes, void* stream);
+/* me_block_bwd issues the weight-gradient GEMMs (and their folds) on a library-owned SIDE stream, forked from / joined to `stream`
+ * by events inside the call (the caller sees plain stream semantics): they fill the CUs the LayerNorm / attention backward kernels
+ * and the tails of the dY -> dX chain leave idle.  On by default; off while `stream` is being captured into a hipGraph, with
+ * ME_WGRAD_OVERLAP=0 in the environment, or after me_block_bwd_overlap(0).  Returns the previous setting. */
+int me_block_bwd_overlap(int enable);
 
 /* The whole encoder, inference: y = Block_{n-1}(... Block_0(x)) -- nn.Sequential(*[Block] * L)(x) of README.md:124-149 as
  * one call for serving hosts.  All blocks share B, N, C and dtypes.  `pingpong` is one token buffer [B*N, C] in res_dtype

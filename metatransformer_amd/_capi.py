@@ -146,6 +146,7 @@ SIGNATURES = {
     "me_encoder_fwd": (c_int, [POINTER(BlockDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "me_block_bwd": (c_int, [POINTER(BlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(BlockGrads), c_void_p,
                              c_size_t, c_void_p]),
+    "me_block_bwd_overlap": (c_int, [c_int]),
     "me_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "me_transpose_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "me_transpose_cast_batched": (c_int, [POINTER(TcBatch), c_void_p]),

@@ -4,8 +4,53 @@
 // ONE call per block and direction and the GPU never waits for the host between the ~10 (forward) / ~20 (backward) kernels.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
+#include <atomic>
+#include <map>
+#include <mutex>
 
 namespace {
+
+// ---- me_block_bwd: the weight-gradient GEMMs (and their folds) on a SIDE stream.  Nothing downstream of a Block's backward needs
+// dW before the call returns, while the chain dY -> dX is serial and a third of its kernels are not matrix-bound (two LayerNorm
+// backward passes and the attention backward per block: ~300 of ~2 500 us): the side stream's wgrad workgroups take the CUs those
+// kernels leave idle, the tails of the resident launches and the launch gaps.  One side stream + fork / join events per main stream
+// and device, created at first use; the call joins before it returns (the caller sees ordinary stream semantics, and the shared
+// backward workspace may be reused by the next call).  Off: me_block_bwd_overlap(0) or ME_WGRAD_OVERLAP=0; always off while the
+// main stream is being captured into a hipGraph.
+struct SideCtx {
+    hipStream_t side = nullptr;
+    hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join = nullptr;
+    bool failed = false;
+};
+std::atomic<int> g_wgrad_overlap{-1};      // -1: not decided yet (environment), 0 / 1
+bool wgrad_overlap_on() {
+    int v = g_wgrad_overlap.load();
+    if (v < 0) {
+        const char* e = getenv("ME_WGRAD_OVERLAP");
+        v = (e && e[0] == '0') ? 0 : 1;
+        g_wgrad_overlap.store(v);
+    }
+    return v != 0;
+}
+SideCtx* side_ctx(hipStream_t main) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, SideCtx> ctxs;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    int dev = 0;
+    if (hipStreamGetDevice(main, &dev) != hipSuccess) (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    SideCtx& c = ctxs[std::make_pair(dev, main)];
+    if (c.failed) return nullptr;
+    if (!c.side) {
+        bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 4; ++i) ok = hipEventCreateWithFlags(&c.fork[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c.join, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { c.failed = true; c.side = nullptr; return nullptr; }
+    }
+    return &c;
+}
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -135,7 +180,8 @@ extern "C" size_t me_block_workspace_bytes(const me_block_desc* d, int backward)
     // dy_c, dh, dxn (shared by dxn2 / dxn1), dx1, dx1_c, do, dqkv, delta
     w += align256(s.M * s.C * s.esz) * 4 + align256(s.M * s.Hd * s.esz) + align256(s.M * s.C * s.rsz) +
          align256(s.M * s.C3 * s.esz) + align256((size_t)d->B * d->heads * d->N * 4);
-    return w + align256(me_layernorm_bwd_workspace(s.C));      // norm2's dgamma / dbeta partials, folded with norm1's at the end
+    w += align256(me_layernorm_bwd_workspace(s.C));            // norm2's dgamma / dbeta partials, folded with norm1's at the end
+    return w + gemm_scratch(d, s, true) + aux_scratch(s);      // the side stream's own GEMM / column-sum scratch
 }
 
 extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void* saved, void* workspace, size_t workspace_bytes,
@@ -241,9 +287,34 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
     char* dqkv = take(s.M * s.C3 * s.esz);
     float* delta = reinterpret_cast<float*>(take((size_t)d->B * d->heads * d->N * 4));
     void* ln2_ws = take(me_layernorm_bwd_workspace(s.C));
+    void* gws2 = take(gsz);
+    void* aws2 = take(aux_scratch(s));
     me_ln_fold_set folds[2];
     const float beta = gr->accumulate ? 1.0f : 0.0f;
     me_gemm_desc g;
+    // weight gradients on the side stream (see SideCtx); sc == null: everything on `stream`, in program order
+    hipStream_t mstream = reinterpret_cast<hipStream_t>(stream);
+    SideCtx* sc = wgrad_overlap_on() ? side_ctx(mstream) : nullptr;
+    void* wstream = sc ? reinterpret_cast<void*>(sc->side) : stream;
+    void* wgws = sc ? gws2 : gws;
+    void* waws = sc ? aws2 : aws;
+    bool forked = false;
+    auto fork = [&](int i) -> int {           // the side stream may start on what `stream` has been given so far
+        if (!sc) return ME_OK;
+        if (hipEventRecord(sc->fork[i], mstream) != hipSuccess || hipStreamWaitEvent(sc->side, sc->fork[i], 0) != hipSuccess) {
+            me_set_error("me_block_bwd: event fork failed");
+            return ME_ERR_HIP;
+        }
+        forked = true;
+        return ME_OK;
+    };
+    auto join = [&](int rc_in) -> int {       // `stream` continues behind everything the side stream was given
+        if (!sc || !forked) return rc_in;
+        if (hipEventRecord(sc->join, sc->side) != hipSuccess || hipStreamWaitEvent(mstream, sc->join, 0) != hipSuccess) {
+            if (rc_in == ME_OK) { me_set_error("me_block_bwd: event join failed"); return ME_ERR_HIP; }
+        }
+        return rc_in;
+    };
 
     auto nt = [&](const void* A, int64_t K, const void* Wt, void* C, int64_t N, const void* aux) -> int {
         gemm_desc(g, ME_GEMM_NT, dt, s.M, N, K, A, K, Wt, K, C, N, dt);
@@ -252,17 +323,20 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
         return me_gemm(&g, stream);
     };
     // dW[out, in] = dOut^T In (+ the bias gradient from the same kernel when it can fuse it)
-    auto wgrad = [&](const void* dOut, int64_t n_out, const void* In, int64_t n_in, void* dW, float* dB) -> int {
+    auto wgrad = [&](int fk, const void* dOut, int64_t n_out, const void* In, int64_t n_in, void* dW, float* dB) -> int {
+        if (!dW && !dB) return ME_OK;             // (frozen parameter)
+        int r = fork(fk);
+        if (r) return r;
         if (dW) {
             gemm_desc(g, ME_GEMM_TN, dt, n_out, n_in, s.M, dOut, n_out, In, n_in, dW, n_in, gr->w_dtype);
-            g.beta = beta; g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+            g.beta = beta; g.workspace = wgws; g.workspace_bytes = (int64_t)gsz;
             const bool fuse = dB && me_gemm_fuses_colsum(&g);
             if (fuse) g.colsum_a = dB;
-            int r = me_gemm(&g, stream);
+            r = me_gemm(&g, wstream);
             if (r) return r;
             if (fuse) return ME_OK;
         }
-        if (dB) return me_colsum(dOut, dt, n_out, s.M, n_out, dB, gr->accumulate, aws, stream);
+        if (dB) return me_colsum(dOut, dt, n_out, s.M, n_out, dB, gr->accumulate, waws, wstream);
         return ME_OK;
     };
 
@@ -272,29 +346,37 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
         if ((rc = me_cast(dy, rdt, dy_c, dt, s.M * s.C, stream))) return rc;
         dyc = dy_c;
     }
-    if ((rc = nt(dyc, s.C, d->fc2_wt, dh, s.Hd, v.hpre))) return rc;                  // dA * gelu'(h)
-    if ((rc = wgrad(dyc, s.C, v.a, s.Hd, gr->fc2_w, gr->fc2_b))) return rc;
-    if ((rc = nt(dh, s.Hd, d->fc1_wt, dxn, s.C, nullptr))) return rc;
-    if ((rc = wgrad(dh, s.Hd, v.xn2, s.C, gr->fc1_w, gr->fc1_b))) return rc;
+    if ((rc = wgrad(0, dyc, s.C, v.a, s.Hd, gr->fc2_w, gr->fc2_b))) return join(rc);
+    if ((rc = nt(dyc, s.C, d->fc2_wt, dh, s.Hd, v.hpre))) return join(rc);                  // dA * gelu'(h)
+    if ((rc = wgrad(1, dh, s.Hd, v.xn2, s.C, gr->fc1_w, gr->fc1_b))) return join(rc);
+    if ((rc = nt(dh, s.Hd, d->fc1_wt, dxn, s.C, nullptr))) return join(rc);
     rc = me_ln_bwd_deferred(dxn, dt, v.x1, rdt, v.mean2, v.rstd2, d->ln2_g, dy, rdt, dx1, rdt, gr->ln2_g, gr->ln2_b, gr->accumulate, s.M,
                             s.C, ln2_ws, stream, &folds[0]);
-    if (rc) return rc;
+    if (rc) return join(rc);
     // ---- attention branch: x1 = x + proj(attn(qkv(LN1(x))))
     const void* dx1c = dx1;
     if (rdt != dt) {
-        if ((rc = me_cast(dx1, rdt, dx1_c, dt, s.M * s.C, stream))) return rc;
+        if ((rc = me_cast(dx1, rdt, dx1_c, dt, s.M * s.C, stream))) return join(rc);
         dx1c = dx1_c;
     }
-    if ((rc = nt(dx1c, s.C, d->proj_wt, dout, s.C, nullptr))) return rc;
-    if ((rc = wgrad(dx1c, s.C, v.o, s.C, gr->proj_w, gr->proj_b))) return rc;
+    if ((rc = wgrad(2, dx1c, s.C, v.o, s.C, gr->proj_w, gr->proj_b))) return join(rc);
+    if ((rc = nt(dx1c, s.C, d->proj_wt, dout, s.C, nullptr))) return join(rc);
     rc = me_attention_bwd(v.qkv, s.C3, v.o, s.C, dout, s.C, v.lse, delta, dqkv, s.C3, d->B, d->N, d->heads, s.hd, d->scale, dt, 0.f, 0, stream);
-    if (rc) return rc;
-    if ((rc = nt(dqkv, s.C3, d->qkv_wt, dxn, s.C, nullptr))) return rc;
-    if ((rc = wgrad(dqkv, s.C3, v.xn1, s.C, gr->qkv_w, gr->qkv_b))) return rc;
+    if (rc) return join(rc);
+    if ((rc = wgrad(3, dqkv, s.C3, v.xn1, s.C, gr->qkv_w, gr->qkv_b))) return join(rc);
+    if ((rc = nt(dqkv, s.C3, d->qkv_wt, dxn, s.C, nullptr))) return join(rc);
     rc = me_ln_bwd_deferred(dxn, dt, x, rdt, v.mean1, v.rstd1, d->ln1_g, dx1, rdt, dx, rdt, gr->ln1_g, gr->ln1_b, gr->accumulate, s.M, s.C,
                             aws, stream, &folds[1]);
-    if (rc) return rc;
-    return me_ln_bwd_fold_sets(folds, 2, s.C, stream);      // dgamma / dbeta of both LayerNorms: one launch
+    if (rc) return join(rc);
+    return join(me_ln_bwd_fold_sets(folds, 2, s.C, stream));      // dgamma / dbeta of both LayerNorms: one launch
+}
+
+// process-wide switch for the side stream of me_block_bwd (default on; ME_WGRAD_OVERLAP=0 in the environment turns it off);
+// returns the previous setting
+extern "C" int me_block_bwd_overlap(int enable) {
+    const int prev = wgrad_overlap_on() ? 1 : 0;
+    g_wgrad_overlap.store(enable ? 1 : 0);
+    return prev;
 }
 
 extern "C" int me_encoder_fwd(const me_block_desc* blocks, int n_blocks, const void* x, void* y, void* pingpong, void* workspace,

@@ -37,6 +37,9 @@
 // (a compile-time false in libmetaenc.so); the dev-only stream-K kernel is in gemm3_dev.hip.
 #include "gemm3_core.h"
 
+#ifndef G3_TRAIN_GELU_POLY
+#define G3_TRAIN_GELU_POLY 0                   // (A/B arm: the two bf16-mode polynomials instead of the shared-exponential erf pair where gelu AND gelu' are stored)
+#endif
 #ifndef G3_ROWOP_AHEAD
 #define G3_ROWOP_AHEAD 4                       // row-operand slabs in flight ahead of their use in a whole tile's epilogue (6 until round 4: proj 84.6 -> 80.6 us,
                                                // fc2 205.7 -> 201.7 us sustained, gpurun_out r4s / profiles/r04_rowop_ahead.txt: fewer spills at the seam)
@@ -389,6 +392,13 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                     // gelu and gelu' from the same Phi / Gaussian parts: the backward GEMM multiplies by the saved factor.  (The
                     // erf form stays here: with BOTH outputs wanted it shares one exponential between them, and the two
                     // polynomial chains of the bf16-mode forms measured no faster -- 344 against 339 us per fc1 launch.)
+#if G3_TRAIN_GELU_POLY
+                    const f32x4 t0 = gelu_clamp4(v0), t1 = gelu_clamp4(v1);
+                    const f32x4 d0 = gelu_bf16_grad_from_t4(v0, t0), d1 = gelu_bf16_grad_from_t4(v1, t1);
+                    __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(d0, d1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, G3_POL_P);
+                    v0 = gelu_bf16_from_t4(v0, t0);
+                    v1 = gelu_bf16_from_t4(v1, t1);
+#else
                     f32x4 ph0, ga0, ph1, ga1;
                     phi_parts4(v0, ph0, ga0);
                     phi_parts4(v1, ph1, ga1);
@@ -396,6 +406,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                     __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(d0, d1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, G3_POL_P);
                     v0 *= ph0;
                     v1 *= ph1;
+#endif
                 } else {
                     if (SAVE) __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(v0, v1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, G3_POL_P);
                     v0 = gelu_bf16_4(v0);

@@ -253,6 +253,11 @@ def encoder_fwd(descs, x2: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def block_bwd_overlap(enable: bool) -> bool:
+    """Switch the side stream of me_block_bwd (weight-gradient GEMMs beside the dY -> dX chain) on / off; returns the previous setting."""
+    return bool(_capi.load().me_block_bwd_overlap(1 if enable else 0))
+
+
 def block_bwd(d, x2: torch.Tensor, dy2: torch.Tensor, saved: torch.Tensor, grads: "_capi.BlockGrads") -> torch.Tensor:
     lib = _capi.load()
     dx = torch.empty_like(x2)

@@ -110,6 +110,45 @@ def test_backward_full_parity_vs_oracle(dev):
             check_close(p.grad, dp_ref[k], t, f"d{k} {dt}")      # (max-abs AND per element)
 
 
+def test_block_backward_side_stream_equals_serial_order(dev):
+    """me_block_bwd issues the weight-gradient GEMMs on its side stream (forked from / joined to the caller's stream inside the call):
+    every gradient is BIT-identical to the serial order (no kernel's arithmetic depends on what shares the chip with it), over
+    several backward passes with unrelated traffic on a third stream, at a shape whose resident kernels claim their tiles, and the
+    caller's stream really is joined (the gradients are read on it right after the call returns)."""
+    from metatransformer_amd import ops, parallel
+    c = dict(depth=3, dim=768, heads=12, eps=1e-6, seed=11)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(96, 197, 768, generator=g).to(dev)
+    go = (torch.randn(96, 197, 768, generator=g) / 1000).to(dev)
+    noise = torch.empty(32 << 20, device=dev)
+    side = torch.cuda.Stream()
+    got = {}
+    prev = ops.block_bwd_overlap(True)
+    try:
+        for overlap in (False, True, True):
+            ops.block_bwd_overlap(overlap)
+            enc = make_encoder(c, dev).train()
+            flat = parallel.FlatParams(enc.parameters())
+            flat.zero_grad()
+            xr = x.clone().requires_grad_(True)
+            for rep in range(2):                              # (accumulating passes: beta = 1 into the flat buffer)
+                with torch.cuda.stream(side):
+                    noise.add_(1.0)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = enc(xr)
+                y.backward(go)
+            snap = (flat.flat_grad.clone(), xr.grad.clone())  # read on the caller's stream, no synchronisation in between
+            key = "overlap" if overlap else "serial"
+            if key in got:
+                assert torch.equal(got[key][0], snap[0]) and torch.equal(got[key][1], snap[1])      # run to run
+            got[key] = snap
+    finally:
+        ops.block_bwd_overlap(prev)
+    assert torch.equal(got["serial"][0], got["overlap"][0])
+    assert torch.equal(got["serial"][1], got["overlap"][1])
+    assert float(got["serial"][0].abs().max()) > 0
+
+
 def test_flat_params_fused_gradient_accumulation(dev):
     """parallel.FlatParams: weight gradients accumulated in place by the wgrad epilogue == autograd's own accumulation,
     over two backward passes (gradient accumulation), and the direct-write listeners fire once per weight per pass"""

@@ -8,10 +8,12 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fwd-leg > $O/train.json 2> $O/train.err
 echo "train rc=$?"
+ME_WGRAD_OVERLAP=0 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_serial -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fwd-leg > $O/train_serial.json 2> $O/train_serial.err
+echo "train (serial order: ME_WGRAD_OVERLAP=0) rc=$?"
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fwd -o t -- python $R/bench.py --steps 5 --warmup 2 --mode fwd --no-cpu-baseline > $O/fwd.json 2> $O/fwd.err
 echo "fwd rc=$?"
 find $O -name "*agent*" -delete
-MODE=train bash $R/tools/pmc_bench.sh
+ME_WGRAD_OVERLAP=0 MODE=train bash $R/tools/pmc_bench.sh
 MODE=fwd bash $R/tools/pmc_bench.sh
 cd $R
 timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_base.json 2> $O/bench_base.err; echo "base rc=$?"
