@@ -44,7 +44,7 @@ SideCtx* side_ctx(hipStream_t main) {
     SideCtx& c = ctxs[std::make_pair(dev, main)];
     if (c.failed) return nullptr;
     if (!c.side) {
-        bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess;
+        bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess;      // (a higher / lower stream priority measured no different)
         for (int i = 0; ok && i < 4; ++i) ok = hipEventCreateWithFlags(&c.fork[i], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c.join, hipEventDisableTiming) == hipSuccess;
         if (!ok) { c.failed = true; c.side = nullptr; return nullptr; }
