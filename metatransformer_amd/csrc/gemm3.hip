@@ -37,6 +37,12 @@
 // (a compile-time false in libmetaenc.so); the dev-only stream-K kernel is in gemm3_dev.hip.
 #include "gemm3_core.h"
 
+#ifndef G3_ROWOP_AHEAD_HALF
+#define G3_ROWOP_AHEAD_HALF 4                  // ... in a 128-row item's epilogue (two: proj 80.5 -> 84.2 us, fc2 203 -> 206 us)
+#endif
+#ifndef G3_ROWOP_AHEAD_STATS
+#define G3_ROWOP_AHEAD_STATS 4                 // ... in the statistics / gelu'(row operand) epilogues
+#endif
 #ifndef G3_TRAIN_GELU_POLY
 #define G3_TRAIN_GELU_POLY 0                   // (A/B arm: the two bf16-mode polynomials instead of the shared-exponential erf pair where gelu AND gelu' are stored)
 #endif
@@ -321,7 +327,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
         const bool part_ok = item_ok && (part + 1) * 64 <= p.N;
         srs = __builtin_amdgcn_make_buffer_rsrc(p.row_stats + (part_ok ? (part * p.M + m0) * 2 : 0), 0, part_ok ? (int)(rows * 8) : 0, 0x00020000);
     }
-    constexpr int AHEAD = HALF ? 4 : (EPI == 3 || STATS) ? 4 : G3_ROWOP_AHEAD;      // row-operand slabs in flight ahead of their use (more spills: into the K-loop for gelu', onto the ticket register otherwise)
+    constexpr int AHEAD = HALF ? G3_ROWOP_AHEAD_HALF : (EPI == 3 || STATS) ? G3_ROWOP_AHEAD_STATS : G3_ROWOP_AHEAD;      // row-operand slabs in flight ahead of their use (more spills: into the K-loop for gelu', onto the ticket register otherwise)
     u32x4 rowop[8][2];
     if (EPI == 2 || EPI == 3 || EPI == 6) {
 #pragma unroll
@@ -900,8 +906,8 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
 #define G3_HI_EPI1 1                           // (A/B arm: ... and in the GELU kernels -- fc1's 2 364 tiles leave a last round of 60)
 #endif
 #ifndef G3_HI_EPI6
-#define G3_HI_EPI6 0                           // (A/B arm: ... and in the x-row-operand kernel, fc2 dgrad, the same 2 364 tiles: 22 scratch
-                                               //  operations at the seam, train 31.2 -> 31.6 ms same box -- off)
+#define G3_HI_EPI6 0                           // (A/B arm: ... and in the x-row-operand kernel, fc2 dgrad, the same 2 364 tiles: 243 -> 251 us
+                                               //  sustained with four row-operand slabs in flight, 263 with two; train +0.4 ms with six -- off)
 #endif
     constexpr bool HI = EPI == 0 || (G3_HI_EPI2 && EPI == 2) || (G3_HI_EPI1 && EPI == 1) || (G3_HI_EPI6 && EPI == 6);      // which forms carry the 128-row items (see the kernel)
     static OncePerDevice once;
