@@ -14,7 +14,7 @@ namespace {
 // ---- me_block_bwd: the weight-gradient GEMMs (and their folds) on a SIDE stream.  Nothing downstream of a Block's backward needs
 // dW before the call returns, while the chain dY -> dX is serial and a third of its kernels are not matrix-bound (two LayerNorm
 // backward passes and the attention backward per block: ~300 of ~2 500 us): the side stream's wgrad workgroups take the CUs those
-// kernels leave idle, the tails of the resident launches and the launch gaps.  One side stream + fork / join events per main stream
+// kernels and the tails of the resident launches leave idle (train step -2.2 % same box; bit-identical gradients).  One side stream + fork / join events per main stream
 // and device, created at first use; the call joins before it returns (the caller sees ordinary stream semantics, and the shared
 // backward workspace may be reused by the next call).  Off: me_block_bwd_overlap(0) or ME_WGRAD_OVERLAP=0; always off while the
 // main stream is being captured into a hipGraph.
