@@ -47,7 +47,7 @@ def _usable_cores() -> int:
         return os.cpu_count() or 1
 
 
-def time_encoder(depth=12, dim=768, heads=12, N=197, backward=True, budget_s=20.0, seed=0, replicas=True):
+def time_encoder(depth=12, dim=768, heads=12, N=197, backward=True, budget_s=20.0, seed=0, replicas=False):
     """Sweep (threads, batch) and report the best samples/s with the configuration that gave it.
 
     Threads ascend through {8, 16, 32, 64, all usable}; a leg that is SLOWER than the best so far ends the ascent (throughput
@@ -89,15 +89,20 @@ def time_encoder(depth=12, dim=768, heads=12, N=197, backward=True, budget_s=20.
             step(x, go)
             it += 1
             el = time.perf_counter() - t0
-            if it >= min_iters and (el >= max_s or it >= 20 or time.perf_counter() - t_start > budget_s):
+            if it >= min_iters and (el >= max_s or it >= 20 or time.perf_counter() - t_start > sweep_s):
                 break
         legs[(th, batch)] = (batch * it / el, it, el)
         return legs[(th, batch)][0]
 
-    asc_s = max(1.5, 0.12 * budget_s)          # per leg of the ascent: the 8 / 16 / 32-thread legs all get their turn
+    # with --replicas the single-process sweep gets 60 % of the budget and the replica leg the rest.  Measured on the 256-core host of
+    # an MI355X box (round 4): 16 replicas x 16 threads = 7.8 samples/s in aggregate against 11.6 for ONE 16-thread process -- the
+    # host is memory-bound long before its cores are used, and starting 16 interpreters costs 80 s -- so the replica leg is opt-in
+    # and the one-process figure is the reported baseline.
+    sweep_s = (0.6 if replicas else 1.0) * budget_s
+    asc_s = max(1.5, 0.1 * budget_s)           # per leg of the ascent: the 8 / 16 / 32-thread legs all get their turn
     best_th, best = cand[0], leg(cand[0], 8, max_s=asc_s)
     for th in cand[1:]:
-        if time.perf_counter() - t_start > 0.5 * budget_s:
+        if time.perf_counter() - t_start > 0.5 * sweep_s:
             break
         v = leg(th, 8, max_s=asc_s)
         if v <= best:
@@ -105,13 +110,13 @@ def time_encoder(depth=12, dim=768, heads=12, N=197, backward=True, budget_s=20.
         best_th, best = th, v
     up = [c for c in cand if c > best_th][:1]
     for batch in (32, 64):
-        if time.perf_counter() - t_start > 0.85 * budget_s:
+        if time.perf_counter() - t_start > 0.85 * sweep_s:
             break
         improved = False
         for th in [best_th] + up:
-            if time.perf_counter() - t_start > budget_s:
+            if time.perf_counter() - t_start > sweep_s:
                 break
-            v = leg(th, batch, max_s=max(2.0, 0.25 * budget_s))
+            v = leg(th, batch, max_s=max(2.0, 0.15 * budget_s))
             if v > best:
                 best, improved = v, True
         if not improved:
@@ -212,11 +217,11 @@ if __name__ == "__main__":
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--budget-s", type=float, default=20.0)
     ap.add_argument("--batch", type=int, default=0, help="(ignored: the batch is swept)")
-    ap.add_argument("--no-replicas", action="store_true")
+    ap.add_argument("--replicas", action="store_true", help="also time cores / threads pinned replicas of the best configuration")
     ap.add_argument("--worker", nargs=4, default=None, metavar=("THREADS", "BATCH", "SECONDS", "CPUS"), help="(internal: one replica)")
     a = ap.parse_args()
     if a.worker:
         th, batch, secs, cpus = int(a.worker[0]), int(a.worker[1]), float(a.worker[2]), [int(c) for c in a.worker[3].split(",") if c]
         _replica_worker(th, batch, a.depth, a.dim, a.heads, a.tokens, not a.forward_only, secs, cpus)
     else:
-        print(json.dumps(time_encoder(a.depth, a.dim, a.heads, a.tokens, not a.forward_only, a.budget_s, replicas=not a.no_replicas)))
+        print(json.dumps(time_encoder(a.depth, a.dim, a.heads, a.tokens, not a.forward_only, a.budget_s, replicas=a.replicas)))
