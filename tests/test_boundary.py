@@ -161,3 +161,14 @@ def test_attention_backward_isa_keeps_its_ticket_register():
         asm = mod.compile_asm(d, mod.SRC_ATTN)
     report, findings = mod.check(asm, kernel="attn_bwd_ring16_kernel", check_loops=False)
     assert len(report) >= 8 and not findings, findings
+    # the 16-wave kernels (ring and streaming forms) are built on four waves per SIMD: <= 128 registers, nothing spilled
+    import re
+    seen = 0
+    for m in re.finditer(r"^(_Z\w*attn_(?:fwd|bwd)\w*(?:ring16|stream16)_kernel\w*):", asm, re.M):
+        body = asm[m.start():asm.find(".end_amdhsa_kernel", m.start())]
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        # (the ring backward at head width 64 sits exactly at 128 registers and keeps one 8-byte value in scratch across an item)
+        allowed = 4 if "attn_bwd_ring16" in m.group(1) else 0
+        assert vgpr <= 128 and body.count("scratch_") <= allowed, (m.group(1), vgpr, body.count("scratch_"))
+        seen += 1
+    assert seen >= 10, seen      # ring16 forward / backward for every sub-tile count and both head widths, three streaming kernels
