@@ -405,6 +405,11 @@ struct GemmPlan {
     int tail_split, tail_ksteps;
 };
 
+#ifndef ME_SMALL_SPLIT_DEN
+#define ME_SMALL_SPLIT_DEN 2                     // whole-problem split-K when tiles <= slots / this.  Measured on the reference's shapes
+                                                 // (profiles/r04_small_split_ab.txt): never = +7..18 % per forward at B = 32..256 x N = 16..197,
+                                                 // B = 1 0.92 -> 1.43 ms; / 3 -> / 2: M = 8 224 fwd + dX 6.9 -> 6.74 ms, the rest unchanged
+#endif
 GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
     GemmPlan pl{0, 0, 128, 0, 1, 0, 0, 0, 1, 0};
     const GemmDev dev = gemm_dev();
@@ -526,7 +531,7 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         // Small problems (small-batch inference: M = B * N rows with B = 1..32): fewer tiles than a third of the chip's
         // workgroup slots means the launch is pure latency -- one workgroup walks the whole reduction while 2/3 of the CUs
         // idle.  The WHOLE problem then runs split over the reduction (same slabs + fold as the tail split, m_main = 0).
-        if (dev.tail_split && pl.tail_rows == 0 && tiles * 3 <= SLOTS && nk >= 16) {
+        if (dev.tail_split && pl.tail_rows == 0 && tiles * ME_SMALL_SPLIT_DEN <= SLOTS && nk >= 16) {
             int s = (int)(SLOTS / tiles);
             while (s > 1 && nk / s < 8) --s;
             if (s >= 2) {
