@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_F32_TFLOPS = 157.3        # f32-input MFMA (v_mfma_f32_32x32x2_f32): the f32 vector rate, 1/16 of bf16 (same guide)
+PEAK_X3_TFLOPS = PEAK_BF16_TFLOPS / 3.0      # fp32-accurate mode: three bf16 MFMA products per fp32 product
 PEAK_HBM_TBPS = 8.0            # HBM3E (same guide)
 
 WORKLOADS = {       # name: (model, per-GPU batch, tokens)
@@ -58,6 +59,9 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16",
                     help="fp32: the reference's default arithmetic (no autocast: README.md:113-150) -- fp32 tokens, exact-fp32 MFMA GEMMs "
                          "and attention; roofline against the 157 TF f32-input MFMA peak")
+    ap.add_argument("--fp32-mode", choices=["exact", "3xbf16"], default="exact",
+                    help="with --dtype fp32: 3xbf16 = fp32-accurate arithmetic on the bf16 matrix pipe (ME_BF16X3: three bf16 products per "
+                         "Linear on hi / lo split operands, ~1e-5 relative; attention on the exact-fp32 kernels); roofline against 2500 / 3 TF")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-leg", action="store_true")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
@@ -142,8 +146,10 @@ def main():
         if p.dim() == 2:
             torch.nn.init.normal_(p, std=0.02)
     f32 = args.dtype == "fp32"
+    x3 = f32 and args.fp32_mode == "3xbf16"
     tdt = torch.float32 if f32 else torch.bfloat16
     for blk in enc:
+        blk.fp32_mode = "3xbf16" if x3 else "exact"
         blk.compute_dtype = tdt                  # fp32 master weights; bf16 MFMA compute on a bf16 token stream, or fp32 throughout
         blk.attn_fp8 = args.attn_dtype == "fp8"
         blk.chain_stats = not args.no_chain_stats
@@ -295,19 +301,23 @@ def main():
 
     def gemm_roofline(recs, wall_s, nsteps, with_wgrad):
         train_now[0] = bool(with_wgrad)
-        cdt_code = _capi.ME_F32 if f32 else _capi.ME_BF16
-        peak = PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS
+        cdt_code = _capi.ME_F32 if (f32 and not x3) else _capi.ME_BF16
+        peak = PEAK_X3_TFLOPS if x3 else (PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS)
         nt = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_NT and dt == cdt_code]
         tn = [(M_, N_, K_, ms_) for (op, dt, M_, N_, K_, ms_) in recs if op == _capi.ME_GEMM_TN and dt == cdt_code]
         if not nt:
             return None
+        if x3:      # a launch runs 3 K long rows (hi / lo planes): the ALGORITHMIC work is that of the fp32 Linear, 2 M N K
+            nt = [(m, n, k // 3, t) for m, n, k, t in nt]
         flops = sum(2.0 * m * n * k for m, n, k, _ in nt)
         ms = sum(t for *_, t in nt)
         ach = flops / (ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic("train" if with_wgrad else "fwd") if args.workload == "base" and B == 256 and not f32 else (None, None)
         esz = 4.0 if f32 else 2.0
         roof = {"bound": "mfma",
-                "kernel": ("gemm_g128_kernel<float> (exact-fp32 NT GEMM on v_mfma_f32_32x32x2_f32, 128x128 tiles: every forward + dgrad launch)" if f32 else
+                "kernel": ("gemm_g3_kernel<4> (bf16 NT MFMA GEMM over ME_BF16X3 three-plane operands, reduction 3 K, fp32 / three-plane output: every "
+                           "forward + dgrad launch; flops counted as the fp32 Linear's 2 M N K, peak = 2500 / 3 TF)" if x3 else
+                           "gemm_g128_kernel<float> (exact-fp32 NT GEMM on v_mfma_f32_32x32x2_f32, 128x128 tiles: every forward + dgrad launch)" if f32 else
                            "gemm_g3r_kernel<EPI> (bf16 NT MFMA GEMM, resident 256x256x64-tile workgroups: every forward + dgrad launch)"),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -374,11 +384,11 @@ def main():
     is_metric = args.workload == "base" and B == 256 and N == 197 and model == "base" and not f32
     what = "forward+backward+AdamW" if train else "encoder forward (no_grad)"
     out = {
-        "metric": "encoder samples/sec at B=256,N=197,C=768 (Base)" if is_metric else f"encoder samples/sec at B={B},N={N},C={C}" + (" (fp32 arithmetic)" if f32 else ""),
+        "metric": "encoder samples/sec at B=256,N=197,C=768 (Base)" if is_metric else f"encoder samples/sec at B={B},N={N},C={C}" + (" (fp32-accurate arithmetic, 3xbf16)" if x3 else " (fp32 arithmetic)" if f32 else ""),
         "value": round(value, 2), "unit": "samples/s", "n_gpus": comm_info["world"] if comm_info else world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * step_s, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if f32 else ("bf16" if args.attn_dtype == "bf16" else "bf16 (attention forward in fp8 e4m3, fp32 softmax statistics)"),
+        "dtype": "f32 as 3xbf16 (three bf16 MFMA products per Linear on hi / lo split operands, fp32 accumulate; attention, LayerNorm, GELU exact fp32)" if x3 else "f32" if f32 else ("bf16" if args.attn_dtype == "bf16" else "bf16 (attention forward in fp8 e4m3, fp32 softmax statistics)"),
         "data": "synthetic",
         "config": {"workload": ("BASELINE config 2: " if is_metric else ("BASELINE config 4 (sequence-concat): " if args.workload == "mixed" else ""))
                                + f"Meta-Transformer-{model.capitalize()} {what}, tokens [{B},{N},{C}] {'fp32' if f32 else 'bf16'} per GPU, "
@@ -391,7 +401,7 @@ def main():
                                       f"RCCL world {comm_info['world']}") if (comm_info and train) else
                                      (f"{comm_fallback}: one all_reduce(sum) per 64 MiB flat fp32 bucket from grad hooks" if (comm_fallback and train) else None)},
         "model_tflops_per_s": round(value * model_flops / 1e12, 2),
-        "mfma_frac_end_to_end": round(value * model_flops / 1e12 / ((PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS) * world), 4),
+        "mfma_frac_end_to_end": round(value * model_flops / 1e12 / ((PEAK_X3_TFLOPS if x3 else PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS) * world), 4),
         "per_rank_gemm": per_rank,
         "roofline": gemm_roofline(prof, serial_el or step_s, psteps, train),
         "other_kernels": other_kernels(prof, serial_el or step_s, psteps),
@@ -409,7 +419,7 @@ def main():
         out["fwd"] = {"what": "encoder forward alone (torch.no_grad), same tokens and weights, same K steps",
                       "ms_per_step": round(1e3 * fs, 3), "samples_per_s": round(fv, 2),
                       "model_tflops_per_s": round(fv * fwd_flops / 1e12, 2),
-                      "mfma_frac": round(fv * fwd_flops / 1e12 / ((PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS) * world), 4),
+                      "mfma_frac": round(fv * fwd_flops / 1e12 / ((PEAK_X3_TFLOPS if x3 else PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS) * world), 4),
                       "roofline": gemm_roofline(fwd_prof, fs, psteps, False),
                       "other_kernels": other_kernels(fwd_prof, fs, psteps)}
     if not args.no_cpu_baseline and world == 1:

@@ -19,8 +19,11 @@
  *     on that stream; no implicit device synchronisation.
  *   - Return value: 0 = OK, negative = error; message via me_last_error() (thread-local).
  *   - Thread-safe for distinct streams.  Process-wide state is limited to: the optional launch-timing records of
- *     me_gemm_profile_* (mutex-protected, off by default), the lazily resolved RCCL entry points (me_comm_*), and
- *     explicit handles (me_comm).  The library reads no environment variables.
+ *     me_gemm_profile_* (mutex-protected, off by default), the lazily resolved RCCL entry points (me_comm_*), explicit
+ *     handles (me_comm), per-device kernel attributes / work counters, the me_block_bwd_overlap() switch and -- for
+ *     me_block_bwd -- one library-owned side stream + five events per (device, caller stream) pair, created at first use
+ *     and kept for the life of the process (at most 64 pairs; later caller streams run the serial order).
+ *     The library reads no environment variables.
  */
 #ifndef METAENC_H
 #define METAENC_H
@@ -35,7 +38,16 @@ extern "C" {
 #define ME_ABI_VERSION 1
 
 enum { ME_F32 = 0, ME_BF16 = 1,
-       ME_F16 = 2 /* storage only: accepted by me_cast / me_transpose_cast, which convert fp16 tensors at the boundary */ };
+       ME_F16 = 2 /* storage only: accepted by me_cast / me_transpose_cast, which convert fp16 tensors at the boundary */,
+       ME_BF16X3 = 3 /* an fp32 matrix [rows, cols] held as THREE bf16 planes side by side in one row of 3 * cols bf16 values:
+                      *   left-operand order  (activations)  [ hi | lo | hi ]      hi = bf16(v), lo = bf16(v - hi)
+                      *   right-operand order (weights)      [ hi | hi | lo ]
+                      * so that an ordinary bf16 NT GEMM over the 3 * K long rows computes A_hi B_hi + A_lo B_hi + A_hi B_lo = A B to
+                      * ~2^-17 relative (the dropped lo x lo term is 2^-18) on the bf16 matrix pipe: fp32-accurate arithmetic at a
+                      * third of the bf16 rate instead of the 1/16 of the exact-fp32 MFMA.  Written by me_split3, by me_layernorm_fwd
+                      * (y_dtype) and by me_gemm (c_dtype, left-operand order: the next Linear's A operand); read by me_gemm as plain
+                      * ME_BF16 operands with K = 3 * cols.  me_block_desc.dtype = ME_BF16X3 selects this arithmetic for a whole Block
+                      * (fp32 tokens in and out).  Reference arithmetic it stands in for: the fp32 default of README.md:113-150. */ };
 
 enum { ME_OK = 0, ME_ERR_ARG = -1, ME_ERR_UNSUPPORTED = -2, ME_ERR_HIP = -3, ME_ERR_WORKSPACE = -4 };
 
@@ -216,7 +228,9 @@ int me_attention_fwd_fp8(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_
  * gamma = absent).  The *_wt pointers are the transposed [in, out] copies backward's dgrad GEMMs read (NULL is fine for
  * forward-only use).  x / y / dx / dy are [B*N, C] in res_dtype (the residual stream). */
 typedef struct me_block_desc {
-    int32_t dtype;        /* compute dtype: ME_BF16 (bf16 MFMA) or ME_F32 (exact fp32 MFMA) */
+    int32_t dtype;        /* compute dtype: ME_BF16 (bf16 MFMA), ME_F32 (exact fp32 MFMA) or ME_BF16X3 (fp32-accurate on the bf16 MFMA:
+                           * res_dtype must be ME_F32, every weight pointer is the ME_BF16X3 right-operand form of the fp32 matrix --
+                           * [out, 3 * in], and [in, 3 * out] for the *_wt copies; attention runs on the exact-fp32 kernels) */
     int32_t res_dtype;    /* dtype of x, y, dx, dy */
     int32_t B, N, C, heads, hidden;
     float eps, scale;     /* LayerNorm eps; attention scale (head_dim^-0.5 unless qk_scale was given) */
@@ -265,8 +279,9 @@ int me_block_bwd(const me_block_desc* d, const void* x, const void* dy, const vo
                  const me_block_grads* g, void* workspace, size_t workspace_bytes, void* stream);
 /* me_block_bwd issues the weight-gradient GEMMs (and their folds) on a library-owned SIDE stream, forked from / joined to `stream`
  * by events inside the call (the caller sees plain stream semantics): they fill the CUs the LayerNorm / attention backward kernels
- * and the tails of the dY -> dX chain leave idle.  On by default; off while `stream` is being captured into a hipGraph, with
- * ME_WGRAD_OVERLAP=0 in the environment, or after me_block_bwd_overlap(0).  Returns the previous setting. */
+ * and the tails of the dY -> dX chain leave idle.  On by default; off while `stream` is being captured into a hipGraph or after
+ * me_block_bwd_overlap(0).  Returns the previous setting.  dx must not alias dy or x (the side stream still reads dy while the
+ * last LayerNorm backward writes dx). */
 int me_block_bwd_overlap(int enable);
 
 /* The whole encoder, inference: y = Block_{n-1}(... Block_0(x)) -- nn.Sequential(*[Block] * L)(x) of README.md:124-149 as
@@ -278,6 +293,10 @@ int me_encoder_fwd(const me_block_desc* blocks, int n_blocks, const void* x, voi
 /* ------------------------------------------------------------------ element-wise helpers */
 /* dst = (dst_dtype) src, n elements */
 int me_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* fp32 [rows, cols] (row stride ld_src elements) -> ME_BF16X3 [rows, 3 * cols] bf16 (dense): right_operand = 0 writes [hi | lo | hi]
+ * (activations / gradients: the A operand of an NT GEMM, and -- plane by plane -- both operands of a TN weight-gradient GEMM),
+ * right_operand = 1 writes [hi | hi | lo] (weights: the B operand).  cols % 4 == 0. */
+int me_split3(const float* src, int64_t ld_src, void* dst, int64_t rows, int64_t cols, int right_operand, void* stream);
 /* dst[c, r] = (dst_dtype) src[r, c]  (weight repack for dgrad: W[out,in] -> W^T[in,out]) */
 int me_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
                       int64_t rows, int64_t cols, void* stream);

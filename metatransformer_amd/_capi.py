@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmetaenc.so")
 
 ME_F32, ME_BF16, ME_F16 = 0, 1, 2      # ME_F16: storage dtype of me_cast / me_transpose_cast only
+ME_BF16X3 = 3                          # an fp32 matrix as three bf16 planes [hi | lo | hi] / [hi | hi | lo] (include/metaenc.h)
 ME_GEMM_NT, ME_GEMM_TN = 0, 1
 ME_ACT_NONE, ME_ACT_GELU = 0, 1
 ME_GEMM_SAVE_GELU_GRAD, ME_GEMM_AUX_IS_FACTOR = 1, 2
@@ -148,6 +149,7 @@ SIGNATURES = {
                              c_size_t, c_void_p]),
     "me_block_bwd_overlap": (c_int, [c_int]),
     "me_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "me_split3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "me_transpose_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "me_transpose_cast_batched": (c_int, [POINTER(TcBatch), c_void_p]),
     "me_add_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
@@ -203,6 +205,10 @@ def load() -> ctypes.CDLL:
         fn.argtypes = args
     if lib.me_abi_version() != 1:
         raise MetaEncError(f"libmetaenc.so ABI version {lib.me_abi_version()} != 1; rebuild it")
+    # profiling scripts switch the weight-gradient side stream off from outside (tools/prof_round.sh: kernels that share the chip
+    # have no duration of their own).  The library reads no environment: the host does, and uses the ABI call.
+    if os.environ.get("ME_WGRAD_OVERLAP", "1") == "0":
+        lib.me_block_bwd_overlap(0)
     _lib = lib
     return lib
 

@@ -16,23 +16,17 @@ namespace {
 // backward passes and the attention backward per block: ~300 of ~2 500 us): the side stream's wgrad workgroups take the CUs those
 // kernels and the tails of the resident launches leave idle (train step -2.2 % same box; bit-identical gradients).  One side stream + fork / join events per main stream
 // and device, created at first use; the call joins before it returns (the caller sees ordinary stream semantics, and the shared
-// backward workspace may be reused by the next call).  Off: me_block_bwd_overlap(0) or ME_WGRAD_OVERLAP=0; always off while the
+// backward workspace may be reused by the next call).  Off: me_block_bwd_overlap(0); always off while the
 // main stream is being captured into a hipGraph.
 struct SideCtx {
     hipStream_t side = nullptr;
     hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join = nullptr;
     bool failed = false;
 };
-std::atomic<int> g_wgrad_overlap{-1};      // -1: not decided yet (environment), 0 / 1
-bool wgrad_overlap_on() {
-    int v = g_wgrad_overlap.load();
-    if (v < 0) {
-        const char* e = getenv("ME_WGRAD_OVERLAP");
-        v = (e && e[0] == '0') ? 0 : 1;
-        g_wgrad_overlap.store(v);
-    }
-    return v != 0;
-}
+std::atomic<int> g_wgrad_overlap{1};       // me_block_bwd_overlap(); the library itself reads no environment (the Python package maps
+                                           // ME_WGRAD_OVERLAP=0 onto that call at import, for the profiling scripts)
+bool wgrad_overlap_on() { return g_wgrad_overlap.load() != 0; }
+constexpr size_t kMaxSideCtx = 64;         // (device, caller stream) pairs that get a side stream; later ones run in serial order
 SideCtx* side_ctx(hipStream_t main) {
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, SideCtx> ctxs;
@@ -41,12 +35,20 @@ SideCtx* side_ctx(hipStream_t main) {
     int dev = 0;
     if (hipStreamGetDevice(main, &dev) != hipSuccess) (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
+    // one side stream + five events per (device, caller stream), kept for the life of the process: bounded, so that a host that
+    // creates streams without end does not leak through here
+    if (ctxs.size() >= kMaxSideCtx && ctxs.find(std::make_pair(dev, main)) == ctxs.end()) return nullptr;
     SideCtx& c = ctxs[std::make_pair(dev, main)];
     if (c.failed) return nullptr;
     if (!c.side) {
+        // streams and events belong to the device that is current when they are created: make that the caller stream's device
+        int cur = dev;
+        (void)hipGetDevice(&cur);
+        if (cur != dev && hipSetDevice(dev) != hipSuccess) { c.failed = true; return nullptr; }
         bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess;      // (a higher / lower stream priority measured no different)
         for (int i = 0; ok && i < 4; ++i) ok = hipEventCreateWithFlags(&c.fork[i], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c.join, hipEventDisableTiming) == hipSuccess;
+        if (cur != dev) (void)hipSetDevice(cur);
         if (!ok) { c.failed = true; c.side = nullptr; return nullptr; }
     }
     return &c;
@@ -61,12 +63,12 @@ struct Dims {
 };
 int get_dims(const me_block_desc* d, Dims& s, const char* fn) {
     ME_CHECK_ARG(d != nullptr, "%s: null descriptor", fn);
-    ME_CHECK_ARG(me_dtype_ok(d->dtype) && me_dtype_ok(d->res_dtype), "%s: bad dtype", fn);
+    ME_CHECK_ARG((me_dtype_ok(d->dtype) || d->dtype == ME_BF16X3) && me_dtype_ok(d->res_dtype), "%s: bad dtype", fn);
     ME_CHECK_ARG(d->B > 0 && d->N > 0 && d->C > 0 && d->heads > 0 && d->hidden > 0 && d->C % d->heads == 0,
                  "%s: bad shape B=%d N=%d C=%d heads=%d hidden=%d", fn, d->B, d->N, d->C, d->heads, d->hidden);
     s.M = (int64_t)d->B * d->N;
     s.C = d->C; s.C3 = 3 * d->C; s.Hd = d->hidden; s.hd = d->C / d->heads;
-    s.esz = me_dtype_size(d->dtype); s.rsz = me_dtype_size(d->res_dtype);
+    s.esz = d->dtype == ME_BF16X3 ? 6 : me_dtype_size(d->dtype); s.rsz = me_dtype_size(d->res_dtype);
     return ME_OK;
 }
 
@@ -138,7 +140,7 @@ size_t aux_scratch(const Dims& s) {      // LayerNorm-backward and column-sum sc
 
 // ---- folded inference: LayerNorm statistics taken from the residual GEMMs' epilogues (me_gemm_desc.row_stats)
 bool wants_fold(const me_block_desc* d) {
-    return d->qkv_wf && d->fc1_wf && d->qkv_s && d->qkv_c && d->fc1_s && d->fc1_c && d->res_dtype == d->dtype;
+    return d->dtype != ME_BF16X3 && d->qkv_wf && d->fc1_wf && d->qkv_s && d->qkv_c && d->fc1_s && d->fc1_c && d->res_dtype == d->dtype;
 }
 // scratch behind the inference intermediates: the [C / 64][M] partials (shared by proj and fc2) + two [M][2] pair buffers that
 // me_encoder_fwd hands from block to block
@@ -158,23 +160,199 @@ bool emits_stats(const me_block_desc* d, const Dims& s) {
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// ME_BF16X3 blocks: the reference's DEFAULT arithmetic (fp32 tokens, fp32 weights: README.md:113-150) at matrix-pipe speed.  Every
+// Linear runs as ONE bf16 NT GEMM over three-plane operands (include/metaenc.h, ME_BF16X3: A = [hi | lo | hi], W = [hi | hi | lo],
+// reduction length 3 K), i.e. A_hi W_hi + A_lo W_hi + A_hi W_lo with fp32 accumulation: ~2^-17 relative, against 2^-9 for plain
+// bf16 operands and at 3x the bf16 flops instead of the 16x of the exact-fp32 MFMA.  The producers write the three planes
+// themselves (LayerNorm, the fc1 epilogue) or one split pass follows them (attention output, incoming gradients); LayerNorm,
+// softmax, GELU (erf form), residual stream and every accumulator stay fp32; attention runs on the exact-fp32 kernels.
+// Weight gradients: dW = dY^T X as three TN launches on the planes (hi,hi) + (lo,hi) + (hi,lo), accumulated by beta = 1.
+struct SavedX3 {
+    char *xn1, *qkv, *o, *o3, *x1, *xn2, *hpre, *a;      // xn1 / o3 / xn2 [M, 3C] bf16, a [M, 3 Hd] bf16; qkv / o / x1 / hpre (= gelu') fp32
+    float *mean1, *rstd1, *mean2, *rstd2, *lse;
+    size_t bytes;
+};
+SavedX3 carve_saved_x3(const me_block_desc* d, const Dims& s, void* base) {
+    SavedX3 v;
+    size_t off = 0;
+    char* b = reinterpret_cast<char*>(base);
+    auto take = [&](size_t n) { char* p = b + off; off += align256(n); return p; };
+    v.xn1 = take(s.M * s.C * 6);
+    v.qkv = take(s.M * s.C3 * 4);
+    v.o = take(s.M * s.C * 4);
+    v.o3 = take(s.M * s.C * 6);
+    v.x1 = take(s.M * s.C * 4);
+    v.xn2 = take(s.M * s.C * 6);
+    v.hpre = take(s.M * s.Hd * 4);
+    v.a = take(s.M * s.Hd * 6);
+    v.mean1 = reinterpret_cast<float*>(take(s.M * 4));
+    v.rstd1 = reinterpret_cast<float*>(take(s.M * 4));
+    v.mean2 = reinterpret_cast<float*>(take(s.M * 4));
+    v.rstd2 = reinterpret_cast<float*>(take(s.M * 4));
+    v.lse = reinterpret_cast<float*>(take((size_t)d->B * d->heads * d->N * 4));
+    v.bytes = off;
+    return v;
+}
+size_t gemm_scratch_x3(const Dims& s, bool backward) {
+    size_t w = 0;
+    me_gemm_desc g;
+    static char dummy_mem[64] __attribute__((aligned(64)));
+    auto probe = [&](int op, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int cdt) {
+        gemm_desc(g, op, ME_BF16, M, N, K, dummy_mem, lda, dummy_mem, ldb, dummy_mem, cdt == ME_BF16X3 ? 3 * N : N, cdt);
+        const size_t b = me_gemm_workspace_bytes(&g);
+        if (b > w) w = b;
+    };
+    probe(ME_GEMM_NT, s.M, s.C3, 3 * s.C, 3 * s.C, 3 * s.C, ME_F32);
+    probe(ME_GEMM_NT, s.M, s.C, 3 * s.C, 3 * s.C, 3 * s.C, ME_F32);
+    probe(ME_GEMM_NT, s.M, s.Hd, 3 * s.C, 3 * s.C, 3 * s.C, ME_BF16X3);
+    probe(ME_GEMM_NT, s.M, s.C, 3 * s.Hd, 3 * s.Hd, 3 * s.Hd, ME_F32);
+    if (backward) {
+        probe(ME_GEMM_NT, s.M, s.Hd, 3 * s.C, 3 * s.C, 3 * s.C, ME_BF16X3);       // dh (x gelu') -> three planes
+        probe(ME_GEMM_NT, s.M, s.C, 3 * s.C3, 3 * s.C3, 3 * s.C3, ME_F32);        // dxn1
+        probe(ME_GEMM_TN, s.C3, s.C, s.M, 3 * s.C3, 3 * s.C, ME_F32);
+        probe(ME_GEMM_TN, s.C, s.C, s.M, 3 * s.C, 3 * s.C, ME_F32);
+        probe(ME_GEMM_TN, s.Hd, s.C, s.M, 3 * s.Hd, 3 * s.C, ME_F32);
+        probe(ME_GEMM_TN, s.C, s.Hd, s.M, 3 * s.C, 3 * s.Hd, ME_F32);
+    }
+    return align256(w);
+}
+size_t bwd_scratch_x3(const me_block_desc* d, const Dims& s) {
+    // dy3, dh3, dxn (fp32), dx1 (fp32), dx1_3, dout (fp32), dqkv (fp32), dqkv3, delta, LayerNorm partials
+    return align256(s.M * s.C * 6) * 2 + align256(s.M * s.Hd * 6) + align256(s.M * s.C * 4) * 3 + align256(s.M * s.C3 * 4) +
+           align256(s.M * s.C3 * 6) + align256((size_t)d->B * d->heads * d->N * 4) + align256(me_layernorm_bwd_workspace(s.C));
+}
+
+int block_fwd_x3(const me_block_desc* d, const Dims& s, const void* x, void* y, void* saved, void* workspace, void* stream) {
+    ME_CHECK_ARG(d->res_dtype == ME_F32, "me_block_fwd: ME_BF16X3 blocks run on an fp32 token stream (res_dtype = ME_F32)");
+    ME_CHECK_ARG(s.C % 256 == 0 && s.Hd % 256 == 0, "me_block_fwd: ME_BF16X3 needs C and hidden to be multiples of 256");
+    char* ws = reinterpret_cast<char*>(workspace);
+    const size_t gsz = gemm_scratch_x3(s, false);
+    const bool keep = saved != nullptr;
+    SavedX3 v = carve_saved_x3(d, s, keep ? saved : ws + gsz);
+    me_gemm_desc g;
+    int rc;
+    auto run = [&](me_gemm_desc& q) { q.workspace = ws; q.workspace_bytes = (int64_t)gsz; return me_gemm(&q, stream); };
+    const int64_t C = s.C, Hd = s.Hd;
+    if ((rc = me_layernorm_fwd(x, ME_F32, d->ln1_g, d->ln1_b, v.xn1, ME_BF16X3, keep ? v.mean1 : nullptr, keep ? v.rstd1 : nullptr, s.M, s.C, d->eps, stream))) return rc;
+    gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, s.C3, 3 * C, v.xn1, 3 * C, d->qkv_w, 3 * C, v.qkv, s.C3, ME_F32);
+    g.bias = d->qkv_b;
+    if ((rc = run(g))) return rc;
+    if ((rc = me_attention_fwd(v.qkv, s.C3, v.o, s.C, keep ? v.lse : nullptr, d->B, d->N, d->heads, s.hd, d->scale, ME_F32, 0.f, 0, stream))) return rc;
+    if ((rc = me_split3(reinterpret_cast<const float*>(v.o), C, v.o3, s.M, C, 0, stream))) return rc;
+    gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, C, 3 * C, v.o3, 3 * C, d->proj_w, 3 * C, v.x1, C, ME_F32);
+    g.bias = d->proj_b; g.colscale = d->gamma1; g.residual = x; g.ldres = C; g.res_dtype = ME_F32;
+    if ((rc = run(g))) return rc;
+    if ((rc = me_layernorm_fwd(v.x1, ME_F32, d->ln2_g, d->ln2_b, v.xn2, ME_BF16X3, keep ? v.mean2 : nullptr, keep ? v.rstd2 : nullptr, s.M, s.C, d->eps, stream))) return rc;
+    gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, Hd, 3 * C, v.xn2, 3 * C, d->fc1_w, 3 * C, v.a, 3 * Hd, ME_BF16X3);
+    g.bias = d->fc1_b; g.act = ME_ACT_GELU;
+    if (keep) { g.preact = v.hpre; g.ldpre = Hd; g.preact_dtype = ME_F32; g.flags = ME_GEMM_SAVE_GELU_GRAD; }
+    if ((rc = run(g))) return rc;
+    gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, C, 3 * Hd, v.a, 3 * Hd, d->fc2_w, 3 * Hd, y, C, ME_F32);
+    g.bias = d->fc2_b; g.colscale = d->gamma2; g.residual = v.x1; g.ldres = C; g.res_dtype = ME_F32;
+    return run(g);
+}
+
+int block_bwd_x3(const me_block_desc* d, const Dims& s, const void* x, const void* dy, const void* saved, void* dx,
+                 const me_block_grads* gr, void* workspace, void* stream) {
+    ME_CHECK_ARG(d->res_dtype == ME_F32, "me_block_bwd: ME_BF16X3 blocks run on an fp32 token stream");
+    const SavedX3 v = carve_saved_x3(d, s, const_cast<void*>(saved));
+    char* ws = reinterpret_cast<char*>(workspace);
+    size_t off = 0;
+    auto take = [&](size_t n) { char* p = ws + off; off += align256(n); return p; };
+    const size_t gsz = gemm_scratch_x3(s, true);
+    void* gws = take(gsz);
+    void* aws = take(aux_scratch(s));
+    const int64_t C = s.C, C3 = s.C3, Hd = s.Hd;
+    uint16_t* dy3 = reinterpret_cast<uint16_t*>(take(s.M * C * 6));
+    uint16_t* dh3 = reinterpret_cast<uint16_t*>(take(s.M * Hd * 6));
+    float* dxn = reinterpret_cast<float*>(take(s.M * C * 4));
+    float* dx1 = reinterpret_cast<float*>(take(s.M * C * 4));
+    uint16_t* dx1_3 = reinterpret_cast<uint16_t*>(take(s.M * C * 6));
+    float* dout = reinterpret_cast<float*>(take(s.M * C * 4));
+    float* dqkv = reinterpret_cast<float*>(take(s.M * C3 * 4));
+    uint16_t* dqkv3 = reinterpret_cast<uint16_t*>(take(s.M * C3 * 6));
+    float* delta = reinterpret_cast<float*>(take((size_t)d->B * d->heads * d->N * 4));
+    void* ln2_ws = take(me_layernorm_bwd_workspace(s.C));
+    me_ln_fold_set folds[2];
+    me_gemm_desc g;
+    int rc;
+    // dX-side GEMM: C[M, N] = A3[M, 3K] W3t[N, 3K]^T
+    auto nt = [&](const void* A3, int64_t K, const void* Wt3, void* Cout, int64_t N, int cdt, const void* factor) -> int {
+        gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, N, 3 * K, A3, 3 * K, Wt3, 3 * K, Cout, cdt == ME_BF16X3 ? 3 * N : N, cdt);
+        if (factor) { g.aux = factor; g.ldaux = N; g.aux_dtype = ME_F32; g.flags = ME_GEMM_AUX_IS_FACTOR; }
+        g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+        return me_gemm(&g, stream);
+    };
+    // dW[n_out, n_in] = dOut^T In from the planes of both: (hi, hi) + (lo, hi) + (hi, lo)
+    auto wgrad = [&](const uint16_t* dOut3, int64_t n_out, const void* In3_, int64_t n_in, void* dW) -> int {
+        if (!dW) return ME_OK;
+        const uint16_t* In3 = reinterpret_cast<const uint16_t*>(In3_);
+        const int64_t pa[3] = {0, n_out, 0}, pb[3] = {0, 0, n_in};
+        for (int t = 0; t < 3; ++t) {
+            gemm_desc(g, ME_GEMM_TN, ME_BF16, n_out, n_in, s.M, dOut3 + pa[t], 3 * n_out, In3 + pb[t], 3 * n_in, dW, n_in, gr->w_dtype);
+            g.beta = (t == 0 && !gr->accumulate) ? 0.0f : 1.0f;
+            g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+            const int r = me_gemm(&g, stream);
+            if (r) return r;
+        }
+        return ME_OK;
+    };
+    auto bias_grad = [&](const void* g32, int64_t n, float* dB) -> int {
+        return dB ? me_colsum(g32, ME_F32, n, s.M, n, dB, gr->accumulate, aws, stream) : ME_OK;
+    };
+    // ---- MLP branch
+    if ((rc = me_split3(reinterpret_cast<const float*>(dy), C, dy3, s.M, C, 0, stream))) return rc;
+    if ((rc = wgrad(dy3, C, v.a, Hd, gr->fc2_w))) return rc;
+    if ((rc = bias_grad(dy, C, gr->fc2_b))) return rc;
+    if ((rc = nt(dy3, C, d->fc2_wt, dh3, Hd, ME_BF16X3, v.hpre))) return rc;                  // dA * gelu'(h), three planes
+    if ((rc = wgrad(dh3, Hd, v.xn2, C, gr->fc1_w))) return rc;
+    if (gr->fc1_b) {      // dh exists as planes only: column sums of hi, then of lo on top (2^-17 relative, as the planes themselves)
+        if ((rc = me_colsum(dh3, ME_BF16, 3 * Hd, s.M, Hd, gr->fc1_b, gr->accumulate, aws, stream))) return rc;
+        if ((rc = me_colsum(dh3 + Hd, ME_BF16, 3 * Hd, s.M, Hd, gr->fc1_b, 1, aws, stream))) return rc;
+    }
+    if ((rc = nt(dh3, Hd, d->fc1_wt, dxn, C, ME_F32, nullptr))) return rc;
+    rc = me_ln_bwd_deferred(dxn, ME_F32, v.x1, ME_F32, v.mean2, v.rstd2, d->ln2_g, dy, ME_F32, dx1, ME_F32, gr->ln2_g, gr->ln2_b, gr->accumulate,
+                            s.M, s.C, ln2_ws, stream, &folds[0]);
+    if (rc) return rc;
+    // ---- attention branch
+    if ((rc = me_split3(dx1, C, dx1_3, s.M, C, 0, stream))) return rc;
+    if ((rc = wgrad(dx1_3, C, v.o3, C, gr->proj_w))) return rc;
+    if ((rc = bias_grad(dx1, C, gr->proj_b))) return rc;
+    if ((rc = nt(dx1_3, C, d->proj_wt, dout, C, ME_F32, nullptr))) return rc;
+    rc = me_attention_bwd(v.qkv, C3, v.o, C, dout, C, v.lse, delta, dqkv, C3, d->B, d->N, d->heads, s.hd, d->scale, ME_F32, 0.f, 0, stream);
+    if (rc) return rc;
+    if ((rc = me_split3(dqkv, C3, dqkv3, s.M, C3, 0, stream))) return rc;
+    if ((rc = wgrad(dqkv3, C3, v.xn1, C, gr->qkv_w))) return rc;
+    if ((rc = bias_grad(dqkv, C3, gr->qkv_b))) return rc;
+    if ((rc = nt(dqkv3, C3, d->qkv_wt, dxn, C, ME_F32, nullptr))) return rc;
+    rc = me_ln_bwd_deferred(dxn, ME_F32, x, ME_F32, v.mean1, v.rstd1, d->ln1_g, dx1, ME_F32, dx, ME_F32, gr->ln1_g, gr->ln1_b, gr->accumulate,
+                            s.M, s.C, aws, stream, &folds[1]);
+    if (rc) return rc;
+    return me_ln_bwd_fold_sets(folds, 2, s.C, stream);
+}
+
 }  // namespace
 
 extern "C" size_t me_block_saved_bytes(const me_block_desc* d) {
     Dims s;
     if (get_dims(d, s, "me_block_saved_bytes") != ME_OK) return 0;
+    if (d->dtype == ME_BF16X3) return carve_saved_x3(d, s, nullptr).bytes;
     return carve_saved(d, s, nullptr).bytes;
 }
 
 extern "C" int me_block_emits_stats(const me_block_desc* d) {
     Dims s;
-    if (get_dims(d, s, "me_block_emits_stats") != ME_OK) return 0;
+    if (get_dims(d, s, "me_block_emits_stats") != ME_OK || d->dtype == ME_BF16X3) return 0;
     return emits_stats(d, s) ? 1 : 0;
 }
 
 extern "C" size_t me_block_workspace_bytes(const me_block_desc* d, int backward) {
     Dims s;
     if (get_dims(d, s, "me_block_workspace_bytes") != ME_OK) return 0;
+    if (d->dtype == ME_BF16X3)
+        return backward ? gemm_scratch_x3(s, true) + aux_scratch(s) + bwd_scratch_x3(d, s)
+                        : gemm_scratch_x3(s, false) + carve_saved_x3(d, s, nullptr).bytes;
     size_t w = gemm_scratch(d, s, backward != 0) + aux_scratch(s);
     if (!backward) return w + carve_saved(d, s, nullptr).bytes + stats_scratch(s);      // inference keeps the intermediates here
     // dy_c, dh, dxn (shared by dxn2 / dxn1), dx1, dx1_c, do, dqkv, delta
@@ -194,6 +372,7 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
                  "me_block_fwd: missing parameter");
     ME_CHECK_ARG(s.M * 2 * 4 <= 2 * (int64_t)align256(s.M * 4), "me_block_fwd: stash layout");
     ME_CHECK_ARG(workspace_bytes >= me_block_workspace_bytes(d, 0), "me_block_fwd: workspace too small");
+    if (d->dtype == ME_BF16X3) return block_fwd_x3(d, s, x, y, saved, workspace, stream);
     char* ws = reinterpret_cast<char*>(workspace);
     const size_t gsz = gemm_scratch(d, s, false);
     void* gws = ws;
@@ -266,10 +445,13 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
     int rc = get_dims(d, s, "me_block_bwd");
     if (rc) return rc;
     ME_CHECK_ARG(x && dy && saved && dx && gr && workspace, "me_block_bwd: null pointer");
+    // (the fc2 weight gradient reads dy on the side stream while the last LayerNorm backward writes dx on `stream`)
+    ME_CHECK_ARG(dx != dy && dx != x, "me_block_bwd: dx must not alias dy or x");
     ME_CHECK_ARG(d->qkv_wt && d->proj_wt && d->fc1_wt && d->fc2_wt && d->ln1_g && d->ln2_g, "me_block_bwd: missing parameter");
     ME_CHECK_ARG(!d->gamma1 && !d->gamma2, "me_block_bwd: layer-scale backward is composed by the host (needs the unscaled branch outputs)");
     ME_CHECK_ARG(me_dtype_ok(gr->w_dtype), "me_block_bwd: bad gradient dtype");
     ME_CHECK_ARG(workspace_bytes >= me_block_workspace_bytes(d, 1), "me_block_bwd: workspace too small");
+    if (d->dtype == ME_BF16X3) return block_bwd_x3(d, s, x, dy, saved, dx, gr, workspace, stream);
     const Saved v = carve_saved(d, s, const_cast<void*>(saved));
     const int dt = d->dtype, rdt = d->res_dtype;
     char* ws = reinterpret_cast<char*>(workspace);
@@ -371,7 +553,7 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
     return join(me_ln_bwd_fold_sets(folds, 2, s.C, stream));      // dgamma / dbeta of both LayerNorms: one launch
 }
 
-// process-wide switch for the side stream of me_block_bwd (default on; ME_WGRAD_OVERLAP=0 in the environment turns it off);
+// process-wide switch for the side stream of me_block_bwd (default on);
 // returns the previous setting
 extern "C" int me_block_bwd_overlap(int enable) {
     const int prev = wgrad_overlap_on() ? 1 : 0;
@@ -397,8 +579,12 @@ extern "C" int me_encoder_fwd(const me_block_desc* blocks, int n_blocks, const v
         if (rc) return rc;
         d.x_stats = st_in;
         d.y_stats = nullptr;
-        const bool chain = i + 1 < n_blocks && emits_stats(&d, s) && wants_fold(&blocks[i + 1]) && blocks[i + 1].C == d.C &&
-                           blocks[i + 1].B == d.B && blocks[i + 1].N == d.N && blocks[i + 1].eps == d.eps &&
+        // (the pair buffers sit at the end of THIS block's workspace layout: the next block may read them only if its own layout
+        //  is the same one -- same widths, heads and dtypes -- or its larger intermediates would overlap them)
+        const me_block_desc& nx = blocks[i + 1 < n_blocks ? i + 1 : i];
+        const bool chain = i + 1 < n_blocks && emits_stats(&d, s) && wants_fold(&nx) && nx.C == d.C && nx.B == d.B && nx.N == d.N &&
+                           nx.eps == d.eps && nx.hidden == d.hidden && nx.heads == d.heads && nx.dtype == d.dtype &&
+                           nx.res_dtype == d.res_dtype && me_block_workspace_bytes(&nx, 0) == me_block_workspace_bytes(&d, 0) &&
                            workspace_bytes >= me_block_workspace_bytes(&d, 0);
         if (chain) {
             char* tail = reinterpret_cast<char*>(workspace) + me_block_workspace_bytes(&d, 0) - 2 * align256((size_t)s.M * 8);

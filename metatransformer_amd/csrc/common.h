@@ -82,6 +82,7 @@ struct ProfScope {
 static inline size_t me_dtype_size(int dt) { return dt == ME_F32 ? 4 : 2; }
 static inline bool me_dtype_ok(int dt) { return dt == ME_F32 || dt == ME_BF16; }                    // compute dtypes
 static inline bool me_storage_dtype_ok(int dt) { return me_dtype_ok(dt) || dt == ME_F16; }          // me_cast only
+static inline bool me_out_dtype_ok(int dt) { return me_dtype_ok(dt) || dt == ME_BF16X3; }           // me_gemm C / me_layernorm_fwd y
 
 // ---- LayerNorm backward with the dgamma / dbeta fold deferred (layernorm.hip; me_block_bwd folds both LayerNorms of a block in one launch)
 constexpr int LN_FOLD_SETS = 4;
@@ -128,6 +129,20 @@ __device__ __forceinline__ void store4_from_f32(void* base, int dt, int64_t idx,
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
     }
 }
+// ME_BF16X3 (include/metaenc.h): four consecutive columns c..c+3 of a row of `cols` fp32 values, stored into the row's three bf16
+// planes (row = first bf16 of the 3 * cols long row).  Left-operand order [hi | lo | hi], right-operand order [hi | hi | lo].
+__device__ __forceinline__ void store4_split3(uint16_t* row, int64_t cols, int64_t c, f32x4 v, bool right_operand = false) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (bf16_t)v[e];
+        l[e] = (bf16_t)(v[e] - (float)h[e]);          // exact difference (hi carries the top 8 bits of v), then 8 more bits
+    }
+    *reinterpret_cast<bf16x4*>(row + c) = h;
+    *reinterpret_cast<bf16x4*>(row + cols + c) = right_operand ? h : l;
+    *reinterpret_cast<bf16x4*>(row + 2 * cols + c) = right_operand ? l : h;
+}
+
 __device__ __forceinline__ float load1_as_f32(const void* base, int dt, int64_t idx) {
     if (dt == ME_BF16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(base)[idx]);
     return reinterpret_cast<const float*>(base)[idx];

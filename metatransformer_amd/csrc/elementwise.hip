@@ -40,6 +40,16 @@ __global__ __launch_bounds__(EW_THREADS) void cast_kernel(const void* __restrict
     }
 }
 
+// fp32 [rows, cols] -> ME_BF16X3 [rows, 3 * cols]: one read of the fp32 values, three bf16 plane stores (6 bytes per element)
+__global__ __launch_bounds__(EW_THREADS) void split3_kernel(const float* __restrict__ src, int64_t ld_src, uint16_t* __restrict__ dst,
+                                                            int64_t rows, int64_t cols, int right_operand) {
+    const int64_t q = cols / 4, n4 = rows * q;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t r = i / q, c = (i - r * q) * 4;
+        store4_split3(dst + r * 3 * cols, cols, c, *reinterpret_cast<const f32x4*>(src + r * ld_src + c), right_operand != 0);
+    }
+}
+
 // dst[c, r] = src[r, c]; 64x64 tiles through LDS (padded), coalesced on both sides
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const void* __restrict__ src, int sdt, void* __restrict__ dst,
                                                              int ddt, int64_t rows, int64_t cols) {
@@ -831,6 +841,17 @@ extern "C" int me_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
     }
     hipLaunchKernelGGL(cast_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(EW_THREADS), 0, stream, src, src_dtype, dst, dst_dtype, n);
     ME_CHECK_LAUNCH("me_cast");
+    return ME_OK;
+}
+
+extern "C" int me_split3(const float* src, int64_t ld_src, void* dst, int64_t rows, int64_t cols, int right_operand, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(src && dst && rows >= 0 && cols > 0 && cols % 4 == 0 && ld_src >= cols && ld_src % 4 == 0, "me_split3: bad args");
+    ME_CHECK_ARG(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 8 == 0), "me_split3: src must be 16-byte, dst 8-byte aligned");
+    if (rows == 0) return ME_OK;
+    hipLaunchKernelGGL(split3_kernel, dim3(ew_blocks(rows * (cols / 4))), dim3(EW_THREADS), 0, stream, src, ld_src,
+                       reinterpret_cast<uint16_t*>(dst), rows, cols, right_operand);
+    ME_CHECK_LAUNCH("me_split3");
     return ME_OK;
 }
 

@@ -359,7 +359,8 @@ static void launch_splitk_reduce(const GemmParams& p, unsigned /*nb*/, hipStream
     const dim3 grid(gx, (unsigned)gy);
 #define ME_FOLD(BIAS, RES, CST, ACT, CS) \
     do { hipLaunchKernelGGL((splitk_fold_kernel<BIAS, RES, CST, ACT, CS>), grid, dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride); return; } while (0)
-    const bool simple = !p.preact && !p.aux && !p.row_affine && !p.colscale && !p.flags && p.res_row_mod == 0 && p.out_group_rows == 0;
+    const bool simple = !p.preact && !p.aux && !p.row_affine && !p.colscale && !p.flags && p.res_row_mod == 0 && p.out_group_rows == 0 &&
+                        p.c_dtype != ME_BF16X3;
     const int res = !p.residual ? 0 : (p.res_dtype == ME_BF16 ? 1 : 2);
     if (simple) {
         const bool bias = p.bias != nullptr, gelu = p.act == ME_ACT_GELU;
@@ -430,6 +431,22 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
     if (ffam < 0 && (d->M < 128 || d->N < 128)) return pl;       // tiny problems: g128 is enough
     pl.family = fam;
     pl.bm = fam == 2 ? 128 : 256;
+    if (kMeDev && fam == 2 && fbn == 64 && d->op == ME_GEMM_NT) pl.bm = 64;      // dev A/B: the 64-row small-M form
+    // Small / mid-size NT problems (fewer than half a chip of 256 x 256 tiles: the reference's own batches, B = 32 x 96 .. 257
+    // tokens, and B = 1 .. 32 inference): pick the TILE so that the launch has enough workgroups for the chip WITHOUT a K split --
+    // the largest of 128 x 256 / 128 x 128 / 64 x 128 that still gives >= 140 tiles, else the smallest.  Measured on M = 197 ..
+    // 6 304 (profiles/r05_small_gemm_plans.txt): 1.2 .. 4x faster per launch than the round-4 plans (256-wide tiles + whole-problem
+    // split-K + fold), e.g. M = 3 072: qkv 36 -> 19 us, proj 23 -> 11 us, fc2 41 -> 31 us; M = 197: fc1 41 -> 10 us.
+    bool small_nt = false;
+    if (ffam < 0 && fam != 4 && d->op == ME_GEMM_NT && d->N % 128 == 0) {
+        fam = 2; pl.family = 2; small_nt = true;
+        const int64_t tm128 = (d->M + 127) / 128, tm64 = (d->M + 63) / 64;
+        const int64_t c256 = tm128 * ((d->N + 255) / 256), c128 = tm128 * (d->N / 128), c64 = tm64 * (d->N / 128);
+        (void)c64;
+        if (c256 >= 140 && d->N % 256 == 0) { pl.bm = 128; pl.bn = 256; }
+        else if (c128 >= 140) { pl.bm = 128; pl.bn = 128; }
+        else { pl.bm = 64; pl.bn = 128; }
+    }
     pl.kstep = 32;
     const int64_t tm = (d->M + pl.bm - 1) / pl.bm;
     const int64_t t256 = tm * ((d->N + 255) / 256), t128 = tm * ((d->N + 127) / 128);
@@ -451,7 +468,9 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         pl.ws_bytes = (size_t)pl.split_k * (size_t)g3_tn_slab_stride(d->M, d->N) * sizeof(float);
         if (d->colsum_a)                  // partial column sums of A: one [M] row per (split, N-tile)
             pl.ws_bytes += (size_t)pl.split_k * (size_t)((d->N + 255) / 256) * (size_t)d->M * sizeof(float);
+#if G3_TN_FOLD
         pl.ws_bytes += 256 + (size_t)((d->M + 255) / 256) * sizeof(unsigned);      // tile-row counters of the in-kernel fold (behind the rest, 256-byte aligned)
+#endif
     } else if (d->op == ME_GEMM_TN) {
         pl.bn = fbn ? fbn : ((d->N % 256 == 0 || d->N > 512) ? 256 : 128);
         const int64_t tiles = pl.bn == 256 ? t256 : t128;
@@ -468,7 +487,8 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         }
     } else {
         if (fam >= 3) pl.bn = 256;
-        else if (fbn) pl.bn = fbn;
+        else if (fbn) pl.bn = fbn == 64 ? 128 : fbn;
+        else if (small_nt) {}                                    // (chosen above)
         else pl.bn = d->N > 128 ? 256 : 128;                     // measured: g2b_256 beats g2b_128 on every encoder shape
         pl.ksteps_per_split = nk;
         if (fam == 4) {
@@ -531,7 +551,8 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         // Small problems (small-batch inference: M = B * N rows with B = 1..32): fewer tiles than a third of the chip's
         // workgroup slots means the launch is pure latency -- one workgroup walks the whole reduction while 2/3 of the CUs
         // idle.  The WHOLE problem then runs split over the reduction (same slabs + fold as the tail split, m_main = 0).
-        if (dev.tail_split && pl.tail_rows == 0 && tiles * ME_SMALL_SPLIT_DEN <= SLOTS && nk >= 16) {
+        // (with the tile chosen by count -- small_nt -- a K split pays only for long reductions on a handful of tiles: B = 1 fc2 / dgrads)
+        if (dev.tail_split && pl.tail_rows == 0 && tiles * ME_SMALL_SPLIT_DEN <= SLOTS && nk >= (small_nt ? 64 : 16) && (!small_nt || tiles <= 96)) {
             int s = (int)(SLOTS / tiles);
             while (s > 1 && nk / s < 8) --s;
             if (s >= 2) {
@@ -548,7 +569,10 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
 int fill_params(const me_gemm_desc* d, GemmParams& p) {
     ME_CHECK_ARG(d != nullptr, "me_gemm: null descriptor");
     ME_CHECK_ARG(d->op == ME_GEMM_NT || d->op == ME_GEMM_TN, "me_gemm: bad op %d", d->op);
-    ME_CHECK_ARG(me_dtype_ok(d->ab_dtype) && me_dtype_ok(d->c_dtype), "me_gemm: bad dtype");
+    ME_CHECK_ARG(me_dtype_ok(d->ab_dtype) && me_out_dtype_ok(d->c_dtype), "me_gemm: bad dtype");
+    if (d->c_dtype == ME_BF16X3)      // fp32 result written as three bf16 planes: the A operand of the next fp32-accurate Linear
+        ME_CHECK_ARG(d->op == ME_GEMM_NT && d->beta == 0.0f && d->ldc >= 3 * d->N && d->out_group_rows == 0 && !d->colsum_a,
+                     "me_gemm: ME_BF16X3 output: NT, beta = 0, ldc >= 3 N, plain rows");
     ME_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "me_gemm: empty problem M=%lld N=%lld K=%lld",
                  (long long)d->M, (long long)d->N, (long long)d->K);
     ME_CHECK_ARG(d->A && d->B && d->C, "me_gemm: null operand");
@@ -703,7 +727,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out) {
                 p.g3_split = pl.tail_split;
                 p.g3_ktp = pl.tail_ksteps;
                 p.g3_slabs = reinterpret_cast<float*>(d->workspace);
-                rc = launch_g3(p, pick_epi(p), nullptr, stream);
+                rc = launch_g3(p, pick_epi_ex(p), nullptr, stream);
                 if (rc) return rc;
                 GemmParams pt = p;                               // the fold sees the tail rows as its own problem
                 pt.M = pl.tail_rows;
@@ -726,7 +750,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out) {
 #else
             void* ws = nullptr;
 #endif
-            return launch_g3(p, pick_epi(p), ws, stream);
+            return launch_g3(p, pick_epi_ex(p), ws, stream);
         }
         auto run = [&](const GemmParams& q) { return launch_g2b(q, d->op, pl.bm, pl.bn, stream); };
         p.tiles_m = (int)((d->M + pl.bm - 1) / pl.bm);

@@ -28,9 +28,10 @@ namespace {
 //   3 ... * gelu'(aux)                          (fc2 dgrad -> dH)             }
 //   4 generic: anything include/metaenc.h allows (beta, row remap, pos-embed modulo, combinations)
 //   5 split-K slab: raw fp32 partial sums (folded by splitk_reduce_kernel, which applies the real epilogue)
+//   6 ... * aux (a saved factor: fc2 dgrad of the training MLP)     7 ... -> save gelu'(h) -> GELU (fc1 forward in training)
 constexpr int SCHED = 1;
 template <int BM, int BN, bool TN, int EPI>
-__global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g2_kernel(const GemmParams p) {
+__global__ __launch_bounds__((BM == 64 ? 256 : BM * 2)) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g2_kernel(const GemmParams p) {
     typedef G2<BM, BN> G;
     constexpr int NSTAGE = G::NSTAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -54,9 +55,10 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     ks_end = ks_end < nk_total ? ks_end : nk_total;
     const int nk = ks_end - ks_begin;
 
-    f32x16 acc[4][G::NI];
+    constexpr int MI = G::MI;
+    f32x16 acc[MI][G::NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < G::NI; ++j)
 #pragma unroll
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int i = 0; i < LOOK; ++i)
         if (i < nk) issue(i, ks_begin + i);
 
-    struct Frags { bf16x8 xb[2][4]; bf16x8 wa[2][G::NI]; };
+    struct Frags { bf16x8 xb[2][MI]; bf16x8 wa[2][G::NI]; };
     // my part of step t has landed (younger steps' DMA may stay in flight); then everybody's part has, and every reader
     // of step t-1's stage is done with it
     auto step_sync = [&](int t) {
@@ -119,12 +121,12 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const char* sb = sa + G::A_BYTES;
         if (TN) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) f.xb[kk][mi] = tn_frag2<BM>((const lds_char*)sa, wr * 128 + mi * 32, kk, lane);
+            for (int mi = 0; mi < MI; ++mi) f.xb[kk][mi] = tn_frag2<BM>((const lds_char*)sa, wr * 128 + mi * 32, kk, lane);
 #pragma unroll
             for (int ni = 0; ni < G::NI; ++ni) f.wa[kk][ni] = tn_frag2<BN>((const lds_char*)sb, wc * (BN / 4) + ni * 32, kk, lane);
         } else {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) f.xb[kk][mi] = nt_frag2(sa, wr * 128 + mi * 32 + l31, 2 * kk + h);
+            for (int mi = 0; mi < MI; ++mi) f.xb[kk][mi] = nt_frag2(sa, wr * 128 + mi * 32 + l31, 2 * kk + h);
 #pragma unroll
             for (int ni = 0; ni < G::NI; ++ni) f.wa[kk][ni] = nt_frag2(sb, wc * (BN / 4) + ni * 32 + l31, 2 * kk + h);
         }
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
     int cs_turn = do_cs ? (tn - ks_begin % p.tiles_n + p.tiles_n) % p.tiles_n : -1;      // steps until my next turn
     auto mma_step = [&](const Frags& f) {
-        if (do_cs) {
+        if constexpr (TN && BM == 128) if (do_cs) {
             if (cs_turn == 0) {
                 // wc is wave-uniform: a scalar switch keeps the fragment index static (a runtime index would demote
                 // the fragment array to scratch)
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < G::NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wa[kk][ni], f.xb[kk][mi], acc[mi][ni], 0, 0, 0);
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (p.debug & 1) {                                    // dev: K-loop only
         float keep = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < G::NI; ++j)
 #pragma unroll
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     asm volatile("" ::"v"(bias0), "v"(bias1), "v"(cs0), "v"(cs1));
     // row operand (EPI 2 / 3): bf16 only on the fast path (fp32 row operands take the generic epilogue); loads are
     // unconditional with clamped coordinates so that no load -- hence no wait -- sits inside a branch
+    constexpr bool ROWOP = EPI == 2 || EPI == 3 || EPI == 6;       // one bf16 row operand, fetched one pass ahead
     const uint16_t* rop = reinterpret_cast<const uint16_t*>(EPI == 2 ? p.residual : p.aux);
     const int64_t rop_ld = EPI == 2 ? p.ldres : p.ldaux;
     const int64_t n_cl = n_ok ? n : 0;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         b[2] = __uint_as_float(r[3] << 16); b[3] = __uint_as_float(r[3] & 0xffff0000u);
     };
     RowOp cur, nxt;
-    if (EPI == 2 || EPI == 3) fetch(0, cur);
+    if (ROWOP) fetch(0, cur);
     auto slab_pass = [&](const int mi, const f32x16 (&am)[G::NI]) {
 #pragma unroll
         for (int ni = 0; ni < G::NI; ++ni)
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(waddr), "v"(v), "i"((ni * 32 + 8 * g) * 4) : "memory");
             }
         // the next slab's row operand goes out BEFORE this slab's stores (in-order vmcnt: see above)
-        if ((EPI == 2 || EPI == 3) && mi + 1 < 4) fetch(mi + 1, nxt);
+        if (ROWOP && mi + 1 < MI) fetch(mi + 1, nxt);
         f32x4 r0[NIT], r1[NIT];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -324,22 +327,30 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 v0 = gelu_for4(v0, p.c_dtype);
                 v1 = gelu_for4(v1, p.c_dtype);
             }
+            if (EPI == 7) {                               // the saved tensor is gelu'(h); the erf pair, as everywhere this flag is served
+                if (ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, gelu_erf_grad4(v0), gelu_erf_grad4(v1));
+                v0 = gelu_erf4(v0);
+                v1 = gelu_erf4(v1);
+            }
             f32x4 ra, rb;
-            if (EPI == 2 || EPI == 3) unpack(cur.raw[i], ra, rb);
+            if (ROWOP) unpack(cur.raw[i], ra, rb);
             if (EPI == 3) {
                 v0 *= gelu_grad_for4(ra, p.c_dtype);
                 v1 *= gelu_grad_for4(rb, p.c_dtype);
             }
+            if (EPI == 6) { v0 *= ra; v1 *= rb; }
             v0 *= cs0; v1 *= cs1;
             if (EPI == 2) { v0 += ra; v1 += rb; }
             if (ok) store8_from_f32(p.C, p.c_dtype, m * p.ldc + n, v0, v1);
         }
-        if ((EPI == 2 || EPI == 3) && mi + 1 < 4) cur = nxt;
+        if (ROWOP && mi + 1 < MI) cur = nxt;
     };
     slab_pass(0, acc[0]);
     slab_pass(1, acc[1]);
-    slab_pass(2, acc[2]);
-    slab_pass(3, acc[3]);
+    if constexpr (MI > 2) {
+        slab_pass(2, acc[2]);
+        slab_pass(3, acc[3]);
+    }
 }
 
 template <int BM, int BN, bool TN, int EPI>
@@ -359,7 +370,7 @@ int launch2e(const GemmParams& p, hipStream_t stream) {
 
 template <int BM, int BN, bool TN>
 int launch2(const GemmParams& p, hipStream_t stream) {
-    const int epi = pick_epi(p);
+    const int epi = pick_epi_ex(p);
     if (TN) {
         if (epi == 5) return launch2e<BM, BN, TN, 5>(p, stream);
         return epi == 0 ? launch2e<BM, BN, TN, 0>(p, stream) : launch2e<BM, BN, TN, 4>(p, stream);
@@ -370,6 +381,8 @@ int launch2(const GemmParams& p, hipStream_t stream) {
         case 2: return launch2e<BM, BN, TN, 2>(p, stream);
         case 3: return launch2e<BM, BN, TN, 3>(p, stream);
         case 5: return launch2e<BM, BN, TN, 5>(p, stream);
+        case 6: return launch2e<BM, BN, TN, 6>(p, stream);
+        case 7: return launch2e<BM, BN, TN, 7>(p, stream);
         default: return launch2e<BM, BN, TN, 4>(p, stream);
     }
 }
@@ -388,6 +401,7 @@ int launch_g2b(const GemmParams& p, int op, int bm, int bn, hipStream_t stream) 
         if (op == ME_GEMM_TN) return launch2<256, 256, true>(p, stream);
         return launch2<256, 256, false>(p, stream);
     }
+    if (bm == 64 && op == ME_GEMM_NT) return launch2<64, 128, false>(p, stream);
     if (op == ME_GEMM_TN) return bn == 256 ? launch2<128, 256, true>(p, stream) : launch2<128, 128, true>(p, stream);
     return bn == 256 ? launch2<128, 256, false>(p, stream) : launch2<128, 128, false>(p, stream);
 }

@@ -968,6 +968,8 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
             if (plain && p.flags == ME_GEMM_SAVE_GELU_GRAD && p.act == ME_ACT_GELU && p.preact && !p.aux) { repi = 1; pre = 2; }
             if (plain && p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_BF16 && !p.preact) repi = 6;
         }
+        if (EPI == 6) repi = 6;                                   // (pick_epi_ex has checked the same conditions)
+        if (EPI == 7) { repi = 1; pre = 2; }
         if (EPI == 2 && p.row_stats) pre = 4;
         const int G = g3_cus() & ~7;
         const int64_t ldmax = std::max(std::max(p.ldc, p.preact ? p.ldpre : 0), std::max(p.residual ? p.ldres : 0, p.aux ? p.ldaux : 0));
@@ -1064,6 +1066,8 @@ int launch_g3(const GemmParams& p, int epi, void* ws, hipStream_t stream) {
         case 1: return launch3e<1>(p, ws, stream);
         case 2: return launch3e<2>(p, ws, stream);
         case 3: return launch3e<3>(p, ws, stream);
+        case 6: return launch3e<6>(p, ws, stream);
+        case 7: return launch3e<7>(p, ws, stream);
         default: return launch3e<4>(p, ws, stream);
     }
 }

@@ -411,7 +411,8 @@ __device__ __forceinline__ void g3_zero(G3State& s) {
 // (r = l & 15, g = l >> 4) holds EIGHT consecutive output columns of row r: n-tile 2q + (g & 1), columns 8 (g >> 1) ..
 // +7 -- one 16-byte bf16 store / row-operand load per lane, 64 contiguous bytes per row and instruction.  The operand
 // buffers in LDS are not touched, so the DMA stream of the next tile keeps running under the epilogue.
-// EPI: 0 bias, 1 + GELU (+ pre-activation save), 2 + residual row operand, 3 * gelu'(aux row operand), 4 generic
+// EPI: 0 bias, 1 + GELU (+ pre-activation save), 2 + residual row operand, 3 * gelu'(aux row operand), 6 * aux row operand,
+// 7 + GELU with gelu'(h) saved as the pre-activation, 4 generic
 // (epilogue_oct: colscale, beta, row remaps, fp32 row operands ...)
 // EPI 5: raw fp32 partial sums into a split-K slab (row-major [rows][N], first row = slab_row0)
 template <int EPI>
@@ -459,15 +460,16 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
     // soon as the first slabs have freed their registers and BEFORE those slabs' stores (vmcnt retires in order) -- one
     // memory latency per tile instead of one per 16-row slab (the K-loop's fragment registers are free here)
     constexpr int AHEAD = 6;
+    constexpr bool ROWOP = EPI == 2 || EPI == 3 || EPI == 6;
     u32x4 rowop[8][2];
-    if (EPI == 2 || EPI == 3) {
+    if (ROWOP) {
 #pragma unroll
         for (int mt = 0; mt < AHEAD; ++mt) fetch(mt, rowop[mt]);
     }
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         f32x4 ro[2][2];
-        if (EPI == 2 || EPI == 3) {
+        if (ROWOP) {
             unpack(rowop[mt][0], ro[0][0], ro[0][1]);
             unpack(rowop[mt][1], ro[1][0], ro[1][1]);
             if (mt + AHEAD < 8) fetch(mt + AHEAD, rowop[mt + AHEAD]);
@@ -503,11 +505,17 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
                 v0 = gelu_for4(v0, p.c_dtype);
                 v1 = gelu_for4(v1, p.c_dtype);
             }
+            if (EPI == 7) {                               // saved: gelu'(h) (ME_GEMM_SAVE_GELU_GRAD), the erf pair as the resident kernel
+                if (ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n[q], gelu_erf_grad4(v0), gelu_erf_grad4(v1));
+                v0 = gelu_erf4(v0);
+                v1 = gelu_erf4(v1);
+            }
             const f32x4 qa = ro[q][0], qb = ro[q][1];
             if (EPI == 3) {
                 v0 *= gelu_grad_for4(qa, p.c_dtype);
                 v1 *= gelu_grad_for4(qb, p.c_dtype);
             }
+            if (EPI == 6) { v0 *= qa; v1 *= qb; }
             if (EPI == 2) { v0 += qa; v1 += qb; }
             if (kMeDev && (p.debug & 4)) {             // dev: epilogue arithmetic without the stores
                 asm volatile("" ::"v"(v0), "v"(v1));

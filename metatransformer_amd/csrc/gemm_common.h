@@ -51,6 +51,10 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, in
     const int64_t orow = p.out_group_rows
                              ? (m / p.out_group_rows) * p.out_group_stride + (m % p.out_group_rows) + p.out_row_offset
                              : m;
+    if (p.c_dtype == ME_BF16X3) {                      // fp32 result as three bf16 planes [hi | lo | hi] (the next Linear's A operand)
+        store4_split3(reinterpret_cast<uint16_t*>(p.C) + orow * p.ldc, p.N, n, v);
+        return;
+    }
     if (p.beta != 0.0f) v += p.beta * load4_as_f32(p.C, p.c_dtype, orow * p.ldc + n);
     store4_from_f32(p.C, p.c_dtype, orow * p.ldc + n, v);
 }
@@ -71,6 +75,10 @@ __device__ __forceinline__ void epilogue_quad_lin(const GemmParams& p, int64_t m
     const int64_t orow = p.out_group_rows
                              ? (m / p.out_group_rows) * p.out_group_stride + (m % p.out_group_rows) + p.out_row_offset
                              : m;
+    if (p.c_dtype == ME_BF16X3) {
+        store4_split3(reinterpret_cast<uint16_t*>(p.C) + orow * p.ldc, p.N, n, v);
+        return;
+    }
     if (p.beta != 0.0f) v += p.beta * load4_as_f32(p.C, p.c_dtype, orow * p.ldc + n);
     store4_from_f32(p.C, p.c_dtype, orow * p.ldc + n, v);
 }
@@ -137,6 +145,12 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
     const int64_t orow = p.out_group_rows
                              ? (m / p.out_group_rows) * p.out_group_stride + (m % p.out_group_rows) + p.out_row_offset
                              : m;
+    if (p.c_dtype == ME_BF16X3) {
+        uint16_t* row = reinterpret_cast<uint16_t*>(p.C) + orow * p.ldc;
+        store4_split3(row, p.N, n, v0);
+        store4_split3(row, p.N, n + 4, v1);
+        return;
+    }
     if (p.beta != 0.0f) {
         f32x4 c0, c1;
         load8_as_f32(p.C, p.c_dtype, orow * p.ldc + n, c0, c1);
@@ -150,6 +164,7 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
 //   3 ... * gelu'(bf16 aux row operand)   4 generic (anything include/metaenc.h allows)   5 raw fp32 split-K slab
 static inline int pick_epi(const GemmParams& p) {
     if (p.split_k > 1) return 5;
+    if (p.c_dtype == ME_BF16X3) return 4;   // (three-plane stores live in the generic epilogue only)
     if (p.flags || p.row_affine) return 4;  // (the resident g3 kernel has its own forms of these: launch_g3)
     if (p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return 4;
     const int nrow = (p.residual ? 1 : 0) + (p.aux ? 1 : 0);
@@ -159,6 +174,18 @@ static inline int pick_epi(const GemmParams& p) {
     if (p.residual) return p.res_dtype == ME_BF16 ? 2 : 4;
     if (p.aux) return p.aux_dtype == ME_BF16 ? 3 : 4;
     return 0;
+}
+
+// ... and the two halves of the "saved gelu'" pair of the training MLP, which pick_epi sends to the generic epilogue (4) because
+// they carry flags: 6 = acc * bf16 aux row operand (ME_GEMM_AUX_IS_FACTOR: the fc2 dgrad), 7 = GELU with gelu'(h) saved as the
+// pre-activation (ME_GEMM_SAVE_GELU_GRAD: fc1 forward in training).  The one-tile-per-workgroup kernels (g2b, g3) have straight-line
+// forms of both: at the reference's batch sizes (M = 3 072 .. 8 224) the generic epilogue cost 45 us against 29 us per launch.
+static inline int pick_epi_ex(const GemmParams& p) {
+    const int e = pick_epi(p);
+    if (e != 4 || p.c_dtype == ME_BF16X3 || p.row_affine || p.colscale || p.residual || p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return e;
+    if (p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_BF16 && !p.preact) return 6;
+    if (p.flags == ME_GEMM_SAVE_GELU_GRAD && p.act == ME_ACT_GELU && p.preact && !p.aux) return 7;
+    return e;
 }
 
 // kernel families (each in its own translation unit)

@@ -19,8 +19,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, lds_char* lds_wave_base
 // BM = 128: 4 waves (1 x 4), 3 stages, two workgroups per CU ("g2b").
 // BM = 256: 8 waves (2 x 4), 4 stages (DMA three steps ahead), one workgroup per CU with the minimum L2 traffic per
 //           flop a CU can have (256 x 256 accumulators = half the register file) ("g2w").
+// BM = 64:  4 waves (1 x 4) with half the rows each (two 32-row m-subtiles instead of four): the small-M form -- M = 3 072 rows
+//           (the reference's B = 32 x 96-token batches) are 288 tiles at N = 768 instead of 144, without a K split.
 template <int BM, int BN> struct G2 {
-    static constexpr int NW = BM / 32;                // waves: 4 / 8
+    static constexpr int NW = BM == 64 ? 4 : BM / 32; // waves: 4 / 4 / 8
+    static constexpr int MI = BM == 64 ? 2 : 4;       // 32-row m-subtiles per wave
     static constexpr int NTH = NW * 64;
     static constexpr int NSTAGE = BM == 128 ? 3 : 4;
     static constexpr int A_BYTES = BM * KS2 * 2;      // 8 / 16 KiB

@@ -5,6 +5,8 @@
 // registers between the statistics pass and the normalise pass (one HBM read, one write), statistics by
 // wavefront xor-shuffles in fp32 with the two-pass (mean, then centred sum of squares) formulation.
 #include "common.h"
+#include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -31,6 +33,8 @@ template <> __device__ __forceinline__ void st4<bf16_t>(void* base, int64_t idx,
     o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
     ME_NT_STORE(ME_POL_LN_ST, __builtin_bit_cast(u32x2, o), reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(base) + idx));
 }
+
+struct me_split3_tag {};                  // TY of ln_fwd_kernel: the normalised row goes out as ME_BF16X3 (three bf16 planes, [hi | lo | hi])
 
 // VPL = number of 4-element vectors per lane (C = 256 * VPL on the fast path); dtypes are template parameters for the
 // reason given above (a runtime switch around the row loads would serialise them).
@@ -94,7 +98,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const void* __restri
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mean[r]) * rstd[r] * g[i][e] + b[i][e];
-            st4<TY>(y, row * C + c, o);
+            if constexpr (std::is_same<TY, me_split3_tag>::value) store4_split3(reinterpret_cast<uint16_t*>(y) + row * 3 * C, C, c, o);
+            else st4<TY>(y, row * C + c, o);
         }
     }
 }
@@ -425,8 +430,11 @@ extern "C" int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
                                 void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ME_CHECK_ARG(x && y && gamma && beta, "me_layernorm_fwd: null pointer");
-    ME_CHECK_ARG(me_dtype_ok(x_dtype) && me_dtype_ok(y_dtype), "me_layernorm_fwd: bad dtype");
+    ME_CHECK_ARG(me_dtype_ok(x_dtype) && me_out_dtype_ok(y_dtype), "me_layernorm_fwd: bad dtype");
     ME_CHECK_ARG(rows >= 0 && cols > 0, "me_layernorm_fwd: bad shape");
+    // (the split output is what the fp32-accurate Linear behind it reads: fp32 tokens, vector path only)
+    ME_CHECK_ARG(y_dtype != ME_BF16X3 || (x_dtype == ME_F32 && cols % 256 == 0 && cols / 256 <= LN_MAX_VEC),
+                 "me_layernorm_fwd: ME_BF16X3 output needs fp32 input and cols = 256 * k <= %d", 256 * LN_MAX_VEC);
     if (rows == 0) return ME_OK;
     ProfScope prof(ME_PROF_LN_FWD, x_dtype, rows, cols, 0, stream);
     const unsigned nblk = (unsigned)((rows + 3) / 4);
@@ -435,7 +443,8 @@ extern "C" int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
                        rows, cols, eps)
 #define LN_FWD_CASE(V)                                                                                         \
     case V:                                                                                                    \
-        if (x_dtype == ME_BF16 && y_dtype == ME_BF16) LN_FWD_LAUNCH(V, bf16_t, bf16_t);                        \
+        if (y_dtype == ME_BF16X3) LN_FWD_LAUNCH(V, float, me_split3_tag);                                      \
+        else if (x_dtype == ME_BF16 && y_dtype == ME_BF16) LN_FWD_LAUNCH(V, bf16_t, bf16_t);                   \
         else if (x_dtype == ME_BF16) LN_FWD_LAUNCH(V, bf16_t, float);                                          \
         else if (y_dtype == ME_BF16) LN_FWD_LAUNCH(V, float, bf16_t);                                          \
         else LN_FWD_LAUNCH(V, float, float);                                                                   \
@@ -495,18 +504,23 @@ extern "C" int me_row_stats_combine(const float* partials, int64_t rows, int col
     return ME_OK;
 }
 
-// blocks of one ln_bwd_kernel instantiation the device holds at once (cached per instantiation and LDS size class)
+// blocks of one ln_bwd_kernel instantiation the device holds at once (cached per instantiation, LDS size class AND device: a
+// process may drive GPUs with different CU counts; the entries are written once each, under a lock)
 template <auto KERNEL>
 static int ln_bwd_resident_blocks(size_t lds_bytes) {
-    static int cached[2] = {0, 0};
-    int& c = cached[lds_bytes ? 1 : 0];
-    if (!c) {
-        int per_cu = 0, dev = 0, cus = 0;
-        (void)hipGetDevice(&dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, LN_THREADS, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        c = per_cu * cus < LNB_BLOCKS ? per_cu * cus : LNB_BLOCKS;
+    static std::atomic<int> cached[64][2] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool cacheable = dev >= 0 && dev < 64;
+    if (cacheable) {
+        const int c = cached[dev][lds_bytes ? 1 : 0].load(std::memory_order_acquire);
+        if (c) return c;
     }
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, LN_THREADS, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const int c = per_cu * cus < LNB_BLOCKS ? per_cu * cus : LNB_BLOCKS;
+    if (cacheable) cached[dev][lds_bytes ? 1 : 0].store(c, std::memory_order_release);      // (racing writers store the same value)
     return c;
 }
 

@@ -33,6 +33,15 @@ from . import _capi, ops
 from ._capi import ME_ACT_GELU, ME_GEMM_AUX_IS_FACTOR, ME_GEMM_SAVE_GELU_GRAD, ME_GEMM_TN, MetaEncError
 
 
+def _tensor_version(t: torch.Tensor):
+    """``t._version``, or None for inference tensors (``torch.inference_mode()``: they carry no version counter and reading
+    the attribute raises)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 def _resolve_eps(norm_layer) -> float:
     """timm passes a class or a functools.partial(nn.LayerNorm, eps=1e-6) (1e-5 vs 1e-6 sites)."""
     probe = norm_layer(8)
@@ -87,6 +96,7 @@ class _WeightCache:
         self._fwd = {}
         self._tr = {}
         self._fold = {}
+        self._x3 = {}
         self._owner = None          # weakref to the Block, set by Block.__init__
         if _WeightCache._live is None:
             _WeightCache._live = weakref.WeakSet()
@@ -112,7 +122,7 @@ class _WeightCache:
         # WEIGHT_EPOCH covers the fused optimizer, which writes parameters through raw pointers (no _version bump); it
         # only ever touches parameters that live in a parallel.FlatParams, so other (e.g. frozen) encoders keep their copies
         epoch = ops.WEIGHT_EPOCH if hasattr(p, "_me_flat") else 0
-        return (p.data_ptr(), p._version, epoch, p.dtype, dtype, p.device)
+        return (p.data_ptr(), _tensor_version(p), epoch, p.dtype, dtype, p.device)
 
     def fwd(self, name: str, p: torch.Tensor, dtype) -> torch.Tensor:
         if p.dtype == dtype:
@@ -129,6 +139,19 @@ class _WeightCache:
         if hit is None or hit[0] != k:
             hit = (k, ops.cast(p.detach().contiguous(), dtype))
             self._fwd[slot] = hit
+        return hit[1]
+
+    def split3(self, name: str, p: torch.Tensor, transposed: bool) -> torch.Tensor:
+        """ME_BF16X3 right-operand copy of a weight ([out, 3 in]; transposed: of W^T, [in, 3 out] for the dgrad GEMMs): the
+        fp32-accurate mode's compute copies, rebuilt when the parameter changes (same keys as the other copies)."""
+        k = self._key(p, "x3t" if transposed else "x3")
+        slot = (name, transposed, p.device)
+        hit = self._x3.get(slot)
+        if hit is None or hit[0] != k:
+            w32 = p.detach().contiguous()
+            w32 = ops.transpose_cast(w32, torch.float32) if transposed else ops.cast(w32, torch.float32)
+            hit = (k, ops.split3(w32, right_operand=True))
+            self._x3[slot] = hit
         return hit[1]
 
     def folded(self, name: str, w: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, bias: Optional[torch.Tensor], dtype):
@@ -207,9 +230,10 @@ class _BlockFn(torch.autograd.Function):
         fp8 = bool(getattr(blk, "attn_fp8", False)) and win is None and cdt == torch.bfloat16 and hd == 64 and stoch is None
         if stoch is None and win is None and blk.c_side and not fp8 and not (need_grad and g1 is not None):
             # plain path: the whole block is ONE library call (me_block_fwd), the launch sequence lives on the C side
+            x3 = blk.uses_3xbf16(cdt, rdt)
             d, keep = _BlockFn._desc(blk, cache, cdt, rdt, B, N, C, H, (n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb,
                                                                         fc1w, fc1b, fc2w, fc2b, g1, g2), False,
-                                     fold=not need_grad and blk.fold_norm)
+                                     fold=not need_grad and blk.fold_norm, x3=x3)
             # LayerNorm statistics handed from block to block (folded inference): the caller (Block.forward) passes the pairs the
             # previous block left on this very tensor, and gets this block's own back through blk._stats_out
             xs = getattr(blk, "_stats_in", None)
@@ -220,7 +244,7 @@ class _BlockFn(torch.autograd.Function):
             del keep
             if need_grad:
                 ctx.save_for_backward(x2, saved, n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb, fc1w, fc1b, fc2w, fc2b)
-                ctx.blk, ctx.cdt, ctx.dims, ctx.in_dtype, ctx.fast = blk, cdt, (B, N, C, H, hd), in_dtype, True
+                ctx.blk, ctx.cdt, ctx.dims, ctx.in_dtype, ctx.fast, ctx.x3 = blk, cdt, (B, N, C, H, hd), in_dtype, True, x3
             return ops.cast(y, in_dtype).reshape(B, N, C)
 
         xn1, mean1, rstd1 = ops.layernorm_fwd(x2, n1w, n1b, blk.eps, cdt, save_stats=need_grad)
@@ -272,18 +296,22 @@ class _BlockFn(torch.autograd.Function):
         return ops.cast(y, in_dtype).reshape(B, N, C)
 
     @staticmethod
-    def _desc(blk, cache, cdt, rdt, B, N, C, H, params, transposed, fold=False):
+    def _desc(blk, cache, cdt, rdt, B, N, C, H, params, transposed, fold=False, x3=False):
         """me_block_desc for this block + the list of tensors that must stay alive while the call is in flight.
         fold: inference with both LayerNorms folded into qkv / fc1 (bf16 compute on a bf16 token stream; the library falls
         back to LayerNorm + GEMM by itself when the descriptor carries no folded weights)."""
         (n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb, fc1w, fc1b, fc2w, fc2b, g1, g2) = params
         ws = {"qkv": qkvw, "proj": projw, "fc1": fc1w, "fc2": fc2w}
-        w = {k: cache.fwd(k, t, cdt) for k, t in ws.items()}
-        wt = {k: cache.transposed(k, t, cdt) for k, t in ws.items()} if transposed else None
+        if x3:            # fp32-accurate mode: three-plane bf16 copies of the fp32 weights (Block.fp32_mode = "3xbf16")
+            w = {k: cache.split3(k, t, False) for k, t in ws.items()}
+            wt = {k: cache.split3(k, t, True) for k, t in ws.items()} if transposed else None
+        else:
+            w = {k: cache.fwd(k, t, cdt) for k, t in ws.items()}
+            wt = {k: cache.transposed(k, t, cdt) for k, t in ws.items()} if transposed else None
         f = lambda t: None if t is None else ops._f32(t).contiguous()      # noqa: E731
         vec = dict(ln1_g=f(n1w), ln1_b=f(n1b), ln2_g=f(n2w), ln2_b=f(n2b), qkv_b=f(qkvb), proj_b=f(projb), fc1_b=f(fc1b),
                    fc2_b=f(fc2b), gamma1=f(g1), gamma2=f(g2))
-        d = ops.block_desc(B, N, C, H, fc1w.shape[0], blk.eps, blk.attn.scale, cdt, rdt, w, wt, vec)
+        d = ops.block_desc(B, N, C, H, fc1w.shape[0], blk.eps, blk.attn.scale, cdt, rdt, w, wt, vec, x3=x3)
         folded = None
         # (only when every CU gets 256 x 256 tiles of qkv: the fold's row-affine epilogue lives in the resident GEMM kernel; below
         #  that the generic epilogue it would fall back to measured slower than LayerNorm + GEMM -- B = 32: 2.95 vs 2.75 ms)
@@ -304,7 +332,7 @@ class _BlockFn(torch.autograd.Function):
         if dy2.dtype != rdt:
             dy2 = ops.cast(dy2, rdt)
         d, keep = _BlockFn._desc(blk, blk._wcache, cdt, rdt, B, N, C, H, (n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb,
-                                                                          fc1w, fc1b, fc2w, fc2b, None, None), True)
+                                                                          fc1w, fc1b, fc2w, fc2b, None, None), True, x3=ctx.x3)
         # gradient destinations: (name in me_block_grads, parameter, index into needs_input_grad)
         slots = [("ln1_g", blk.norm1.weight, 1), ("ln1_b", blk.norm1.bias, 2), ("qkv_w", blk.attn.qkv.weight, 3),
                  ("qkv_b", blk.attn.qkv.bias, 4), ("proj_w", blk.attn.proj.weight, 5), ("proj_b", blk.attn.proj.bias, 6),
@@ -485,11 +513,26 @@ class Block(nn.Module):
         self.attn_fp8 = False       # True: e4m3 attention forward (me_attention_fwd_fp8; bf16 compute, head_dim 64) -- config 5
         self.fold_norm = True       # (True: when it pays, see _desc; "always": whenever it is legal; False: never)  inference (no gradient wanted), bf16 compute on a bf16 token stream: norm1 / norm2 folded into
                                     # qkv / fc1 (me_row_stats + row_affine GEMM epilogue instead of me_layernorm_fwd + GEMM)
+        # fp32 compute: "exact" = the exact-fp32 MFMA (157 TF peak; parity mode, the default), "3xbf16" = fp32-accurate arithmetic on
+        # the bf16 matrix pipe (three bf16 products per Linear on hi / lo split operands, ~1e-5 relative; plain blocks -- no windowed /
+        # stochastic / layer-scale-gradient path -- with C and hidden multiples of 256; anything else runs exact).  Also selected by
+        # compute_dtype = "fp32_3xbf16".
+        self.fp32_mode = "exact"
         self._wcache = _WeightCache()
         self.chain_stats = True     # folded inference: LayerNorm statistics from the proj / fc2 epilogues, handed from block to block
         self._stats_in = self._stats_out = None      # (per-call hand-over between forward() and the autograd Function)
 
+    def uses_3xbf16(self, cdt, rdt) -> bool:
+        """does the plain (one-call) path of this block run in the fp32-accurate three-product mode for these dtypes?"""
+        want = self.fp32_mode == "3xbf16" or self.compute_dtype == "fp32_3xbf16"
+        if self.fp32_mode not in ("exact", "3xbf16"):
+            raise MetaEncError(f"Block.fp32_mode must be 'exact' or '3xbf16' (got {self.fp32_mode!r})")
+        C, hidden = self.attn.qkv.weight.shape[1], self.mlp.fc1.weight.shape[0]
+        return bool(want and cdt == torch.float32 and rdt == torch.float32 and C % 256 == 0 and hidden % 256 == 0)
+
     def _compute_dtype(self, x: torch.Tensor) -> torch.dtype:
+        if self.compute_dtype == "fp32_3xbf16":
+            return torch.float32
         if self.compute_dtype is not None:
             return self.compute_dtype
         if torch.is_autocast_enabled():
@@ -532,9 +575,12 @@ class Block(nn.Module):
         # TENSOR OBJECT (attribute _me_ln_stats = (pairs, eps, version)) to whichever Block is handed that same object next --
         # nn.Sequential, a `for blk in blocks` loop.  Anything else (a new tensor from x + pos, an in-place edit: the version
         # moves) simply finds no statistics and reads its input once more (me_row_stats).
+        # Inference tensors (torch.inference_mode) have no version counter: nothing can vouch for "not written since", so they
+        # are neither tagged nor trusted (the block reads its input once more; encoder_forward_inference chains on the C side).
         tag = getattr(x, "_me_ln_stats", None)
         self._stats_in = None
-        if (tag is not None and self.chain_stats and tag[1] == self.eps and tag[2] == x._version
+        ver = _tensor_version(x) if tag is not None else None
+        if (tag is not None and ver is not None and self.chain_stats and tag[1] == self.eps and tag[2] == ver
                 and tag[0].shape[0] == x.shape[0] * x.shape[1]):
             self._stats_in = tag[0]
         self._stats_out = None
@@ -543,7 +589,9 @@ class Block(nn.Module):
                            m.fc2.weight, m.fc2.bias, g1, g2, self, cdt, stoch, torch.is_grad_enabled(), win)
         self._stats_in = None
         if self._stats_out is not None:
-            y._me_ln_stats = (self._stats_out, self.eps, y._version)
+            ver = _tensor_version(y)
+            if ver is not None:
+                y._me_ln_stats = (self._stats_out, self.eps, ver)
             self._stats_out = None
         return y
 
@@ -610,17 +658,27 @@ def build_encoder(depth: int = 12, dim: int = 768, num_heads: int = 12, mlp_rati
                                  norm_layer=norm_layer, act_layer=nn.GELU, **kw) for _ in range(depth)])
 
 
-@torch.no_grad()
-def encoder_forward_inference(encoder: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
-    """``encoder(x)`` for a plain stack of Blocks in eval mode as ONE library call (me_encoder_fwd): what a serving host that
-    is not Python would do.  Falls back to nothing: raises if a block is not a plain Block."""
-    blocks = list(encoder)
-    if not blocks or any(not isinstance(b, Block) or b.windowed for b in blocks):
-        raise MetaEncError("encoder_forward_inference: a non-empty nn.Sequential of plain (non-windowed) Blocks is required")
-    if x.dim() != 3 or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
-        raise MetaEncError("encoder_forward_inference: [B, N, C] fp32 / bf16 CUDA tokens required")
-    B, N, C = x.shape
-    x2 = x.contiguous().reshape(B * N, C)
+# encoder_forward_inference replays a captured hipGraph for small batches: below ~1 000 token rows the 84 launches of a Base
+# forward are latency-bound and the host's launch path is a visible part of it (N = 197: B = 1 0.84 ms eager, 0.63 ms replayed;
+# B = 2 0.87 / 0.68; B = 4 0.84 / 0.76; B = 8 0.99 / 0.99; B = 16 1.29 / 1.34 -- profiles/r05_latency.txt).
+GRAPH_MAX_ROWS = 1024
+_graphs = None      # weakref.WeakKeyDictionary: encoder -> {(B, N, C, dtype, device): _EncoderGraph}
+
+
+class _EncoderGraph:
+    """One captured forward: static input / output buffers, the graph, and what it was captured against (the weights' identity:
+    a graph bakes device pointers in, so an optimizer step, load_state_dict or .to() re-captures)."""
+
+    def __init__(self, wkey, x_static, y_static, graph):
+        self.wkey, self.x, self.y, self.graph = wkey, x_static, y_static, graph
+
+
+def _encoder_weight_key(blocks):
+    return (ops.WEIGHT_EPOCH,) + tuple((p.data_ptr(), _tensor_version(p), p.dtype) for b in blocks for p in b.parameters()) + tuple(
+        (b.compute_dtype, b.fold_norm, b.eps, b.fp32_mode) for b in blocks)
+
+
+def _encoder_descs(blocks, x: torch.Tensor, B: int, N: int, C: int):
     descs, keep = [], []
     for b in blocks:
         b._wcache.bind(b)
@@ -631,12 +689,62 @@ def encoder_forward_inference(encoder: nn.Sequential, x: torch.Tensor) -> torch.
         d, k = _BlockFn._desc(b, b._wcache, cdt, x.dtype, B, N, C, a.num_heads,
                               (b.norm1.weight, b.norm1.bias, b.norm2.weight, b.norm2.bias, a.qkv.weight, a.qkv.bias,
                                a.proj.weight, a.proj.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, g1, g2), False,
-                              fold=b.fold_norm)
+                              fold=b.fold_norm, x3=b.uses_3xbf16(cdt, x.dtype))
         descs.append(d)
         keep.append(k)
-    y = ops.encoder_fwd(descs, x2)
-    del keep
-    return y.reshape(B, N, C)
+    return descs, keep
+
+
+@torch.no_grad()
+def encoder_forward_inference(encoder: nn.Sequential, x: torch.Tensor, graph: Optional[bool] = None) -> torch.Tensor:
+    """``encoder(x)`` for a plain stack of Blocks in eval mode as ONE library call (me_encoder_fwd): what a serving host that
+    is not Python would do.  Falls back to nothing: raises if a block is not a plain Block.
+
+    graph: None (default) = replay a cached hipGraph of that call when B * N <= GRAPH_MAX_ROWS (one graph per (B, N, C, dtype),
+    re-captured when a weight changes; input copied into / output cloned out of the graph's static buffers); True / False force it."""
+    blocks = list(encoder)
+    if not blocks or any(not isinstance(b, Block) or b.windowed for b in blocks):
+        raise MetaEncError("encoder_forward_inference: a non-empty nn.Sequential of plain (non-windowed) Blocks is required")
+    if x.dim() != 3 or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
+        raise MetaEncError("encoder_forward_inference: [B, N, C] fp32 / bf16 CUDA tokens required")
+    B, N, C = x.shape
+    x2 = x.contiguous().reshape(B * N, C)
+    if graph is None:
+        graph = B * N <= GRAPH_MAX_ROWS
+    if graph and torch.cuda.is_current_stream_capturing():
+        graph = False                       # (already inside somebody else's capture: just enqueue)
+    if not graph:
+        descs, keep = _encoder_descs(blocks, x, B, N, C)
+        y = ops.encoder_fwd(descs, x2)
+        del keep
+        return y.reshape(B, N, C)
+
+    global _graphs
+    if _graphs is None:
+        import weakref
+        _graphs = weakref.WeakKeyDictionary()
+    per_enc = _graphs.setdefault(encoder, {})
+    gkey = (B, N, C, x.dtype, x.device)
+    wkey = _encoder_weight_key(blocks)
+    g = per_enc.get(gkey)
+    if g is None or g.wkey != wkey:
+        descs, keep = _encoder_descs(blocks, x, B, N, C)
+        xs = torch.empty_like(x2)
+        xs.copy_(x2)
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):       # warm-up outside the capture: weight copies, per-stream work counters, lazy attributes
+            ops.encoder_fwd(descs, xs)
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            ys = ops.encoder_fwd(descs, xs)
+        g = _EncoderGraph(wkey, xs, ys, cg)
+        g.keep = (descs, keep)              # the compute copies of the weights the graph points at
+        per_enc[gkey] = g
+    g.x.copy_(x2)
+    g.graph.replay()
+    return g.y.clone().reshape(B, N, C)
 
 
 def encoder_flops_per_sample(N: int, C: int, L: int) -> float:

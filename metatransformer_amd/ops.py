@@ -203,12 +203,13 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
 
 # ----------------------------------------------------------------------------- whole block (C-side composition)
 
-def block_desc(B, N, C, heads, hidden, eps, scale, cdt, rdt, w, wt, vec) -> "_capi.BlockDesc":
+def block_desc(B, N, C, heads, hidden, eps, scale, cdt, rdt, w, wt, vec, x3: bool = False) -> "_capi.BlockDesc":
     """w / wt: dicts name -> tensor (compute dtype) for qkv, proj, fc1, fc2 (wt may be None); vec: dict of fp32 vectors
     ln1_g, ln1_b, ln2_g, ln2_b, qkv_b, proj_b, fc1_b, fc2_b, gamma1, gamma2 (None = absent).  The caller keeps the
     tensors alive for the duration of the call."""
     d = _capi.BlockDesc()
-    d.dtype, d.res_dtype = dtype_code(cdt), dtype_code(rdt)
+    # x3: fp32-accurate arithmetic on the bf16 matrix pipe (me_block_desc.dtype = ME_BF16X3; the weights are ops.split3 right operands)
+    d.dtype, d.res_dtype = (_capi.ME_BF16X3 if x3 else dtype_code(cdt)), dtype_code(rdt)
     d.B, d.N, d.C, d.heads, d.hidden, d.eps, d.scale = B, N, C, heads, hidden, eps, scale
     for k in ("qkv", "proj", "fc1", "fc2"):
         setattr(d, k + "_w", ptr(w[k]))
@@ -319,6 +320,20 @@ def cast(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None
         raise MetaEncError("cast: `out` must be a contiguous tensor of the target dtype with as many elements as x")
     y = out if out is not None else torch.empty(x.shape, dtype=dtype, device=x.device)
     check(lib.me_cast(ptr(x), dtype_code(x.dtype, True), ptr(y), dtype_code(dtype, True), x.numel(), stream_ptr()), "me_cast")
+    return y
+
+
+def split3(x: torch.Tensor, right_operand: bool = False) -> torch.Tensor:
+    """fp32 [rows, cols] -> ME_BF16X3: bf16 [rows, 3 * cols] = [hi | lo | hi] (left operand: activations, gradients) or
+    [hi | hi | lo] (right operand: weights), hi = bf16(x), lo = bf16(x - hi).  A bf16 NT GEMM over two such operands
+    (K = 3 * cols) computes x @ w^T to ~2^-17 relative on the bf16 matrix pipe (me_split3)."""
+    lib = _capi.load()
+    _req(x, "x")
+    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] % 4:
+        raise MetaEncError("split3: a contiguous 2-D float32 tensor with cols % 4 == 0 is required")
+    rows, cols = x.shape
+    y = torch.empty((rows, 3 * cols), dtype=torch.bfloat16, device=x.device)
+    check(lib.me_split3(ptr(x), cols, ptr(y), rows, cols, 1 if right_operand else 0, stream_ptr()), "me_split3")
     return y
 
 

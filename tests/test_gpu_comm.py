@@ -251,3 +251,49 @@ def test_blocks_inside_distributed_data_parallel_world1():
         if p.is_alive():
             p.kill()
     assert msg == "ok", msg
+
+
+def test_gradients_bit_identical_while_a_communication_kernel_holds_cus():
+    """Rehearsal of multi-GPU CU contention on one GPU (tools/cu_hog.hip, tools/contention.py): while backward runs, a kernel on
+    another stream holds 16 / 40 CUs the way an RCCL all-reduce would (launched from the reducer's bucket hooks, optimizer joins).
+    The resident NT GEMMs and the persistent attention backward claim their work from counters, the weight-gradient GEMMs run on
+    me_block_bwd's side stream: whatever the schedule, every gradient must equal the undisturbed run bit for bit (no kernel's
+    arithmetic depends on which CUs it got), and the step must terminate (claimed work, no workgroup waiting for a CU it cannot get)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import contention
+    if not os.path.isfile(contention.HOG):
+        pytest.skip("tools/_build/libcuhog.so not built (python __graft_entry__.py builds it)")
+    from metatransformer_amd import parallel, ops
+    dev = torch.device("cuda:0")
+    lib = contention.load_hog()
+    results = {}
+    for R in (0, 16, 40):
+        comm = contention.HogComm(lib, R, 20.0, dev)          # 20 GB/s: every bucket's hold outlasts the rest of backward
+        step, flat = contention.build_step(dev, comm, B=128, N=197, L=3)
+        step()                                                # (first step: weight copies, counters, lazy attributes)
+        flat.zero_grad()
+        # one more backward WITHOUT the optimizer so that the gradient buffer is what is compared
+        import metatransformer_amd as M
+        torch.manual_seed(0)
+        enc = M.build_encoder(3, 768, 12).to(dev)
+        for p in enc.parameters():
+            if p.dim() == 2:
+                torch.nn.init.normal_(p, std=0.02)
+        for blk in enc:
+            blk.compute_dtype = torch.bfloat16
+        enc.train()
+        fl = parallel.FlatParams(enc.named_parameters())
+        red = parallel.OverlappedGradReducer(fl, comm=comm, force=True, bucket_bytes=8 << 20)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(128, 197, 768, generator=g).to(dev).bfloat16().requires_grad_(True)
+        gy = (torch.randn(128, 197, 768, generator=g) / 1000).to(dev).bfloat16()
+        fl.zero_grad()
+        n0 = comm.launched
+        enc(x).backward(gy)
+        red.finish()
+        torch.cuda.synchronize()
+        assert comm.launched - n0 >= 2                        # the hog really ran beside backward (several buckets)
+        results[R] = (fl.flat_grad.clone(), x.grad.clone())
+        red.remove()
+    for R in (16, 40):
+        assert torch.equal(results[R][0], results[0][0]) and torch.equal(results[R][1], results[0][1]), R

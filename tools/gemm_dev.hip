@@ -170,7 +170,7 @@ struct PowerProbe {
 static int family_code(const std::string& f) {
     if (f == "auto") return -1;
     if (f == "g128") return 0;
-    if (f == "g2b") return 2;
+    if (f == "g2b" || f == "g2bn" || f == "g2bw" || f == "g2bs") return 2;      // g2bn / g2bw: 128 x 128 / 128 x 256 tiles, NO split-K (small-M planning A/B)
     if (f == "g2w") return 3;
     if (f == "g3" || f == "g3x" || f == "g3p" || f == "g3t" || f == "g3s" || f == "g3f") return 4;      // g3f: resident, whole tiles only (no 128-row items in the last round)      // g3: shipped form (resident); g3t: one tile per workgroup; g3x: without the tail split; g3p: persistent stream-K
     fprintf(stderr, "unknown family %s\n", f.c_str());
@@ -293,8 +293,9 @@ int main(int argc, char** argv) {
             return 2;
         }
         me_dev_set("family", family_code(fam));
+        me_dev_set("bn", strcmp(fam, "g2bn") == 0 ? 128 : strcmp(fam, "g2bw") == 0 ? 256 : strcmp(fam, "g2bs") == 0 ? 64 : 0);      // g2bs: 64 x 128 tiles
         me_dev_set("g3_persistent", strcmp(fam, "g3p") == 0 ? 2 : strcmp(fam, "g3t") == 0 ? 0 : 1);
-        me_dev_set("tail_split", strcmp(fam, "g3s") == 0 ? 2 : strcmp(fam, "g3f") == 0 ? 3 : strcmp(fam, "g3x") != 0);      // g3s: resident, static schedule; g3f: no half items
+        me_dev_set("tail_split", strcmp(fam, "g3s") == 0 ? 2 : strcmp(fam, "g3f") == 0 ? 3 : (strcmp(fam, "g3x") != 0 && strcmp(fam, "g2bn") != 0 && strcmp(fam, "g2bw") != 0 && strcmp(fam, "g2bs") != 0));      // g3s: resident, static schedule; g3f: no half items
         me_dev_set("debug", debug);
         uint16_t *A[NSET], *C[NSET], *P[NSET], *Bw, *rowop = nullptr;
         float *bias, *ref = nullptr, *ref_pre = nullptr;

@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--dtypes", default="fp32,bf16")
     a = ap.parse_args()
     res = {"_meta": {"mode": "frozen encoder (requires_grad=False on every Block parameter): forward + dL/dx; `fwd` = forward alone under no_grad",
                      "peaks_TFLOPs": {"fp32": 157.3, "bf16": 2500.0}, "device": torch.cuda.get_device_name(0)}}
@@ -114,6 +115,8 @@ def main():
             continue
         res[name] = {"source": src, "B": B, "N": N, "C": C, "heads": H, "depth": L}
         for dtype, dn in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+            if dn not in a.dtypes.split(","):
+                continue
             steps = 5 if (dtype == torch.float32 or a.quick) else 20
             r = run_shape(name, B, N, C, H, L, dtype, steps, 2)
             res[name][dn] = r
