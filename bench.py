@@ -270,7 +270,7 @@ def main():
         cannot run inside the process: tools/pmc_bench.sh collects FETCH_SIZE / WRITE_SIZE in separate passes and
         tools/pmc_summary.py folds them, traffic = 2 * FETCH_SIZE + WRITE_SIZE).  None when the file is not there."""
         pm, src = None, None
-        for rnd in ("r04", "r03"):            # the newest committed set
+        for rnd in ("r05", "r04", "r03"):            # the newest committed set
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{rnd}_pmc_{mode}.json")
             try:
                 with open(path) as f:
@@ -280,6 +280,20 @@ def main():
                 continue
         if pm is None:
             return None, None
+        # stale? the file records the hash of the sources that define the roofline kernel at collection time
+        meta = pm.get("_meta", {})
+        try:
+            import hashlib
+            h = hashlib.sha256()
+            for fn in meta.get("kernel_src", ["gemm3.hip", "gemm3_core.h", "gemm_common.h", "gemm.hip", "common.h"]):
+                with open(os.path.join(ROOT, "metatransformer_amd", "csrc", fn), "rb") as fh:
+                    h.update(fh.read())
+            now = h.hexdigest()[:16]
+        except OSError:
+            now = None
+        if meta.get("kernel_src_sha16") != now:
+            return None, (f"{src} is STALE for this tree (collected on kernel sources {meta.get('kernel_src_sha16')}, head {meta.get('head')}; "
+                          f"running {now}): re-run tools/pmc_bench.sh + tools/pmc_summary.py")
         rows = [(v["launches"], v["hbm_traffic_MB"]) for k, v in pm.items()
                 if k.startswith("gemm_g3r_kernel") and isinstance(v, dict) and "hbm_traffic_MB" in v and v.get("launches")]
         if not rows:
@@ -330,7 +344,9 @@ def main():
         if with_wgrad and tn:
             f2 = sum(2.0 * m * n * k for m, n, k, _ in tn)
             ms2 = sum(t for *_, t in tn)
-            roof["wgrad_kernel"] = {"kernel": ("gemm_g128_kernel<float, TN> (exact-fp32 wgrad)" if f32 else
+            roof["wgrad_kernel"] = {"kernel": ("gemm_g3tn_kernel + fold on ME_BF16X3 planes: three launches per weight gradient, (hi,hi) + (lo,hi) + (hi,lo) accumulated by "
+                                               "beta = 1; `achieved` counts the bf16 flops as launched (3x the fp32 Linear's)" if x3 else
+                                               "gemm_g128_kernel<float, TN> (exact-fp32 wgrad)" if f32 else
                                                "gemm_g3tn_kernel + splitk_reduce_kernel (wgrad dW = dY^T X with the bias-gradient column sums fused; 256x256x64 tiles, split-K folded in fixed order)"),
                                     "achieved": round(f2 / (ms2 * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                                     "avg_launch_us": round(1e3 * ms2 / len(tn), 2),

@@ -218,6 +218,16 @@ size_t me_attention_fp8_workspace(int B, int N, int H, int head_dim);
 int me_attention_fwd_fp8(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, float* lse, int B, int N, int H,
                          int head_dim, float scale, void* workspace, size_t workspace_bytes, void* stream);
 
+/* fp32-ACCURATE forward on the bf16 matrix pipe -- the attention of an ME_BF16X3 Block (fp32 qkv in, fp32 out).  Same contract and
+ * math as me_attention_fwd with dtype ME_F32 (attention.py:28-35), but Q, K, V and the softmax probabilities are split into bf16
+ * hi / lo parts inside the kernel and every product is formed three times (hi hi + lo hi + hi lo) on v_mfma_f32_16x16x32_bf16 with
+ * fp32 accumulation: ~1e-5 relative where bf16 operands give ~3e-3, at ~5x the speed of the exact-fp32 MFMA kernel.  out (fp32,
+ * [B*N, ld_out]) and out3 (the ME_BF16X3 planes [hi | lo | hi] of the same values, dense [B*N, 3 * H * head_dim]: the A operand of
+ * the proj Linear) are both optional, at least one must be given; lse as me_attention_fwd.  head_dim 64 only (ME_ERR_UNSUPPORTED
+ * otherwise: use me_attention_fwd).  Backward: me_attention_bwd (ME_F32) with this call's out and lse. */
+int me_attention_fwd_x3(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_out, void* out3, float* lse, int B, int N, int H,
+                        int head_dim, float scale, void* stream);
+
 /* ------------------------------------------------------------------ One encoder Block, composed on the C side
  * Block.forward / its autograd (PointCloud/openpoints/models/layers/attention.py:55-58) as ONE call each: the same
  * kernels as the entry points above, launched back to back on `stream` without returning to the host in between --

@@ -24,6 +24,10 @@ OUT = os.path.join(HERE, "libmetaenc.so")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value", "-ffp-contract=fast"]
+# per-source extra flags.  attention_x3.hip: its MFMA accumulators are read and rescaled by VALU code every key chunk (online softmax);
+# left to itself hipcc parks them in AGPRs and moves all 96 of them out and back per chunk (v_accvgpr_read / _write: a third of the
+# loop's VALU instructions) -- the VGPR form of the MFMA keeps them where the VALU reads them (gfx950's register file is unified).
+FILE_FLAGS = {"attention_x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -74,7 +78,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, variant:
         if (not force and os.path.isfile(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and os.path.getmtime(obj) > hdr_t):
             return obj
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print("[metaenc build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

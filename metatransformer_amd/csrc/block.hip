@@ -238,8 +238,16 @@ int block_fwd_x3(const me_block_desc* d, const Dims& s, const void* x, void* y, 
     gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, s.C3, 3 * C, v.xn1, 3 * C, d->qkv_w, 3 * C, v.qkv, s.C3, ME_F32);
     g.bias = d->qkv_b;
     if ((rc = run(g))) return rc;
-    if ((rc = me_attention_fwd(v.qkv, s.C3, v.o, s.C, keep ? v.lse : nullptr, d->B, d->N, d->heads, s.hd, d->scale, ME_F32, 0.f, 0, stream))) return rc;
-    if ((rc = me_split3(reinterpret_cast<const float*>(v.o), C, v.o3, s.M, C, 0, stream))) return rc;
+    if (s.hd == 64) {
+        // three-product attention on the bf16 MFMA (attention_x3.hip): writes the proj Linear's planes itself; the fp32 copy only
+        // when backward will want it (me_attention_bwd reads o and lse)
+        rc = me_attention_fwd_x3(reinterpret_cast<const float*>(v.qkv), s.C3, keep ? reinterpret_cast<float*>(v.o) : nullptr, s.C, v.o3,
+                                 keep ? v.lse : nullptr, d->B, d->N, d->heads, s.hd, d->scale, stream);
+        if (rc) return rc;
+    } else {
+        if ((rc = me_attention_fwd(v.qkv, s.C3, v.o, s.C, keep ? v.lse : nullptr, d->B, d->N, d->heads, s.hd, d->scale, ME_F32, 0.f, 0, stream))) return rc;
+        if ((rc = me_split3(reinterpret_cast<const float*>(v.o), C, v.o3, s.M, C, 0, stream))) return rc;
+    }
     gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, C, 3 * C, v.o3, 3 * C, d->proj_w, 3 * C, v.x1, C, ME_F32);
     g.bias = d->proj_b; g.colscale = d->gamma1; g.residual = x; g.ldres = C; g.res_dtype = ME_F32;
     if ((rc = run(g))) return rc;

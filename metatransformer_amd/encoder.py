@@ -165,13 +165,19 @@ class _WeightCache:
         hit = self._fold.get(slot)
         if hit is None or hit[0] != k:
             with torch.no_grad():
-                w32, g32, b32 = w.detach().float(), ln_w.detach().float(), ln_b.detach().float()
-                wf = (w32 * g32[None, :]).to(dtype).contiguous()
-                s_vec = wf.float().sum(dim=1).contiguous()
-                c_vec = (w32 * b32[None, :]).sum(dim=1)        # (elementwise + reduce: no vendor BLAS call anywhere in the package)
-                if bias is not None:
-                    c_vec = c_vec + bias.detach().float()
-                hit = (k, (wf, s_vec, c_vec.contiguous()))
+                # every number here comes out of the library (this used to be at::native mul / reduce kernels):
+                #   W' = gamma o W rounded to the compute dtype   -- the column-scale form of me_dropout_add (p = 0)
+                #   s  = W' 1   (of the ROUNDED values, fp32 sums) -- me_gemm: four rows of ones x W'^T, row 0
+                #   c  = W beta + bias                             -- exact-fp32 me_gemm: four copies of beta x W^T + the bias epilogue
+                w32 = ops.cast(w.detach().contiguous(), torch.float32)
+                g32, b32 = ops._f32(ln_w.detach()).contiguous(), ops._f32(ln_b.detach()).contiguous()
+                wf = ops.dropout_add(w32, None, w32.shape[0], 0.0, 0.0, 0, out_dtype=dtype, colscale=g32)
+                K = w32.shape[1]
+                ones = torch.ones((4, K), dtype=dtype, device=w.device)
+                s_vec = ops.gemm(ones, wf, out_dtype=torch.float32)[0].contiguous()
+                c_vec = ops.gemm(b32[None, :].expand(4, K).contiguous(), w32, bias=None if bias is None else ops._f32(bias.detach()),
+                                 out_dtype=torch.float32)[0].contiguous()
+                hit = (k, (wf, s_vec, c_vec))
             self._fold[slot] = hit
         return hit[1]
 

@@ -254,6 +254,23 @@ def encoder_fwd(descs, x2: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def attention_fwd_x3(qkv: torch.Tensor, B: int, N: int, H: int, hd: int, scale: float, need_lse: bool = False, planes: bool = False,
+                     want_out: bool = True):
+    """fp32-accurate attention forward on the bf16 matrix pipe (me_attention_fwd_x3): fp32 qkv [B*N, 3*H*hd] -> (out fp32 [B*N, H*hd],
+    lse or None, ME_BF16X3 planes [B*N, 3*H*hd] bf16 or None)."""
+    lib = _capi.load()
+    _req(qkv, "qkv")
+    if qkv.dtype != torch.float32:
+        raise MetaEncError("attention_fwd_x3: float32 qkv required")
+    C = H * hd
+    out = torch.empty((B * N, C), dtype=torch.float32, device=qkv.device) if want_out else None
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if need_lse else None
+    o3 = torch.empty((B * N, 3 * C), dtype=torch.bfloat16, device=qkv.device) if planes else None
+    check(lib.me_attention_fwd_x3(ptr(qkv), qkv.stride(-2), ptr(out), C, ptr(o3), ptr(lse), B, N, H, hd, float(scale), stream_ptr()),
+          "me_attention_fwd_x3")
+    return out, lse, o3
+
+
 def block_bwd_overlap(enable: bool) -> bool:
     """Switch the side stream of me_block_bwd (weight-gradient GEMMs beside the dY -> dX chain) on / off; returns the previous setting."""
     return bool(_capi.load().me_block_bwd_overlap(1 if enable else 0))

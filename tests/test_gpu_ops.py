@@ -251,9 +251,13 @@ def test_attention_bwd(dev, B, N, H, hd, dt):
     # per element, and dQ / dK / dV each against its OWN scale (dV is ~10x larger than dQ at these sizes: a wrong dQ tail would
     # pass a bound taken over the whole [M, 3C] tensor)
     C = H * hd
+    whole = float(qr.grad.abs().max())
     for j, nm in enumerate(("dQ", "dK", "dV")):
-        check_close(dqkv.float()[:, j * C:(j + 1) * C], qr.grad[:, j * C:(j + 1) * C], 5e-5 if dt == torch.float32 else 3e-2,
-                    f"attention backward {nm} {B}x{N}x{H}x{hd}")
+        got, want = dqkv.float()[:, j * C:(j + 1) * C], qr.grad[:, j * C:(j + 1) * C]
+        if float(want.abs().max()) < 1e-3 * whole:       # (N = 1: dQ and dK are identically zero -- no scale of their own)
+            assert float((got.cpu().double() - want).abs().max()) <= (5e-5 if dt == torch.float32 else 3e-2) * whole, nm
+            continue
+        check_close(got, want, 5e-5 if dt == torch.float32 else 3e-2, f"attention backward {nm} {B}x{N}x{H}x{hd}")
 
 
 @pytest.mark.parametrize("B,N,H,hd", [(96, 197, 12, 64), (70, 100, 12, 48)])

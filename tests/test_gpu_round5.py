@@ -300,3 +300,41 @@ def test_bf16_stream_layer_by_layer_vs_oracle(dev, route):
             worst = max(worst, rel_err(nxt.float(), ref))
             cur = nxt
     assert worst < TOL_BF16_STREAM1
+
+
+X3_ATTN_SHAPES = [(2, 197, 12, 64), (1, 64, 2, 64), (3, 37, 2, 64), (1, 1, 1, 64), (1, 257, 2, 64), (1, 513, 1, 64), (2, 1568, 2, 64), (64, 65, 3, 64)]
+
+
+@pytest.mark.parametrize("B,N,H,hd", X3_ATTN_SHAPES)
+def test_attention_fwd_x3_vs_fp64(dev, B, N, H, hd):
+    """me_attention_fwd_x3 (three bf16 products per MFMA operand pair, fp32 softmax) against fp64 attention on the same fp32 qkv:
+    output and lse at the mode's 1e-4 bound (measured ~1e-5), the ME_BF16X3 planes = the split of the fp32 output bit for bit,
+    ragged query blocks / key chunks (N = 1, 37, 65, 197, 257, 513, 1568), and agreement with the exact-fp32 kernel."""
+    qkv = rnd(B * N, 3 * H * hd, seed=B * 1000 + N)
+    scale = hd ** -0.5
+    q, k, v = qkv.double().reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * scale
+    ref = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B * N, H * hd)
+    lse_ref = torch.logsumexp(s, dim=-1)
+    out, lse, o3 = ops.attention_fwd_x3(qkv.to(dev), B, N, H, hd, scale, need_lse=True, planes=True)
+    check_close(out, ref, TOL_3X, f"x3 attention {B}x{N}x{H}x{hd}")
+    assert rel_err(out, ref) < 3e-5
+    assert rel_err(lse, lse_ref) < 1e-5
+    assert torch.equal(o3, ops.split3(out))
+    exact, _ = ops.attention_fwd(qkv.to(dev), B, N, H, hd, scale, False)
+    assert rel_err(out, exact) < 3e-5
+    # peaked rows (one key far above the rest, in the LAST chunk): the running-max rescale path
+    if N >= 130:
+        qk = 0.3 * rnd(B * N, 3 * H * hd, seed=7)
+        qk[N - 3, H * hd:H * hd + hd] = 6.0 * qk[5, 0:hd] / qk[5, 0:hd].norm() * 8
+        q, k, v = qk.double().reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+        ref2 = (torch.softmax((q @ k.transpose(-2, -1)) * scale, dim=-1) @ v).transpose(1, 2).reshape(B * N, H * hd)
+        out2, _, _ = ops.attention_fwd_x3(qk.to(dev), B, N, H, hd, scale)
+        check_close(out2, ref2, TOL_3X, "x3 attention, peaked rows")
+
+
+def test_attention_fwd_x3_rejects_other_head_dims(dev):
+    with pytest.raises(_capi.MetaEncError):
+        ops.attention_fwd_x3(rnd(40, 3 * 2 * 32, seed=1).to(dev), 1, 40, 2, 32, 32 ** -0.5)
+    with pytest.raises(_capi.MetaEncError):
+        ops.attention_fwd_x3(rnd(40, 3 * 2 * 64, seed=1).to(dev).bfloat16(), 1, 40, 2, 64, 0.125)

@@ -1,13 +1,24 @@
 """Fold the rocprofv3 --pmc passes of tools/pmc_bench.sh into one JSON per mode (per-kernel averages per launch).
 HBM traffic = 2 * FETCH_SIZE + WRITE_SIZE  (KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced
 streams -- MI355X_MICROARCH.md "HBM" -- hence the factor 2; WRITE_SIZE is uncalibrated and taken as reported)."""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, hashlib, json, os, re, sys
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     return re.sub(r"\(.*", "", name)
 
-ROUND = "r04"
+ROUND = os.environ.get("ROUND", "r05")
+# the sources that define the roofline kernel (gemm_g3r_kernel): bench.py prints `traffic: null` when the running tree's differ from
+# the ones these counters were collected on (a committed constant silently going stale)
+KERNEL_SRC = ["gemm3.hip", "gemm3_core.h", "gemm_common.h", "gemm.hip", "common.h"]
+
+
+def kernel_src_sha16(root="."):
+    h = hashlib.sha256()
+    for f in KERNEL_SRC:
+        with open(os.path.join(root, "metatransformer_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def main(mode):
@@ -40,7 +51,9 @@ def main(mode):
         if "TCC_HIT_sum" in c:
             e["l2_hit"] = round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3)
         out[k] = e
-    out["_meta"] = {"bench_steps_in_pass": 2, "note": "tools/pmc_bench.sh runs bench.py --steps 1 --warmup 1: launch counts cover 2 steps"}
+    out["_meta"] = {"bench_steps_in_pass": 2, "note": "tools/pmc_bench.sh runs bench.py --steps 1 --warmup 1: launch counts cover 2 steps",
+                    "kernel_src_sha16": kernel_src_sha16(), "kernel_src": KERNEL_SRC,
+                    "head": os.popen("git rev-parse --short HEAD 2>/dev/null").read().strip() or None}
     json.dump(out, open(f"profiles/{ROUND}_pmc_{mode}.json", "w"), indent=1, sort_keys=True)
     for k, e in sorted(((k, e) for k, e in out.items() if k != "_meta"), key=lambda kv: -kv[1]["launches"] * kv[1]["avg_us_profiled"])[:12]:
         print(f"{k[:60]:60s}", {x: e[x] for x in e if x != "wave_cycles"})

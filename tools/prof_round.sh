@@ -3,7 +3,7 @@
 # the bench lines of the other BASELINE configurations.  Everything lands under gpurun_out/; tools/prof_summary.py and
 # tools/pmc_summary.py fold it into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/prof_r04
+O=$R/gpurun_out/prof_r05
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fwd-leg > $O/train.json 2> $O/train.err
@@ -24,6 +24,7 @@ timeout 300 python bench.py --workload large1568 --mode fwd --attn-dtype fp8 --s
 timeout 300 python bench.py --workload large1568 --steps 6 --warmup 2 --no-cpu-baseline --no-fwd-leg > $O/bench_large1568_train.json 2>> $O/bench_other.err; echo rc=$?
 timeout 300 python bench.py --workload mixed --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_mixed.json 2>> $O/bench_other.err; echo rc=$?
 timeout 600 python bench.py --dtype fp32 --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_fp32.json 2>> $O/bench_other.err; echo rc=$?
+timeout 600 python bench.py --dtype fp32 --fp32-mode 3xbf16 --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_fp32_3xbf16.json 2>> $O/bench_other.err; echo rc=$?
 timeout 900 python tools/refshapes.py --out $O/refshapes.json > $O/refshapes.txt 2>> $O/bench_other.err; echo rc=$?
 tail -3 $O/bench_other.err
 du -sh $R/gpurun_out/*
