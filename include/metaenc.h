@@ -227,6 +227,13 @@ int me_attention_fwd_fp8(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_
  * otherwise: use me_attention_fwd).  Backward: me_attention_bwd (ME_F32) with this call's out and lse. */
 int me_attention_fwd_x3(const float* qkv, int64_t ld_qkv, float* out, int64_t ld_out, void* out3, float* lse, int B, int N, int H,
                         int head_dim, float scale, void* stream);
+/* Backward of the above (what autograd derives from attention.py:28-35), same three-product arithmetic: P recomputed from the
+ * forward's lse, delta = dO . O in fp32 (written to `delta`, [B, H, N] scratch), dV = P^T dO, dP = dO V^T, dS = P o (dP - delta),
+ * dQ = scale dS K, dK = scale dS^T Q -- every product three bf16 MFMAs on hi / lo split operands with fp32 accumulation.  All tensors
+ * fp32; dqkv has the layout of qkv and is fully written.  head_dim 64 only (ME_ERR_UNSUPPORTED otherwise: me_attention_bwd, ME_F32). */
+int me_attention_bwd_x3(const float* qkv, int64_t ld_qkv, const float* out, int64_t ld_out, const float* dout, int64_t ld_dout,
+                        const float* lse, float* delta, float* dqkv, int64_t ld_dqkv, int B, int N, int H, int head_dim, float scale,
+                        void* stream);
 
 /* ------------------------------------------------------------------ One encoder Block, composed on the C side
  * Block.forward / its autograd (PointCloud/openpoints/models/layers/attention.py:55-58) as ONE call each: the same

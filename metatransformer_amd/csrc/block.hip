@@ -328,7 +328,11 @@ int block_bwd_x3(const me_block_desc* d, const Dims& s, const void* x, const voi
     if ((rc = wgrad(dx1_3, C, v.o3, C, gr->proj_w))) return rc;
     if ((rc = bias_grad(dx1, C, gr->proj_b))) return rc;
     if ((rc = nt(dx1_3, C, d->proj_wt, dout, C, ME_F32, nullptr))) return rc;
-    rc = me_attention_bwd(v.qkv, C3, v.o, C, dout, C, v.lse, delta, dqkv, C3, d->B, d->N, d->heads, s.hd, d->scale, ME_F32, 0.f, 0, stream);
+    if (s.hd == 64)      // three-product attention backward on the bf16 MFMA (attention_x3.hip); other head sizes: the exact-fp32 kernel
+        rc = me_attention_bwd_x3(reinterpret_cast<const float*>(v.qkv), C3, reinterpret_cast<const float*>(v.o), C, dout, C, v.lse, delta, dqkv, C3,
+                                 d->B, d->N, d->heads, s.hd, d->scale, stream);
+    else
+        rc = me_attention_bwd(v.qkv, C3, v.o, C, dout, C, v.lse, delta, dqkv, C3, d->B, d->N, d->heads, s.hd, d->scale, ME_F32, 0.f, 0, stream);
     if (rc) return rc;
     if ((rc = me_split3(dqkv, C3, dqkv3, s.M, C3, 0, stream))) return rc;
     if ((rc = wgrad(dqkv3, C3, v.xn1, C, gr->qkv_w))) return rc;

@@ -271,6 +271,22 @@ def attention_fwd_x3(qkv: torch.Tensor, B: int, N: int, H: int, hd: int, scale: 
     return out, lse, o3
 
 
+def attention_bwd_x3(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, hd: int,
+                     scale: float) -> torch.Tensor:
+    """backward of attention_fwd_x3 (me_attention_bwd_x3): fp32 tensors, three bf16 products per operand pair -> dqkv [B*N, 3*H*hd]"""
+    lib = _capi.load()
+    for t, n in ((qkv, "qkv"), (out, "out"), (dout, "dout"), (lse, "lse")):
+        _req(t, n)
+        if t.dtype != torch.float32:
+            raise MetaEncError(f"attention_bwd_x3: {n} must be float32")
+    C = H * hd
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    check(lib.me_attention_bwd_x3(ptr(qkv), qkv.stride(-2), ptr(out), C, ptr(dout), C, ptr(lse), ptr(delta), ptr(dqkv), dqkv.stride(-2),
+                                  B, N, H, hd, float(scale), stream_ptr()), "me_attention_bwd_x3")
+    return dqkv
+
+
 def block_bwd_overlap(enable: bool) -> bool:
     """Switch the side stream of me_block_bwd (weight-gradient GEMMs beside the dY -> dX chain) on / off; returns the previous setting."""
     return bool(_capi.load().me_block_bwd_overlap(1 if enable else 0))

@@ -338,3 +338,29 @@ def test_attention_fwd_x3_rejects_other_head_dims(dev):
         ops.attention_fwd_x3(rnd(40, 3 * 2 * 32, seed=1).to(dev), 1, 40, 2, 32, 32 ** -0.5)
     with pytest.raises(_capi.MetaEncError):
         ops.attention_fwd_x3(rnd(40, 3 * 2 * 64, seed=1).to(dev).bfloat16(), 1, 40, 2, 64, 0.125)
+
+
+@pytest.mark.parametrize("B,N,H,hd", X3_ATTN_SHAPES)
+def test_attention_bwd_x3_vs_fp64(dev, B, N, H, hd):
+    """me_attention_bwd_x3 (dQ / dK / dV as three bf16 products per operand pair, P recomputed from the forward's lse) against fp64
+    autograd of the same attention, per element and each of dQ / dK / dV on its own scale, at the mode's 1e-4 bound; ragged query and
+    key blocks (N = 1, 37, 65, 197, 257, 513, 1568); and against the exact-fp32 backward kernel."""
+    qkv = rnd(B * N, 3 * H * hd, seed=B * 1000 + N + 1)
+    do = rnd(B * N, H * hd, seed=77)
+    scale = hd ** -0.5
+    qr = qkv.double().requires_grad_(True)
+    q, k, v = qr.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax((q @ k.transpose(-2, -1)) * scale, dim=-1) @ v).transpose(1, 2).reshape(B * N, H * hd)
+    ref.backward(do.double())
+    out, lse, _ = ops.attention_fwd_x3(qkv.to(dev), B, N, H, hd, scale, need_lse=True)
+    dqkv = ops.attention_bwd_x3(qkv.to(dev), out, do.to(dev), lse, B, N, H, hd, scale)
+    C = H * hd
+    whole = float(qr.grad.abs().max())
+    for j, nm in enumerate(("dQ", "dK", "dV")):
+        got, want = dqkv[:, j * C:(j + 1) * C], qr.grad[:, j * C:(j + 1) * C]
+        if float(want.abs().max()) < 1e-3 * whole:       # (N = 1: dQ and dK are identically zero)
+            assert float((got.cpu().double() - want).abs().max()) <= TOL_3X * whole, nm
+            continue
+        check_close(got, want, TOL_3X, f"x3 attention backward {nm} {B}x{N}x{H}x{hd}")
+    exact = ops.attention_bwd(qkv.to(dev), out, do.to(dev), lse, B, N, H, hd, scale)
+    assert rel_err(dqkv, exact) < 5e-5

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round-5 GPU call K: Block-level 3xbf16 tests with the three-product attention backward + the fp32 3xbf16 bench
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r5k
+mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_round5.py -m gpu -q -k "x3 or 3xbf16 or split3 or three_plane" 2>&1 | tail -8 | tee $O/pytest_x3.txt
+timeout 600 python bench.py --dtype fp32 --fp32-mode 3xbf16 --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_fp32_3xbf16.json 2> $O/bench_fp32_3xbf16.err || tail -5 $O/bench_fp32_3xbf16.err
+python -c "import json; j=json.load(open('$O/bench_fp32_3xbf16.json')); print('3xbf16 train', j['ms_per_step'], 'fwd', j['fwd']['ms_per_step'], j['fwd']['mfma_frac'], {k: v['avg_launch_us'] for k, v in j['fwd']['other_kernels'].items()}, {k: v['avg_launch_us'] for k, v in j['other_kernels'].items()})" 2>&1 | tee $O/bench.txt
+python __graft_entry__.py smoke 2>&1 | tail -4 | tee $O/smoke.txt
