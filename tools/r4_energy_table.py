@@ -1,4 +1,4 @@
-"""Fold the round-4 cache-policy A/B (tools/r4_run_a.sh / r4_run_b.sh / r4_run_c.sh outputs under gpurun_out/) into the two tables
+"""Fold the round-4 cache-policy A/B (tools/runs/r4_run_a.sh / r4_run_b.sh / r4_run_c.sh outputs under gpurun_out/) into the two tables
 committed under profiles/: r04_energy.txt (every arm x launch: sustained time, socket power, pJ/flop, shader clock, fabric traffic)
 and r04_policy_ab.txt (bench-level same-box A/B).      python tools/r4_energy_table.py"""
 import csv, collections, glob, json, os, re, sys
@@ -46,7 +46,7 @@ def parse_pmc(base):
 
 
 def main():
-    lines = ["Round 4 -- energy per flop of the resident NT GEMM by cache-policy arm (tools/r4_run_a.sh, r4_run_b.sh; one MI355X box per call).",
+    lines = ["Round 4 -- energy per flop of the resident NT GEMM by cache-policy arm (tools/runs/r4_run_a.sh, r4_run_b.sh; one MI355X box per call).",
              "Sustained loop of >= 0.6 s per case (rotating operand / output sets, random full-range data), socket power = amdgpu hwmon",
              "power1_average sampled every 20 ms, pJ/flop = mean power x time / flops.  The socket sits at its ~1.4 kW cap under every arm:",
              "pJ/flop ranks the arms exactly as time does -- what an arm saves is stall time at the cap, i.e. energy.  clk = shader clock",
