@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--no-fwd-leg", action="store_true")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="train: keep the weight-gradient GEMMs in program order on the one stream (me_block_bwd_overlap(0))")
+    ap.add_argument("--opt-overlap", action="store_true",
+                    help="A/B arm (single GPU): per-Block AdamW launches + gradient zero-fill + weight transposes on the optimizer's side stream "
+                         "(FusedAdamW(overlap=True)) instead of one pass behind backward")
     ap.add_argument("--no-chain-stats", action="store_true",
                     help="A/B: folded inference reads every LayerNorm input once more (me_row_stats) instead of taking the statistics from the residual GEMMs' epilogues")
     ap.add_argument("--attn-dtype", choices=["bf16", "fp8"], default="bf16",
@@ -185,7 +188,9 @@ def main():
         enc.train()
         # 1-D parameters and biases carry no weight decay, as in the reference recipes (Video/optim_factory.py:67-73)
         flat = parallel.FlatParams(enc.named_parameters(), no_decay=parallel.no_decay_rule)
-        opt = parallel.FusedAdamW(flat, lr=1e-4, weight_decay=0.05)
+        # (--opt-overlap: per-Block AdamW + zero-fill + weight transposes on the optimizer's side stream under backward / the next forward --
+        #  measured SLOWER than the one-pass form, 30.4 vs 29.8 ms same box: profiles/r05_opt_overlap_ab.txt; the arm stays for A/B)
+        opt = parallel.FusedAdamW(flat, lr=1e-4, weight_decay=0.05, overlap=args.opt_overlap and not use_dist, grad_scale=1.0 / world)
         reducer = parallel.OverlappedGradReducer(flat, group=tgroup, comm=comm, force=use_dist,
                                                  wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None) if use_dist else None
         x.requires_grad_(True)                   # the tokenizer in front of the encoder needs dL/dx

@@ -510,7 +510,7 @@ def unpatchify_add(dcols: torch.Tensor, x_shape, kt, kh, kw, st, sh, sw) -> torc
 
 def adamw_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
                betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01, step: int = 1,
-               grad_scale: float = 1.0, bf16_mirror: Optional[torch.Tensor] = None) -> None:
+               grad_scale: float = 1.0, bf16_mirror: Optional[torch.Tensor] = None, bump_epoch: bool = True) -> None:
     """Raw fused AdamW on flat fp32 buffers (me_adamw_step).  The kernel writes `param` through its raw pointer, so
     torch's tensor version counters do not move; Block weight-copy caches notice the update through WEIGHT_EPOCH, which
     they consult for parameters registered in a parallel.FlatParams -- use parallel.FusedAdamW rather than this call
@@ -524,6 +524,13 @@ def adamw_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
             raise MetaEncError(f"adamw_step: {n} must be float32")
     check(lib.me_adamw_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, betas[0], betas[1],
                             eps, weight_decay, step, grad_scale, ptr(bf16_mirror), stream_ptr()), "me_adamw_step")
+    if bump_epoch:        # (False: a caller that steps slice by slice and announces the new weights once, with weights_updated())
+        weights_updated()
+
+
+def weights_updated() -> None:
+    """Announce that parameters registered in a parallel.FlatParams were written through raw pointers (Block weight caches re-derive
+    their compute copies)."""
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
 

@@ -215,7 +215,10 @@ class FlatParams:
             cb(i)
 
     def zero_grad(self) -> None:
-        self.flat_grad.zero_()
+        if getattr(self, "_zero_is_free", False):      # FusedAdamW(overlap=True) zeroed every slice behind its update
+            self._zero_is_free = False
+        else:
+            self.flat_grad.zero_()
         for p, o in zip(self.params, self.offsets):       # re-attach views if something replaced them
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
@@ -464,9 +467,17 @@ class FusedAdamW:
         device tensors (total_norm, found_inf) without synchronising -- feed found_inf to `DynamicLossScale.update`."""
 
     def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bf16_mirror: bool = True,
-                 lr_scale=None, max_norm: float = 0.0, loss_scale: Optional[torch.Tensor] = None):
+                 lr_scale=None, max_norm: float = 0.0, loss_scale: Optional[torch.Tensor] = None, overlap: bool = False,
+                 grad_scale: float = 1.0):
         """bf16_mirror: also emit the updated parameters in bf16 (FlatParams.flat_bf16) from the same kernel; Blocks
-        running in bf16 then take their forward weight copies from it instead of re-casting every weight."""
+        running in bf16 then take their forward weight copies from it instead of re-casting every weight.
+        overlap (plain form, ONE backward per step, no gradient exchange between ranks): the update of a parameter UNIT (one Block's
+        parameters: a contiguous slice of the decay region and one of the no-decay region) is enqueued on a side stream as soon as
+        backward has written the unit's last gradient -- the HBM-bound AdamW pass (2.6 GB for Base) then runs under the rest of
+        backward, which is matrix-bound -- followed by the zero-fill of that gradient slice (`flat.zero_grad()` of the next step
+        becomes free) and, behind the last unit, by the refresh of the transposed weight copies the next backward needs.  `step()`
+        launches whatever is left and joins.  `grad_scale` must be given HERE (the launches happen before `step()` is called);
+        after `step()` the gradients read as zero.  Same arithmetic, same bits as the one-pass form (tests)."""
         if flat.flat_param.dtype != torch.float32:
             raise MetaEncError("FusedAdamW needs fp32 master parameters")
         self.flat, self.lr, self.betas, self.eps, self.wd = flat, lr, betas, eps, weight_decay
@@ -479,6 +490,111 @@ class FusedAdamW:
         self.groups = None
         if self.fine_tune:
             self._build_segments(lr_scale)
+        self.overlap = bool(overlap)
+        self.grad_scale = float(grad_scale)
+        if self.overlap:
+            if self.fine_tune:
+                raise MetaEncError("FusedAdamW(overlap=True): the plain form only (clipping / loss scaling need the whole gradient first)")
+            self._setup_overlap()
+
+    # ---- overlap=True: per-unit updates launched from the gradient notifications ---------------------------------------------
+    def _setup_overlap(self) -> None:
+        f = self.flat
+        dev = f.flat_param.device
+        self._side = torch.cuda.Stream(device=dev)
+        # unit of a parameter: its leading numeric name component ("3.attn.qkv.weight" / "blocks.3...": Block 3), else the parameter alone
+        def unit_of(name: str, i: int):
+            for part in name.split("."):
+                if part.isdigit():
+                    return ("block", int(part))
+            return ("param", i)
+        units = {}
+        for i, name in enumerate(f.names):
+            units.setdefault(unit_of(name, i), []).append(i)
+        self._units = []                  # [(param indices, [(lo, hi, weight_decay), ...])]
+        for key, idx in units.items():
+            ranges = []
+            for region_lo, region_hi, wd in ((0, f.no_decay_numel, 0.0), (f.no_decay_numel, f.numel, self.wd)):
+                mine = sorted(i for i in idx if region_lo <= f.offsets[i] < region_hi)
+                if not mine:
+                    continue
+                if mine != list(range(mine[0], mine[-1] + 1)):
+                    raise MetaEncError(f"FusedAdamW(overlap=True): the parameters of unit {key} are not contiguous in the flat buffer")
+                lo = f.offsets[mine[0]]
+                hi = f.offsets[mine[-1] + 1] if mine[-1] + 1 < len(f.offsets) else f.numel
+                hi = min(hi, region_hi)
+                ranges.append((lo, hi, wd))
+            self._units.append((idx, ranges))
+        self._unit_of = {}
+        for u, (idx, _) in enumerate(self._units):
+            for i in idx:
+                self._unit_of[i] = u
+        self._left = [len(idx) for idx, _ in self._units]
+        self._seen = [False] * len(f.params)
+        self._launched = [False] * len(self._units)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(f.params)]
+        f._listeners.append(self._fire)                 # gradients the fused Block backward wrote in place
+        f._zero_is_free = False
+
+    def _make_hook(self, i):
+        def hook(param):
+            self._fire(i)
+        return hook
+
+    def _fire(self, i: int) -> None:
+        if self._seen[i]:
+            return                                      # (announced through both routes: counted once)
+        self._seen[i] = True
+        u = self._unit_of[i]
+        self._left[u] -= 1
+        if self._left[u] == 0 and not self._launched[u]:
+            self._launch_unit(u)
+
+    def _ensure_mirror(self) -> None:
+        f = self.flat
+        if self.bf16_mirror and f.flat_bf16 is None:
+            f.flat_bf16 = torch.empty(f.numel, dtype=torch.bfloat16, device=f.flat_param.device)
+            ops.cast(f.flat_param, torch.bfloat16, out=f.flat_bf16)
+
+    def _launch_unit(self, u: int) -> None:
+        f = self.flat
+        self._ensure_mirror()
+        main = torch.cuda.current_stream(f.flat_param.device)
+        self._side.wait_stream(main)                    # behind the kernel that wrote the unit's last gradient
+        with torch.cuda.stream(self._side):
+            for lo, hi, wd in self._units[u][1]:
+                ops.adamw_step(f.flat_param[lo:hi], f.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], lr=self.lr,
+                               betas=self.betas, eps=self.eps, weight_decay=wd, step=self.t + 1, grad_scale=self.grad_scale,
+                               bf16_mirror=f.flat_bf16[lo:hi] if self.bf16_mirror else None, bump_epoch=False)
+                f.flat_grad[lo:hi].zero_()              # nobody reads this slice again before the next backward writes it
+        self._launched[u] = True
+
+    def _step_overlapped(self, grad_scale: float) -> None:
+        f = self.flat
+        if abs(grad_scale - self.grad_scale) > 1e-12 * max(1.0, abs(grad_scale)):
+            raise MetaEncError(f"FusedAdamW(overlap=True): step(grad_scale={grad_scale}) differs from the grad_scale={self.grad_scale} the "
+                               "already-launched updates used; set opt.grad_scale before backward")
+        for u in range(len(self._units)):
+            if not self._launched[u]:                   # a unit whose gradients never arrived (frozen late / unused): its slice is zeros
+                self._launch_unit(u)
+        self.t += 1
+        ops.weights_updated()                           # ONE epoch for the whole step: the compute copies re-derive now, not mid-backward
+        if self.bf16_mirror:
+            f._mirror_epoch = ops.WEIGHT_EPOCH
+            f._mirror_versions = [p._version for p in f.params]
+        # the forward that follows reads the new parameters (fp32 masters / bf16 mirror): it waits for the updates and zero-fills ...
+        ev = torch.cuda.Event()
+        ev.record(self._side)
+        torch.cuda.current_stream(f.flat_param.device).wait_event(ev)
+        # ... but not for the transposed copies of the next BACKWARD, rebuilt behind them on the side stream (under the next forward);
+        # their first use waits for them by itself (_WeightCache.transposed)
+        with torch.cuda.stream(self._side):
+            from .encoder import _WeightCache
+            _WeightCache.prefetch_transposed(f.flat_param.device)
+        self._left = [len(idx) for idx, _ in self._units]
+        self._seen = [False] * len(f.params)
+        self._launched = [False] * len(self._units)
+        f._zero_is_free = True                          # every gradient slice was zeroed behind its update
 
     def _build_segments(self, lr_scale) -> None:
         import ctypes
@@ -501,6 +617,9 @@ class FusedAdamW:
         self._stats = torch.zeros(2, dtype=torch.float32, device=f.flat_param.device)
 
     def step(self, grad_scale: float = 1.0):
+        if self.overlap:
+            self.flat.check()
+            return self._step_overlapped(grad_scale)
         self.t += 1
         f = self.flat
         f.check()
