@@ -705,6 +705,7 @@ def build_encoder(depth: int = 12, dim: int = 768, num_heads: int = 12, mlp_rati
 # forward are latency-bound and the host's launch path is a visible part of it (N = 197: B = 1 0.84 ms eager, 0.63 ms replayed;
 # B = 2 0.87 / 0.68; B = 4 0.84 / 0.76; B = 8 0.99 / 0.99; B = 16 1.29 / 1.34 -- profiles/r05_latency.txt).
 GRAPH_MAX_ROWS = 1024
+GRAPH_MAX_CACHED = 8      # captured graphs kept per encoder (one per (B, N, C, dtype); each pins its static buffers and workspace)
 _graphs = None      # weakref.WeakKeyDictionary: encoder -> {(B, N, C, dtype, device): _EncoderGraph}
 
 
@@ -784,6 +785,9 @@ def encoder_forward_inference(encoder: nn.Sequential, x: torch.Tensor, graph: Op
             ys = ops.encoder_fwd(descs, xs)
         g = _EncoderGraph(wkey, xs, ys, cg)
         g.keep = (descs, keep)              # the compute copies of the weights the graph points at
+        per_enc.pop(gkey, None)
+        while len(per_enc) >= GRAPH_MAX_CACHED:      # oldest shape out (dicts keep insertion order): a graph pins its buffers
+            per_enc.pop(next(iter(per_enc)))
         per_enc[gkey] = g
     g.x.copy_(x2)
     g.graph.replay()
