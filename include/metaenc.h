@@ -229,11 +229,13 @@ int me_attention_fwd_x3(const float* qkv, int64_t ld_qkv, float* out, int64_t ld
                         int head_dim, float scale, void* stream);
 /* Backward of the above (what autograd derives from attention.py:28-35), same three-product arithmetic: P recomputed from the
  * forward's lse, delta = dO . O in fp32 (written to `delta`, [B, H, N] scratch), dV = P^T dO, dP = dO V^T, dS = P o (dP - delta),
- * dQ = scale dS K, dK = scale dS^T Q -- every product three bf16 MFMAs on hi / lo split operands with fp32 accumulation.  All tensors
- * fp32; dqkv has the layout of qkv and is fully written.  head_dim 64 only (ME_ERR_UNSUPPORTED otherwise: me_attention_bwd, ME_F32). */
+ * dQ = scale dS K, dK = scale dS^T Q -- every product three bf16 MFMAs on hi / lo split operands with fp32 accumulation.  Inputs
+ * fp32.  The gradient goes out as fp32 `dqkv` (layout of qkv, fully written) and / or as `dqkv3`, the ME_BF16X3 planes of the same
+ * [B*N, 3C] matrix (dense [B*N, 9C] bf16, [hi | lo | hi]: what the qkv weight-gradient and dgrad GEMMs of an ME_BF16X3 Block read) --
+ * either may be NULL, not both.  head_dim 64 only (ME_ERR_UNSUPPORTED otherwise: me_attention_bwd, ME_F32). */
 int me_attention_bwd_x3(const float* qkv, int64_t ld_qkv, const float* out, int64_t ld_out, const float* dout, int64_t ld_dout,
-                        const float* lse, float* delta, float* dqkv, int64_t ld_dqkv, int B, int N, int H, int head_dim, float scale,
-                        void* stream);
+                        const float* lse, float* delta, float* dqkv, int64_t ld_dqkv, void* dqkv3, int B, int N, int H, int head_dim,
+                        float scale, void* stream);
 
 /* ------------------------------------------------------------------ One encoder Block, composed on the C side
  * Block.forward / its autograd (PointCloud/openpoints/models/layers/attention.py:55-58) as ONE call each: the same

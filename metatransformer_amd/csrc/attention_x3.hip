@@ -438,8 +438,9 @@ __device__ __forceinline__ void x3_stage(const f32x4 (&reg)[4], int row0, int nr
     }
 }
 // the wave's 32 x 64 fp32 block (lane (g, q) holds hd = 16 t + 4 g + r of local row 16 u + q) through its LDS slice to whole-row stores
+// (dst: fp32 rows, may be null; planes: the ME_BF16X3 form of a `pcols` wide row whose columns pcol0 .. pcol0 + 63 these are, may be null)
 __device__ __forceinline__ void x3_store_rows(char* stage, const f32x4 (&acc)[X3_QT][4], float mul, int lane, float* dst, int64_t ld, int row0,
-                                              int nrows) {
+                                              int nrows, uint16_t* planes = nullptr, int64_t pcols = 0, int pcol0 = 0) {
     constexpr int OP = 272;
     const int g = lane >> 4, q = lane & 15;
 #pragma unroll
@@ -451,7 +452,10 @@ __device__ __forceinline__ void x3_store_rows(char* stage, const f32x4 (&acc)[X3
     for (int i = 0; i < 4 * X3_QT; ++i) {
         const int lr = 4 * i + rl;
         const f32x4 o = *reinterpret_cast<const f32x4*>(stage + lr * OP + ch * 16);
-        if (row0 + lr < nrows) *reinterpret_cast<f32x4*>(dst + (int64_t)(row0 + lr) * ld + 4 * ch) = o;
+        if (row0 + lr < nrows) {
+            if (dst) *reinterpret_cast<f32x4*>(dst + (int64_t)(row0 + lr) * ld + 4 * ch) = o;
+            if (planes) store4_split3(planes + (int64_t)(row0 + lr) * 3 * pcols, pcols, pcol0 + 4 * ch, o);
+        }
     }
 }
 
@@ -461,8 +465,8 @@ constexpr int X3_LDS_DKV = 8 * X3_TILE + 512;              // Q rows, dO rows, Q
 // ---- dQ (and delta): a workgroup owns 128 queries, streams {K, V}
 __global__ __launch_bounds__(256) void attn_bwd_dq_x3_kernel(const float* __restrict__ qkv, int64_t ld_qkv, const float* __restrict__ o, int64_t ld_o,
                                                              const float* __restrict__ dout, int64_t ld_do, const float* __restrict__ lse,
-                                                             float* __restrict__ delta, float* __restrict__ dqkv, int64_t ld_dqkv, int N, int H,
-                                                             float scale) {
+                                                             float* __restrict__ delta, float* __restrict__ dqkv, int64_t ld_dqkv,
+                                                             uint16_t* __restrict__ dqkv3, int N, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Krh = lds;                 char* Krl = lds + X3_TILE;
     char* Vrh = lds + 2 * X3_TILE;   char* Vrl = lds + 3 * X3_TILE;
@@ -567,13 +571,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_kernel(const float* __rest
             }
     }
     __syncthreads();
-    x3_store_rows(lds + wave * (16 * X3_QT * 272), dq, scale, lane, dqkv + (int64_t)b * N * ld_dqkv + h * X3_HD, ld_dqkv, q0, N);
+    x3_store_rows(lds + wave * (16 * X3_QT * 272), dq, scale, lane, dqkv ? dqkv + (int64_t)b * N * ld_dqkv + h * X3_HD : nullptr, ld_dqkv, q0, N,
+                  dqkv3 ? dqkv3 + (int64_t)b * N * 9 * C : nullptr, 3 * C, h * X3_HD);
 }
 
 // ---- dK, dV: a workgroup owns 128 keys, streams {Q, dO, lse, delta}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkdv_x3_kernel(const float* __restrict__ qkv, int64_t ld_qkv, const float* __restrict__ dout,
                                                                int64_t ld_do, const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               float* __restrict__ dqkv, int64_t ld_dqkv, int N, int H, float scale) {
+                                                               float* __restrict__ dqkv, int64_t ld_dqkv, uint16_t* __restrict__ dqkv3, int N, int H,
+                                                               float scale) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Qrh = lds;                 char* Qrl = lds + X3_TILE;
     char* Drh = lds + 2 * X3_TILE;   char* Drl = lds + 3 * X3_TILE;
@@ -685,9 +691,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();
     char* stage = lds + wave * (16 * X3_QT * 272);
-    float* dst = dqkv + (int64_t)b * N * ld_dqkv + h * X3_HD;
-    x3_store_rows(stage, dk, scale, lane, dst + C, ld_dqkv, k0, N);
-    x3_store_rows(stage, dv, 1.0f, lane, dst + 2 * C, ld_dqkv, k0, N);
+    float* dst = dqkv ? dqkv + (int64_t)b * N * ld_dqkv + h * X3_HD : nullptr;
+    uint16_t* pl3 = dqkv3 ? dqkv3 + (int64_t)b * N * 9 * C : nullptr;
+    x3_store_rows(stage, dk, scale, lane, dst ? dst + C : nullptr, ld_dqkv, k0, N, pl3, 3 * C, C + h * X3_HD);
+    x3_store_rows(stage, dv, 1.0f, lane, dst ? dst + 2 * C : nullptr, ld_dqkv, k0, N, pl3, 3 * C, 2 * C + h * X3_HD);
 }
 
 }  // namespace
@@ -714,20 +721,20 @@ extern "C" int me_attention_fwd_x3(const float* qkv, int64_t ld_qkv, float* out,
 }
 
 extern "C" int me_attention_bwd_x3(const float* qkv, int64_t ld_qkv, const float* out, int64_t ld_out, const float* dout, int64_t ld_dout,
-                                   const float* lse, float* delta, float* dqkv, int64_t ld_dqkv, int B, int N, int H, int head_dim, float scale,
-                                   void* stream_) {
+                                   const float* lse, float* delta, float* dqkv, int64_t ld_dqkv, void* dqkv3, int B, int N, int H, int head_dim,
+                                   float scale, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ProfScope prof(ME_PROF_ATTN_BWD, ME_BF16X3, (int64_t)B * H, N, head_dim, stream);
-    ME_CHECK_ARG(qkv && out && dout && lse && delta && dqkv, "me_attention_bwd_x3: null pointer");
+    ME_CHECK_ARG(qkv && out && dout && lse && delta && (dqkv || dqkv3), "me_attention_bwd_x3: null pointer");
     ME_CHECK_ARG(B > 0 && N > 0 && H > 0, "me_attention_bwd_x3: bad shape B=%d N=%d H=%d", B, N, H);
     if (head_dim != X3_HD) {
         me_set_error("me_attention_bwd_x3: head_dim %d (64 only; use me_attention_bwd with ME_F32)", head_dim);
         return ME_ERR_UNSUPPORTED;
     }
     const int C = H * head_dim;
-    ME_CHECK_ARG(ld_qkv % 4 == 0 && ld_qkv >= 3 * C && ld_dqkv % 4 == 0 && ld_dqkv >= 3 * C && ld_out % 4 == 0 && ld_out >= C && ld_dout % 4 == 0 &&
+    ME_CHECK_ARG(ld_qkv % 4 == 0 && ld_qkv >= 3 * C && (!dqkv || (ld_dqkv % 4 == 0 && ld_dqkv >= 3 * C)) && ld_out % 4 == 0 && ld_out >= C && ld_dout % 4 == 0 &&
                      ld_dout >= C, "me_attention_bwd_x3: bad strides");
-    ME_CHECK_ARG(((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) % 16 == 0, "me_attention_bwd_x3: alignment");
+    ME_CHECK_ARG(((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) % 16 == 0 && (uintptr_t)dqkv3 % 8 == 0, "me_attention_bwd_x3: alignment");
     ME_CHECK_ARG((int64_t)N * ld_qkv < (int64_t)0x7fffffff && (int64_t)N * ld_dout < (int64_t)0x7fffffff, "me_attention_bwd_x3: N * ld must fit 31 bits");
     const int64_t nwg = (int64_t)B * H * ((N + X3_QB - 1) / X3_QB);
     ME_CHECK_ARG(nwg < (int64_t)0x7fffffff, "me_attention_bwd_x3: too many workgroups");
@@ -737,10 +744,10 @@ extern "C" int me_attention_bwd_x3(const float* qkv, int64_t ld_qkv, const float
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_DKV);
     }
     hipLaunchKernelGGL(attn_bwd_dq_x3_kernel, dim3((unsigned)nwg), dim3(256), X3_LDS_DQ, stream, qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv,
-                       ld_dqkv, N, H, scale);
+                       ld_dqkv, reinterpret_cast<uint16_t*>(dqkv3), N, H, scale);
     ME_CHECK_LAUNCH("me_attention_bwd_x3(dq)");
     hipLaunchKernelGGL(attn_bwd_dkdv_x3_kernel, dim3((unsigned)nwg), dim3(256), X3_LDS_DKV, stream, qkv, ld_qkv, dout, ld_dout, lse, delta, dqkv, ld_dqkv,
-                       N, H, scale);
+                       reinterpret_cast<uint16_t*>(dqkv3), N, H, scale);
     ME_CHECK_LAUNCH("me_attention_bwd_x3(dkdv)");
     return ME_OK;
 }

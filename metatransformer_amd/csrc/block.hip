@@ -328,15 +328,23 @@ int block_bwd_x3(const me_block_desc* d, const Dims& s, const void* x, const voi
     if ((rc = wgrad(dx1_3, C, v.o3, C, gr->proj_w))) return rc;
     if ((rc = bias_grad(dx1, C, gr->proj_b))) return rc;
     if ((rc = nt(dx1_3, C, d->proj_wt, dout, C, ME_F32, nullptr))) return rc;
-    if (s.hd == 64)      // three-product attention backward on the bf16 MFMA (attention_x3.hip); other head sizes: the exact-fp32 kernel
-        rc = me_attention_bwd_x3(reinterpret_cast<const float*>(v.qkv), C3, reinterpret_cast<const float*>(v.o), C, dout, C, v.lse, delta, dqkv, C3,
-                                 d->B, d->N, d->heads, s.hd, d->scale, stream);
-    else
+    if (s.hd == 64) {
+        // three-product attention backward on the bf16 MFMA (attention_x3.hip): writes the planes the two qkv GEMMs read by itself --
+        // no fp32 dqkv, no split pass; the bias gradient is the column sums of the hi and the lo plane
+        rc = me_attention_bwd_x3(reinterpret_cast<const float*>(v.qkv), C3, reinterpret_cast<const float*>(v.o), C, dout, C, v.lse, delta, nullptr, C3,
+                                 dqkv3, d->B, d->N, d->heads, s.hd, d->scale, stream);
+        if (rc) return rc;
+        if (gr->qkv_b) {
+            if ((rc = me_colsum(dqkv3, ME_BF16, 3 * C3, s.M, C3, gr->qkv_b, gr->accumulate, aws, stream))) return rc;
+            if ((rc = me_colsum(dqkv3 + C3, ME_BF16, 3 * C3, s.M, C3, gr->qkv_b, 1, aws, stream))) return rc;
+        }
+    } else {             // other head sizes: the exact-fp32 kernel + one split pass
         rc = me_attention_bwd(v.qkv, C3, v.o, C, dout, C, v.lse, delta, dqkv, C3, d->B, d->N, d->heads, s.hd, d->scale, ME_F32, 0.f, 0, stream);
-    if (rc) return rc;
-    if ((rc = me_split3(dqkv, C3, dqkv3, s.M, C3, 0, stream))) return rc;
+        if (rc) return rc;
+        if ((rc = me_split3(dqkv, C3, dqkv3, s.M, C3, 0, stream))) return rc;
+        if ((rc = bias_grad(dqkv, C3, gr->qkv_b))) return rc;
+    }
     if ((rc = wgrad(dqkv3, C3, v.xn1, C, gr->qkv_w))) return rc;
-    if ((rc = bias_grad(dqkv, C3, gr->qkv_b))) return rc;
     if ((rc = nt(dqkv3, C3, d->qkv_wt, dxn, C, ME_F32, nullptr))) return rc;
     rc = me_ln_bwd_deferred(dxn, ME_F32, x, ME_F32, v.mean1, v.rstd1, d->ln1_g, dx1, ME_F32, dx, ME_F32, gr->ln1_g, gr->ln1_b, gr->accumulate,
                             s.M, s.C, aws, stream, &folds[1]);

@@ -272,8 +272,9 @@ def attention_fwd_x3(qkv: torch.Tensor, B: int, N: int, H: int, hd: int, scale: 
 
 
 def attention_bwd_x3(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, hd: int,
-                     scale: float) -> torch.Tensor:
-    """backward of attention_fwd_x3 (me_attention_bwd_x3): fp32 tensors, three bf16 products per operand pair -> dqkv [B*N, 3*H*hd]"""
+                     scale: float, planes: bool = False):
+    """backward of attention_fwd_x3 (me_attention_bwd_x3): fp32 tensors, three bf16 products per operand pair -> dqkv [B*N, 3*H*hd]
+    (planes=True: -> (dqkv, its ME_BF16X3 planes [B*N, 9*H*hd] bf16))"""
     lib = _capi.load()
     for t, n in ((qkv, "qkv"), (out, "out"), (dout, "dout"), (lse, "lse")):
         _req(t, n)
@@ -282,9 +283,10 @@ def attention_bwd_x3(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, l
     C = H * hd
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    d3 = torch.empty((B * N, 9 * C), dtype=torch.bfloat16, device=qkv.device) if planes else None
     check(lib.me_attention_bwd_x3(ptr(qkv), qkv.stride(-2), ptr(out), C, ptr(dout), C, ptr(lse), ptr(delta), ptr(dqkv), dqkv.stride(-2),
-                                  B, N, H, hd, float(scale), stream_ptr()), "me_attention_bwd_x3")
-    return dqkv
+                                  ptr(d3), B, N, H, hd, float(scale), stream_ptr()), "me_attention_bwd_x3")
+    return (dqkv, d3) if planes else dqkv
 
 
 def block_bwd_overlap(enable: bool) -> bool:

@@ -353,7 +353,8 @@ def test_attention_bwd_x3_vs_fp64(dev, B, N, H, hd):
     ref = (torch.softmax((q @ k.transpose(-2, -1)) * scale, dim=-1) @ v).transpose(1, 2).reshape(B * N, H * hd)
     ref.backward(do.double())
     out, lse, _ = ops.attention_fwd_x3(qkv.to(dev), B, N, H, hd, scale, need_lse=True)
-    dqkv = ops.attention_bwd_x3(qkv.to(dev), out, do.to(dev), lse, B, N, H, hd, scale)
+    dqkv, d3 = ops.attention_bwd_x3(qkv.to(dev), out, do.to(dev), lse, B, N, H, hd, scale, planes=True)
+    assert torch.equal(d3, ops.split3(dqkv))                  # the planes the qkv GEMMs of an ME_BF16X3 Block read
     C = H * hd
     whole = float(qr.grad.abs().max())
     for j, nm in enumerate(("dQ", "dK", "dV")):
