@@ -620,6 +620,11 @@ class Block(nn.Module):
         # moves) simply finds no statistics and reads its input once more (me_row_stats).
         # Inference tensors (torch.inference_mode) have no version counter: nothing can vouch for "not written since", so they
         # are neither tagged nor trusted (the block reads its input once more; encoder_forward_inference chains on the C side).
+        # Assumptions of the hand-over: (1) whoever writes the tagged tensor bumps its `_version` -- torch ops do; a write
+        # through a raw pointer (this library's own `out=` forms, `x.data` edits, foreign kernels) does not, and must drop the tag
+        # (`del y._me_ln_stats`) or set `blk.chain_stats = False`; (2) one forward at a time per Block object: `_stats_in / _stats_out`
+        # are per-call state on the module -- a Block shared by two host threads needs `chain_stats = False` (me_encoder_fwd, the
+        # one-call route, keeps the hand-over inside the library and has neither restriction).
         tag = getattr(x, "_me_ln_stats", None)
         self._stats_in = None
         ver = _tensor_version(x) if tag is not None else None
