@@ -178,11 +178,11 @@ def test_split3_planes_and_gemm_accuracy(dev):
     assert rel_err(plain, ref) > 20 * rel_err(y, ref)            # (what the split buys)
 
 
-@pytest.mark.parametrize("M_", [300, 50432 // 8])
-def test_gemm_writes_three_plane_output(dev, M_):
-    """c_dtype ME_BF16X3 is reachable through the C ABI only (no torch dtype): the GELU Linear writes [hi | lo | hi] of its fp32 result"""
+@pytest.mark.parametrize("M_,N,K", [(300, 1024, 256), (50432 // 8, 1024, 256), (256 * 90 + 77, 768, 768)])
+def test_gemm_writes_three_plane_output(dev, M_, N, K):
+    """c_dtype ME_BF16X3 is reachable through the C ABI only (no torch dtype): the GELU Linear writes [hi | lo | hi] of its fp32 result
+    (small-M plan, one-tile g3 kernel, and -- 273 tiles with a long reduction -- the g3 tail split whose fold writes the planes)"""
     import ctypes
-    N, K = 1024, 256
     a, w, bias = rnd(M_, K, seed=5), 0.05 * rnd(N, K, seed=6), 0.1 * rnd(N, seed=7)
     a3, w3 = ops.split3(a.to(dev)), ops.split3(w.to(dev), right_operand=True)
     out = torch.zeros(M_, 3 * N, dtype=torch.bfloat16, device=dev)
