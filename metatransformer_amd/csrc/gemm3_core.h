@@ -459,6 +459,72 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
     // row operand (residual / gelu' input): twelve of the tile's sixteen 16-byte loads go out at once, the last four as
     // soon as the first slabs have freed their registers and BEFORE those slabs' stores (vmcnt retires in order) -- one
     // memory latency per tile instead of one per 16-row slab (the K-loop's fragment registers are free here)
+    if constexpr (EPI == 9 || EPI == 10) {
+        // ---- fp32 result as the three bf16 planes of ME_BF16X3 ([hi | lo | hi], ldc >= 3 N) -- the MLP of an ME_BF16X3 Block:
+        //   EPI 9   bias -> (p.preact, fp32: gelu'(h) saved for backward) -> GELU (erf form: fp32 accuracy) -> planes     (fc1)
+        //   EPI 10  acc * fp32 row operand (the saved gelu') -> planes                                                    (fc2 dgrad)
+        // Straight-line, as the other specialised forms: clamped unconditional loads, only the stores are guarded -- the generic
+        // epilogue these launches used to take waits for every bias / factor load inside its `if (ok)` (draining the stores before
+        // it each time): 869 us per fc1 launch at [50 432, 3 x 768] x 3 072 against 640 us for the same GEMM with a bias epilogue.
+        const float* fac = reinterpret_cast<const float*>(p.aux);
+        uint16_t* Cp = reinterpret_cast<uint16_t*>(p.C);
+        f32x4 fa[2][2][2];                                       // [slab parity][q][half]: factor rows one slab ahead
+        auto fetchf = [&](const int mt, f32x4 (&dst)[2][2]) {
+            int64_t m = mrow + mt * 16;
+            m = m < p.M ? m : p.M - 1;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float* fp = fac + m * p.ldaux + (n_ok[q] ? n[q] : 0);
+                dst[q][0] = *reinterpret_cast<const f32x4*>(fp);
+                dst[q][1] = *reinterpret_cast<const f32x4*>(fp + 4);
+            }
+        };
+        if (EPI == 10) fetchf(0, fa[0]);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            if (EPI == 10 && mt + 1 < 8) fetchf(mt + 1, fa[(mt + 1) & 1]);
+            const int64_t m = mrow + mt * 16;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x4 v0 = s.acc[mt][2 * q], v1 = s.acc[mt][2 * q + 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0[e]), __float_as_uint(v1[e]), false, false);
+                    v0[e] = __uint_as_float(sw[0]);
+                    v1[e] = __uint_as_float(sw[1]);
+                }
+                const bool ok = m < p.M && n_ok[q];
+                v0 = v0 * alpha4 + bias[q][0];
+                v1 = v1 * alpha4 + bias[q][1];
+                if (EPI == 9) {
+                    if (p.preact && ok) {
+                        float* pp = reinterpret_cast<float*>(p.preact) + m * p.ldpre + n[q];
+                        *reinterpret_cast<f32x4*>(pp) = gelu_erf_grad4(v0);
+                        *reinterpret_cast<f32x4*>(pp + 4) = gelu_erf_grad4(v1);
+                    }
+                    v0 = gelu_erf4(v0);
+                    v1 = gelu_erf4(v1);
+                } else {
+                    v0 *= fa[mt & 1][q][0];
+                    v1 *= fa[mt & 1][q][1];
+                }
+                // eight consecutive columns -> one 16-byte store per plane
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = (bf16_t)v0[e];     lo[e] = (bf16_t)(v0[e] - (float)hi[e]);
+                    hi[4 + e] = (bf16_t)v1[e]; lo[4 + e] = (bf16_t)(v1[e] - (float)hi[4 + e]);
+                }
+                if (ok) {
+                    uint16_t* row = Cp + m * p.ldc + n[q];
+                    *reinterpret_cast<bf16x8*>(row) = hi;
+                    *reinterpret_cast<bf16x8*>(row + p.N) = lo;
+                    *reinterpret_cast<bf16x8*>(row + 2 * p.N) = hi;
+                }
+            }
+        }
+        return;
+    }
     constexpr int AHEAD = 6;
     constexpr bool ROWOP = EPI == 2 || EPI == 3 || EPI == 6;
     u32x4 rowop[8][2];

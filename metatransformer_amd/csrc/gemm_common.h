@@ -182,6 +182,14 @@ static inline int pick_epi(const GemmParams& p) {
 // forms of both: at the reference's batch sizes (M = 3 072 .. 8 224) the generic epilogue cost 45 us against 29 us per launch.
 static inline int pick_epi_ex(const GemmParams& p) {
     const int e = pick_epi(p);
+    // three-plane (ME_BF16X3) outputs of the MLP of an ME_BF16X3 Block: straight-line forms in the one-tile g3 kernel (9: bias + erf GELU,
+    // optionally saving gelu' as an fp32 pre-activation; 10: x fp32 row operand); the other families take the generic epilogue for them
+    if (p.c_dtype == ME_BF16X3 && p.split_k <= 1 && !p.row_affine && !p.colscale && !p.residual && p.beta == 0.0f && p.out_group_rows == 0 &&
+        p.res_row_mod == 0 && p.ldc % 8 == 0 && p.N % 8 == 0) {
+        if (p.act == ME_ACT_GELU && !p.aux && (!p.preact ? p.flags == 0 : (p.flags == ME_GEMM_SAVE_GELU_GRAD && p.preact_dtype == ME_F32 && p.ldpre % 4 == 0)))
+            return 9;
+        if (p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_F32 && p.flags == ME_GEMM_AUX_IS_FACTOR && !p.preact && p.ldaux % 4 == 0) return 10;
+    }
     if (e != 4 || p.c_dtype == ME_BF16X3 || p.row_affine || p.colscale || p.residual || p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return e;
     if (p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_BF16 && !p.preact) return 6;
     if (p.flags == ME_GEMM_SAVE_GELU_GRAD && p.act == ME_ACT_GELU && p.preact && !p.aux) return 7;

@@ -187,7 +187,7 @@ def test_overlapped_optimizer_equals_the_one_pass_form(dev):
             flat.zero_grad()
             x.grad = None
             y = enc(x)
-            losses.append(float((y.float() * gy.to(dev)).sum()))
+            losses.append(float((y.detach().float() * gy.to(dev)).sum()))
             y.backward(gy.to(dev).bfloat16())
             opt.step(grad_scale=0.5)
             if overlap:
