@@ -200,6 +200,7 @@ size_t gemm_scratch_x3(const Dims& s, bool backward) {
     static char dummy_mem[64] __attribute__((aligned(64)));
     auto probe = [&](int op, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int cdt) {
         gemm_desc(g, op, ME_BF16, M, N, K, dummy_mem, lda, dummy_mem, ldb, dummy_mem, cdt == ME_BF16X3 ? 3 * N : N, cdt);
+        if (op == ME_GEMM_TN) g.colsum_a = reinterpret_cast<float*>(dummy_mem);      // (the fused bias gradient's partial rows)
         const size_t b = me_gemm_workspace_bytes(&g);
         if (b > w) w = b;
     };
@@ -293,58 +294,57 @@ int block_bwd_x3(const me_block_desc* d, const Dims& s, const void* x, const voi
         return me_gemm(&g, stream);
     };
     // dW[n_out, n_in] = dOut^T In from the planes of both: (hi, hi) + (lo, hi) + (hi, lo)
-    auto wgrad = [&](const uint16_t* dOut3, int64_t n_out, const void* In3_, int64_t n_in, void* dW) -> int {
-        if (!dW) return ME_OK;
+    // The bias gradient db = colsum(dOut) rides on the first two launches where the kernel can fuse it (me_gemm_desc.colsum_a: the column
+    // sums of the A operand from the fragments the kernel stages anyway, accumulated with C's beta): term 0 leaves colsum(hi), term 1
+    // adds colsum(lo) -- 2^-17 relative, as the planes themselves; otherwise two plane passes of me_colsum.
+    auto wgrad = [&](const uint16_t* dOut3, int64_t n_out, const void* In3_, int64_t n_in, void* dW, float* dB) -> int {
         const uint16_t* In3 = reinterpret_cast<const uint16_t*>(In3_);
         const int64_t pa[3] = {0, n_out, 0}, pb[3] = {0, 0, n_in};
-        for (int t = 0; t < 3; ++t) {
-            gemm_desc(g, ME_GEMM_TN, ME_BF16, n_out, n_in, s.M, dOut3 + pa[t], 3 * n_out, In3 + pb[t], 3 * n_in, dW, n_in, gr->w_dtype);
-            g.beta = (t == 0 && !gr->accumulate) ? 0.0f : 1.0f;
-            g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
-            const int r = me_gemm(&g, stream);
-            if (r) return r;
+        bool db_done = dB == nullptr;
+        if (dW) {
+            for (int t = 0; t < 3; ++t) {
+                gemm_desc(g, ME_GEMM_TN, ME_BF16, n_out, n_in, s.M, dOut3 + pa[t], 3 * n_out, In3 + pb[t], 3 * n_in, dW, n_in, gr->w_dtype);
+                g.beta = (t == 0 && !gr->accumulate) ? 0.0f : 1.0f;
+                g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+                if (dB && t < 2 && (t == 1 ? db_done : me_gemm_fuses_colsum(&g))) {      // (both or neither: term 1 adds onto term 0's sums)
+                    g.colsum_a = dB;
+                    db_done = true;
+                }
+                const int r = me_gemm(&g, stream);
+                if (r) return r;
+            }
+        }
+        if (!db_done) {
+            const int r = me_colsum(dOut3, ME_BF16, 3 * n_out, s.M, n_out, dB, gr->accumulate, aws, stream);
+            return r ? r : me_colsum(dOut3 + n_out, ME_BF16, 3 * n_out, s.M, n_out, dB, 1, aws, stream);
         }
         return ME_OK;
     };
-    auto bias_grad = [&](const void* g32, int64_t n, float* dB) -> int {
-        return dB ? me_colsum(g32, ME_F32, n, s.M, n, dB, gr->accumulate, aws, stream) : ME_OK;
-    };
     // ---- MLP branch
     if ((rc = me_split3(reinterpret_cast<const float*>(dy), C, dy3, s.M, C, 0, stream))) return rc;
-    if ((rc = wgrad(dy3, C, v.a, Hd, gr->fc2_w))) return rc;
-    if ((rc = bias_grad(dy, C, gr->fc2_b))) return rc;
+    if ((rc = wgrad(dy3, C, v.a, Hd, gr->fc2_w, gr->fc2_b))) return rc;
     if ((rc = nt(dy3, C, d->fc2_wt, dh3, Hd, ME_BF16X3, v.hpre))) return rc;                  // dA * gelu'(h), three planes
-    if ((rc = wgrad(dh3, Hd, v.xn2, C, gr->fc1_w))) return rc;
-    if (gr->fc1_b) {      // dh exists as planes only: column sums of hi, then of lo on top (2^-17 relative, as the planes themselves)
-        if ((rc = me_colsum(dh3, ME_BF16, 3 * Hd, s.M, Hd, gr->fc1_b, gr->accumulate, aws, stream))) return rc;
-        if ((rc = me_colsum(dh3 + Hd, ME_BF16, 3 * Hd, s.M, Hd, gr->fc1_b, 1, aws, stream))) return rc;
-    }
+    if ((rc = wgrad(dh3, Hd, v.xn2, C, gr->fc1_w, gr->fc1_b))) return rc;
     if ((rc = nt(dh3, Hd, d->fc1_wt, dxn, C, ME_F32, nullptr))) return rc;
     rc = me_ln_bwd_deferred(dxn, ME_F32, v.x1, ME_F32, v.mean2, v.rstd2, d->ln2_g, dy, ME_F32, dx1, ME_F32, gr->ln2_g, gr->ln2_b, gr->accumulate,
                             s.M, s.C, ln2_ws, stream, &folds[0]);
     if (rc) return rc;
     // ---- attention branch
     if ((rc = me_split3(dx1, C, dx1_3, s.M, C, 0, stream))) return rc;
-    if ((rc = wgrad(dx1_3, C, v.o3, C, gr->proj_w))) return rc;
-    if ((rc = bias_grad(dx1, C, gr->proj_b))) return rc;
+    if ((rc = wgrad(dx1_3, C, v.o3, C, gr->proj_w, gr->proj_b))) return rc;
     if ((rc = nt(dx1_3, C, d->proj_wt, dout, C, ME_F32, nullptr))) return rc;
     if (s.hd == 64) {
         // three-product attention backward on the bf16 MFMA (attention_x3.hip): writes the planes the two qkv GEMMs read by itself --
-        // no fp32 dqkv, no split pass; the bias gradient is the column sums of the hi and the lo plane
+        // no fp32 dqkv, no split pass
         rc = me_attention_bwd_x3(reinterpret_cast<const float*>(v.qkv), C3, reinterpret_cast<const float*>(v.o), C, dout, C, v.lse, delta, nullptr, C3,
                                  dqkv3, d->B, d->N, d->heads, s.hd, d->scale, stream);
         if (rc) return rc;
-        if (gr->qkv_b) {
-            if ((rc = me_colsum(dqkv3, ME_BF16, 3 * C3, s.M, C3, gr->qkv_b, gr->accumulate, aws, stream))) return rc;
-            if ((rc = me_colsum(dqkv3 + C3, ME_BF16, 3 * C3, s.M, C3, gr->qkv_b, 1, aws, stream))) return rc;
-        }
     } else {             // other head sizes: the exact-fp32 kernel + one split pass
         rc = me_attention_bwd(v.qkv, C3, v.o, C, dout, C, v.lse, delta, dqkv, C3, d->B, d->N, d->heads, s.hd, d->scale, ME_F32, 0.f, 0, stream);
         if (rc) return rc;
         if ((rc = me_split3(dqkv, C3, dqkv3, s.M, C3, 0, stream))) return rc;
-        if ((rc = bias_grad(dqkv, C3, gr->qkv_b))) return rc;
     }
-    if ((rc = wgrad(dqkv3, C3, v.xn1, C, gr->qkv_w))) return rc;
+    if ((rc = wgrad(dqkv3, C3, v.xn1, C, gr->qkv_w, gr->qkv_b))) return rc;
     if ((rc = nt(dqkv3, C3, d->qkv_wt, dxn, C, ME_F32, nullptr))) return rc;
     rc = me_ln_bwd_deferred(dxn, ME_F32, x, ME_F32, v.mean1, v.rstd1, d->ln1_g, dx1, ME_F32, dx, ME_F32, gr->ln1_g, gr->ln1_b, gr->accumulate,
                             s.M, s.C, aws, stream, &folds[1]);
