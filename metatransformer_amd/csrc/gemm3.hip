@@ -1068,6 +1068,7 @@ int launch_g3(const GemmParams& p, int epi, void* ws, hipStream_t stream) {
         case 3: return launch3e<3>(p, ws, stream);
         case 6: return launch3e<6>(p, ws, stream);
         case 7: return launch3e<7>(p, ws, stream);
+        case 8: return launch3e<8>(p, ws, stream);
         case 9: return launch3e<9>(p, ws, stream);
         case 10: return launch3e<10>(p, ws, stream);
         default: return launch3e<4>(p, ws, stream);

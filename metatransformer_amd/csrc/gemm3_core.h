@@ -459,14 +459,17 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
     // row operand (residual / gelu' input): twelve of the tile's sixteen 16-byte loads go out at once, the last four as
     // soon as the first slabs have freed their registers and BEFORE those slabs' stores (vmcnt retires in order) -- one
     // memory latency per tile instead of one per 16-row slab (the K-loop's fragment registers are free here)
-    if constexpr (EPI == 9 || EPI == 10) {
+    if constexpr (EPI == 8 || EPI == 9 || EPI == 10) {
+        //   EPI 8   bias + fp32 row operand (the residual stream) -> fp32: proj / fc2 on an fp32 token stream -- the reference's autocast
+        //           recipes (fp32 tokens, bf16 compute: Video/engine_for_finetuning.py:92-99) and the ME_BF16X3 Blocks
         // ---- fp32 result as the three bf16 planes of ME_BF16X3 ([hi | lo | hi], ldc >= 3 N) -- the MLP of an ME_BF16X3 Block:
         //   EPI 9   bias -> (p.preact, fp32: gelu'(h) saved for backward) -> GELU (erf form: fp32 accuracy) -> planes     (fc1)
         //   EPI 10  acc * fp32 row operand (the saved gelu') -> planes                                                    (fc2 dgrad)
         // Straight-line, as the other specialised forms: clamped unconditional loads, only the stores are guarded -- the generic
         // epilogue these launches used to take waits for every bias / factor load inside its `if (ok)` (draining the stores before
         // it each time): 869 us per fc1 launch at [50 432, 3 x 768] x 3 072 against 640 us for the same GEMM with a bias epilogue.
-        const float* fac = reinterpret_cast<const float*>(p.aux);
+        const float* fac = reinterpret_cast<const float*>(EPI == 8 ? p.residual : p.aux);
+        const int64_t ldf = EPI == 8 ? p.ldres : p.ldaux;
         uint16_t* Cp = reinterpret_cast<uint16_t*>(p.C);
         f32x4 fa[2][2][2];                                       // [slab parity][q][half]: factor rows one slab ahead
         auto fetchf = [&](const int mt, f32x4 (&dst)[2][2]) {
@@ -474,15 +477,15 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
             m = m < p.M ? m : p.M - 1;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const float* fp = fac + m * p.ldaux + (n_ok[q] ? n[q] : 0);
+                const float* fp = fac + m * ldf + (n_ok[q] ? n[q] : 0);
                 dst[q][0] = *reinterpret_cast<const f32x4*>(fp);
                 dst[q][1] = *reinterpret_cast<const f32x4*>(fp + 4);
             }
         };
-        if (EPI == 10) fetchf(0, fa[0]);
+        if (EPI != 9) fetchf(0, fa[0]);
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
-            if (EPI == 10 && mt + 1 < 8) fetchf(mt + 1, fa[(mt + 1) & 1]);
+            if (EPI != 9 && mt + 1 < 8) fetchf(mt + 1, fa[(mt + 1) & 1]);
             const int64_t m = mrow + mt * 16;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -504,9 +507,18 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
                     }
                     v0 = gelu_erf4(v0);
                     v1 = gelu_erf4(v1);
-                } else {
+                } else if (EPI == 10) {
                     v0 *= fa[mt & 1][q][0];
                     v1 *= fa[mt & 1][q][1];
+                } else {
+                    v0 += fa[mt & 1][q][0];
+                    v1 += fa[mt & 1][q][1];
+                    if (ok) {
+                        float* row = reinterpret_cast<float*>(p.C) + m * p.ldc + n[q];
+                        *reinterpret_cast<f32x4*>(row) = v0;
+                        *reinterpret_cast<f32x4*>(row + 4) = v1;
+                    }
+                    continue;
                 }
                 // eight consecutive columns -> one 16-byte store per plane
                 bf16x8 hi, lo;

@@ -416,3 +416,17 @@ def test_three_plane_mlp_epilogues_on_the_one_tile_kernel(dev, M_):
     ref = (a.double() @ w.double().t()) * fac.cpu().double()
     check_close(out3[:, :N].float() + out3[:, N:2 * N].float(), ref, TOL_3X, "fc2 dgrad: x saved factor, planes")
     assert torch.equal(out3[:, :N], out3[:, 2 * N:])
+
+
+@pytest.mark.parametrize("M_,N,K", [(256 * 40 + 100, 1024, 256), (256 * 90 + 77, 768, 768), (256 * 90 + 77, 768, 3072), (50432, 768, 768)])
+def test_fp32_residual_epilogue_on_the_one_tile_kernel(dev, M_, N, K):
+    """bias + fp32 residual -> fp32 with bf16 operands: proj / fc2 of the reference's AUTOCAST recipes (fp32 tokens, bf16 compute) and
+    of the ME_BF16X3 Blocks -- the straight-line EPI 8 of the 256 x 256 one-tile kernel (whole tiles, ragged last row, and the tail
+    split whose fold applies the same epilogue), per element against fp64."""
+    dt = torch.bfloat16
+    a, w, bias, res = rnd(M_, K, seed=1).to(dt), (0.05 * rnd(N, K, seed=2)).to(dt), 0.1 * rnd(N, seed=3), rnd(M_, N, seed=4)
+    y = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), residual=res.to(dev), out_dtype=torch.float32)
+    ref = a.double() @ w.double().t() + bias.double() + res.double()
+    check_close(y, ref, 2e-5, "bias + fp32 residual -> fp32")
+    y2 = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), residual=res.to(dev), out_dtype=torch.float32)
+    assert torch.equal(y, y2)
