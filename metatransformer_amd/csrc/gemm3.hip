@@ -973,7 +973,7 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
         if (EPI == 2 && p.row_stats) pre = 4;
         const int G = g3_cus() & ~7;
         const int64_t ldmax = std::max(std::max(p.ldc, p.preact ? p.ldpre : 0), std::max(p.residual ? p.ldres : 0, p.aux ? p.ldaux : 0));
-        if (repi >= 0 && G >= 8 && nwg >= G && q.g3_split <= 1 && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!(pre == 1 || pre == 2) || p.preact_dtype == ME_BF16) &&
+        if (repi >= 0 && !p.colscale && G >= 8 && nwg >= G && q.g3_split <= 1 && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!(pre == 1 || pre == 2) || p.preact_dtype == ME_BF16) &&
             256 * ldmax * 2 < (1ll << 31))
             return launch3r_any(repi, pre, q, G, stream);
     }
@@ -1060,7 +1060,7 @@ size_t g3_workspace_bytes() {
 
 // one tile per workgroup; in the dev build ws != nullptr (>= g3_workspace_bytes()) selects the persistent stream-K form
 int launch_g3(const GemmParams& p, int epi, void* ws, hipStream_t stream) {
-    if (p.colscale) epi = 4;                       // (the specialised epilogues of this family carry no column scale)
+    if (p.colscale && epi != 2 && epi != 8) epi = 4;      // (the residual forms carry the column scale -- layer-scale Blocks; the others do not)
     switch (epi) {
         case 0: return launch3e<0>(p, ws, stream);
         case 1: return launch3e<1>(p, ws, stream);

@@ -438,6 +438,21 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
             bias[q][1] = *reinterpret_cast<const f32x4*>(p.bias + nc + 4);
         }
     }
+    // per-column scale (layer-scale gamma of the detection / Video Blocks: vit.py:313-316), carried by the residual forms 2 and 8 -- the
+    // launches that have one: x + gamma * branch(x).  Ones when absent (a wave-uniform choice ahead of the straight-line part).
+    f32x4 cscale[2][2];
+    constexpr bool CS = EPI == 2 || EPI == 8;
+    if (CS) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            cscale[q][0] = cscale[q][1] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (p.colscale) {
+                cscale[q][0] = *reinterpret_cast<const f32x4*>(p.colscale + (n_ok[q] ? n[q] : 0));
+                cscale[q][1] = *reinterpret_cast<const f32x4*>(p.colscale + (n_ok[q] ? n[q] : 0) + 4);
+            }
+        }
+        asm volatile("" ::"v"(cscale[0][0]), "v"(cscale[0][1]), "v"(cscale[1][0]), "v"(cscale[1][1]));
+    }
     // pin the per-column operands in registers NOW (straight-line code): otherwise hipcc waits for them with vmcnt(0)
     // inside every guarded store block, which drains the stores of the previous rows each time
     asm volatile("" ::"v"(bias[0][0]), "v"(bias[0][1]), "v"(bias[1][0]), "v"(bias[1][1]));
@@ -511,8 +526,8 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
                     v0 *= fa[mt & 1][q][0];
                     v1 *= fa[mt & 1][q][1];
                 } else {
-                    v0 += fa[mt & 1][q][0];
-                    v1 += fa[mt & 1][q][1];
+                    v0 = v0 * cscale[q][0] + fa[mt & 1][q][0];
+                    v1 = v1 * cscale[q][1] + fa[mt & 1][q][1];
                     if (ok) {
                         float* row = reinterpret_cast<float*>(p.C) + m * p.ldc + n[q];
                         *reinterpret_cast<f32x4*>(row) = v0;
@@ -594,7 +609,7 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
                 v1 *= gelu_grad_for4(qb, p.c_dtype);
             }
             if (EPI == 6) { v0 *= qa; v1 *= qb; }
-            if (EPI == 2) { v0 += qa; v1 += qb; }
+            if (EPI == 2) { v0 = v0 * cscale[q][0] + qa; v1 = v1 * cscale[q][1] + qb; }
             if (kMeDev && (p.debug & 4)) {             // dev: epilogue arithmetic without the stores
                 asm volatile("" ::"v"(v0), "v"(v1));
                 continue;

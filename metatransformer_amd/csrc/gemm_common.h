@@ -192,7 +192,7 @@ static inline int pick_epi_ex(const GemmParams& p) {
     }
     // bias + fp32 residual -> fp32 (8): the residual GEMMs of an fp32 token stream (autocast recipes, ME_BF16X3 Blocks)
     if (e == 4 && p.c_dtype == ME_F32 && p.residual && p.res_dtype == ME_F32 && !p.aux && !p.preact && p.act == ME_ACT_NONE && !p.flags &&
-        !p.row_affine && !p.colscale && p.beta == 0.0f && p.out_group_rows == 0 && p.res_row_mod == 0 && p.split_k <= 1 && p.ldres % 4 == 0)
+        !p.row_affine && p.beta == 0.0f && p.out_group_rows == 0 && p.res_row_mod == 0 && p.split_k <= 1 && p.ldres % 4 == 0)
         return 8;
     if (e != 4 || p.c_dtype == ME_BF16X3 || p.row_affine || p.colscale || p.residual || p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return e;
     if (p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_BF16 && !p.preact) return 6;

@@ -430,3 +430,36 @@ def test_fp32_residual_epilogue_on_the_one_tile_kernel(dev, M_, N, K):
     check_close(y, ref, 2e-5, "bias + fp32 residual -> fp32")
     y2 = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), residual=res.to(dev), out_dtype=torch.float32)
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("mode", ["bf16_tokens", "autocast_fp32_tokens", "fp32_3xbf16"])
+def test_layer_scale_block_at_a_size_the_one_tile_kernel_takes(dev, mode):
+    """x + gamma * branch(x) (the detection / segmentation ViT's layer scale, vit.py:313-316) at B x N = 64 x 197: proj / fc2 run on the
+    256 x 256 one-tile kernel, whose residual epilogues (EPI 2: bf16 stream, EPI 8: fp32 stream) carry the per-column scale -- against
+    the oracle, inference (the forward with gamma inside me_block_fwd)."""
+    torch.manual_seed(3)
+    blk = M.Block(768, 12, qkv_bias=True, layer_scale=True).to(dev).eval()
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 2:
+                torch.nn.init.normal_(p, std=0.02)
+        blk.gamma1.uniform_(0.1, 1.5)
+        blk.gamma2.uniform_(0.1, 1.5)
+    sd = {k: v.detach().cpu().float() for k, v in blk.state_dict().items()}
+    x = rnd(64, 197, 768, seed=4)
+    ref = bo.block_forward(x, sd, 12, gamma1=sd["gamma1"], gamma2=sd["gamma2"])
+    with torch.no_grad():
+        if mode == "bf16_tokens":
+            blk.compute_dtype = torch.bfloat16
+            y = blk(x.to(dev).bfloat16()).float()
+            tol = TOL_BF16_STREAM1
+        elif mode == "autocast_fp32_tokens":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = blk(x.to(dev))
+            assert y.dtype == torch.float32
+            tol = TOL_BF16_STREAM1
+        else:
+            blk.fp32_mode = "3xbf16"
+            y = blk(x.to(dev))
+            tol = TOL_3X
+    check_close(y, ref, tol, f"layer-scale block, {mode}")
