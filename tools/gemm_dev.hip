@@ -3,7 +3,7 @@
 //   python -m metatransformer_amd.build --dev      # builds tools/_build/libmetaenc_dev.so and tools/_build/gemm_dev
 //   tools/_build/gemm_dev [--iters N] [--check] case [case ...]
 //   case  = family:M:N:K:epi[:debug]      family in {auto, g128, g2b, g2w, g3, g3x, g3p, g3s, g3t, g3f}; epi 0 bias, 1 gelu(+preact), 2 residual,
-//           3 gelu'(aux), 6 * aux (ME_GEMM_AUX_IS_FACTOR), 7 gelu + saved gelu' (ME_GEMM_SAVE_GELU_GRAD), 8 residual + row statistics
+//           3 gelu'(aux), 6 * aux (ME_GEMM_AUX_IS_FACTOR), 7 gelu + saved gelu' (ME_GEMM_SAVE_GELU_GRAD), 9 fp32 residual -> fp32 output, 8 residual + row statistics
 //           (me_gemm_desc.row_stats); debug = GemmDev::debug bits
 //           tn-family:M:N:K               wgrad form C[M, N] = A[K, M]^T B[K, N] (fp32 output), family in {auto, g2b, g3}
 //
@@ -79,13 +79,17 @@ __global__ void ref_kernel(const uint16_t* A, const uint16_t* B, const float* bi
         v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
     } else if (epi == 6) {
         v *= bf2f(rowop[m * N + n]);
-    } else if (epi == 2 || epi == 8) {
+    } else if (epi == 2 || epi == 8 || epi == 9) {
         v += bf2f(rowop[m * N + n]);
     } else if (epi == 3) {
         const float x = bf2f(rowop[m * N + n]);
         v *= 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
     }
     out[m * N + n] = v;
+}
+
+__global__ void expand_f32_kernel(const uint16_t* src, float* dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = bf2f(src[i]);
 }
 
 __global__ void ref_tn_kernel(const uint16_t* A, const uint16_t* B, int64_t M, int64_t N, int64_t K, float* out) {
@@ -301,19 +305,24 @@ int main(int argc, char** argv) {
         float *bias, *ref = nullptr, *ref_pre = nullptr;
         for (int s = 0; s < NSET; ++s) {
             CK(hipMalloc(&A[s], (size_t)M * K * 2));
-            CK(hipMalloc(&C[s], (size_t)M * N * 2));
+            CK(hipMalloc(&C[s], (size_t)M * N * (epi == 9 ? 4 : 2)));
             P[s] = nullptr;
             if (epi == 1 || epi == 7) CK(hipMalloc(&P[s], (size_t)M * N * 2));
             fill_kernel<<<2048, 256, 0, st>>>(A[s], (size_t)M * K, 17, 1.0f);     // same content in every set
-            CK(hipMemsetAsync(C[s], 0xff, (size_t)M * N * 2, st));
+            CK(hipMemsetAsync(C[s], 0xff, (size_t)M * N * (epi == 9 ? 4 : 2), st));
         }
         CK(hipMalloc(&Bw, (size_t)N * K * 2));
         CK(hipMalloc(&bias, (size_t)N * 4));
         fill_kernel<<<2048, 256, 0, st>>>(Bw, (size_t)N * K, 99, 0.05f);
         fill_f32_kernel<<<64, 256, 0, st>>>(bias, (size_t)N, 5, 0.5f);
-        if (epi == 2 || epi == 3 || epi == 6 || epi == 8) {
+        float* rowop32 = nullptr;
+        if (epi == 2 || epi == 3 || epi == 6 || epi == 8 || epi == 9) {
             CK(hipMalloc(&rowop, (size_t)M * N * 2));
             fill_kernel<<<2048, 256, 0, st>>>(rowop, (size_t)M * N, 1234, 1.0f);
+        }
+        if (epi == 9) {           // bias + fp32 residual -> fp32 (an fp32 token stream: autocast recipes, ME_BF16X3 blocks)
+            CK(hipMalloc(&rowop32, (size_t)M * N * 4));
+            expand_f32_kernel<<<2048, 256, 0, st>>>(rowop, rowop32, (size_t)M * N);
         }
         me_gemm_desc d;
         memset(&d, 0, sizeof(d));
@@ -324,6 +333,7 @@ int main(int argc, char** argv) {
         if (epi == 7) d.flags = ME_GEMM_SAVE_GELU_GRAD;
         if (epi == 6) { d.aux = rowop; d.ldaux = N; d.aux_dtype = ME_BF16; d.flags = ME_GEMM_AUX_IS_FACTOR; }
         if (epi == 2 || epi == 8) { d.residual = rowop; d.ldres = N; d.res_dtype = ME_BF16; }
+        if (epi == 9) { d.residual = rowop32; d.ldres = N; d.res_dtype = ME_F32; d.c_dtype = ME_F32; }
         float* rstats = nullptr;
         if (epi == 3) { d.aux = rowop; d.ldaux = N; d.aux_dtype = ME_BF16; }
         d.A = A[0]; d.C = C[0]; d.preact = P[0];
@@ -359,7 +369,8 @@ int main(int argc, char** argv) {
                     CK(hipMemsetAsync(nbad, 0, 8, st));
                     CK(hipMemsetAsync(maxerr, 0, 4, st));
                     // bf16 output rounding (2^-9 relative) + accumulation-order noise
-                    cmp_kernel<<<1024, 256, 0, st>>>(which ? P[s] : C[s], which ? ref_pre : ref, (size_t)M * N, 2e-2f, 8e-3f, nbad, maxerr);
+                    if (epi == 9) cmp_f32_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const float*>(C[s]), ref, (size_t)M * N, 2e-3f, 2e-4f, nbad, maxerr);
+                    else cmp_kernel<<<1024, 256, 0, st>>>(which ? P[s] : C[s], which ? ref_pre : ref, (size_t)M * N, 2e-2f, 8e-3f, nbad, maxerr);
                     unsigned long long hb;
                     float hm;
                     CK(hipMemcpyAsync(&hb, nbad, 8, hipMemcpyDeviceToHost, st));
@@ -492,6 +503,7 @@ int main(int argc, char** argv) {
         }
         CK(hipFree(Bw)); CK(hipFree(bias));
         if (rowop) CK(hipFree(rowop));
+        if (rowop32) CK(hipFree(rowop32));
         if (rstats) CK(hipFree(rstats));
         if (ws) CK(hipFree(ws));
     }
