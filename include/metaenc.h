@@ -372,6 +372,40 @@ int me_unpatchify_add(const void* dcols, int dcols_dtype, float* dx,
                       int B, int Cin, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw,
                       void* stream);
 
+/* The whole patch embed -- Conv2d / Conv3d(Cin, Cout, kernel (kt, kh, kw), stride (st, sh, sw)) + flatten(2).transpose(1, 2)
+ * (Data2Seq/Image.py:19-28, Video/models/modeling_finetune.py:283-297, Data2Seq/Acoustic.py:16-22) -- as one call:
+ *   out[b * (prefix_rows + tokens) + prefix_rows + t, :] = patch(b, t) . weight^T + bias (+ pos[t, :])
+ * with the token / feature order of me_patchify.  weight = the conv weight viewed as [Cout, Cin*kt*kh*kw] in the compute dtype
+ * (ME_BF16: bf16 MFMA, fp32 accumulation; ME_F32: exact).  When x and weight are bf16, kh * kw == 256 with kw in {8, 16, 32, 64}
+ * and the patch rows of x are 16-byte aligned (W, sw, H*W multiples of 8; the reference's image and tubelet embeds), the gather
+ * runs INSIDE the GEMM's operand stager (csrc/patch_embed.hip): the gathered matrix is never materialised, no workspace is
+ * needed and me_patch_embed_fused() returns 1.  Every other case (fp32 pixels, the spectrogram's stride-10 patches) runs
+ * me_patchify into the caller's workspace followed by me_gemm -- same results as the two calls, one entry point. */
+typedef struct me_patch_embed_desc {
+    const void* x; int32_t x_dtype;         /* [B, Cin, T, H, W] contiguous (T = 1 for images) */
+    int32_t B, Cin, T, H, W, kt, kh, kw, st, sh, sw;
+    const void* weight; int32_t w_dtype;    /* [Cout, Cin*kt*kh*kw] */
+    int32_t Cout;
+    const float* bias;                      /* [Cout] or NULL */
+    const void* pos; int32_t pos_dtype; int64_t ld_pos;    /* optional [tokens, Cout], added to every sample's tokens */
+    int32_t prefix_rows;                    /* rows left untouched in front of every sample's tokens (cls / register tokens) */
+    void* out; int32_t out_dtype; int64_t ld_out;          /* [B * (prefix_rows + tokens), Cout] */
+    void* workspace; int64_t workspace_bytes;
+} me_patch_embed_desc;
+int me_patch_embed_fused(const me_patch_embed_desc* d);
+size_t me_patch_embed_workspace_bytes(const me_patch_embed_desc* d);     /* 0 when fused */
+int me_patch_embed(const me_patch_embed_desc* d, void* stream);
+/* Gradients of the patch embed's parameters (what autograd derives from the Conv2d / Conv3d above; the tokenizer is the trainable part
+ * of the frozen-encoder recipes):  dW[Cout, Cin*kt*kh*kw] = beta * dW + dY^T . patches(x),   dbias[Cout] = beta * dbias + colsum(dY)
+ * (dbias may be NULL).  dy: [B * tokens, Cout] in the compute dtype d->w_dtype (prefix rows already dropped), row stride ld_dy.  Of *d
+ * the input (x, x_dtype, geometry), w_dtype, Cout and the workspace are read.  In the fused case of me_patch_embed (and x < 1 GiB, a
+ * problem the split-K wgrad kernel takes) the patches are gathered in THAT kernel's operand stager; otherwise me_patchify runs into the
+ * workspace first.  workspace: me_patch_embed_wgrad_workspace_bytes(). */
+int me_patch_embed_wgrad_fused(const me_patch_embed_desc* d, int dw_dtype);      /* 1: gathered inside the wgrad kernel */
+size_t me_patch_embed_wgrad_workspace_bytes(const me_patch_embed_desc* d, int dw_dtype, int with_bias);
+int me_patch_embed_wgrad(const me_patch_embed_desc* d, const void* dy, int64_t ld_dy, void* dw, int dw_dtype, float* dbias,
+                         float beta, void* stream);
+
 /* Time-series DataEmbedding (Data2Seq/Time_Series.py:109-126), eval-mode:
  *   out[b,l,:] = sum_{j<3} Wc[:, :, j] x[b,(l-1+j) mod L,:]  (Conv1d k3 circular, no bias, :29-42)
  *              + sum_f table_f[mark[b,l,f]]                     (TemporalEmbedding gathers, :82-93)

@@ -59,6 +59,16 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class PatchEmbedDesc(ctypes.Structure):
+    """Mirror of ``struct me_patch_embed_desc`` (include/metaenc.h)."""
+    _fields_ = ([("x", c_void_p), ("x_dtype", c_int32)]
+                + [(n, c_int32) for n in ("B", "Cin", "T", "H", "W", "kt", "kh", "kw", "st", "sh", "sw")]
+                + [("weight", c_void_p), ("w_dtype", c_int32), ("Cout", c_int32), ("bias", c_void_p),
+                   ("pos", c_void_p), ("pos_dtype", c_int32), ("ld_pos", c_int64), ("prefix_rows", c_int32),
+                   ("out", c_void_p), ("out_dtype", c_int32), ("ld_out", c_int64),
+                   ("workspace", c_void_p), ("workspace_bytes", c_int64)])
+
+
 class GemmProfileRec(ctypes.Structure):
     """Mirror of ``struct me_gemm_profile_rec``."""
     _fields_ = [("op", c_int32), ("ab_dtype", c_int32), ("M", c_int64), ("N", c_int64), ("K", c_int64), ("ms", c_float),
@@ -161,6 +171,12 @@ SIGNATURES = {
                                ctypes.c_uint64, c_void_p, c_void_p]),
     "me_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 11 + [c_void_p]),
     "me_unpatchify_add": (c_int, [c_void_p, c_int, c_void_p] + [c_int] * 11 + [c_void_p]),
+    "me_patch_embed_fused": (c_int, [POINTER(PatchEmbedDesc)]),
+    "me_patch_embed_workspace_bytes": (c_size_t, [POINTER(PatchEmbedDesc)]),
+    "me_patch_embed": (c_int, [POINTER(PatchEmbedDesc), c_void_p]),
+    "me_patch_embed_wgrad_fused": (c_int, [POINTER(PatchEmbedDesc), c_int]),
+    "me_patch_embed_wgrad_workspace_bytes": (c_size_t, [POINTER(PatchEmbedDesc), c_int, c_int]),
+    "me_patch_embed_wgrad": (c_int, [POINTER(PatchEmbedDesc), c_void_p, c_int64, c_void_p, c_int, c_void_p, c_float, c_void_p]),
     "me_timeseries_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_void_p), POINTER(c_int32),
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "me_timeseries_unfold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

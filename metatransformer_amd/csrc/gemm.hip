@@ -427,7 +427,9 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
     }
     if (fam == 4 && d->op == ME_GEMM_NT && !g3_supported(p, d->op)) fam = 3;
     if (fam == 4 && d->op == ME_GEMM_TN && (!g3_tn_supported(p) || d->M < 256 || d->N < 256)) fam = 2;
-    if (!g2b_supported(p, d->op)) return pl;
+    // (the g3 wgrad kernel takes any reduction length: rows past K read zeros through its descriptors -- a ragged token count,
+    //  B x N not a multiple of 32, no longer sends the weight gradients of a whole Block to the generic kernel)
+    if (!(fam == 4 && d->op == ME_GEMM_TN) && !g2b_supported(p, d->op)) return pl;
     if (ffam < 0 && (d->M < 128 || d->N < 128)) return pl;       // tiny problems: g128 is enough
     pl.family = fam;
     pl.bm = fam == 2 ? 128 : 256;
@@ -624,6 +626,9 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
 
 }  // namespace
 
+// (patch_embed.hip: the same validation and parameter block for the projection it runs on its own kernel)
+int gemm_fill_params(const me_gemm_desc* d, GemmParams& p) { return fill_params(d, p); }
+
 extern "C" size_t me_gemm_workspace_bytes(const me_gemm_desc* d) {
     GemmParams p;
     if (fill_params(d, p) != ME_OK) return 0;
@@ -651,7 +656,10 @@ extern "C" int me_gemm_emits_row_stats(const me_gemm_desc* d) {
 }
 
 namespace {
-int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out);
+// tn_launch: a replacement for launch_g3_tn (patch_embed.hip: the wgrad kernel that gathers its B operand from the image); with it,
+// a problem the planner does not give to the g3 wgrad family is refused (ME_ERR_UNSUPPORTED) instead of run
+typedef int (*TnLaunch)(const GemmParams& p, hipStream_t stream, const void* ctx);
+int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out, TnLaunch tn_launch = nullptr, const void* tn_ctx = nullptr);
 }
 
 extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
@@ -661,11 +669,12 @@ extern "C" int me_gemm(const me_gemm_desc* d, void* stream_) {
 }
 
 namespace {
-int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out) {
+int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out, TnLaunch tn_launch, const void* tn_ctx) {
     GemmParams p;
     int rc = fill_params(d, p);
     if (rc) return rc;
     GemmPlan pl = plan_gemm(d, p);
+    if (tn_launch && !(pl.family == 4 && d->op == ME_GEMM_TN && !G3_TN_FOLD)) return ME_ERR_UNSUPPORTED;
     {   // me_gemm_profile_rec.plan
         const bool have_ws = pl.ws_bytes && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes;
         const int parts = pl.split_k > 1 ? pl.split_k : (pl.tail_rows > 0 ? pl.tail_split : 1);
@@ -704,7 +713,7 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out) {
                 return launch_g3_tn_fold(pf, stream);
             }
 #endif
-            rc = launch_g3_tn(ps, stream);
+            rc = tn_launch ? tn_launch(ps, stream, tn_ctx) : launch_g3_tn(ps, stream);
             if (rc) return rc;
             p.split_k = 1;
             const int64_t quads = d->M * (d->N / 4);
@@ -814,3 +823,13 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out) {
 }
 }  // namespace
 
+// (patch_embed.hip) me_gemm for a g3 wgrad problem with the split-K kernel launch replaced; 1 / 0: would the planner take that route
+int gemm_tn_with_launcher(const me_gemm_desc* d, hipStream_t stream, int (*launch)(const GemmParams&, hipStream_t, const void*), const void* ctx) {
+    ProfScope prof(d ? d->op : 0, d ? d->ab_dtype : 0, d ? d->M : 0, d ? d->N : 0, d ? d->K : 0, stream);
+    return gemm_impl(d, stream, &prof.plan, launch, ctx);
+}
+int gemm_tn_is_g3(const me_gemm_desc* d) {
+    GemmParams p;
+    if (!d || d->op != ME_GEMM_TN || fill_params(d, p) != ME_OK) return 0;
+    return (plan_gemm(d, p).family == 4 && !G3_TN_FOLD) ? 1 : 0;
+}

@@ -3,7 +3,7 @@
 Mirrors the reference's tokenizer plugin point (Data2Seq/Data2Seq.py:19-55, README.md:113-122) for the
 modalities whose tokenizers are on the north-star path:
 
-  image        Data2Seq/Image.py:8-28        Conv2d(3, C, k16, s16)           -> patch gather + MFMA GEMM
+  image        Data2Seq/Image.py:8-28        Conv2d(3, C, k16, s16)           -> MFMA GEMM gathering its own patches
   audio        Data2Seq/Acoustic.py:5-23     Conv2d(1, C, k16, stride 10x10)  -> overlapping gather + GEMM
                (as written the reference class cannot be constructed -- it double-tuples patch_size; the working
                construction is Audio/src/models/ast_models.py:86, which this follows)
@@ -42,8 +42,9 @@ def _boundary_dtypes(weight: torch.Tensor):
 
 
 class _PatchEmbedFn(torch.autograd.Function):
-    """conv-as-GEMM: gather patches (integer index math, bit-exact), project with the MFMA GEMM, fuse bias,
-    optional pos-embed add and cls-token row offset into the GEMM epilogue."""
+    """conv-as-GEMM through me_patch_embed: for bf16 compute on the reference's image / tubelet geometries the patch gather runs
+    inside the MFMA GEMM's operand stager (no gathered matrix in memory); bias, optional pos-embed add and the cls-token row offset
+    are the GEMM's epilogue.  Backward: me_patch_embed_wgrad gathers the same patches inside the weight-gradient kernel."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, pos, geom, cdt, prefix_rows, odt=None):
@@ -54,33 +55,27 @@ class _PatchEmbedFn(torch.autograd.Function):
         x = x.contiguous()
         if x.dtype == torch.float16:                      # fp16 is converted at the boundary (me_cast), never computed in
             x = ops.cast(x, torch.bfloat16)
-        cols, tps = ops.patchify(x, kt, kh, kw, st, sh, sw, cdt)
+        if cdt == torch.bfloat16 and x.dtype == torch.float32 and ops.patch_embed_fused(x, geom, cdt, Cout, x_dtype=cdt):
+            # the gather rounds the pixels to bf16 either way: one vectorised cast pass, then the fused kernel reads them where they lie
+            x = ops.cast(x, cdt)
         w2 = ops.cast(weight.detach().reshape(Cout, -1).contiguous(), cdt)
-        out_tps = tps + prefix_rows
-        if prefix_rows:
-            y = torch.zeros((B * out_tps, Cout), dtype=cdt, device=x.device)
-        else:
-            y = torch.empty((B * out_tps, Cout), dtype=cdt, device=x.device)
         pos2 = None
         if pos is not None:
             pos2 = pos.detach().reshape(-1, Cout)
-            if pos2.shape[0] != tps:
-                raise MetaEncError(f"pos-embed has {pos2.shape[0]} rows, tokenizer produces {tps} tokens")
-            pos2 = pos2.contiguous()
-        ops.gemm(cols, w2, out=y, bias=bias, residual=pos2, res_row_mod=tps if pos2 is not None else 0,
-                 out_group=(tps, out_tps, prefix_rows) if prefix_rows else (0, 0, 0))
-        ctx.save_for_backward(cols, weight)
-        ctx.meta = (tuple(x.shape), geom, cdt, tps, out_tps, prefix_rows, bias is not None, pos is not None, x_dtype)
+        y, tps = ops.patch_embed(x, w2, bias, pos2, geom, prefix_rows, cdt)
+        out_tps = tps + prefix_rows
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (geom, cdt, tps, out_tps, prefix_rows, bias is not None, pos is not None, x_dtype)
         if odt is not None and odt != y.dtype:
             y = ops.cast(y, odt)
         return y.reshape(B, out_tps, Cout)
 
     @staticmethod
     def backward(ctx, dy):
-        cols, weight = ctx.saved_tensors
-        x_shape, geom, cdt, tps, out_tps, prefix_rows, has_bias, has_pos, x_dtype = ctx.meta
+        x, weight = ctx.saved_tensors
+        geom, cdt, tps, out_tps, prefix_rows, has_bias, has_pos, x_dtype = ctx.meta
         kt, kh, kw, st, sh, sw = geom
-        B = x_shape[0]
+        B = x.shape[0]
         Cout = weight.shape[0]
         dy = dy.contiguous()
         if prefix_rows:
@@ -88,15 +83,19 @@ class _PatchEmbedFn(torch.autograd.Function):
         dy2 = ops.cast(dy.reshape(B * tps, Cout), cdt)
         ng = ctx.needs_input_grad
         dW = db = dx = dpos = None
+        want_db = bool(ng[2] and has_bias)
         if ng[1]:
             wdt = torch.float32 if weight.dtype == torch.float16 else weight.dtype
-            dW = ops.cast(ops.gemm(dy2, cols, op=ME_GEMM_TN, out_dtype=wdt), weight.dtype).reshape(weight.shape)
-        if ng[2] and has_bias:
+            dW, db = ops.patch_embed_wgrad(x, geom, dy2, wdt, want_db)
+            dW = ops.cast(dW, weight.dtype).reshape(weight.shape)
+            if db is not None:
+                db = db.to(weight.dtype)
+        elif want_db:
             db = ops.colsum(dy2).to(weight.dtype)
         if ng[0]:
             wT = ops.transpose_cast(weight.detach().reshape(Cout, -1).contiguous(), cdt)     # [K, Cout]
             dcols = ops.gemm(dy2, wT)                                                        # [B*tps, K]
-            dx = ops.unpatchify_add(dcols, x_shape, kt, kh, kw, st, sh, sw)
+            dx = ops.unpatchify_add(dcols, tuple(x.shape), kt, kh, kw, st, sh, sw)
             if dx.dtype != x_dtype:
                 dx = ops.cast(dx, x_dtype)
         if has_pos and ng[3]:

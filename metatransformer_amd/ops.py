@@ -496,6 +496,93 @@ def patchify(x: torch.Tensor, kt: int, kh: int, kw: int, st: int, sh: int, sw: i
     return cols, gt * gh * gw
 
 
+def _patch_embed_desc(x: torch.Tensor, geom, w_dtype: torch.dtype, Cout: int):
+    kt, kh, kw, st, sh, sw = geom
+    if x.dim() == 4:
+        B, Cin, H, W = x.shape
+        T = 1
+    else:
+        B, Cin, T, H, W = x.shape
+    d = _capi.PatchEmbedDesc()
+    d.x, d.x_dtype = ptr(x), dtype_code(x.dtype)
+    d.B, d.Cin, d.T, d.H, d.W = B, Cin, T, H, W
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw = kt, kh, kw, st, sh, sw
+    d.w_dtype, d.Cout = dtype_code(w_dtype), Cout
+    tokens = ((T - kt) // st + 1) * ((H - kh) // sh + 1) * ((W - kw) // sw + 1)
+    return d, B, tokens
+
+
+def patch_embed_fused(x: torch.Tensor, geom, w_dtype: torch.dtype, Cout: int, x_dtype: Optional[torch.dtype] = None) -> bool:
+    """Will me_patch_embed gather this input (as it is, or once cast to x_dtype) inside the GEMM's operand stager -- no gathered
+    matrix, no workspace?"""
+    lib = _capi.load()
+    d, _, _ = _patch_embed_desc(x, geom, w_dtype, Cout)
+    if x_dtype is not None:
+        d.x_dtype = dtype_code(x_dtype)
+    return bool(lib.me_patch_embed_fused(ctypes.byref(d)))
+
+
+def patch_embed_wgrad_fused(x: torch.Tensor, geom, compute_dtype: torch.dtype, Cout: int, dw_dtype: torch.dtype) -> bool:
+    """Will me_patch_embed_wgrad gather the patches inside the weight-gradient kernel?"""
+    lib = _capi.load()
+    d, _, _ = _patch_embed_desc(x, geom, compute_dtype, Cout)
+    return bool(lib.me_patch_embed_wgrad_fused(ctypes.byref(d), dtype_code(dw_dtype)))
+
+
+def patch_embed(x: torch.Tensor, w2: torch.Tensor, bias: Optional[torch.Tensor], pos: Optional[torch.Tensor], geom,
+                prefix_rows: int = 0, out_dtype: Optional[torch.dtype] = None):
+    """Conv patch embed as one call (me_patch_embed): x [B,Cin,(T,)H,W], w2 [Cout, Cin*kt*kh*kw] in the compute dtype ->
+    ([B*(prefix_rows+tokens), Cout], tokens).  Rows of the prefix are zero."""
+    lib = _capi.load()
+    _req(x, "x"); _req(w2, "weight")
+    if not x.is_contiguous() or not w2.is_contiguous():
+        raise MetaEncError("patch_embed: x and weight must be contiguous")
+    Cout = w2.shape[0]
+    d, B, tokens = _patch_embed_desc(x, geom, w2.dtype, Cout)
+    if w2.shape[1] != d.Cin * d.kt * d.kh * d.kw:
+        raise MetaEncError(f"patch_embed: weight has {w2.shape[1]} columns, the patch has {d.Cin * d.kt * d.kh * d.kw} features")
+    odt = out_dtype or w2.dtype
+    rows = B * (tokens + prefix_rows)
+    y = (torch.zeros if prefix_rows else torch.empty)((rows, Cout), dtype=odt, device=x.device)
+    d.weight = ptr(w2)
+    if bias is not None:
+        bias = bias.detach().float().contiguous()
+        d.bias = ptr(bias)
+    if pos is not None:
+        if pos.shape != (tokens, Cout):
+            raise MetaEncError(f"pos-embed has shape {tuple(pos.shape)}, tokenizer produces [{tokens}, {Cout}]")
+        pos = pos.contiguous()
+        d.pos, d.pos_dtype, d.ld_pos = ptr(pos), dtype_code(pos.dtype), pos.stride(0)
+    d.prefix_rows = prefix_rows
+    d.out, d.out_dtype, d.ld_out = ptr(y), dtype_code(odt), y.stride(0)
+    nws = lib.me_patch_embed_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+    d.workspace, d.workspace_bytes = ptr(ws), nws
+    check(lib.me_patch_embed(ctypes.byref(d), stream_ptr()), "me_patch_embed")
+    return y, tokens
+
+
+def patch_embed_wgrad(x: torch.Tensor, geom, dy2: torch.Tensor, dw_dtype: torch.dtype, want_bias: bool):
+    """(dW [Cout, Cin*kt*kh*kw], dbias [Cout] fp32 or None) of the patch embed from dY [B*tokens, Cout] (me_patch_embed_wgrad)."""
+    lib = _capi.load()
+    _req(x, "x"); _req(dy2, "dy")
+    if not x.is_contiguous() or dy2.stride(1) != 1:
+        raise MetaEncError("patch_embed_wgrad: x must be contiguous, dy row-major")
+    Cout = dy2.shape[1]
+    d, B, tokens = _patch_embed_desc(x, geom, dy2.dtype, Cout)
+    if dy2.shape[0] != B * tokens:
+        raise MetaEncError(f"patch_embed_wgrad: dy has {dy2.shape[0]} rows, the input makes {B * tokens} tokens")
+    K = d.Cin * d.kt * d.kh * d.kw
+    dw = torch.empty((Cout, K), dtype=dw_dtype, device=x.device)
+    db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_bias else None
+    nws = lib.me_patch_embed_wgrad_workspace_bytes(ctypes.byref(d), dtype_code(dw_dtype), 1 if want_bias else 0)
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=x.device)
+    d.workspace, d.workspace_bytes = ptr(ws), nws
+    check(lib.me_patch_embed_wgrad(ctypes.byref(d), ptr(dy2), dy2.stride(0), ptr(dw), dtype_code(dw_dtype), ptr(db), 0.0, stream_ptr()),
+          "me_patch_embed_wgrad")
+    return dw, db
+
+
 def unpatchify_add(dcols: torch.Tensor, x_shape, kt, kh, kw, st, sh, sw) -> torch.Tensor:
     lib = _capi.load()
     _req(dcols, "dcols")

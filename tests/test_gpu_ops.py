@@ -145,7 +145,7 @@ def test_gemm_tn_wgrad(dev, T, M, N, dt):
 
 
 @pytest.mark.parametrize("T,M,N", [(256 * 197, 768, 768), (256 * 197, 2304, 768), (8192, 768, 3072), (4096 + 32, 256, 512),
-                                   (640, 128, 256)])
+                                   (640, 128, 256), (33 * 197, 768, 768), (4096 + 37, 2304, 768)])      # (the last two: ragged token counts)
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gemm_tn_fused_bias_gradient(dev, T, M, N, dt):
     """wgrad with the bias gradient (column sums of dY) from the same kernel; falls back to me_colsum when not fusable"""
@@ -153,6 +153,7 @@ def test_gemm_tn_fused_bias_gradient(dev, T, M, N, dt):
     x = rnd(T, N, seed=6).to(dt)
     dw, db = ops.gemm(dy.to(dev), x.to(dev), op=_capi.ME_GEMM_TN, out_dtype=torch.float32, want_colsum_a=True)
     assert rel_err(dw, dy.double().t() @ x.double()) < 3e-5      # reduction length up to 50 432
+    check_close(dw, dy.double().t() @ x.double(), 3e-5, "wgrad")
     ref = dy.double().sum(0)
     assert (db.double().cpu() - ref).abs().max() / ref.abs().max() < 1e-5
     dw2, db2 = ops.gemm(dy.to(dev), x.to(dev), op=_capi.ME_GEMM_TN, out_dtype=torch.float32, want_colsum_a=True)

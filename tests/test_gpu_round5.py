@@ -463,3 +463,142 @@ def test_layer_scale_block_at_a_size_the_one_tile_kernel_takes(dev, mode):
             y = blk(x.to(dev))
             tol = TOL_3X
     check_close(y, ref, tol, f"layer-scale block, {mode}")
+
+
+# ---- the patch embed as one kernel (me_patch_embed / me_patch_embed_wgrad, csrc/patch_embed.hip): the gather of Data2Seq/Image.py:19-28
+# and Video/models/modeling_finetune.py:283-297 inside the GEMM's operand stager.  Checker: fp64 on the same bf16-exact operands, the
+# patches taken by oracle slicing (oracle/tokenizer_oracle.py).
+from oracle import tokenizer_oracle as to
+
+PE_CASES = [
+    # (x shape, geom (kt, kh, kw, st, sh, sw), Cout, pos, prefix_rows)
+    ((3, 3, 224, 224), (1, 16, 16, 1, 16, 16), 768, True, 1),          # Data2Seq.Image + fused pos-embed behind a cls row
+    ((5, 3, 240, 208), (1, 16, 16, 1, 16, 16), 768, False, 0),         # 15 x 13 patches: ragged rows, 975 tokens = 3.8 row tiles
+    ((2, 3, 4, 64, 64), (2, 16, 16, 2, 16, 16), 768, False, 0),        # tubelets (2, 16, 16): six planes
+    ((2, 3, 6, 64, 96), (2, 16, 16, 2, 16, 16), 384, True, 0),         # three tubelet steps, Cout = 1.5 column tiles
+    ((4, 1, 64, 128), (1, 8, 32, 1, 8, 32), 256, False, 2),            # kh x kw = 8 x 32: two patch rows per K-tile, one plane
+    ((2, 2, 48, 64), (1, 32, 8, 1, 16, 8), 264, False, 0),             # 32 x 8 patches overlapping vertically (stride 16), Cout % 256 != 0
+    ((1, 3, 16, 16), (1, 16, 16, 1, 16, 16), 768, False, 0),           # a single token
+]
+
+
+def _patches(x, geom):
+    kt, kh, kw, st, sh, sw = geom
+    if x.dim() == 4:
+        return to.patchify_2d(x, kh, kw, sh, sw)
+    assert (st, sh, sw) == (kt, kh, kw)
+    return to.patchify_3d(x, kt, kh, kw)
+
+
+@pytest.mark.parametrize("case", PE_CASES, ids=lambda c: "x".join(map(str, c[0])) + "_k" + "x".join(map(str, c[1][:3])))
+def test_patch_embed_gathers_inside_the_gemm(dev, case):
+    shape, geom, Cout, with_pos, prefix = case
+    dt = torch.bfloat16
+    x = rnd(*shape, seed=11).to(dt)
+    cols = _patches(x.float(), geom)                       # [B, tokens, K] fp32, bf16-exact values
+    B, tokens, K = cols.shape
+    w = (0.05 * rnd(Cout, K, seed=12)).to(dt)
+    bias = 0.1 * rnd(Cout, seed=13)
+    pos = rnd(tokens, Cout, seed=14) if with_pos else None
+    xd, wd = x.to(dev), w.to(dev)
+    assert ops.patch_embed_fused(xd, geom, dt, Cout), "this geometry is meant to run fused"
+    ref = cols.double() @ w.double().t() + bias.double()
+    if pos is not None:
+        ref = ref + pos.double()
+    # fp32 output: what is left is the accumulation order
+    y, tps = ops.patch_embed(xd, wd, bias.to(dev), None if pos is None else pos.to(dev), geom, prefix, torch.float32)
+    assert tps == tokens and y.shape == (B * (tokens + prefix), Cout)
+    y = y.reshape(B, tokens + prefix, Cout)
+    if prefix:
+        assert torch.all(y[:, :prefix] == 0)
+    check_close(y[:, prefix:], ref, 2e-5, "fused patch embed, fp32 out")
+    yb, _ = ops.patch_embed(xd, wd, bias.to(dev), None if pos is None else pos.to(dev), geom, prefix, dt)
+    check_close(yb.reshape(B, tokens + prefix, Cout)[:, prefix:].float(), ref, TOL_BF16_OP, "fused patch embed, bf16 out")
+    # the two-pass route (me_patchify + me_gemm) on the same operands
+    c2, _ = ops.patchify(xd, *geom, dt)
+    assert torch.equal(c2.cpu().float().reshape(B, tokens, K), cols)
+    y2 = ops.gemm(c2, wd, bias=bias.to(dev), out_dtype=torch.float32).reshape(B, tokens, Cout)
+    check_close(y[:, prefix:], y2.double().cpu() + (0 if pos is None else pos.double()), 2e-5, "fused against two-pass")
+    # parameter gradients: dW = dY^T patches (fp32 out), db = colsum(dY).  At this size the planner keeps the weight gradient on the
+    # small split-K family (two passes inside the entry point); the gathering wgrad kernel takes over from 4 096 tokens on (next test)
+    dy = rnd(B * tokens, Cout, seed=15).to(dt)
+    dw, db = ops.patch_embed_wgrad(xd, geom, dy.to(dev), torch.float32, True)
+    dw_ref = dy.double().t() @ cols.reshape(B * tokens, K).double()
+    check_close(dw, dw_ref, 2e-5, "patch-embed wgrad")
+    check_close(db, dy.double().sum(0), 2e-5, "bias gradient")
+    dw2, db2 = ops.patch_embed_wgrad(xd, geom, dy.to(dev), dt, False)
+    assert db2 is None
+    check_close(dw2.float(), dw_ref, TOL_BF16_OP, "wgrad, bf16 out")
+
+
+@pytest.mark.parametrize("case", PE_CASES[1:6], ids=lambda c: "x".join(map(str, c[0][1:])) + "_k" + "x".join(map(str, c[1][:3])))
+def test_patch_embed_wgrad_gathers_inside_the_kernel(dev, case):
+    """the same geometries with enough samples for the split-K wgrad kernel (>= 4 096 tokens, a ragged count): patches gathered in its B
+    stager, patch origins recomputed per K-tile by multiplication; dW and the bias gradient per element against fp64"""
+    shape, geom, Cout, _, _ = case
+    dt = torch.bfloat16
+    one = _patches(torch.zeros(1, *shape[1:]), geom).shape[1]
+    B = (4096 + 37 + one - 1) // one
+    x = rnd(B, *shape[1:], seed=41).to(dt)
+    cols = _patches(x.float(), geom).reshape(B * one, -1)
+    dy = rnd(B * one, Cout, seed=42).to(dt)
+    xd = x.to(dev)
+    assert ops.patch_embed_wgrad_fused(xd, geom, dt, Cout, torch.float32), "meant to run on the gathering wgrad kernel"
+    dw, db = ops.patch_embed_wgrad(xd, geom, dy.to(dev), torch.float32, True)
+    dw_ref = dy.double().t() @ cols.double()
+    check_close(dw, dw_ref, 2e-5, "fused patch-embed wgrad")
+    check_close(db, dy.double().sum(0), 2e-5, "bias gradient on the wgrad launch")
+    dwb, _ = ops.patch_embed_wgrad(xd, geom, dy.to(dev), dt, False)
+    check_close(dwb.float(), dw_ref, TOL_BF16_OP, "fused wgrad, bf16 out")
+
+
+def test_patch_embed_config2_batch_and_every_token(dev):
+    """B = 64 images (12 544 tokens = 49 row tiles x 3 column tiles): every output element against the two-pass route, and the tokenizer
+    module end to end (fp32 pixels under bf16 compute take ONE cast pass and the fused kernel) with gradients against nn.Conv2d"""
+    dt = torch.bfloat16
+    geom = (1, 16, 16, 1, 16, 16)
+    x = rnd(64, 3, 224, 224, seed=21).to(dt).to(dev)
+    w = (0.03 * rnd(768, 768, seed=22)).to(dt).to(dev)
+    bias = (0.1 * rnd(768, seed=23)).to(dev)
+    y, _ = ops.patch_embed(x, w, bias, None, geom, 0, dt)
+    c2, _ = ops.patchify(x, *geom, dt)
+    y2 = ops.gemm(c2, w, bias=bias)
+    check_close(y.float(), y2.float(), TOL_BF16_OP, "64 images")
+    dy = rnd(64 * 196, 768, seed=24).to(dt).to(dev)
+    dw, db = ops.patch_embed_wgrad(x, geom, dy, torch.float32, True)
+    dw2 = ops.gemm(dy, c2, op=_capi.ME_GEMM_TN, out_dtype=torch.float32)
+    check_close(dw, dw2, 2e-5, "wgrad against the two-pass TN GEMM")
+    check_close(db, dy.float().sum(0), 2e-5, "bias gradient")
+    # module level
+    pe = M.PatchEmbed(img_size=224, patch_size=16, in_c=3, embed_dim=768).to(dev).to(dt)
+    conv = torch.nn.Conv2d(3, 768, 16, 16).double()
+    conv.load_state_dict({k.replace("proj.", ""): v.detach().cpu().double() for k, v in pe.state_dict().items()})
+    xi = rnd(4, 3, 224, 224, seed=25)
+    go = rnd(4, 196, 768, seed=26)
+    out = pe(xi.to(dev).to(dt))
+    (out.float() * go.to(dev)).sum().backward()
+    ref = conv(xi.to(dt).double()).flatten(2).transpose(1, 2)
+    (ref * go.double()).sum().backward()
+    check_close(out.float(), ref, TOL_BF16_OP, "PatchEmbed forward")
+    check_close(pe.proj.weight.grad.float(), conv.weight.grad, TOL_BF16_GRAD, "PatchEmbed dW")
+    check_close(pe.proj.bias.grad.float(), conv.bias.grad, TOL_BF16_GRAD, "PatchEmbed db")
+
+
+def test_patch_embed_two_pass_cases_share_the_entry_point(dev):
+    """fp32 pixels with fp32 weights (exact arithmetic) and the spectrogram's stride-10 patches are not fusable: same entry points,
+    me_patchify + me_gemm inside"""
+    geom = (1, 16, 16, 1, 10, 10)
+    x = rnd(2, 1, 128, 100, seed=31)
+    cols = to.patchify_2d(x, 16, 16, 10, 10)
+    B, tokens, K = cols.shape
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, TOL_BF16_OP)):
+        xq = x.to(dt)
+        w = (0.05 * rnd(256, K, seed=32)).to(dt)
+        assert not ops.patch_embed_fused(xq.to(dev), geom, dt, 256)
+        y, tps = ops.patch_embed(xq.to(dev), w.to(dev), None, None, geom, 0, torch.float32)
+        ref = to.patchify_2d(xq.float(), 16, 16, 10, 10).double() @ w.double().t()
+        check_close(y.reshape(B, tokens, 256), ref, tol, f"two-pass {dt}")
+        dy = rnd(B * tokens, 256, seed=33).to(dt)
+        dw, db = ops.patch_embed_wgrad(xq.to(dev), geom, dy.to(dev), torch.float32, True)
+        check_close(dw, dy.double().t() @ to.patchify_2d(xq.float(), 16, 16, 10, 10).reshape(B * tokens, K).double(), tol, f"two-pass wgrad {dt}")
+        check_close(db, dy.double().sum(0), tol, "two-pass bias gradient")
