@@ -44,7 +44,8 @@ def test_header_symbols_all_bound_and_exported(lib):
 
 @pytest.mark.parametrize("cname,pyname", [("me_gemm_desc", "GemmDesc"), ("me_block_desc", "BlockDesc"),
                                           ("me_block_grads", "BlockGrads"), ("me_gemm_profile_rec", "GemmProfileRec"),
-                                          ("me_adamw_segment", "AdamwSegment"), ("me_adamw_ctl", "AdamwCtl")])
+                                          ("me_adamw_segment", "AdamwSegment"), ("me_adamw_ctl", "AdamwCtl"),
+                                          ("me_patch_embed_desc", "PatchEmbedDesc")])
 def test_struct_layouts_match_c(cname, pyname):
     """every struct that crosses the C ABI: size and field offsets of the ctypes mirror == what gcc lays out from the header"""
     cls = getattr(_capi, pyname)
@@ -61,6 +62,32 @@ def test_struct_layouts_match_c(cname, pyname):
     assert int(got.pop("size")) == ctypes.sizeof(cls)
     for name in fields:
         assert int(got[name]) == getattr(cls, name).offset, name
+
+
+def test_patch_embed_fuses_the_reference_geometries(lib):
+    """host-side decision only (no kernel runs): the image and tubelet embeds of the reference gather inside the GEMM's operand stager
+    when pixels and weight are bf16; the spectrogram's stride-10 patches, fp32 arithmetic and odd patch shapes take the two-pass route and
+    ask for a workspace"""
+    def desc(shape, geom, xdt=_capi.ME_BF16, wdt=_capi.ME_BF16, cout=768):
+        d = _capi.PatchEmbedDesc()
+        d.x, d.x_dtype = 4096, xdt                                  # (an aligned address; never dereferenced by these two queries)
+        B, Cin, T, H, W = shape
+        d.B, d.Cin, d.T, d.H, d.W = B, Cin, T, H, W
+        d.kt, d.kh, d.kw, d.st, d.sh, d.sw = geom
+        d.w_dtype, d.Cout = wdt, cout
+        return d
+    image = desc((256, 3, 1, 224, 224), (1, 16, 16, 1, 16, 16))                      # Data2Seq/Image.py:19-28
+    video = desc((8, 3, 16, 224, 224), (2, 16, 16, 2, 16, 16))                       # Video/models/modeling_finetune.py:283-297
+    audio = desc((12, 1, 1, 128, 1024), (1, 16, 16, 1, 10, 10))                      # Audio/src/models/ast_models.py:86
+    for d, want in ((image, 1), (video, 1), (audio, 0), (desc((2, 3, 1, 224, 224), (1, 16, 16, 1, 16, 16), xdt=_capi.ME_F32), 0),
+                    (desc((2, 3, 1, 224, 224), (1, 16, 16, 1, 16, 16), xdt=_capi.ME_F32, wdt=_capi.ME_F32), 0),
+                    (desc((2, 3, 1, 224, 224), (1, 14, 14, 1, 14, 14)), 0), (desc((2, 3, 1, 220, 220), (1, 16, 16, 1, 16, 16)), 0),
+                    (desc((2, 3, 1, 224, 224), (1, 16, 16, 1, 16, 16), cout=772), 0)):
+        assert lib.me_patch_embed_fused(ctypes.byref(d)) == want
+        assert (lib.me_patch_embed_workspace_bytes(ctypes.byref(d)) == 0) == bool(want)
+    bad = desc((2, 3, 1, 8, 8), (1, 16, 16, 1, 16, 16))
+    assert lib.me_patch_embed_fused(ctypes.byref(bad)) == 0 and lib.me_patch_embed(ctypes.byref(bad), None) != 0
+    assert b"kernel larger than input" in lib.me_last_error()
 
 
 def test_product_never_imports_oracle():
