@@ -411,6 +411,9 @@ struct GemmPlan {
                                                  // (profiles/r04_small_split_ab.txt): never = +7..18 % per forward at B = 32..256 x N = 16..197,
                                                  // B = 1 0.92 -> 1.43 ms; / 3 -> / 2: M = 8 224 fwd + dX 6.9 -> 6.74 ms, the rest unchanged
 #endif
+#ifndef ME_SMALL_SPLIT_LONGK
+#define ME_SMALL_SPLIT_LONGK 192
+#endif
 GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
     GemmPlan pl{0, 0, 128, 0, 1, 0, 0, 0, 1, 0};
     const GemmDev dev = gemm_dev();
@@ -554,7 +557,10 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         // workgroup slots means the launch is pure latency -- one workgroup walks the whole reduction while 2/3 of the CUs
         // idle.  The WHOLE problem then runs split over the reduction (same slabs + fold as the tail split, m_main = 0).
         // (with the tile chosen by count -- small_nt -- a K split pays only for long reductions on a handful of tiles: B = 1 fc2 / dgrads)
-        if (dev.tail_split && pl.tail_rows == 0 && tiles * ME_SMALL_SPLIT_DEN <= SLOTS && nk >= (small_nt ? 64 : 16) && (!small_nt || tiles <= 96)) {
+        // ... or a very long one on up to half the slots: K >= 6 144 only occurs as the three-plane (ME_BF16X3) form of fc2 / the fc1 dgrad,
+        // 144 tiles x 288 K-steps at the reference's M = 3 072 (ME_SMALL_SPLIT_LONGK K-steps of 32; measured below)
+        if (dev.tail_split && pl.tail_rows == 0 && tiles * ME_SMALL_SPLIT_DEN <= SLOTS && nk >= (small_nt ? 64 : 16) &&
+            (!small_nt || tiles <= 96 || nk >= ME_SMALL_SPLIT_LONGK)) {
             int s = (int)(SLOTS / tiles);
             while (s > 1 && nk / s < 8) --s;
             if (s >= 2) {

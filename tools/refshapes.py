@@ -5,7 +5,8 @@ Hyper-spectrum/metatransformer.py:146-165) and bf16.  Per shape: ms per step, sa
 peak, and per kernel family the launches, mean microseconds, TFLOP/s or TB/s and -- for the GEMMs -- the plan the library chose
 (me_gemm_profile_rec.plan).  VERDICT r3 item 4b.
 
-    python tools/refshapes.py [--out profiles/r04_refshapes.json] [--quick]
+    python tools/refshapes.py [--out profiles/r04_refshapes.json] [--quick] [--dtypes fp32,fp32x3,bf16]
+(fp32x3 = fp32 tokens and weights with Block.fp32_mode = "3xbf16": fp32-accurate on the bf16 matrix pipe; its peak is 2 500 / 3 TF)
 """
 import argparse
 import json
@@ -34,7 +35,7 @@ PEAK = {torch.float32: 157.3, torch.bfloat16: 2500.0}
 FAMILY = {0: "g128", 2: "g2b", 3: "g2w", 4: "g3"}
 
 
-def run_shape(name, B, N, C, H, L, dtype, steps, warmup):
+def run_shape(name, B, N, C, H, L, dtype, steps, warmup, fp32_mode="exact"):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     enc = M.build_encoder(L, C, H).to(dev)
@@ -44,6 +45,7 @@ def run_shape(name, B, N, C, H, L, dtype, steps, warmup):
         p.requires_grad_(False)                       # frozen encoder
     for blk in enc:
         blk.compute_dtype = dtype
+        blk.fp32_mode = fp32_mode                     # "3xbf16": fp32-accurate arithmetic on the bf16 matrix pipe (Block.fp32_mode)
     enc.eval()
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, N, C, generator=g).to(dev).to(dtype).requires_grad_(True)
@@ -96,7 +98,8 @@ def run_shape(name, B, N, C, H, L, dtype, steps, warmup):
                     "TFLOPs": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flop"] else None,
                     "share_of_kernel_time": round(v["ms"] / sum(q["ms"] for q in fam.values()), 3)} for k, v in sorted(fam.items())}
         out[label] = {"ms_per_step": round(1e3 * el, 3), "samples_per_s": round(B / el, 1),
-                      "model_TFLOPs": round(flops / el / 1e12, 1), "frac_of_mfma_peak": round(flops / el / 1e12 / PEAK[dtype], 4),
+                      "model_TFLOPs": round(flops / el / 1e12, 1),
+                      "frac_of_mfma_peak": round(flops / el / 1e12 / (PEAK[torch.bfloat16] / 3 if fp32_mode == "3xbf16" else PEAK[dtype]), 4),
                       "kernel_ms_per_step": round(sum(v["ms"] for v in fam.values()) / 3, 3), "kernels": fams}
     return out
 
@@ -109,16 +112,16 @@ def main():
     ap.add_argument("--dtypes", default="fp32,bf16")
     a = ap.parse_args()
     res = {"_meta": {"mode": "frozen encoder (requires_grad=False on every Block parameter): forward + dL/dx; `fwd` = forward alone under no_grad",
-                     "peaks_TFLOPs": {"fp32": 157.3, "bf16": 2500.0}, "device": torch.cuda.get_device_name(0)}}
+                     "peaks_TFLOPs": {"fp32": 157.3, "fp32x3": 833.3, "bf16": 2500.0}, "device": torch.cuda.get_device_name(0)}}
     for name, B, N, C, H, L, src in SHAPES:
         if a.only and a.only not in name:
             continue
         res[name] = {"source": src, "B": B, "N": N, "C": C, "heads": H, "depth": L}
-        for dtype, dn in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        for dtype, dn in ((torch.float32, "fp32"), (torch.float32, "fp32x3"), (torch.bfloat16, "bf16")):
             if dn not in a.dtypes.split(","):
                 continue
-            steps = 5 if (dtype == torch.float32 or a.quick) else 20
-            r = run_shape(name, B, N, C, H, L, dtype, steps, 2)
+            steps = 5 if (dn == "fp32" or a.quick) else 20
+            r = run_shape(name, B, N, C, H, L, dtype, steps, 2, "3xbf16" if dn == "fp32x3" else "exact")
             res[name][dn] = r
             print(f"{name:20s} {dn}: fwd+dx {r['fwd_dx']['ms_per_step']:8.3f} ms ({r['fwd_dx']['frac_of_mfma_peak']:.3f} of peak)  fwd {r['fwd']['ms_per_step']:8.3f} ms "
                   f"({r['fwd']['frac_of_mfma_peak']:.3f})  gemm plans: {[k for k in r['fwd']['kernels'] if k.startswith('gemm')]}", flush=True)
