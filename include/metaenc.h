@@ -327,6 +327,10 @@ typedef struct me_tc_batch {
     struct { const void* src; void* dst; int64_t rows, cols; } item[ME_TC_BATCH];
 } me_tc_batch;
 int me_transpose_cast_batched(const me_tc_batch* b, void* stream);
+/* me_split3 for up to ME_TC_BATCH fp32 matrices in one launch (src_dtype = ME_F32, dst_dtype = ME_BF16X3; rows, cols multiples of 4):
+ * transposed = 0: item dst [rows, 3 cols] = planes of the matrix; transposed = 1: dst [cols, 3 rows] = planes of its TRANSPOSE (the
+ * dgrad GEMMs' B operand) -- every ME_BF16X3 compute copy of an encoder's weights after an optimizer step in two launches. */
+int me_split3_batched(const me_tc_batch* b, int transposed, int right_operand, void* stream);
 /* y = x + pos (pos broadcast over batch: row m uses pos row m % pos_rows); PointCloud re-injects pos before
  * every block (PointCloud/openpoints/models/backbone/metatransformer.py:161-163). */
 int me_add_rows(const void* x, int x_dtype, const void* pos, int pos_dtype, void* y, int y_dtype,

@@ -165,6 +165,7 @@ SIGNATURES = {
     "me_split3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "me_transpose_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "me_transpose_cast_batched": (c_int, [POINTER(TcBatch), c_void_p]),
+    "me_split3_batched": (c_int, [POINTER(TcBatch), c_int, c_int, c_void_p]),
     "me_add_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "me_window_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "me_dropout_add": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_float, c_float,

@@ -9,6 +9,8 @@
 #include <map>
 #include <mutex>
 
+int gemm_tn_x3_planes(const me_gemm_desc* d, hipStream_t stream);      // gemm3_x3.hip
+
 namespace {
 
 // ---- me_block_bwd: the weight-gradient GEMMs (and their folds) on a SIDE stream.  Nothing downstream of a Block's backward needs
@@ -302,6 +304,15 @@ int block_bwd_x3(const me_block_desc* d, const Dims& s, const void* x, const voi
         const int64_t pa[3] = {0, n_out, 0}, pb[3] = {0, 0, n_in};
         bool db_done = dB == nullptr;
         if (dW) {
+            // one launch + one fold: the three products as three segments of the wgrad kernel's reduction (gemm3_x3.hip); the bias gradient
+            // rides on it.  Not for problems the planner keeps off the g3 wgrad family (few tokens): the three me_gemm calls below.
+            gemm_desc(g, ME_GEMM_TN, ME_BF16, n_out, n_in, s.M, dOut3, 3 * n_out, In3, 3 * n_in, dW, n_in, gr->w_dtype);
+            g.beta = gr->accumulate ? 1.0f : 0.0f;
+            g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
+            g.colsum_a = dB;
+            const int r1 = gemm_tn_x3_planes(&g, reinterpret_cast<hipStream_t>(stream));
+            if (r1 == ME_OK) return ME_OK;
+            if (r1 != ME_ERR_UNSUPPORTED) return r1;
             for (int t = 0; t < 3; ++t) {
                 gemm_desc(g, ME_GEMM_TN, ME_BF16, n_out, n_in, s.M, dOut3 + pa[t], 3 * n_out, In3 + pb[t], 3 * n_in, dW, n_in, gr->w_dtype);
                 g.beta = (t == 0 && !gr->accumulate) ? 0.0f : 1.0f;

@@ -67,6 +67,51 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const void* __restr
     }
 }
 
+// fp32 weights -> ME_BF16X3 right-operand planes [hi | hi | lo], of W itself (transposed = 0: dst [rows, 3 cols]) or of W^T
+// (transposed = 1: dst [cols, 3 rows], the dgrad GEMMs' B operand), for up to ME_TC_BATCH matrices in one launch.  Same 64 x 64 tiles as
+// the batched transpose; rows and cols multiples of 4.
+__global__ __launch_bounds__(256) void split3_batched_kernel(const me_tc_batch b, int transposed, int right_operand) {
+    __shared__ float tile[64][65];
+    int64_t t = blockIdx.x;
+    int k = 0;
+    int64_t tx_tiles = 0;
+    for (; k < b.n; ++k) {
+        tx_tiles = (b.item[k].cols + 63) / 64;
+        const int64_t nt = tx_tiles * ((b.item[k].rows + 63) / 64);
+        if (t < nt) break;
+        t -= nt;
+    }
+    if (k >= b.n) return;
+    const float* src = reinterpret_cast<const float*>(b.item[k].src);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(b.item[k].dst);
+    const int64_t rows = b.item[k].rows, cols = b.item[k].cols;
+    const int64_t r0 = (t / tx_tiles) * 64, c0 = (t % tx_tiles) * 64;
+    const int q = threadIdx.x & 15, p = threadIdx.x >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int i = p + 16 * pass;
+        const int64_t r = r0 + i, c = c0 + 4 * q;
+        if (r < rows && c < cols) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * cols + c);
+            if (!transposed) {
+                store4_split3(dst + r * 3 * cols, cols, c, v, right_operand != 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tile[i][4 * q + e] = v[e];
+            }
+        }
+    }
+    if (!transposed) return;          // (block-uniform)
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int i = p + 16 * pass;
+        const int64_t c = c0 + i, r = r0 + 4 * q;
+        if (c < cols && r < rows)
+            store4_split3(dst + c * 3 * rows, rows, r, f32x4{tile[4 * q][i], tile[4 * q + 1][i], tile[4 * q + 2][i], tile[4 * q + 3][i]}, right_operand != 0);
+    }
+}
+
 // batched form: the block finds its matrix by walking the (<= 48 entry) tile-count prefix
 __global__ __launch_bounds__(256) void transpose_cast_batched_kernel(const me_tc_batch b) {
     __shared__ float tile[64][65];
@@ -880,6 +925,24 @@ extern "C" int me_transpose_cast_batched(const me_tc_batch* b, void* stream_) {
     ME_CHECK_ARG(tiles < (1ll << 31), "me_transpose_cast_batched: too many tiles");
     hipLaunchKernelGGL(transpose_cast_batched_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, *b);
     ME_CHECK_LAUNCH("me_transpose_cast_batched");
+    return ME_OK;
+}
+
+extern "C" int me_split3_batched(const me_tc_batch* b, int transposed, int right_operand, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ME_CHECK_ARG(b && b->n >= 0 && b->n <= ME_TC_BATCH, "me_split3_batched: bad batch");
+    ME_CHECK_ARG(b->src_dtype == ME_F32 && b->dst_dtype == ME_BF16X3, "me_split3_batched: fp32 sources, ME_BF16X3 destinations");
+    int64_t tiles = 0;
+    for (int k = 0; k < b->n; ++k) {
+        ME_CHECK_ARG(b->item[k].src && b->item[k].dst && b->item[k].rows > 0 && b->item[k].cols > 0 && b->item[k].rows % 4 == 0 &&
+                         b->item[k].cols % 4 == 0 && (uintptr_t)b->item[k].src % 16 == 0 && (uintptr_t)b->item[k].dst % 8 == 0,
+                     "me_split3_batched: bad item %d (rows, cols multiples of 4; src 16-byte, dst 8-byte aligned)", k);
+        tiles += ((b->item[k].cols + 63) / 64) * ((b->item[k].rows + 63) / 64);
+    }
+    if (tiles == 0) return ME_OK;
+    ME_CHECK_ARG(tiles < (1ll << 31), "me_split3_batched: too many tiles");
+    hipLaunchKernelGGL(split3_batched_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, *b, transposed, right_operand);
+    ME_CHECK_LAUNCH("me_split3_batched");
     return ME_OK;
 }
 

@@ -144,15 +144,35 @@ class _WeightCache:
     def split3(self, name: str, p: torch.Tensor, transposed: bool) -> torch.Tensor:
         """ME_BF16X3 right-operand copy of a weight ([out, 3 in]; transposed: of W^T, [in, 3 out] for the dgrad GEMMs): the
         fp32-accurate mode's compute copies, rebuilt when the parameter changes (same keys as the other copies)."""
-        k = self._key(p, "x3t" if transposed else "x3")
+        kind = "x3t" if transposed else "x3"
+        k = self._key(p, kind)
         slot = (name, transposed, p.device)
         hit = self._x3.get(slot)
-        if hit is None or hit[0] != k:
-            w32 = p.detach().contiguous()
-            w32 = ops.transpose_cast(w32, torch.float32) if transposed else ops.cast(w32, torch.float32)
-            hit = (k, ops.split3(w32, right_operand=True))
-            self._x3[slot] = hit
-        return hit[1]
+        if hit is not None and hit[0] == k:
+            return hit[1]
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            w32 = ops.cast(p.detach().contiguous(), torch.float32)
+            w32 = ops.transpose_cast(w32, torch.float32) if transposed else w32
+            out = ops.split3(w32, right_operand=True)
+            self._x3[slot] = (k, out)
+            return out
+        # refresh, in ONE launch, this copy and every stale copy of the same kind that some live Block on the device has used before
+        # (after an optimizer step that is all of them: 2 launches per step for the encoder instead of 12 per Block)
+        todo = [(self, name, k, p)]
+        for c in list(_WeightCache._live):
+            for n, w in c._weights().items():
+                if (c is self and n == name) or w.device != p.device or w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous():
+                    continue
+                h = c._x3.get((n, transposed, w.device))
+                if h is None:
+                    continue
+                kk = _WeightCache._key(w, kind)
+                if h[0] != kk:
+                    todo.append((c, n, kk, w))
+        outs = ops.split3_many([w.detach() for _, _, _, w in todo], transposed)
+        for (c, n, kk, w), t in zip(todo, outs):
+            c._x3[(n, transposed, w.device)] = (kk, t)
+        return outs[0]
 
     def folded(self, name: str, w: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, bias: Optional[torch.Tensor], dtype):
         """LayerNorm folded into the Linear behind it (inference; me_gemm_desc.row_affine):

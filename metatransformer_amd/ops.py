@@ -403,6 +403,27 @@ def transpose_cast_many(ws, dtype: torch.dtype):
     return outs
 
 
+def split3_many(ws, transposed: bool, right_operand: bool = True):
+    """ME_BF16X3 planes of a list of fp32 matrices [rows, cols] -- of each matrix ([rows, 3 cols]) or of its transpose ([cols, 3 rows]) --
+    ME_TC_BATCH per launch (me_split3_batched): the fp32-accurate mode's compute copies of every weight after an optimizer step."""
+    lib = _capi.load()
+    outs = []
+    for i in range(0, len(ws), _capi.ME_TC_BATCH):
+        chunk = ws[i:i + _capi.ME_TC_BATCH]
+        b = _capi.TcBatch()
+        b.n, b.src_dtype, b.dst_dtype = len(chunk), _capi.ME_F32, _capi.ME_BF16X3
+        for k, w in enumerate(chunk):
+            _req(w, "w")
+            if w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous():
+                raise MetaEncError("split3_many: contiguous fp32 matrices")
+            rows, cols = w.shape
+            y = torch.empty((cols, 3 * rows) if transposed else (rows, 3 * cols), dtype=torch.bfloat16, device=w.device)
+            outs.append(y)
+            b.item[k].src, b.item[k].dst, b.item[k].rows, b.item[k].cols = ptr(w), ptr(y), rows, cols
+        check(lib.me_split3_batched(ctypes.byref(b), 1 if transposed else 0, 1 if right_operand else 0, stream_ptr()), "me_split3_batched")
+    return outs
+
+
 def add_rows(x: torch.Tensor, pos: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """x[B*N, C] + pos[(row % pos_rows), C]"""
     lib = _capi.load()

@@ -57,9 +57,10 @@ def test_small_m_gemm_plans_every_epilogue(dev, M_, N, K):
     check_close(y.float(), (a.double() @ w.double().t()) * fac.double(), TOL_BF16_OP, "x saved factor")
 
 
-@pytest.mark.parametrize("M_,N,K", [(197, 768, 3072), (394, 768, 2304), (64, 768, 3072)])
+@pytest.mark.parametrize("M_,N,K", [(197, 768, 3072), (394, 768, 2304), (64, 768, 3072), (3072, 768, 9216), (1576, 768, 9216)])
 def test_small_m_long_reduction_split(dev, M_, N, K):
-    """a handful of 64 x 128 tiles with a long reduction still takes the whole-problem K split (fp32 slabs + deterministic fold)"""
+    """a handful of 64 x 128 tiles with a long reduction still takes the whole-problem K split (fp32 slabs + deterministic fold); so do
+    up to half the chip's slots when K >= 6 144 (the three-plane fc2 of an ME_BF16X3 Block at the reference's batch sizes)"""
     dt = torch.bfloat16
     a, w, bias, res = rnd(M_, K, seed=1).to(dt), (0.05 * rnd(N, K, seed=2)).to(dt), 0.1 * rnd(N, seed=3), rnd(M_, N, seed=4).to(dt)
     y1 = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), residual=res.to(dev))
@@ -232,13 +233,16 @@ def test_forward_3xbf16_matches_reference_golden(dev, name):
     assert not torch.equal(ye, y) and rel_err(y, ye) < TOL_3X
 
 
-def test_backward_3xbf16_every_gradient_vs_oracle(dev):
-    """forward, dL/dx and all parameter gradients of a two-block stack in the three-product mode, per element, against the CPU
-    oracle (fp32 torch restatement of the reference Block); ragged token count; then in-place accumulation into a FlatParams buffer"""
-    depth, C, H = 2, 768, 12
+@pytest.mark.parametrize("B,N,depth", [(3, 70, 2), (24, 197, 1)], ids=["210_tokens", "4728_tokens"])
+def test_backward_3xbf16_every_gradient_vs_oracle(dev, B, N, depth):
+    """forward, dL/dx and all parameter gradients of a block stack in the three-product mode, per element, against the CPU
+    oracle (fp32 torch restatement of the reference Block); ragged token counts; then in-place accumulation into a FlatParams buffer.
+    From 4 096 tokens on a weight gradient is ONE launch of the split-K wgrad kernel over three plane segments (csrc/gemm3_x3.hip) with
+    the bias gradient on it; below, three me_gemm calls."""
+    C, H = 768, 12
     sd = bo.make_encoder_state_dict(depth, C, seed=5)
     g = torch.Generator().manual_seed(42)
-    x, go = torch.randn(3, 70, C, generator=g), torch.randn(3, 70, C, generator=g)
+    x, go = torch.randn(B, N, C, generator=g), torch.randn(B, N, C, generator=g)
     y_ref, dx_ref, dp_ref = bo.encoder_forward_backward(x, sd, H, go)
     enc = make_encoder(depth, C, H, dev, seed=5).train()
     for b in enc:
@@ -602,3 +606,18 @@ def test_patch_embed_two_pass_cases_share_the_entry_point(dev):
         dw, db = ops.patch_embed_wgrad(xq.to(dev), geom, dy.to(dev), torch.float32, True)
         check_close(dw, dy.double().t() @ to.patchify_2d(xq.float(), 16, 16, 10, 10).reshape(B * tokens, K).double(), tol, f"two-pass wgrad {dt}")
         check_close(db, dy.double().sum(0), tol, "two-pass bias gradient")
+
+
+def test_split3_batched_is_split3_per_matrix(dev):
+    """me_split3_batched: the planes of each matrix / of its transpose for a batch in one launch, bit for bit what me_split3 (after
+    me_transpose_cast) writes one matrix at a time; 50 matrices = two launches; ragged 64 x 64 edge tiles"""
+    shapes = [(768, 768), (2304, 768), (768, 3072), (68, 260), (4, 4)] * 10
+    ws = [(0.05 * rnd(r, c, seed=100 + i)).to(dev) for i, (r, c) in enumerate(shapes)]
+    for transposed in (False, True):
+        outs = ops.split3_many(ws, transposed)
+        assert len(outs) == len(ws)
+        for w, o in zip(ws[:5] + ws[-5:], outs[:5] + outs[-5:]):
+            src = ops.transpose_cast(w, torch.float32) if transposed else w
+            assert torch.equal(o, ops.split3(src, right_operand=True))
+    with pytest.raises(_capi.MetaEncError):
+        ops.split3_many([ws[0][:6, :6].contiguous()], False)           # rows / cols not multiples of 4
