@@ -204,7 +204,10 @@ def attn_ref(qkv, B, N, H, hd, scale):
 ATTN_SHAPES = [(2, 197, 12, 64), (1, 64, 2, 64), (3, 37, 2, 64), (2, 5, 2, 16), (2, 40, 32, 24), (1, 300, 4, 32),
                (1, 130, 2, 128), (1, 1, 1, 64), (1, 256, 2, 64), (2, 224, 3, 32), (2, 33, 1, 8),
                (1, 64, 2, 32), (2, 65, 2, 64), (1, 257, 2, 64), (1, 1568, 2, 64), (2, 512, 3, 64), (1, 400, 2, 64), (1, 513, 1, 64),
-               (2, 128, 32, 24), (1, 300, 32, 24), (1, 600, 4, 24)]      # Graph: 32 heads x hd 24 on the resident / mid / chunked paths      # both sides of the resident-sequence window
+               (2, 128, 32, 24), (1, 300, 32, 24), (1, 600, 4, 24),      # Graph: 32 heads x hd 24 on the resident / mid / chunked paths; both sides of the resident-sequence window
+               # N <= 64: one wave per (batch, head) (attention_tiny.hip) -- Tabular (16 column tokens), Graph (~50 tokens, 32 x 24), every
+               # (N class, head-dim class) pair with ragged N and head dims that are not tile multiples
+               (16, 16, 12, 64), (4, 50, 32, 24), (2, 17, 3, 48), (2, 16, 2, 40), (1, 32, 2, 56), (3, 48, 2, 64), (2, 31, 4, 32), (5, 9, 2, 24)]
 
 
 @pytest.mark.parametrize("B,N,H,hd", ATTN_SHAPES)

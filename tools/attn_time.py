@@ -1,10 +1,15 @@
 """Developer tool: time the attention forward / backward entry points through the product library (no stamps) on rotating
-buffers.    python tools/attn_time.py [B N H hd]"""
+buffers.    python tools/attn_time.py [--lib tools/_build_prod_X/libmetaenc.so] [B N H hd]"""
+import os
 import sys
 import torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
-from metatransformer_amd import ops
+from metatransformer_amd import _capi, ops
 
+if "--lib" in sys.argv:          # an A/B arm of the library (python -m metatransformer_amd.build --variant NAME -D...)
+    i = sys.argv.index("--lib")
+    _capi.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 B, N, H, hd = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (256, 197, 12, 64)
 dev = torch.device("cuda:0")
 C = H * hd
