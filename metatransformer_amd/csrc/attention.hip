@@ -21,10 +21,11 @@
 #ifndef ME_TINY_ATTN
 #define ME_TINY_ATTN 1
 #endif
-bool attn_tiny_ok(int64_t ld_qkv, int64_t ld_out, int B, int N, int H, int hd);
-int launch_attn_tiny_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale, hipStream_t stream);
-int launch_attn_tiny_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta,
-                         void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream);
+bool attn_tiny_ok(int dtype, int64_t ld_qkv, int64_t ld_out, int B, int N, int H, int hd);
+int launch_attn_tiny_fwd(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
+                         hipStream_t stream);
+int launch_attn_tiny_bwd(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                         float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream);
 
 namespace {
 
@@ -3083,8 +3084,8 @@ extern "C" int me_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int6
     ME_CHECK_ARG(ld_out % 4 == 0, "me_attention_fwd: ld_out must be a multiple of 4");
     ME_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "me_attention_fwd: p_drop must be in [0, 1)");
     // very short sequences (the Tabular / Graph recipes): one wave per (batch, head), attention_tiny.hip
-    if (ME_TINY_ATTN && p_drop == 0.f && dtype == ME_BF16 && N <= SM_MINN && attn_tiny_ok(ld_qkv, ld_out, B, N, H, head_dim))
-        return launch_attn_tiny_fwd(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
+    if (ME_TINY_ATTN && p_drop == 0.f && N <= SM_MINN && attn_tiny_ok(dtype, ld_qkv, ld_out, B, N, H, head_dim))
+        return launch_attn_tiny_fwd(dtype, qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
     if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN) {
         if (N <= RS_MAXN && (int64_t)N * ld_qkv * 2 < (int64_t)0x7e000000) {
             if (head_dim <= 32) return launch_fwd_ring16<32>(qkv, ld_qkv, out, ld_out, lse, B, N, H, head_dim, scale, stream);
@@ -3121,8 +3122,8 @@ extern "C" int me_attention_bwd(const void* qkv, int64_t ld_qkv, const void* out
     const int E = dtype == ME_BF16 ? 8 : 4;
     ME_CHECK_ARG(ld_dout % E == 0 && ld_dqkv % 4 == 0, "me_attention_bwd: bad strides");
     ME_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "me_attention_bwd: p_drop must be in [0, 1)");
-    if (ME_TINY_ATTN && p_drop == 0.f && dtype == ME_BF16 && N <= SM_MINN && attn_tiny_ok(ld_qkv, ld_out, B, N, H, head_dim) && ld_dout % 8 == 0 && ld_dqkv % 8 == 0)
-        return launch_attn_tiny_bwd(qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale, stream);
+    if (ME_TINY_ATTN && p_drop == 0.f && N <= SM_MINN && attn_tiny_ok(dtype, ld_qkv, ld_out, B, N, H, head_dim) && ld_dout % E == 0 && ld_dqkv % E == 0)
+        return launch_attn_tiny_bwd(dtype, qkv, ld_qkv, out, ld_out, dout, ld_dout, lse, delta, dqkv, ld_dqkv, B, N, H, head_dim, scale, stream);
     if (p_drop == 0.f && dtype == ME_BF16 && head_dim <= 64 && N > SM_MINN && N <= SM_MAXN && ld_out % 8 == 0) {
         if (N <= RS_MAXN && (int64_t)N * ld_qkv * 2 < (int64_t)0x7e000000 && (int64_t)N * ld_dout * 2 < (int64_t)0x7e000000) {
             if (head_dim <= 32)

@@ -1,5 +1,5 @@
-// attention_tiny.hip -- self-attention for very short sequences (N <= 64 tokens, head_dim <= 64, bf16): one small workgroup per
-// (batch, head) -- ONE WAVE PER 16 TOKENS (1, 2 or 4 waves) -- with the whole head resident in LDS.
+// attention_tiny.hip -- self-attention for very short sequences (N <= 64 tokens, head_dim <= 64; bf16, and fp32 on the exact-fp32 MFMA):
+// one small workgroup per (batch, head) -- ONE WAVE PER 16 TOKENS (1, 2 or 4 waves) -- with the whole head resident in LDS.
 //
 // Who runs this: the reference's Tabular recipe drives the encoder with one token per column (N ~ 14 .. 20, batch 256:
 // Tabular/run_experiments/adult/adult_meta-transformer.py:103-161), the Graph recipe with N ~ 30 .. 70 node / edge tokens and 32 heads
@@ -21,6 +21,10 @@
 // Two or three workgroup barriers, no atomics, deterministic.  LDS per head 5 .. 65 KB by (N, head_dim) class, i.e. 2 .. 16 heads in
 // flight per CU; the arithmetic is a few dozen MFMAs per wave -- the kernel is one memory round trip long.  (One wave per HEAD was
 // measured first: it loses to the tiled forward at N > 32, where a single wave's staging + 16-tile score chain is too long.)
+//
+// fp32 (the reference's default arithmetic; Tabular runs it): the same kernels on v_mfma_f32_16x16x4_f32 -- exact products, fp32 P and dS.
+// A lane's 16-byte fragment is then 4 floats = its share of FOUR k-steps of 4 (the contraction order inside a 16-long block is permuted
+// identically on both operands), so the LDS addressing is byte for byte the bf16 one: row * pitch + 64 * kstep + 16 * g.
 #include "common.h"
 
 namespace {
@@ -28,14 +32,54 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
-template <int HD, int NMAX> struct TinyCfg {
+// element traits: T = bf16_t (v_mfma_f32_16x16x32_bf16, 8 elements per 16-byte fragment) or float (v_mfma_f32_16x16x4_f32 x 4)
+template <typename T> struct Tr;
+template <> struct Tr<bf16_t> {
+    static constexpr int ES = 2;
+    static __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void put1(char* p, float v) { *reinterpret_cast<bf16_t*>(p) = (bf16_t)v; }
+    static __device__ __forceinline__ void put4(void* p, f32x4 v) {          // four consecutive elements (8 bytes)
+        const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(p) = o;
+    }
+    static __device__ __forceinline__ float dot(u32x4 a, u32x4 b) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            s += __uint_as_float(a[e] << 16) * __uint_as_float(b[e] << 16) + __uint_as_float(a[e] & 0xffff0000u) * __uint_as_float(b[e] & 0xffff0000u);
+        return s;
+    }
+};
+template <> struct Tr<float> {
+    static constexpr int ES = 4;
+    static __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+        return c;
+    }
+    static __device__ __forceinline__ void put1(char* p, float v) { *reinterpret_cast<float*>(p) = v; }
+    static __device__ __forceinline__ void put4(void* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    static __device__ __forceinline__ float dot(u32x4 a, u32x4 b) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += __uint_as_float(a[e]) * __uint_as_float(b[e]);
+        return s;
+    }
+};
+
+template <typename T, int HD, int NMAX> struct TinyCfg {
+    static constexpr int ES = Tr<T>::ES;
     static constexpr int NQ = NMAX / 16;                 // token tiles
     static constexpr int ND = HD / 16;                   // channel tiles
-    static constexpr int KD = HD / 32;                   // k-steps when the contraction runs over channels
-    static constexpr int KN = (NMAX + 31) / 32;          // ... over tokens (NMAX = 16: half a step, lanes g >= 2 supply zeros)
-    static constexpr int CPR = HD / 8;                   // 16-byte chunks per token row
-    static constexpr int PR = HD * 2 + 16;               // row pitch in bytes of [token][d] arrays
-    static constexpr int PT = NMAX * 2 + 16;             // row pitch of [d][token] and [token][token] arrays
+    static constexpr int KD = HD * ES / 64;              // 64-byte k-steps when the contraction runs over channels
+    static constexpr int KN = (NMAX * ES + 63) / 64;     // ... over tokens (bf16, NMAX = 16: half a step, lanes g >= 2 supply zeros)
+    static constexpr bool HALF = NMAX * ES < 64;
+    static constexpr int CPR = HD * ES / 16;             // 16-byte chunks per token row
+    static constexpr int EPC = 16 / ES;                  // elements per chunk
+    static constexpr int PR = HD * ES + 16;              // row pitch in bytes of [token][d] arrays
+    static constexpr int PT = NMAX * ES + 16;            // row pitch of [d][token] and [token][token] arrays
     static constexpr int ROWMAJ = NMAX * PR;             // one [token][d] array
     static constexpr int TRANS = HD * PT;                // one [d][token] array
     static constexpr int SQUARE = NMAX * PT;             // one [token][token] array
@@ -44,46 +88,39 @@ template <int HD, int NMAX> struct TinyCfg {
     static constexpr int BWD_LDS = BWD_A + 3 * TRANS + 2 * NMAX * 4;
 };
 
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-
-// fragment of a k-step over CHANNELS: row `row` of a [token][d] array
-__device__ __forceinline__ bf16x8 frag_d(const char* base, int pitch, int row, int ks, int g) {
-    return *reinterpret_cast<const bf16x8*>(base + row * pitch + (ks * 32 + 8 * g) * 2);
+// the 16-byte fragment of lane group g for k-step ks of row `row` (either element type: 64 bytes per k-step, 16 per lane group)
+__device__ __forceinline__ u32x4 frag(const char* base, int pitch, int row, int ks, int g) {
+    return *reinterpret_cast<const u32x4*>(base + row * pitch + ks * 64 + 16 * g);
 }
-// fragment of a k-step over TOKENS: row `row` of a [..][token] array; with 16 tokens the upper half of the step is zeros
-template <int NMAX> __device__ __forceinline__ bf16x8 frag_t(const char* base, int pitch, int row, int ks, int g) {
-    if (NMAX == 16 && g >= 2) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        return __builtin_bit_cast(bf16x8, z);
-    }
-    return *reinterpret_cast<const bf16x8*>(base + row * pitch + (ks * 32 + 8 * g) * 2);
+// ... of a contraction over TOKENS: with 16 bf16 tokens a row is half a k-step, lane groups 2 and 3 supply zeros
+template <bool HALF> __device__ __forceinline__ u32x4 frag_t(const char* base, int pitch, int row, int ks, int g) {
+    if (HALF && g >= 2) return u32x4{0u, 0u, 0u, 0u};
+    return *reinterpret_cast<const u32x4*>(base + row * pitch + ks * 64 + 16 * g);
 }
 
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-    const bf16_t x = (bf16_t)a, y = (bf16_t)b;
-    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+// 16-byte chunk c of token row `row` of one of the head's operands, zeros past the sequence / the head's channels
+template <typename T> __device__ __forceinline__ u32x4 load_chunk(const T* base, int64_t ld, int row, int c, int N, int hd) {
+    constexpr int EPC = 16 / Tr<T>::ES;
+    if (row >= N || c * EPC >= hd) return u32x4{0u, 0u, 0u, 0u};
+    return *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + c * EPC);
 }
-
-// 16-byte chunk c8 of token row `row` of one of the head's operands, zeros past the sequence / the head's channels
-__device__ __forceinline__ u32x4 load_chunk(const bf16_t* base, int64_t ld, int row, int c8, int N, int hd) {
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    if (row >= N || c8 * 8 >= hd) return z;
-    return *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + c8 * 8);
-}
-__device__ __forceinline__ void put_row(char* arr, int pitch, int row, int c8, u32x4 v) { *reinterpret_cast<u32x4*>(arr + row * pitch + c8 * 16) = v; }
-// the same chunk into the transposed array: element e of the chunk is channel 8 c8 + e of token `row`
-__device__ __forceinline__ void put_trans(char* arr, int pitch, int row, int c8, u32x4 v) {
+__device__ __forceinline__ void put_row(char* arr, int pitch, int row, int c, u32x4 v) { *reinterpret_cast<u32x4*>(arr + row * pitch + c * 16) = v; }
+// the same chunk into the transposed array: element e of the chunk is channel EPC c + e of token `row`
+template <typename T> __device__ __forceinline__ void put_trans(char* arr, int pitch, int row, int c, u32x4 v) {
+    if (Tr<T>::ES == 2) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const uint16_t x = (uint16_t)(v[e >> 1] >> (16 * (e & 1)));
-        *reinterpret_cast<uint16_t*>(arr + (8 * c8 + e) * pitch + row * 2) = x;
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<uint16_t*>(arr + (8 * c + e) * pitch + row * 2) = (uint16_t)(v[e >> 1] >> (16 * (e & 1)));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<uint32_t*>(arr + (4 * c + e) * pitch + row * 4) = v[e];
     }
 }
 
-template <int HD, int NMAX>
-__global__ __launch_bounds__(NMAX * 4) void attn_tiny_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t ld, bf16_t* __restrict__ out, int64_t ldo,
+template <typename T, int HD, int NMAX>
+__global__ __launch_bounds__(NMAX * 4) void attn_tiny_fwd_kernel(const T* __restrict__ qkv, int64_t ld, T* __restrict__ out, int64_t ldo,
                                                            float* __restrict__ lse, int N, int H, int hd, float scale) {
-    typedef TinyCfg<HD, NMAX> C;
+    typedef TinyCfg<T, HD, NMAX> C;
+    typedef Tr<T> X;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;
     char* Ks = Qs + C::ROWMAJ;
@@ -94,28 +131,28 @@ __global__ __launch_bounds__(NMAX * 4) void attn_tiny_fwd_kernel(const bf16_t* _
     const int64_t bh = blockIdx.x;
     const int b = (int)(bh / H), head = (int)(bh - (int64_t)b * H);
     const int Cdim = H * hd;
-    const bf16_t* qp = qkv + (int64_t)b * N * ld + head * hd;
+    const T* qp = qkv + (int64_t)b * N * ld + head * hd;
 #pragma unroll
     for (int c = tid; c < NMAX * C::CPR; c += NMAX * 4) {
         const int row = c / C::CPR, c8 = c % C::CPR;
-        put_row(Qs, C::PR, row, c8, load_chunk(qp, ld, row, c8, N, hd));
-        put_row(Ks, C::PR, row, c8, load_chunk(qp + Cdim, ld, row, c8, N, hd));
-        put_trans(Vt, C::PT, row, c8, load_chunk(qp + 2 * Cdim, ld, row, c8, N, hd));
+        put_row(Qs, C::PR, row, c8, load_chunk<T>(qp, ld, row, c8, N, hd));
+        put_row(Ks, C::PR, row, c8, load_chunk<T>(qp + Cdim, ld, row, c8, N, hd));
+        put_trans<T>(Vt, C::PT, row, c8, load_chunk<T>(qp + 2 * Cdim, ld, row, c8, N, hd));
     }
     __syncthreads();
     const float sl = scale * LOG2E;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     {
-        bf16x8 qf[C::KD];
+        u32x4 qf[C::KD];
 #pragma unroll
-        for (int ks = 0; ks < C::KD; ++ks) qf[ks] = frag_d(Qs, C::PR, 16 * tq + r, ks, g);
+        for (int ks = 0; ks < C::KD; ++ks) qf[ks] = frag(Qs, C::PR, 16 * tq + r, ks, g);
         f32x4 st[C::NQ];
         float m = -INFINITY;
 #pragma unroll
         for (int tk = 0; tk < C::NQ; ++tk) {
             f32x4 a = zero;
 #pragma unroll
-            for (int ks = 0; ks < C::KD; ++ks) a = mma(frag_d(Ks, C::PR, 16 * tk + r, ks, g), qf[ks], a);
+            for (int ks = 0; ks < C::KD; ++ks) a = X::mma(frag(Ks, C::PR, 16 * tk + r, ks, g), qf[ks], a);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 a[i] = (16 * tk + 4 * g + i < N) ? a[i] * sl : -INFINITY;
@@ -138,39 +175,34 @@ __global__ __launch_bounds__(NMAX * 4) void attn_tiny_fwd_kernel(const bf16_t* _
         const float inv = 1.0f / sum;
         const int q = 16 * tq + r;
 #pragma unroll
-        for (int tk = 0; tk < C::NQ; ++tk) {
-            const u32x2 w = {pack2(st[tk][0] * inv, st[tk][1] * inv), pack2(st[tk][2] * inv, st[tk][3] * inv)};
-            *reinterpret_cast<u32x2*>(Ps + q * C::PT + (16 * tk + 4 * g) * 2) = w;
-        }
+        for (int tk = 0; tk < C::NQ; ++tk) X::put4(Ps + q * C::PT + (16 * tk + 4 * g) * C::ES, st[tk] * inv);
         if (lse && g == 0 && q < N) lse[bh * N + q] = (m + __builtin_amdgcn_logf(sum)) * LN2;
     }
     __syncthreads();
-    bf16_t* op = out + (int64_t)b * N * ldo + head * hd;
+    T* op = out + (int64_t)b * N * ldo + head * hd;
     {
-        bf16x8 pf[C::KN];
+        u32x4 pf[C::KN];
 #pragma unroll
-        for (int ks = 0; ks < C::KN; ++ks) pf[ks] = frag_t<NMAX>(Ps, C::PT, 16 * tq + r, ks, g);
+        for (int ks = 0; ks < C::KN; ++ks) pf[ks] = frag_t<C::HALF>(Ps, C::PT, 16 * tq + r, ks, g);
         const int q = 16 * tq + r;
 #pragma unroll
         for (int td = 0; td < C::ND; ++td) {
             f32x4 a = zero;
 #pragma unroll
-            for (int ks = 0; ks < C::KN; ++ks) a = mma(frag_t<NMAX>(Vt, C::PT, 16 * td + r, ks, g), pf[ks], a);
+            for (int ks = 0; ks < C::KN; ++ks) a = X::mma(frag_t<C::HALF>(Vt, C::PT, 16 * td + r, ks, g), pf[ks], a);
             const int d0 = 16 * td + 4 * g;
-            if (q < N && d0 < hd) {
-                const u32x2 w = {pack2(a[0], a[1]), pack2(a[2], a[3])};
-                *reinterpret_cast<u32x2*>(op + (int64_t)q * ldo + d0) = w;
-            }
+            if (q < N && d0 < hd) X::put4(op + (int64_t)q * ldo + d0, a);
         }
     }
 }
 
-template <int HD, int NMAX>
-__global__ __launch_bounds__(NMAX * 4) void attn_tiny_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t ld, const bf16_t* __restrict__ out, int64_t ldo,
-                                                           const bf16_t* __restrict__ dout, int64_t lddo, const float* __restrict__ lse,
-                                                           float* __restrict__ delta, bf16_t* __restrict__ dqkv, int64_t lddq, int N, int H, int hd,
+template <typename T, int HD, int NMAX>
+__global__ __launch_bounds__(NMAX * 4) void attn_tiny_bwd_kernel(const T* __restrict__ qkv, int64_t ld, const T* __restrict__ out, int64_t ldo,
+                                                           const T* __restrict__ dout, int64_t lddo, const float* __restrict__ lse,
+                                                           float* __restrict__ delta, T* __restrict__ dqkv, int64_t lddq, int N, int H, int hd,
                                                            float scale) {
-    typedef TinyCfg<HD, NMAX> C;
+    typedef TinyCfg<T, HD, NMAX> C;
+    typedef Tr<T> X;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;                       // phase 1: rows of Q, K, V, dO
     char* Ks = Qs + C::ROWMAJ;
@@ -189,22 +221,19 @@ __global__ __launch_bounds__(NMAX * 4) void attn_tiny_bwd_kernel(const bf16_t* _
     const int64_t bh = blockIdx.x;
     const int b = (int)(bh / H), head = (int)(bh - (int64_t)b * H);
     const int Cdim = H * hd;
-    const bf16_t* qp = qkv + (int64_t)b * N * ld + head * hd;
-    const bf16_t* dop = dout + (int64_t)b * N * lddo + head * hd;
-    const bf16_t* outp = out + (int64_t)b * N * ldo + head * hd;
+    const T* qp = qkv + (int64_t)b * N * ld + head * hd;
+    const T* dop = dout + (int64_t)b * N * lddo + head * hd;
+    const T* outp = out + (int64_t)b * N * ldo + head * hd;
 #pragma unroll
     for (int c = tid; c < NMAX * C::CPR; c += NMAX * 4) {
         const int row = c / C::CPR, c8 = c % C::CPR;
-        const u32x4 q = load_chunk(qp, ld, row, c8, N, hd), k = load_chunk(qp + Cdim, ld, row, c8, N, hd);
-        const u32x4 v = load_chunk(qp + 2 * Cdim, ld, row, c8, N, hd), d = load_chunk(dop, lddo, row, c8, N, hd);
-        const u32x4 o = load_chunk(outp, ldo, row, c8, N, hd);
+        const u32x4 q = load_chunk<T>(qp, ld, row, c8, N, hd), k = load_chunk<T>(qp + Cdim, ld, row, c8, N, hd);
+        const u32x4 v = load_chunk<T>(qp + 2 * Cdim, ld, row, c8, N, hd), d = load_chunk<T>(dop, lddo, row, c8, N, hd);
+        const u32x4 o = load_chunk<T>(outp, ldo, row, c8, N, hd);
         put_row(Qs, C::PR, row, c8, q); put_row(Ks, C::PR, row, c8, k); put_row(Vs, C::PR, row, c8, v); put_row(Ds, C::PR, row, c8, d);
-        put_trans(Qt, C::PT, row, c8, q); put_trans(Kt, C::PT, row, c8, k); put_trans(Dt, C::PT, row, c8, d);
+        put_trans<T>(Qt, C::PT, row, c8, q); put_trans<T>(Kt, C::PT, row, c8, k); put_trans<T>(Dt, C::PT, row, c8, d);
         // delta = dO . O: the row's CPR chunks sit in CPR neighbouring lanes
-        float part = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            part += __uint_as_float(o[e] << 16) * __uint_as_float(d[e] << 16) + __uint_as_float(o[e] & 0xffff0000u) * __uint_as_float(d[e] & 0xffff0000u);
+        float part = X::dot(o, d);
 #pragma unroll
         for (int s = 1; s < C::CPR; s <<= 1) part += __shfl_xor(part, s, 64);
         if (c8 == 0) {
@@ -218,11 +247,11 @@ __global__ __launch_bounds__(NMAX * 4) void attn_tiny_bwd_kernel(const bf16_t* _
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 p[C::NQ], ds[C::NQ];          // [key tile]: lane holds keys 16 tk + 4 g + i of query 16 tq + r
     {
-        bf16x8 qf[C::KD], df[C::KD];
+        u32x4 qf[C::KD], df[C::KD];
 #pragma unroll
         for (int ks = 0; ks < C::KD; ++ks) {
-            qf[ks] = frag_d(Qs, C::PR, 16 * tq + r, ks, g);
-            df[ks] = frag_d(Ds, C::PR, 16 * tq + r, ks, g);
+            qf[ks] = frag(Qs, C::PR, 16 * tq + r, ks, g);
+            df[ks] = frag(Ds, C::PR, 16 * tq + r, ks, g);
         }
         const float lq = lse_s[16 * tq + r], dq = del_s[16 * tq + r];
 #pragma unroll
@@ -230,8 +259,8 @@ __global__ __launch_bounds__(NMAX * 4) void attn_tiny_bwd_kernel(const bf16_t* _
             f32x4 s = zero, dp = zero;
 #pragma unroll
             for (int ks = 0; ks < C::KD; ++ks) {
-                s = mma(frag_d(Ks, C::PR, 16 * tk + r, ks, g), qf[ks], s);
-                dp = mma(frag_d(Vs, C::PR, 16 * tk + r, ks, g), df[ks], dp);
+                s = X::mma(frag(Ks, C::PR, 16 * tk + r, ks, g), qf[ks], s);
+                dp = X::mma(frag(Vs, C::PR, 16 * tk + r, ks, g), df[ks], dp);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -247,24 +276,22 @@ __global__ __launch_bounds__(NMAX * 4) void attn_tiny_bwd_kernel(const bf16_t* _
         const int q = 16 * tq + r, k0 = 16 * tk + 4 * g;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bf16_t pv = (bf16_t)p[tk][i], dv = (bf16_t)ds[tk][i];
-            *reinterpret_cast<bf16_t*>(Pt + (k0 + i) * C::PT + q * 2) = pv;
-            *reinterpret_cast<bf16_t*>(dSt + (k0 + i) * C::PT + q * 2) = dv;
+            X::put1(Pt + (k0 + i) * C::PT + q * C::ES, p[tk][i]);
+            X::put1(dSt + (k0 + i) * C::PT + q * C::ES, ds[tk][i]);
         }
-        const u32x2 w = {pack2(ds[tk][0], ds[tk][1]), pack2(ds[tk][2], ds[tk][3])};
-        *reinterpret_cast<u32x2*>(dSs + q * C::PT + k0 * 2) = w;
+        X::put4(dSs + q * C::PT + k0 * C::ES, ds[tk]);
     }
     __syncthreads();
-    bf16_t* gp = dqkv + (int64_t)b * N * lddq + head * hd;
+    T* gp = dqkv + (int64_t)b * N * lddq + head * hd;
     // token tile tt = this wave's: dQ^T[d][q] = K^T dS-rows, dK^T[d][key] = Q^T dS^T-rows, dV^T[d][key] = dO^T P^T-rows
     {
         const int tt = tq;
-        bf16x8 sq[C::KN], sk[C::KN], pk[C::KN];
+        u32x4 sq[C::KN], sk[C::KN], pk[C::KN];
 #pragma unroll
         for (int ks = 0; ks < C::KN; ++ks) {
-            sq[ks] = frag_t<NMAX>(dSs, C::PT, 16 * tt + r, ks, g);
-            sk[ks] = frag_t<NMAX>(dSt, C::PT, 16 * tt + r, ks, g);
-            pk[ks] = frag_t<NMAX>(Pt, C::PT, 16 * tt + r, ks, g);
+            sq[ks] = frag_t<C::HALF>(dSs, C::PT, 16 * tt + r, ks, g);
+            sk[ks] = frag_t<C::HALF>(dSt, C::PT, 16 * tt + r, ks, g);
+            pk[ks] = frag_t<C::HALF>(Pt, C::PT, 16 * tt + r, ks, g);
         }
         const int tok = 16 * tt + r;
 #pragma unroll
@@ -272,42 +299,39 @@ __global__ __launch_bounds__(NMAX * 4) void attn_tiny_bwd_kernel(const bf16_t* _
             f32x4 aq = zero, ak = zero, av = zero;
 #pragma unroll
             for (int ks = 0; ks < C::KN; ++ks) {
-                aq = mma(frag_t<NMAX>(Kt, C::PT, 16 * td + r, ks, g), sq[ks], aq);
-                ak = mma(frag_t<NMAX>(Qt, C::PT, 16 * td + r, ks, g), sk[ks], ak);
-                av = mma(frag_t<NMAX>(Dt, C::PT, 16 * td + r, ks, g), pk[ks], av);
+                aq = X::mma(frag_t<C::HALF>(Kt, C::PT, 16 * td + r, ks, g), sq[ks], aq);
+                ak = X::mma(frag_t<C::HALF>(Qt, C::PT, 16 * td + r, ks, g), sk[ks], ak);
+                av = X::mma(frag_t<C::HALF>(Dt, C::PT, 16 * td + r, ks, g), pk[ks], av);
             }
             const int d0 = 16 * td + 4 * g;
             if (tok < N && d0 < hd) {
-                bf16_t* row = gp + (int64_t)tok * lddq + d0;
-                const u32x2 wq = {pack2(aq[0] * scale, aq[1] * scale), pack2(aq[2] * scale, aq[3] * scale)};
-                const u32x2 wk = {pack2(ak[0] * scale, ak[1] * scale), pack2(ak[2] * scale, ak[3] * scale)};
-                const u32x2 wv = {pack2(av[0], av[1]), pack2(av[2], av[3])};
-                *reinterpret_cast<u32x2*>(row) = wq;
-                *reinterpret_cast<u32x2*>(row + Cdim) = wk;
-                *reinterpret_cast<u32x2*>(row + 2 * Cdim) = wv;
+                T* row = gp + (int64_t)tok * lddq + d0;
+                X::put4(row, aq * scale);
+                X::put4(row + Cdim, ak * scale);
+                X::put4(row + 2 * Cdim, av);
             }
         }
     }
 }
 
-template <int HD, int NMAX>
+template <typename T, int HD, int NMAX>
 int launch_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale, hipStream_t stream) {
-    typedef TinyCfg<HD, NMAX> C;
+    typedef TinyCfg<T, HD, NMAX> C;
     static OncePerDevice once;
-    if (once.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_tiny_fwd_kernel<HD, NMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, C::FWD_LDS);
-    hipLaunchKernelGGL((attn_tiny_fwd_kernel<HD, NMAX>), dim3((unsigned)((int64_t)B * H)), dim3(NMAX * 4), C::FWD_LDS, stream, reinterpret_cast<const bf16_t*>(qkv), ld,
-                       reinterpret_cast<bf16_t*>(out), ldo, lse, N, H, hd, scale);
+    if (once.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_tiny_fwd_kernel<T, HD, NMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, C::FWD_LDS);
+    hipLaunchKernelGGL((attn_tiny_fwd_kernel<T, HD, NMAX>), dim3((unsigned)((int64_t)B * H)), dim3(NMAX * 4), C::FWD_LDS, stream, reinterpret_cast<const T*>(qkv), ld,
+                       reinterpret_cast<T*>(out), ldo, lse, N, H, hd, scale);
     ME_CHECK_LAUNCH("me_attention_fwd(tiny)");
     return ME_OK;
 }
-template <int HD, int NMAX>
+template <typename T, int HD, int NMAX>
 int launch_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta, void* dqkv,
                int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
-    typedef TinyCfg<HD, NMAX> C;
+    typedef TinyCfg<T, HD, NMAX> C;
     static OncePerDevice once;
-    if (once.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_tiny_bwd_kernel<HD, NMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, C::BWD_LDS);
-    hipLaunchKernelGGL((attn_tiny_bwd_kernel<HD, NMAX>), dim3((unsigned)((int64_t)B * H)), dim3(NMAX * 4), C::BWD_LDS, stream, reinterpret_cast<const bf16_t*>(qkv), ld,
-                       reinterpret_cast<const bf16_t*>(out), ldo, reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq,
+    if (once.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_tiny_bwd_kernel<T, HD, NMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, C::BWD_LDS);
+    hipLaunchKernelGGL((attn_tiny_bwd_kernel<T, HD, NMAX>), dim3((unsigned)((int64_t)B * H)), dim3(NMAX * 4), C::BWD_LDS, stream, reinterpret_cast<const T*>(qkv), ld,
+                       reinterpret_cast<const T*>(out), ldo, reinterpret_cast<const T*>(dout), lddo, lse, delta, reinterpret_cast<T*>(dqkv), lddq,
                        N, H, hd, scale);
     ME_CHECK_LAUNCH("me_attention_bwd(tiny)");
     return ME_OK;
@@ -315,34 +339,49 @@ int launch_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const 
 
 }  // namespace
 
-// bf16, no dropout, N <= 64, head_dim <= 64 and a multiple of 8, 16-byte aligned head rows (ld, ld_out, ld_dout, ld_dqkv and head_dim multiples of 8)
-bool attn_tiny_ok(int64_t ld_qkv, int64_t ld_out, int B, int N, int H, int hd) {
-    return N >= 1 && N <= 64 && hd >= 8 && hd <= 64 && hd % 8 == 0 && ld_qkv % 8 == 0 && ld_out % 8 == 0 && (int64_t)B * H < (1ll << 31);
+// no dropout, N <= 64, head_dim <= 64, 16-byte aligned head rows (row strides and head_dim multiples of 8 bf16 / 4 fp32 elements)
+bool attn_tiny_ok(int dtype, int64_t ld_qkv, int64_t ld_out, int B, int N, int H, int hd) {
+    const int E = dtype == ME_BF16 ? 8 : 4;
+    return (dtype == ME_BF16 || dtype == ME_F32) && N >= 1 && N <= 64 && hd >= E && hd <= 64 && hd % E == 0 && ld_qkv % E == 0 && ld_out % E == 0 &&
+           (int64_t)B * H < (1ll << 31);
 }
 
-int launch_attn_tiny_fwd(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale, hipStream_t stream) {
-#define TINY_FWD(HD_, NM_) return launch_fwd<HD_, NM_>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream)
-    if (hd <= 32) {
-        if (N <= 16) TINY_FWD(32, 16);
-        if (N <= 32) TINY_FWD(32, 32);
-        TINY_FWD(32, 64);
-    }
-    if (N <= 16) TINY_FWD(64, 16);
-    if (N <= 32) TINY_FWD(64, 32);
-    TINY_FWD(64, 64);
+int launch_attn_tiny_fwd(int dtype, const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int N, int H, int hd, float scale,
+                         hipStream_t stream) {
+#define TINY_FWD(T_, HD_, NM_) return launch_fwd<T_, HD_, NM_>(qkv, ld, out, ldo, lse, B, N, H, hd, scale, stream)
+#define TINY_FWD_T(T_)                      \
+    do {                                    \
+        if (hd <= 32) {                     \
+            if (N <= 16) TINY_FWD(T_, 32, 16); \
+            if (N <= 32) TINY_FWD(T_, 32, 32); \
+            TINY_FWD(T_, 32, 64);           \
+        }                                   \
+        if (N <= 16) TINY_FWD(T_, 64, 16);  \
+        if (N <= 32) TINY_FWD(T_, 64, 32);  \
+        TINY_FWD(T_, 64, 64);               \
+    } while (0)
+    if (dtype == ME_BF16) TINY_FWD_T(bf16_t);
+    TINY_FWD_T(float);
+#undef TINY_FWD_T
 #undef TINY_FWD
 }
 
-int launch_attn_tiny_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta,
-                         void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
-#define TINY_BWD(HD_, NM_) return launch_bwd<HD_, NM_>(qkv, ld, out, ldo, dout, lddo, lse, delta, dqkv, lddq, B, N, H, hd, scale, stream)
-    if (hd <= 32) {
-        if (N <= 16) TINY_BWD(32, 16);
-        if (N <= 32) TINY_BWD(32, 32);
-        TINY_BWD(32, 64);
-    }
-    if (N <= 16) TINY_BWD(64, 16);
-    if (N <= 32) TINY_BWD(64, 32);
-    TINY_BWD(64, 64);
+int launch_attn_tiny_bwd(int dtype, const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                         float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
+#define TINY_BWD(T_, HD_, NM_) return launch_bwd<T_, HD_, NM_>(qkv, ld, out, ldo, dout, lddo, lse, delta, dqkv, lddq, B, N, H, hd, scale, stream)
+#define TINY_BWD_T(T_)                      \
+    do {                                    \
+        if (hd <= 32) {                     \
+            if (N <= 16) TINY_BWD(T_, 32, 16); \
+            if (N <= 32) TINY_BWD(T_, 32, 32); \
+            TINY_BWD(T_, 32, 64);           \
+        }                                   \
+        if (N <= 16) TINY_BWD(T_, 64, 16);  \
+        if (N <= 32) TINY_BWD(T_, 64, 32);  \
+        TINY_BWD(T_, 64, 64);               \
+    } while (0)
+    if (dtype == ME_BF16) TINY_BWD_T(bf16_t);
+    TINY_BWD_T(float);
+#undef TINY_BWD_T
 #undef TINY_BWD
 }

@@ -241,7 +241,7 @@ int block_fwd_x3(const me_block_desc* d, const Dims& s, const void* x, void* y, 
     gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, s.C3, 3 * C, v.xn1, 3 * C, d->qkv_w, 3 * C, v.qkv, s.C3, ME_F32);
     g.bias = d->qkv_b;
     if ((rc = run(g))) return rc;
-    if (s.hd == 64) {
+    if (s.hd == 64 && d->N > 64) {       // (N <= 64: the exact-fp32 one-workgroup-per-head kernels, attention_tiny.hip, are faster and exact)
         // three-product attention on the bf16 MFMA (attention_x3.hip): writes the proj Linear's planes itself; the fp32 copy only
         // when backward will want it (me_attention_bwd reads o and lse)
         rc = me_attention_fwd_x3(reinterpret_cast<const float*>(v.qkv), s.C3, keep ? reinterpret_cast<float*>(v.o) : nullptr, s.C, v.o3,
@@ -344,7 +344,7 @@ int block_bwd_x3(const me_block_desc* d, const Dims& s, const void* x, const voi
     if ((rc = me_split3(dx1, C, dx1_3, s.M, C, 0, stream))) return rc;
     if ((rc = wgrad(dx1_3, C, v.o3, C, gr->proj_w, gr->proj_b))) return rc;
     if ((rc = nt(dx1_3, C, d->proj_wt, dout, C, ME_F32, nullptr))) return rc;
-    if (s.hd == 64) {
+    if (s.hd == 64 && d->N > 64) {
         // three-product attention backward on the bf16 MFMA (attention_x3.hip): writes the planes the two qkv GEMMs read by itself --
         // no fp32 dqkv, no split pass
         rc = me_attention_bwd_x3(reinterpret_cast<const float*>(v.qkv), C3, reinterpret_cast<const float*>(v.o), C, dout, C, v.lse, delta, nullptr, C3,

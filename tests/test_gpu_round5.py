@@ -71,7 +71,8 @@ def test_small_m_long_reduction_split(dev, M_, N, K):
 
 # ---- the reference's batches through the encoder (two blocks: the CPU oracle finishes in seconds), forward and dL/dx through
 # frozen blocks -- the mode PointCloud / Time-Series / Graph / Hyper-spectral / Tabular drive it in
-REF_BATCHES = [("timeseries", 32, 96, 12), ("graph", 128, 50, 32), ("pointcloud", 32, 257, 12), ("hyperspectral", 64, 201, 12)]
+REF_BATCHES = [("timeseries", 32, 96, 12), ("graph", 128, 50, 32), ("pointcloud", 32, 257, 12), ("hyperspectral", 64, 201, 12),
+               ("tabular", 256, 16, 12)]      # (graph, tabular: N <= 64 -> the one-workgroup-per-head attention kernels, fp32 and bf16)
 
 
 @pytest.mark.parametrize("name,B,N,H", REF_BATCHES)
@@ -233,7 +234,7 @@ def test_forward_3xbf16_matches_reference_golden(dev, name):
     assert not torch.equal(ye, y) and rel_err(y, ye) < TOL_3X
 
 
-@pytest.mark.parametrize("B,N,depth", [(3, 70, 2), (24, 197, 1)], ids=["210_tokens", "4728_tokens"])
+@pytest.mark.parametrize("B,N,depth", [(3, 70, 2), (24, 197, 1), (40, 16, 1)], ids=["210_tokens", "4728_tokens", "tabular_16_tokens"])
 def test_backward_3xbf16_every_gradient_vs_oracle(dev, B, N, depth):
     """forward, dL/dx and all parameter gradients of a block stack in the three-product mode, per element, against the CPU
     oracle (fp32 torch restatement of the reference Block); ragged token counts; then in-place accumulation into a FlatParams buffer.

@@ -7,9 +7,9 @@ for l in rows:
     if l.startswith("=="):
         lib = "old" if "notiny" in l else "new"
         continue
-    m = re.match(r"(fwd|bwd)\s+(B=\d+ N=\d+ H=\d+ hd=\d+):\s+([\d.]+) us", l)
+    m = re.match(r"(fwd|bwd)\s+(B=\d+ N=\d+ H=\d+ hd=\d+(?: fp32)?):\s+([\d.]+) us", l)
     if m:
         d.setdefault(m.group(2), {})[(m.group(1), lib)] = float(m.group(3))
 print("# shape                         tiled kernels -> attention_tiny.hip (one wave per 16 tokens), us per launch, same box")
 for k, v in d.items():
-    print("%-28s fwd %7.1f -> %7.1f   bwd %7.1f -> %7.1f" % (k, v[("fwd", "old")], v[("fwd", "new")], v[("bwd", "old")], v[("bwd", "new")]))
+    print("%-34s fwd %7.1f -> %7.1f   bwd %7.1f -> %7.1f" % (k, v[("fwd", "old")], v[("fwd", "new")], v[("bwd", "old")], v[("bwd", "new")]))

@@ -10,4 +10,10 @@ for s in "1024 16 12 64" "2048 8 12 64" "512 32 12 64" "256 48 12 64" "256 64 12
     python tools/attn_time.py --lib $lib $s 2>&1 | grep -v "amdgpu.ids\|no lse" >> $O
   done
 done
-cat $O
+for s in "1024 16 12 64" "512 32 12 64" "256 64 12 64" "512 50 32 24" "256 40 16 40"; do
+  for lib in tools/_build_prod_notiny/libmetaenc.so metatransformer_amd/libmetaenc.so; do
+    echo "== $lib" >> $O
+    python tools/attn_time.py --fp32 --lib $lib $s 2>&1 | grep -v "amdgpu.ids\|no lse" >> $O
+  done
+done
+python tools/attn_tiny_fold.py $O
