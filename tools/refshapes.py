@@ -121,7 +121,7 @@ def main():
             if dn not in a.dtypes.split(","):
                 continue
             steps = 5 if (dn == "fp32" or a.quick) else 20
-            r = run_shape(name, B, N, C, H, L, dtype, steps, 2, "3xbf16" if dn == "fp32x3" else "exact")
+            r = run_shape(name, B, N, C, H, L, dtype, steps, 2 if dn == "fp32" else 4, "3xbf16" if dn == "fp32x3" else "exact")
             res[name][dn] = r
             print(f"{name:20s} {dn}: fwd+dx {r['fwd_dx']['ms_per_step']:8.3f} ms ({r['fwd_dx']['frac_of_mfma_peak']:.3f} of peak)  fwd {r['fwd']['ms_per_step']:8.3f} ms "
                   f"({r['fwd']['frac_of_mfma_peak']:.3f})  gemm plans: {[k for k in r['fwd']['kernels'] if k.startswith('gemm')]}", flush=True)
