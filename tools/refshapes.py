@@ -66,8 +66,17 @@ def run_shape(name, B, N, C, H, L, dtype, steps, warmup, fp32_mode="exact"):
             fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
+        if os.environ.get("REFSHAPES_STEP_TIMES") == "1":          # (diagnostic: every step synchronised and printed)
+            ts = []
+            for _ in range(steps):
+                t1 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(round(1e3 * (time.perf_counter() - t1), 3))
+            print(f"    {name} {label} per-step ms: {ts}", flush=True)
+        else:
+            for _ in range(steps):
+                fn()
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / steps
         ops.gemm_profile(True)
