@@ -622,3 +622,87 @@ def test_split3_batched_is_split3_per_matrix(dev):
             assert torch.equal(o, ops.split3(src, right_operand=True))
     with pytest.raises(_capi.MetaEncError):
         ops.split3_many([ws[0][:6, :6].contiguous()], False)           # rows / cols not multiples of 4
+
+
+# ---- seeded random sweeps over the two kernels of this round whose index arithmetic has the most corners
+def test_attention_short_sequences_random_sweep(dev):
+    """60 random (B, N <= 64, heads, head_dim) problems per dtype through attention_tiny.hip -- every token class (16 / 32 / 64), both
+    head-dim classes, head dims that are not tile multiples, odd strides between heads -- forward, lse and all three gradients per
+    element against fp64; bf16 head dims are multiples of 8, fp32 of 4 (the kernels' alignment classes)"""
+    import random
+    rng = random.Random(20260924)
+    for dt, tol_o, tol_g in ((torch.bfloat16, 1.5e-2, 3e-2), (torch.float32, 2e-5, 5e-5)):
+        step = 8 if dt == torch.bfloat16 else 4
+        for case in range(60):
+            B, N, H = rng.randint(1, 5), rng.randint(1, 64), rng.randint(1, 6)
+            hd = step * rng.randint(1, 64 // step)
+            g = torch.Generator().manual_seed(1000 + case)
+            qkv = torch.randn(B * N, 3 * H * hd, generator=g).to(dt)
+            do = torch.randn(B * N, H * hd, generator=g).to(dt)
+            scale = hd ** -0.5
+            qr = qkv.double().requires_grad_(True)
+            q, k, v = qr.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+            s = (q @ k.transpose(-2, -1)) * scale
+            ref = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B * N, H * hd)
+            ref.backward(do.double())
+            out, lse = ops.attention_fwd(qkv.to(dev), B, N, H, hd, scale, True)
+            what = f"{dt} B={B} N={N} H={H} hd={hd}"
+            check_close(out.float(), ref.detach(), tol_o, "forward " + what)
+            check_close(lse, torch.logsumexp(s.detach(), dim=-1), 5e-3 if dt == torch.bfloat16 else 1e-5, "lse " + what)
+            dqkv = ops.attention_bwd(qkv.to(dev), out, do.to(dev), lse, B, N, H, hd, scale).float().cpu().double()
+            C = H * hd
+            whole = float(qr.grad.abs().max())
+            for name, sl in (("dQ", slice(0, C)), ("dK", slice(C, 2 * C)), ("dV", slice(2 * C, 3 * C))):
+                r = qr.grad[:, sl]
+                if float(r.abs().max()) < 1e-3 * whole:          # (N = 1: dQ and dK vanish identically)
+                    assert float((dqkv[:, sl] - r).abs().max()) <= tol_g * whole, f"{name} {what}"
+                else:
+                    check_close(dqkv[:, sl], r, tol_g, f"{name} {what}")
+
+
+def test_patch_embed_random_geometries(dev):
+    """40 random fusable geometries (kh x kw = 256 in all four shapes, 1 .. 3 channels, 1 .. 2 frames per tubelet, overlapping and gapped
+    strides, ragged token counts, Cout not a multiple of the tile) through the gathering GEMM, and -- with enough samples for the
+    split-K wgrad kernel -- through the gathering weight-gradient kernel; fp64 on the same bf16-exact operands"""
+    import random
+    rng = random.Random(7)
+    dt = torch.bfloat16
+    fused_wgrads = 0
+    for case in range(40):
+        kw = rng.choice([8, 16, 32, 64]); kh = 256 // kw
+        kt = rng.choice([1, 1, 2]); Cin = rng.randint(1, 3)
+        sw = 8 * rng.randint(1, max(1, kw // 8) + 1); sh = rng.randint(max(1, kh // 2), kh + 2); st = kt
+        gw, gh, gt = rng.randint(1, 5), rng.randint(1, 5), rng.randint(1, 3)
+        W = ((gw - 1) * sw + kw + 7) // 8 * 8; H = (gh - 1) * sh + kh + rng.randint(0, 3); T = gt * kt
+        while (H * W) % 8:
+            H += 1
+        gw, gh = (W - kw) // sw + 1, (H - kh) // sh + 1
+        tokens = gt * gh * gw
+        big = case % 4 == 0
+        B = (4096 + tokens) // tokens + 1 if big else rng.randint(1, 4)
+        Cout = 8 * rng.randint(32, 70) if big else 8 * rng.randint(1, 70)
+        geom = (kt, kh, kw, st, sh, sw)
+        shape = (B, Cin, T, H, W) if kt > 1 or case % 2 else (B, Cin, H, W)
+        if len(shape) == 4 and T != 1:
+            shape = (B, Cin, T, H, W)
+        g = torch.Generator().manual_seed(500 + case)
+        x = torch.randn(*shape, generator=g).to(dt)
+        x5 = x.float().reshape(B, Cin, T, H, W)
+        # the gathered matrix by slicing: token order (t, h, w), feature order (c, dt, dy, dx)
+        cols = torch.stack([x5[:, :, pt * st:pt * st + kt, py * sh:py * sh + kh, px * sw:px * sw + kw].reshape(B, -1)
+                            for pt in range(gt) for py in range(gh) for px in range(gw)], dim=1)
+        K = Cin * kt * 256
+        w = (0.05 * torch.randn(Cout, K, generator=g)).to(dt)
+        bias = 0.1 * torch.randn(Cout, generator=g)
+        xd = x.to(dev)
+        what = f"case {case}: x{tuple(shape)} k({kt},{kh},{kw}) s({st},{sh},{sw}) Cout={Cout}"
+        assert ops.patch_embed_fused(xd, geom, dt, Cout), what
+        y, tps = ops.patch_embed(xd, w.to(dev), bias.to(dev), None, geom, 0, torch.float32)
+        assert tps == tokens, what
+        check_close(y.reshape(B, tokens, Cout), cols.double() @ w.double().t() + bias.double(), 2e-5, "forward, " + what)
+        dy = torch.randn(B * tokens, Cout, generator=g).to(dt)
+        fused_wgrads += bool(ops.patch_embed_wgrad_fused(xd, geom, dt, Cout, torch.float32))
+        dw, db = ops.patch_embed_wgrad(xd, geom, dy.to(dev), torch.float32, True)
+        check_close(dw, dy.double().t() @ cols.reshape(B * tokens, K).double(), 3e-5, "wgrad, " + what)
+        check_close(db, dy.double().sum(0), 3e-5, "bias gradient, " + what)
+    assert fused_wgrads >= 8, f"only {fused_wgrads} cases reached the gathering wgrad kernel"
