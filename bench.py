@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-fwd-leg", action="store_true")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="train: keep the weight-gradient GEMMs in program order on the one stream (me_block_bwd_overlap(0))")
+    ap.add_argument("--opt-prefetch", action="store_true",
+                    help="A/B arm: rebuild the transposed weight copies on a side stream behind the optimizer step (under the next forward)")
     ap.add_argument("--opt-overlap", action="store_true",
                     help="A/B arm (single GPU): per-Block AdamW launches + gradient zero-fill + weight transposes on the optimizer's side stream "
                          "(FusedAdamW(overlap=True)) instead of one pass behind backward")
@@ -190,7 +192,8 @@ def main():
         flat = parallel.FlatParams(enc.named_parameters(), no_decay=parallel.no_decay_rule)
         # (--opt-overlap: per-Block AdamW + zero-fill + weight transposes on the optimizer's side stream under backward / the next forward --
         #  measured SLOWER than the one-pass form, 30.4 vs 29.8 ms same box: profiles/r05_opt_overlap_ab.txt; the arm stays for A/B)
-        opt = parallel.FusedAdamW(flat, lr=1e-4, weight_decay=0.05, overlap=args.opt_overlap and not use_dist, grad_scale=1.0 / world)
+        opt = parallel.FusedAdamW(flat, lr=1e-4, weight_decay=0.05, overlap=args.opt_overlap and not use_dist, grad_scale=1.0 / world,
+                                  prefetch_transposes=args.opt_prefetch)
         reducer = parallel.OverlappedGradReducer(flat, group=tgroup, comm=comm, force=use_dist,
                                                  wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None) if use_dist else None
         x.requires_grad_(True)                   # the tokenizer in front of the encoder needs dL/dx

@@ -468,7 +468,7 @@ class FusedAdamW:
 
     def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bf16_mirror: bool = True,
                  lr_scale=None, max_norm: float = 0.0, loss_scale: Optional[torch.Tensor] = None, overlap: bool = False,
-                 grad_scale: float = 1.0):
+                 grad_scale: float = 1.0, prefetch_transposes: bool = False):
         """bf16_mirror: also emit the updated parameters in bf16 (FlatParams.flat_bf16) from the same kernel; Blocks
         running in bf16 then take their forward weight copies from it instead of re-casting every weight.
         overlap (plain form, ONE backward per step, no gradient exchange between ranks): the update of a parameter UNIT (one Block's
@@ -477,7 +477,11 @@ class FusedAdamW:
         backward, which is matrix-bound -- followed by the zero-fill of that gradient slice (`flat.zero_grad()` of the next step
         becomes free) and, behind the last unit, by the refresh of the transposed weight copies the next backward needs.  `step()`
         launches whatever is left and joins.  `grad_scale` must be given HERE (the launches happen before `step()` is called);
-        after `step()` the gradients read as zero.  Same arithmetic, same bits as the one-pass form (tests)."""
+        after `step()` the gradients read as zero.  Same arithmetic, same bits as the one-pass form (tests).
+        prefetch_transposes (one-pass form): rebuild the transposed weight copies the next BACKWARD needs on a side stream right behind
+        the update, i.e. under the next forward, instead of at the head of that backward (one batched launch, ~0.15 ms for Base)."""
+        self.prefetch_transposes = bool(prefetch_transposes) and not overlap
+        self._pf_stream = None
         if flat.flat_param.dtype != torch.float32:
             raise MetaEncError("FusedAdamW needs fp32 master parameters")
         self.flat, self.lr, self.betas, self.eps, self.wd = flat, lr, betas, eps, weight_decay
@@ -648,6 +652,14 @@ class FusedAdamW:
         if self.bf16_mirror:      # valid for this weight epoch as long as nobody else writes the parameters
             f._mirror_epoch = ops.WEIGHT_EPOCH
             f._mirror_versions = [p._version for p in f.params]
+        if self.prefetch_transposes:
+            dev = f.flat_param.device
+            if self._pf_stream is None:
+                self._pf_stream = torch.cuda.Stream(device=dev)
+            self._pf_stream.wait_stream(torch.cuda.current_stream(dev))       # behind the update
+            with torch.cuda.stream(self._pf_stream):
+                from .encoder import _WeightCache
+                _WeightCache.prefetch_transposed(dev)       # (its first user waits for the event recorded there)
         return out
 
 
