@@ -403,7 +403,9 @@ def test_attention_dropout(dev, B, N, H, hd, dt):
 # ----------------------------------------------------------------------------- tokenizer kernels
 
 @pytest.mark.parametrize("geom", [((2, 3, 64, 48), (1, 16, 16, 1, 16, 16)), ((2, 1, 40, 57), (1, 16, 16, 1, 10, 10)),
-                                  ((1, 3, 4, 32, 32), (2, 16, 16, 2, 16, 16))])
+                                  ((1, 3, 4, 32, 32), (2, 16, 16, 2, 16, 16)),
+                                  ((3, 2, 30, 27), (1, 6, 6, 1, 5, 7)),            # kw % 4 != 0: the element-wise kernel
+                                  ((2, 3, 36, 44), (1, 8, 12, 1, 7, 4))])          # quads, aligned sources, overlapping rows
 def test_patchify_bit_exact(dev, geom):
     shape, (kt, kh, kw, st, sh, sw) = geom
     x = rnd(*shape, seed=3)
@@ -411,6 +413,13 @@ def test_patchify_bit_exact(dev, geom):
     ref = to.patchify_2d(x, kh, kw, sh, sw) if len(shape) == 4 else to.patchify_3d(x, kt, kh, kw)
     assert tps == ref.shape[1]
     assert torch.equal(cols.cpu().reshape(ref.shape), ref), "patch gather must be bit-exact"
+    # every dtype pair the tokenizers use: bf16 pixels -> bf16, fp32 pixels -> bf16 (rounded once, as a cast would)
+    xb = x.bfloat16()
+    cb, _ = ops.patchify(xb.to(dev), kt, kh, kw, st, sh, sw, torch.bfloat16)
+    refb = to.patchify_2d(xb.float(), kh, kw, sh, sw) if len(shape) == 4 else to.patchify_3d(xb.float(), kt, kh, kw)
+    assert torch.equal(cb.cpu().float().reshape(refb.shape), refb)
+    cfb, _ = ops.patchify(x.to(dev), kt, kh, kw, st, sh, sw, torch.bfloat16)
+    assert torch.equal(cfb.cpu().float().reshape(refb.shape), refb)
     # scatter-add back: adjoint of the gather
     d = rnd(*cols.shape, seed=4)
     dx = ops.unpatchify_add(d.to(dev), shape, kt, kh, kw, st, sh, sw)
