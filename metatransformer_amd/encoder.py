@@ -726,6 +726,22 @@ def build_encoder(depth: int = 12, dim: int = 768, num_heads: int = 12, mlp_rati
                                  norm_layer=norm_layer, act_layer=nn.GELU, **kw) for _ in range(depth)])
 
 
+def set_fp32_mode(model: nn.Module, mode: str) -> int:
+    """Select the fp32 arithmetic of every Block inside `model` (any module tree: the reference's `nn.Sequential` encoder, or a task model
+    that owns one): "exact" -- the exact-fp32 MFMA, the parity default -- or "3xbf16" -- fp32-accurate (~5e-6 of the reference, bound 1e-4;
+    the north star's fp32 bound is 1e-3) on the bf16 matrix pipe: 2.3 .. 2.9x per step on the reference's fp32 recipes
+    (profiles/r05_refshapes.txt).  Returns the number of Blocks set.  One line at a call site that runs the encoder in fp32
+    (README.md:113-150): `metatransformer_amd.set_fp32_mode(encoder, "3xbf16")`."""
+    if mode not in ("exact", "3xbf16"):
+        raise MetaEncError(f"fp32 mode must be 'exact' or '3xbf16' (got {mode!r})")
+    n = 0
+    for m in model.modules():
+        if isinstance(m, Block):
+            m.fp32_mode = mode
+            n += 1
+    return n
+
+
 # encoder_forward_inference replays a captured hipGraph for small batches: below ~1 000 token rows the 84 launches of a Base
 # forward are latency-bound and the host's launch path is a visible part of it (N = 197: B = 1 0.84 ms eager, 0.63 ms replayed;
 # B = 2 0.87 / 0.68; B = 4 0.84 / 0.76; B = 8 0.99 / 0.99; B = 16 1.29 / 1.34 -- profiles/r05_latency.txt).

@@ -146,6 +146,18 @@ def test_block_mirrors_reference_interface():
         M.Block(64, 5)
 
 
+def test_set_fp32_mode_reaches_every_block_of_a_task_model():
+    """one line at an fp32 call site selects the fp32-accurate three-product arithmetic for the whole encoder, wherever it sits"""
+    import torch
+    enc = M.build_encoder(3, 256, 4)
+    model = torch.nn.ModuleDict({"tokenizer": torch.nn.Linear(7, 256), "encoder": enc, "head": torch.nn.Linear(256, 10)})
+    assert all(b.fp32_mode == "exact" for b in enc)
+    assert M.set_fp32_mode(model, "3xbf16") == 3 and all(b.fp32_mode == "3xbf16" for b in enc)
+    assert M.set_fp32_mode(enc, "exact") == 3 and all(b.fp32_mode == "exact" for b in enc)
+    with pytest.raises(M.MetaEncError):
+        M.set_fp32_mode(model, "tf32")
+
+
 def test_tokenizer_parameter_names_match_reference():
     assert list(M.PatchEmbed().state_dict()) == ["proj.weight", "proj.bias"]
     assert M.PatchEmbed().proj.weight.shape == (768, 3, 16, 16)
