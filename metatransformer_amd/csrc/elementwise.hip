@@ -1127,6 +1127,29 @@ extern "C" int me_colsum_mul(const void* x, int x_dtype, int64_t ldx, const void
     return ME_OK;
 }
 
+// non-overlapping patches (stride >= kernel on every axis), kw % 4 == 0, aligned quads: the scatter four pixels at a time
+__global__ __launch_bounds__(EW_THREADS) void unpatchify_add4_kernel(const void* __restrict__ dcols, int ddt, float* __restrict__ dx_out, PatchGeom g) {
+    const int64_t feat4 = (int64_t)g.Cin * g.kt * g.kh * (g.kw / 4);
+    const int64_t ntok = (int64_t)g.B * g.gt * g.gh * g.gw;
+    const int64_t total = ntok * feat4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t tok = i / feat4;
+        int64_t f = i - tok * feat4;
+        const int dx = (int)(f % (g.kw / 4)) * 4; f /= (g.kw / 4);
+        const int dy = (int)(f % g.kh); f /= g.kh;
+        const int dt = (int)(f % g.kt); f /= g.kt;
+        const int c = (int)f;
+        int64_t t = tok;
+        const int px = (int)(t % g.gw); t /= g.gw;
+        const int py = (int)(t % g.gh); t /= g.gh;
+        const int pt = (int)(t % g.gt); t /= g.gt;
+        const int b = (int)t;
+        const int64_t dst = ((((int64_t)b * g.Cin + c) * g.T + (pt * g.st + dt)) * g.H + (py * g.sh + dy)) * g.W + (px * g.sw + dx);
+        f32x4* q = reinterpret_cast<f32x4*>(dx_out + dst);
+        *q = *q + load4_as_f32(dcols, ddt, i * 4);
+    }
+}
+
 static int make_geom(PatchGeom& g, int B, int Cin, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw) {
     ME_CHECK_ARG(B > 0 && Cin > 0 && T > 0 && H > 0 && W > 0 && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
                  "patchify: bad geometry");
@@ -1164,6 +1187,12 @@ extern "C" int me_unpatchify_add(const void* dcols, int dcols_dtype, float* dx, 
     int rc = make_geom(g, B, Cin, T, H, W, kt, kh, kw, st, sh, sw);
     if (rc) return rc;
     const int64_t total = (int64_t)B * g.gt * g.gh * g.gw * Cin * kt * kh * kw;
+    const bool overlap = st < kt || sh < kh || sw < kw;
+    if (!overlap && kw % 4 == 0 && W % 4 == 0 && sw % 4 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)dcols % 16 == 0) {
+        hipLaunchKernelGGL(unpatchify_add4_kernel, dim3(ew_blocks(total / 4)), dim3(EW_THREADS), 0, stream, dcols, dcols_dtype, dx, g);
+        ME_CHECK_LAUNCH("me_unpatchify_add");
+        return ME_OK;
+    }
     hipLaunchKernelGGL(unpatchify_add_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, stream, dcols, dcols_dtype, dx, g);
     ME_CHECK_LAUNCH("me_unpatchify_add");
     return ME_OK;
