@@ -146,6 +146,14 @@ typedef struct me_gemm_desc {
      * me_row_stats_combine folds into the (rstd, -rstd * mean) pairs of me_row_stats.  Only when me_gemm_emits_row_stats(d)
      * != 0 (whole 256 x 256 tiles on every CU, N % 64 == 0, plain residual epilogue); otherwise me_gemm rejects it. */
     float* row_stats;
+    /* optional, ME_GEMM_NT, with col_shift and INSTEAD of row_affine: the folded LayerNorm's statistics handed over as the partials
+     * themselves -- row_parts = the [row_nparts][M] (mean, M2) pairs a previous me_gemm left in ITS row_stats (row_nparts = that
+     * launch's N / 64 = this launch's K / 64); the kernel forms the (rstd, -rstd * mean) pairs of LayerNorm(K, row_eps) in its own
+     * epilogue, so no me_row_stats_combine launch sits between the two GEMMs.  Only when me_gemm_takes_row_parts(d) != 0 (the resident
+     * 256 x 256 kernel takes the problem; row_nparts even, 2 .. 16; plain bias / GELU epilogue); otherwise me_gemm rejects it. */
+    const float* row_parts;
+    int32_t row_nparts;
+    float row_eps;
 } me_gemm_desc;
 
 /* Scratch the kernel selected for this problem can use (0 = none).  wgrad-shaped problems (tiny output, very long
@@ -156,12 +164,14 @@ size_t me_gemm_workspace_bytes(const me_gemm_desc* d);
 int me_gemm_fuses_colsum(const me_gemm_desc* d);
 /* 1 if me_gemm(d) can serve d->row_stats (evaluated as if it were set) */
 int me_gemm_emits_row_stats(const me_gemm_desc* d);
+/* 1 if me_gemm(d) can serve d->row_parts (which must be set) */
+int me_gemm_takes_row_parts(const me_gemm_desc* d);
 int me_gemm(const me_gemm_desc* d, void* stream);
 
 /* Per-launch timing for roofline accounting (bench.py): while enabled, every me_gemm call -- including those made from
  * me_block_fwd / me_block_bwd -- and every LayerNorm / attention call is bracketed by HIP events on its stream.  Records
  * carry op = ME_GEMM_NT / ME_GEMM_TN with (M, N, K), or one of the codes below with (M, N, K) = (rows, cols, 0) for
- * LayerNorm / me_row_stats and (B * heads, N, head_dim) for attention.  me_gemm_profile_read synchronises
+ * LayerNorm / me_row_stats ((rows, cols, 1) for me_row_stats_combine) and (B * heads, N, head_dim) for attention.  me_gemm_profile_read synchronises
  * on the recorded events, fills up to `max` records in call order and returns how many there are (and clears them).
  * Off by default; costs two event records per GEMM when on. */
 enum { ME_PROF_LN_FWD = 16, ME_PROF_LN_BWD = 17, ME_PROF_ATTN_FWD = 18, ME_PROF_ATTN_BWD = 19, ME_PROF_ROW_STATS = 20 };
@@ -249,7 +259,8 @@ int me_attention_bwd_x3(const float* qkv, int64_t ld_qkv, const float* out, int6
 typedef struct me_block_desc {
     int32_t dtype;        /* compute dtype: ME_BF16 (bf16 MFMA), ME_F32 (exact fp32 MFMA) or ME_BF16X3 (fp32-accurate on the bf16 MFMA:
                            * res_dtype must be ME_F32, every weight pointer is the ME_BF16X3 right-operand form of the fp32 matrix --
-                           * [out, 3 * in], and [in, 3 * out] for the *_wt copies; attention runs on the exact-fp32 kernels) */
+                           * [out, 3 * in], and [in, 3 * out] for the *_wt copies; attention runs as three-product bf16 MFMA too
+                           * (me_attention_fwd_x3 / _bwd_x3, ~1e-5) for head_dim 64 and N > 64, on the exact-fp32 kernels otherwise) */
     int32_t res_dtype;    /* dtype of x, y, dx, dy */
     int32_t B, N, C, heads, hidden;
     float eps, scale;     /* LayerNorm eps; attention scale (head_dim^-0.5 unless qk_scale was given) */
@@ -271,6 +282,13 @@ typedef struct me_block_desc {
      * me_encoder_fwd chains them by itself. */
     const float* x_stats;
     float* y_stats;
+    /* The same hand-over WITHOUT the combine launch (what me_encoder_fwd and metatransformer_amd.Block use): y_parts = where the fc2
+     * epilogue leaves the 64-column partials of y themselves ([C / 64][B*N] (mean, M2) pairs, me_row_stats_partial_bytes(B*N, C)
+     * bytes; written when me_block_emits_stats(d) != 0), x_parts = the previous block's y_parts on this block's input -- its qkv GEMM
+     * forms the pairs in its own epilogue (me_gemm_desc.row_parts) where me_gemm_takes_row_parts allows, else one combine launch
+     * runs first.  x_parts takes precedence over x_stats; y_stats may be asked for beside y_parts (one combine launch). */
+    const float* x_parts;
+    float* y_parts;
 } me_block_desc;
 
 /* Gradient destinations of me_block_bwd; any pointer may be NULL (that gradient is skipped -- frozen encoder).

@@ -56,6 +56,7 @@ class GemmDesc(ctypes.Structure):
         ("colsum_a", c_void_p),
         ("row_affine", c_void_p), ("col_shift", c_void_p),
         ("row_stats", c_void_p),
+        ("row_parts", c_void_p), ("row_nparts", c_int32), ("row_eps", c_float),
     ]
 
 
@@ -95,7 +96,7 @@ class BlockDesc(ctypes.Structure):
                 + [(n, c_void_p) for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_wt", "proj_wt", "fc1_wt", "fc2_wt",
                                            "ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_b", "proj_b", "fc1_b", "fc2_b",
                                            "gamma1", "gamma2", "qkv_wf", "fc1_wf", "qkv_s", "qkv_c", "fc1_s", "fc1_c",
-                                           "x_stats", "y_stats")])
+                                           "x_stats", "y_stats", "x_parts", "y_parts")])
 
 
 class BlockGrads(ctypes.Structure):
@@ -135,6 +136,7 @@ SIGNATURES = {
     "me_gemm_workspace_bytes": (c_size_t, [POINTER(GemmDesc)]),
     "me_gemm_fuses_colsum": (c_int, [POINTER(GemmDesc)]),
     "me_gemm_emits_row_stats": (c_int, [POINTER(GemmDesc)]),
+    "me_gemm_takes_row_parts": (c_int, [POINTER(GemmDesc)]),
     "me_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
     "me_gemm_profile_enable": (c_int, [c_int]),
     "me_gemm_profile_read": (c_int, [POINTER(GemmProfileRec), c_int]),

@@ -146,7 +146,9 @@ bool wants_fold(const me_block_desc* d) {
 }
 // scratch behind the inference intermediates: the [C / 64][M] partials (shared by proj and fc2) + two [M][2] pair buffers that
 // me_encoder_fwd hands from block to block
-size_t stats_scratch(const Dims& s) { return align256(me_row_stats_partial_bytes(s.M, s.C)) + 2 * align256((size_t)s.M * 8); }
+// (round 6: + a second partials buffer, the one me_encoder_fwd hands from block to block as y_parts / x_parts; layout
+//  [partials proj -> fc1][partials fc2 -> next qkv][pairs][pairs])
+size_t stats_scratch(const Dims& s) { return 2 * align256(me_row_stats_partial_bytes(s.M, s.C)) + 2 * align256((size_t)s.M * 8); }
 // can the proj / fc2 launches of this block emit statistics?  (both have the same M, N = C; K differs -- ask for each)
 bool emits_stats(const me_block_desc* d, const Dims& s) {
     if (!wants_fold(d) || d->gamma1 || d->gamma2 || s.C % 64) return false;
@@ -158,6 +160,23 @@ bool emits_stats(const me_block_desc* d, const Dims& s) {
         g.residual = dummy_mem; g.ldres = s.C; g.res_dtype = d->res_dtype;
         g.workspace = dummy_mem; g.workspace_bytes = (int64_t)1 << 40;      // (as me_block_fwd calls it: with a workspace)
         if (!me_gemm_emits_row_stats(&g)) return false;
+    }
+    return true;
+}
+
+// can the qkv / fc1 launches of this (folded) block take the partials directly (me_gemm_desc.row_parts: no combine launch)?
+bool takes_parts(const me_block_desc* d, const Dims& s) {
+    if (!wants_fold(d) || s.C % 128 || s.C > 1024) return false;
+    static char dummy_mem[64] __attribute__((aligned(64)));
+    me_gemm_desc g;
+    for (int64_t N : {(int64_t)s.C3, (int64_t)s.Hd}) {
+        gemm_desc(g, ME_GEMM_NT, d->dtype, s.M, N, s.C, dummy_mem, s.C, dummy_mem, s.C, dummy_mem, N, d->dtype);
+        g.bias = reinterpret_cast<const float*>(dummy_mem);
+        g.col_shift = reinterpret_cast<const float*>(dummy_mem);
+        g.row_parts = reinterpret_cast<const float*>(dummy_mem); g.row_nparts = (int32_t)(s.C / 64); g.row_eps = d->eps;
+        if (N == s.Hd) g.act = ME_ACT_GELU;
+        g.workspace = dummy_mem; g.workspace_bytes = (int64_t)1 << 40;
+        if (!me_gemm_takes_row_parts(&g)) return false;
     }
     return true;
 }
@@ -420,15 +439,25 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     // ... and, where the residual GEMMs can emit them, the statistics come out of the proj / fc2 epilogues (one tiny combine pass
     // each) instead of a pass over the token stream: norm2's from proj, the NEXT block's norm1's from fc2 (d->y_stats)
     const bool stats = fold && emits_stats(d, s);
+    // ... and where the qkv / fc1 launches can form the pairs from those partials themselves (row_parts), not even that
+    const bool parts = fold && takes_parts(d, s);
     float* partials = reinterpret_cast<float*>(ws + gsz + aux_scratch(s) + v.bytes);
     if (fold) {
-        const float* st1 = d->x_stats;
-        if (!st1) {
-            if ((rc = me_row_stats(x, rdt, v.mean1, s.M, s.C, d->eps, stream))) return rc;
-            st1 = v.mean1;
-        }
         gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C3, s.C, x, s.C, d->qkv_wf, s.C, v.qkv, s.C3, dt);
-        g.bias = d->qkv_c; g.row_affine = st1; g.col_shift = d->qkv_s;
+        g.bias = d->qkv_c; g.col_shift = d->qkv_s;
+        if (d->x_parts && parts) {
+            g.row_parts = d->x_parts; g.row_nparts = (int32_t)(s.C / 64); g.row_eps = d->eps;
+        } else {
+            const float* st1 = d->x_stats;
+            if (d->x_parts) {
+                if ((rc = me_row_stats_combine(d->x_parts, s.M, s.C, d->eps, v.mean1, stream))) return rc;
+                st1 = v.mean1;
+            } else if (!st1) {
+                if ((rc = me_row_stats(x, rdt, v.mean1, s.M, s.C, d->eps, stream))) return rc;
+                st1 = v.mean1;
+            }
+            g.row_affine = st1;
+        }
     } else {
         rc = me_layernorm_fwd(x, rdt, d->ln1_g, d->ln1_b, v.xn1, dt, keep ? v.mean1 : nullptr, keep ? v.rstd1 : nullptr, s.M, s.C, d->eps, stream);
         if (rc) return rc;
@@ -445,11 +474,16 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     if (stats) g.row_stats = partials;
     if ((rc = me_gemm(&g, stream))) return rc;
     if (fold) {
-        if (stats) rc = me_row_stats_combine(partials, s.M, s.C, d->eps, v.mean2, stream);
-        else rc = me_row_stats(v.x1, rdt, v.mean2, s.M, s.C, d->eps, stream);
-        if (rc) return rc;
         gemm_desc(g, ME_GEMM_NT, dt, s.M, s.Hd, s.C, v.x1, s.C, d->fc1_wf, s.C, v.a, s.Hd, dt);
-        g.bias = d->fc1_c; g.row_affine = v.mean2; g.col_shift = d->fc1_s;
+        g.bias = d->fc1_c; g.col_shift = d->fc1_s;
+        if (stats && parts) {
+            g.row_parts = partials; g.row_nparts = (int32_t)(s.C / 64); g.row_eps = d->eps;
+        } else {
+            if (stats) rc = me_row_stats_combine(partials, s.M, s.C, d->eps, v.mean2, stream);
+            else rc = me_row_stats(v.x1, rdt, v.mean2, s.M, s.C, d->eps, stream);
+            if (rc) return rc;
+            g.row_affine = v.mean2;
+        }
     } else {
         rc = me_layernorm_fwd(v.x1, rdt, d->ln2_g, d->ln2_b, v.xn2, dt, keep ? v.mean2 : nullptr, keep ? v.rstd2 : nullptr, s.M, s.C, d->eps, stream);
         if (rc) return rc;
@@ -464,9 +498,10 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C, s.Hd, v.a, s.Hd, d->fc2_w, s.Hd, y, s.C, rdt);
     g.bias = d->fc2_b; g.colscale = d->gamma2; g.residual = v.x1; g.ldres = s.C; g.res_dtype = rdt;
     g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
-    if (stats && d->y_stats) g.row_stats = partials;
+    float* yp = d->y_parts ? d->y_parts : partials;
+    if (stats && (d->y_stats || d->y_parts)) g.row_stats = yp;
     if ((rc = me_gemm(&g, stream))) return rc;
-    if (stats && d->y_stats) return me_row_stats_combine(partials, s.M, s.C, d->eps, d->y_stats, stream);
+    if (stats && d->y_stats) return me_row_stats_combine(yp, s.M, s.C, d->eps, d->y_stats, stream);
     return ME_OK;
 }
 
@@ -602,6 +637,7 @@ extern "C" int me_encoder_fwd(const me_block_desc* blocks, int n_blocks, const v
     // end of the workspace, block i + 1 (same width, same eps) starts from them instead of reading its input once more
     const void* in = x;
     const float* st_in = nullptr;
+    const float* parts_in = nullptr;
     for (int i = 0; i < n_blocks; ++i) {
         void* out = ((n_blocks - 1 - i) % 2 == 0) ? y : pingpong;
         me_block_desc d = blocks[i];
@@ -610,6 +646,8 @@ extern "C" int me_encoder_fwd(const me_block_desc* blocks, int n_blocks, const v
         if (rc) return rc;
         d.x_stats = st_in;
         d.y_stats = nullptr;
+        d.x_parts = parts_in;
+        d.y_parts = nullptr;
         // (the pair buffers sit at the end of THIS block's workspace layout: the next block may read them only if its own layout
         //  is the same one -- same widths, heads and dtypes -- or its larger intermediates would overlap them)
         const me_block_desc& nx = blocks[i + 1 < n_blocks ? i + 1 : i];
@@ -619,11 +657,18 @@ extern "C" int me_encoder_fwd(const me_block_desc* blocks, int n_blocks, const v
                            workspace_bytes >= me_block_workspace_bytes(&d, 0);
         if (chain) {
             char* tail = reinterpret_cast<char*>(workspace) + me_block_workspace_bytes(&d, 0) - 2 * align256((size_t)s.M * 8);
-            d.y_stats = reinterpret_cast<float*>(tail + (i & 1) * align256((size_t)s.M * 8));
+            Dims sn;
+            if (get_dims(&nx, sn, "me_encoder_fwd") == ME_OK && takes_parts(&nx, sn))
+                // the partials themselves travel (second partials buffer, right in front of the pair buffers): no combine launch.  One
+                // buffer is enough: block i + 1's qkv has read it before its fc2 writes it again (same stream)
+                d.y_parts = reinterpret_cast<float*>(tail - align256(me_row_stats_partial_bytes(s.M, s.C)));
+            else
+                d.y_stats = reinterpret_cast<float*>(tail + (i & 1) * align256((size_t)s.M * 8));
         }
         rc = me_block_fwd(&d, in, out, nullptr, workspace, workspace_bytes, stream);
         if (rc) return rc;
         st_in = d.y_stats;
+        parts_in = d.y_parts;
         in = out;
     }
     return ME_OK;

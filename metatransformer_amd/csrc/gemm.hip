@@ -617,6 +617,14 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     ME_CHECK_ARG((d->row_affine == nullptr) == (d->col_shift == nullptr), "me_gemm: row_affine and col_shift go together");
     ME_CHECK_ARG(!d->row_affine || d->op == ME_GEMM_NT, "me_gemm: row_affine (folded LayerNorm) is defined for ME_GEMM_NT");
     p.row_affine = d->row_affine; p.col_shift = d->col_shift;
+    p.row_nparts = 0; p.row_eps = 0.0f;
+    if (d->row_parts) {      // the same fold, its pairs formed in the kernel from a previous launch's row_stats partials
+        ME_CHECK_ARG(!d->row_affine && d->col_shift && d->op == ME_GEMM_NT, "me_gemm: row_parts replaces row_affine (NT, with col_shift)");
+        ME_CHECK_ARG(d->row_nparts >= 2 && d->row_nparts <= 16 && d->row_nparts % 2 == 0 && (int64_t)d->row_nparts * 64 == d->K && d->row_eps >= 0.0f,
+                     "me_gemm: row_parts: row_nparts = K / 64, even, 2 .. 16 (see me_gemm_takes_row_parts)");
+        ME_CHECK_ARG((uintptr_t)d->row_parts % 8 == 0, "me_gemm: row_parts must be 8-byte aligned");
+        p.row_affine = d->row_parts; p.row_nparts = d->row_nparts; p.row_eps = d->row_eps;
+    }
     ME_CHECK_ARG(!d->row_stats || (d->op == ME_GEMM_NT && d->residual && (uintptr_t)d->row_stats % 8 == 0),
                  "me_gemm: row_stats goes with ME_GEMM_NT and a residual operand (8-byte aligned)");
     p.row_stats = d->row_stats;
@@ -661,6 +669,14 @@ extern "C" int me_gemm_emits_row_stats(const me_gemm_desc* d) {
     return g3_emits_row_stats(p) ? 1 : 0;
 }
 
+extern "C" int me_gemm_takes_row_parts(const me_gemm_desc* d) {
+    GemmParams p;
+    if (!d || d->op != ME_GEMM_NT || d->ab_dtype != ME_BF16 || !d->row_parts || fill_params(d, p) != ME_OK) return 0;
+    const GemmPlan pl = plan_gemm(d, p);
+    if (pl.family != 4 || pl.tail_rows > 0) return 0;
+    return g3_takes_row_parts(p) ? 1 : 0;
+}
+
 namespace {
 // tn_launch: a replacement for launch_g3_tn (patch_embed.hip: the wgrad kernel that gathers its B operand from the image); with it,
 // a problem the planner does not give to the g3 wgrad family is refused (ME_ERR_UNSUPPORTED) instead of run
@@ -691,6 +707,9 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out, TnLaunch
                      "me_gemm: colsum_a needs the split-K wgrad kernel and its workspace (see me_gemm_fuses_colsum)");
     if (d->row_stats)
         ME_CHECK_ARG(pl.family == 4 && d->op == ME_GEMM_NT && pl.tail_rows == 0, "me_gemm: row_stats is not available for this problem (see me_gemm_emits_row_stats)");
+    if (d->row_parts)
+        ME_CHECK_ARG(pl.family == 4 && d->op == ME_GEMM_NT && pl.tail_rows == 0 && g3_takes_row_parts(p),
+                     "me_gemm: row_parts is not available for this problem (see me_gemm_takes_row_parts)");
     if (pl.family >= 1) {
         if (pl.family == 4 && d->op == ME_GEMM_TN) {
             ME_CHECK_ARG(d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes,

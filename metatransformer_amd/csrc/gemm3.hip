@@ -244,6 +244,13 @@ __device__ __forceinline__ u32x4 g3r_lanes(const u32x4& v, int addr) {
 // PRE 3 (EPI 0 / 1): a LayerNorm folded into this Linear (GemmParams::row_affine / col_shift): the accumulators start at zero
 // and the epilogue applies v = rstd_m * acc + (-rstd_m mean_m) * s[n] + c[n] in the accumulator layout (one row per lane and
 // 16-row slab, four consecutive columns per register quad), ahead of the activation; nothing is saved.
+// PRE 5 (EPI 0 / 1): the same folded LayerNorm, its row pairs formed HERE from the 64-column partials (mean_i, M2_i) the residual
+// launch in front of this one left behind (PRE 4; GemmParams::row_affine = [row_nparts][M] pairs, row_nparts even, <= 16): thread t of
+// the workgroup takes row t >> 1 of the item and the even / odd parts (all loads up front, the two halves meet through one DPP
+// swap; the arithmetic of row_stats_combine_kernel: mean of the part means, M2 = sum M2_i + 64 sum (mean_i - mean)^2), the 256
+// pairs go through 2 KiB of LDS BESIDE the operand buffers (inline-asm ds operations: a compiler-visible LDS access would be
+// guarded with vmcnt(0) while the next tile's DMA is in flight) and one workgroup barrier -- both wave rows stand side by side
+// here anyway.  Replaces the row_stats_combine launch between the two GEMMs (24 per Base forward).
 // PRE 4 (EPI 2): the per-row statistics of the OUTPUT rows on the side (GemmParams::row_stats) -- the LayerNorm that reads this
 // residual stream next then needs no pass of its own over it (me_row_stats_combine folds the partials).  After the row re-deal
 // eight lanes hold one row's 64 columns of this wave: per half slab every lane forms (S, Q) = sum (v - P), sum (v - P)^2 of its
@@ -261,7 +268,7 @@ template <int EPI, int PRE, bool HALF = false>
 __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int64_t m0, int tn, int lane, const G3Src& nxt, int nk,
                                               const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero, unsigned* ctr, int nx,
                                               uint32_t lds_tick) {
-    constexpr bool SAVE = PRE == 1 || PRE == 2, LNF = PRE == 3, STATS = PRE == 4;
+    constexpr bool SAVE = PRE == 1 || PRE == 2, LNF = PRE == 3 || PRE == 5, LNP = PRE == 5, STATS = PRE == 4;
     static_assert(!STATS || EPI == 2, "row statistics: the residual epilogue");
     constexpr int NMT = HALF ? 4 : 8, WROWS = HALF ? 64 : 128;      // 16-row slabs per wave, rows per wave row
     // (claimed schedule: wave 0 draws the ticket for the item after next FIRST, ahead of every store of this epilogue)
@@ -336,12 +343,25 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     // folded LayerNorm: this tile's per-row pairs (rows wr*128 + 16 mt + r) and per-column s / c, all ahead of the DMA below
     f32x2 lnf_row[8];
     G3Bias lnf_s, lnf_c;
+    f32x2 lnp[8];                               // (LNP) this thread's share of the partials: parts hs, hs + 2, .. of row t >> 1
     if (LNF) {
-        const __amdgpu_buffer_rsrc_t rars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.row_affine) + m0 * 2, 0, item_ok ? (int)(rows * 8) : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.col_shift), 0, (int)(p.N * 4), 0x00020000);
+        if (LNP) {
+            const int t = s.wave * 64 + lane, lr = t >> 1, hs = t & 1, nh = p.row_nparts >> 1;
+            // [part][M] pairs seen from row m0: the last part ends `rows` rows in (rows past the item / the matrix: out of range -> zeros)
+            const __amdgpu_buffer_rsrc_t pars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.row_affine) + m0 * 2, 0,
+                                                                                   item_ok ? (int)((((int64_t)p.row_nparts - 1) * p.M + rows) * 8) : 0, 0x00020000);
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)    // (rows past the edge: out of range -> zeros; their outputs are never stored)
-            lnf_row[mt] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rars, (wr * WROWS + mt * 16 + r) * 8, 0, 0));
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t off = (i < nh && lr < (int)rows) ? (uint32_t)((((int64_t)(2 * i + hs)) * p.M + lr) * 8) : 0x80000000u;
+                lnp[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(pars, (int)off, 0, 0));
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.row_affine) + m0 * 2, 0, item_ok ? (int)(rows * 8) : 0, 0x00020000);
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)    // (rows past the edge: out of range -> zeros; their outputs are never stored)
+                lnf_row[mt] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rars, (wr * WROWS + mt * 16 + r) * 8, 0, 0));
+        }
         lnf_s = g3r_bias(srs, tn, s.wave, lane);
         lnf_c = g3r_bias(brs, tn, s.wave, lane);
     }
@@ -351,6 +371,40 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     else g3_issue<3>(s, nxt, 1, nk);
     const G3Bias nb = g3r_bias(brs, ntn, s.wave, lane);
     __builtin_amdgcn_sched_barrier(0);
+    if (LNP) {
+        const int t = s.wave * 64 + lane, lr = t >> 1, nh = p.row_nparts >> 1;
+        auto swap1 = [](float x) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xf, 0xf, true)); };      // quad_perm [1, 0, 3, 2]
+        float ms = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ms += lnp[i][0]; m2 += lnp[i][1]; }      // (parts past nh / rows past the item are zeros)
+        ms += swap1(ms);
+        m2 += swap1(m2);
+        const float mean = ms / (float)p.row_nparts;
+        float dev = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float w = i < nh ? 1.0f : 0.0f;                              // (wave-uniform)
+            const float d = (lnp[i][0] - mean) * w;
+            dev += d * d;
+        }
+        dev += swap1(dev);
+        const float rstd = rsqrtf((m2 + 64.0f * dev) / (64.0f * (float)p.row_nparts) + p.row_eps);
+        const u32x2 pair = {__float_as_uint(rstd), __float_as_uint(-rstd * mean)};
+        // both lanes of a row hold the same pair (the sums above commute) and write it to the same word: no exec-mask games
+        const uint32_t lds_pairs = lds_tick + 64;
+        asm volatile("ds_write_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(lds_pairs + (uint32_t)lr * 8), "v"(pair) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint32_t pa = lds_pairs + (uint32_t)(wr * WROWS + r) * 8;
+        u32x2 q[8];
+#define G3R_PAIR(i) if ((i) < NMT) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[i]) : "v"(pa), "i"((i) * 128) : "memory");
+        G3R_PAIR(0) G3R_PAIR(1) G3R_PAIR(2) G3R_PAIR(3) G3R_PAIR(4) G3R_PAIR(5) G3R_PAIR(6) G3R_PAIR(7)
+#undef G3R_PAIR
+        if (NMT == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3])::"memory");
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) lnf_row[mt] = __builtin_bit_cast(f32x2, q[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) {
         f32x4 ro[2][2];
@@ -567,7 +621,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     g3_issue<0>(s, cur, 1, kt0 + 1); g3_issue<1>(s, cur, 1, kt0 + 1); g3_issue<2>(s, cur, 1, kt0 + 1); g3_issue<3>(s, cur, 1, kt0 + 1);
     {
         const G3Bias b0 = g3r_bias(brs, tn, wave, lane);
-        g3r_set_binit(s, b0, PRE == 3);
+        g3r_set_binit(s, b0, PRE == 3 || PRE == 5);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (dyn && wave == 0) g3r_publish(drawn0, ctr, nx, lds_tick);
@@ -644,7 +698,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             G3R_STAMP(3)
             if (wr == 0) __builtin_amdgcn_s_barrier();
             G3R_STAMP(4)
-            g3_epilogue_r<EPI, PRE, HALF>(p, s, (int64_t)tm * G3_BM + (HALF ? part * 128 : 0), tn, 0, nxt, nkt0 + 1, brs, ntn, PRE == 3,
+            g3_epilogue_r<EPI, PRE, HALF>(p, s, (int64_t)tm * G3_BM + (HALF ? part * 128 : 0), tn, 0, nxt, nkt0 + 1, brs, ntn, PRE == 3 || PRE == 5,
                                           has_next ? ctr : nullptr, nx, lds_tick);
         };
         if constexpr (HI) {
@@ -910,9 +964,10 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
                                                //  sustained with four row-operand slabs in flight, 263 with two; train +0.4 ms with six -- off)
 #endif
     constexpr bool HI = EPI == 0 || (G3_HI_EPI2 && EPI == 2) || (G3_HI_EPI1 && EPI == 1) || (G3_HI_EPI6 && EPI == 6);      // which forms carry the 128-row items (see the kernel)
+    constexpr int LDS_BYTES = G3_LDS + 64 + (PRE == 5 ? 2048 : 0);      // operand buffers + the ticket word (+ PRE 5: 256 LayerNorm row pairs)
     static OncePerDevice once;
     if (once.need())
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE, HI>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS + 64);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE, HI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     GemmParams q = q0;
     // Tile quantisation: T tiles on G resident workgroups take ceil(T / G) rounds, and the encoder's N = 768 outputs are 591 tiles =
     // 2.31 rounds (N = 3072: 9.23).  When at most half the CUs would work in the last round, its tiles run as two 128-row items
@@ -927,15 +982,15 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
     q.g3_tickets = (q.K >= 4 * G3_BK && gemm_dev().g3_persistent == 1) ? g3r_tickets(stream) : nullptr;
     if (kMeDev && gemm_dev().tail_split == 2) q.g3_tickets = nullptr;          // dev: "g3s" = static schedule
     ME_DEV_ONLY(q.colsum_ws = (q.debug & 8) ? reinterpret_cast<float*>(g_gemm_dev_trace) : nullptr;)
-    hipLaunchKernelGGL((gemm_g3r_kernel<EPI, PRE, HI>), dim3((unsigned)G), dim3(512), G3_LDS + 64, stream, q);
+    hipLaunchKernelGGL((gemm_g3r_kernel<EPI, PRE, HI>), dim3((unsigned)G), dim3(512), LDS_BYTES, stream, q);
     ME_CHECK_LAUNCH("me_gemm(g3 resident)");
     return ME_OK;
 }
 
 int launch3r_any(int epi, int pre, const GemmParams& q, int G, hipStream_t stream) {
     switch (epi) {
-        case 0: return pre == 3 ? launch3r<0, 3>(q, G, stream) : launch3r<0, 0>(q, G, stream);
-        case 1: return pre == 3 ? launch3r<1, 3>(q, G, stream) : pre == 2 ? launch3r<1, 2>(q, G, stream) : pre ? launch3r<1, 1>(q, G, stream) : launch3r<1, 0>(q, G, stream);
+        case 0: return pre == 5 ? launch3r<0, 5>(q, G, stream) : pre == 3 ? launch3r<0, 3>(q, G, stream) : launch3r<0, 0>(q, G, stream);
+        case 1: return pre == 5 ? launch3r<1, 5>(q, G, stream) : pre == 3 ? launch3r<1, 3>(q, G, stream) : pre == 2 ? launch3r<1, 2>(q, G, stream) : pre ? launch3r<1, 1>(q, G, stream) : launch3r<1, 0>(q, G, stream);
         case 2: return pre == 4 ? launch3r<2, 4>(q, G, stream) : launch3r<2, 0>(q, G, stream);
         case 3: return launch3r<3, 0>(q, G, stream);
         default: return launch3r<6, 0>(q, G, stream);
@@ -961,7 +1016,7 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
         const bool plain = p.beta == 0.0f && p.out_group_rows == 0 && p.res_row_mod == 0 && !p.colscale && !p.residual;
         if (EPI == 4 && p.row_affine && !p.flags && plain && !p.preact && !p.aux) {       // folded LayerNorm (bias / GELU forms)
             repi = p.act == ME_ACT_GELU ? 1 : 0;
-            pre = 3;
+            pre = p.row_nparts ? 5 : 3;       // (5: row_affine holds the 64-column partials of the launch in front, see g3_epilogue_r)
         }
         if (EPI == 4 && p.flags && !p.row_affine) {
             // the two halves of the "save gelu'" pair (pick_epi sends flagged descriptors to the generic epilogue)
@@ -979,6 +1034,10 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
     }
     if (p.row_stats) {
         me_set_error("me_gemm: row_stats needs the resident residual kernel (see me_gemm_emits_row_stats)");
+        return ME_ERR_UNSUPPORTED;
+    }
+    if (p.row_nparts) {
+        me_set_error("me_gemm: row_parts needs the resident kernel's folded-LayerNorm epilogue (see me_gemm_takes_row_parts)");
         return ME_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL((gemm_g3_kernel<EPI>), dim3((unsigned)nwg), dim3(512), G3_LDS, stream, q);
@@ -1049,6 +1108,21 @@ bool g3_emits_row_stats(const GemmParams& p) {
     const int64_t ldmax = std::max(p.ldc, p.ldres);
     return G >= 8 && tiles >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && p.res_dtype == ME_BF16 && p.N % 64 == 0 &&
            256 * ldmax * 2 < (1ll << 31) && p.M * 8 < (1ll << 31);
+}
+
+// Will launch_g3 run the resident kernel's folded-LayerNorm epilogue on partials (PRE 5), i.e. can me_gemm_desc.row_parts be served?
+// (the conditions of launch3e restated, as above; p.row_affine / row_nparts / col_shift already set by fill_params)
+#ifndef ME_NO_ROW_PARTS
+#define ME_NO_ROW_PARTS 0                      // (A/B arm: 1 = never; the Blocks then run me_row_stats_combine between the GEMMs, as round 5 did)
+#endif
+bool g3_takes_row_parts(const GemmParams& p) {
+    if (ME_NO_ROW_PARTS) return false;
+    if (!g3_supported(p, ME_GEMM_NT) || gemm_dev().g3_persistent != 1 || !p.row_affine || !p.col_shift) return false;
+    if (p.row_nparts < 2 || p.row_nparts > 16 || (p.row_nparts & 1) || (int64_t)p.row_nparts * 64 != p.K) return false;
+    if (p.flags || p.preact || p.aux || p.residual || p.colscale || p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return false;
+    const int G = g3_cus() & ~7;
+    const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    return G >= 8 && tiles >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && 256 * p.ldc * 2 < (1ll << 31) && p.M * 8 * 16 < (1ll << 31);
 }
 
 // scratch of the persistent stream-K form (dev build): one fp32 partial tile per workgroup + the hand-over flags (+ 1

@@ -25,6 +25,8 @@ struct GemmParams {
     unsigned* g3_tickets;                   // resident g3 kernel: per-XCD work counters (16 words apart), null = static schedule
     int64_t slab_stride;                    // g3 wgrad: floats between the split-K slabs in C (>= M * N, padded: see g3_tn_slab_stride)
     const float* row_affine;                // folded LayerNorm (me_gemm_desc.row_affine): [M][2] = (rstd, -rstd * mean), or null
+    int row_nparts; float row_eps;          // row_nparts > 0 (me_gemm_desc.row_parts): row_affine holds [row_nparts][M] partial (mean, M2) pairs instead --
+                                            // resident kernel only (g3_takes_row_parts); the pairs are LayerNorm(K = 64 row_nparts, row_eps)'s
     const float* col_shift;                 // ... and s[n] = sum_k W'[n, k]
     float* tn_colsum_out;                   // g3 wgrad with the in-kernel fold: where the folded column sums of A go (follows C's beta), or null
     float* row_stats;                       // resident EPI 2 kernel only (me_gemm_desc.row_stats): per-row partial statistics of the OUTPUT,
@@ -206,6 +208,7 @@ bool g2b_supported(const GemmParams& p, int op);
 int launch_g3(const GemmParams& p, int epi, void* ws, hipStream_t stream);      // ws = nullptr: one tile per workgroup
 bool g3_supported(const GemmParams& p, int op);
 bool g3_emits_row_stats(const GemmParams& p);          // will launch_g3 run the resident residual kernel that can emit p.row_stats?
+bool g3_takes_row_parts(const GemmParams& p);          // ... the resident folded-LayerNorm epilogue that consumes such partials directly (p.row_nparts)?
 size_t g3_workspace_bytes();
 int launch_g3_tn(const GemmParams& p, hipStream_t stream);      // p.split_k slabs into p.C, p.ksteps_per_split K-tiles of 64 each
 // A/B arm, measured and NOT shipped (round 4): -DG3_TN_FOLD=1 = the split-K fold of the wgrad kernel INSIDE its launch.  Same-box

@@ -498,6 +498,7 @@ extern "C" int me_row_stats_combine(const float* partials, int64_t rows, int col
     ME_CHECK_ARG(rows >= 0 && cols > 0 && cols % 64 == 0, "me_row_stats_combine: cols must be a positive multiple of 64");
     ME_CHECK_ARG((uintptr_t)partials % 8 == 0 && (uintptr_t)out % 8 == 0, "me_row_stats_combine: 8-byte aligned buffers");
     if (rows == 0) return ME_OK;
+    ProfScope prof(ME_PROF_ROW_STATS, ME_F32, rows, cols, 1, stream);      // (K = 1: the combine pass; K = 0: me_row_stats over the tokens)
     hipLaunchKernelGGL(row_stats_combine_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream,
                        reinterpret_cast<const float2*>(partials), cols / 64, rows, 1.0f / (float)cols, eps, out);
     ME_CHECK_LAUNCH("me_row_stats_combine");

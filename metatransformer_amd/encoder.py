@@ -649,7 +649,7 @@ class Block(nn.Module):
         self._stats_in = None
         ver = _tensor_version(x) if tag is not None else None
         if (tag is not None and ver is not None and self.chain_stats and tag[1] == self.eps and tag[2] == ver
-                and tag[0].shape[0] == x.shape[0] * x.shape[1]):
+                and tag[0].shape[-2] == x.shape[0] * x.shape[1]):
             self._stats_in = tag[0]
         self._stats_out = None
         y = _BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,

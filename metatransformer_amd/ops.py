@@ -104,7 +104,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
          aux: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, alpha: float = 1.0,
          beta: float = 0.0, out_rows: Optional[int] = None, out_group: Tuple[int, int, int] = (0, 0, 0),
          want_colsum_a: bool = False, colsum_out: Optional[torch.Tensor] = None, flags: int = 0,
-         row_affine: Optional[torch.Tensor] = None, col_shift: Optional[torch.Tensor] = None, want_row_stats: bool = False):
+         row_affine: Optional[torch.Tensor] = None, col_shift: Optional[torch.Tensor] = None, want_row_stats: bool = False,
+         row_parts: Optional[torch.Tensor] = None, row_eps: float = 0.0):
     """NT: out[M,N] = a[M,K] @ b[N,K]^T ;  TN: out[M,N] = a[K,M]^T @ b[K,N]; fused epilogue per include/metaenc.h.
     want_colsum_a (TN): also return sum_k a[k, :] (fp32 [M]) -- the bias gradient that goes with a weight gradient --
     from the same kernel when the library can fuse it, else from me_colsum; the result is then (out, colsum).
@@ -112,7 +113,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
     flags: ME_GEMM_SAVE_GELU_GRAD (preact receives gelu'(pre-activation)) / ME_GEMM_AUX_IS_FACTOR (multiply by aux itself).
     want_row_stats (NT + residual): also return the per-row partial statistics of the OUTPUT, [N / 64, M, 2] fp32 (mean, M2) over
     64-column groups (me_gemm_desc.row_stats; fold with row_stats_combine) -- None when the kernel for this problem cannot emit
-    them (me_gemm_emits_row_stats); the result is then (out, partials or None)."""
+    them (me_gemm_emits_row_stats); the result is then (out, partials or None).
+    row_parts (NT, with col_shift, instead of row_affine): such partials of THIS launch's A operand, [K / 64, M, 2] -- the kernel forms the
+    folded LayerNorm(K, row_eps) pairs itself (me_gemm_desc.row_parts); raises where me_gemm_takes_row_parts says no (gemm_takes_row_parts)."""
     lib = _capi.load()
     _req(a, "a"); _req(b, "b")
     if a.dtype != b.dtype:
@@ -144,6 +147,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
             raise MetaEncError("gemm: row_affine must be [M, 2] float32 (ops.row_stats) and col_shift [N]")
         col_shift = _f32(col_shift).contiguous(); keep.append(col_shift)
         d.row_affine, d.col_shift = ptr(_req(row_affine, "row_affine")), ptr(col_shift)
+    if row_parts is not None:
+        if row_affine is not None or col_shift is None or col_shift.numel() != N or row_parts.dtype != torch.float32 or \
+                tuple(row_parts.shape) != (K // 64, M, 2):
+            raise MetaEncError("gemm: row_parts must be [K / 64, M, 2] float32 partials (gemm(..., want_row_stats=True)), with col_shift [N], without row_affine")
+        col_shift = _f32(col_shift).contiguous(); keep.append(col_shift)
+        d.row_parts, d.row_nparts, d.row_eps, d.col_shift = ptr(_req(row_parts, "row_parts")), K // 64, float(row_eps), ptr(col_shift)
     if bias is not None:
         bias = _f32(bias).contiguous(); keep.append(bias)
         d.bias = ptr(bias)
@@ -220,9 +229,10 @@ def block_desc(B, N, C, heads, hidden, eps, scale, cdt, rdt, w, wt, vec, x3: boo
 
 
 def block_fwd(d, x2: torch.Tensor, keep: bool, x_stats: Optional[torch.Tensor] = None, want_stats: bool = False):
-    """-> (y, saved or None, y_stats or None).  x_stats: the [M, 2] LayerNorm pairs of x for this block's norm1 (folded inference;
-    me_block_desc.x_stats); want_stats: also return the pairs of y, taken from the fc2 epilogue, when the block can emit them
-    (me_block_emits_stats) -- for the next block's x_stats."""
+    """-> (y, saved or None, y_stats or None).  x_stats: the LayerNorm statistics of x for this block's norm1 (folded inference): the
+    [M, 2] pairs of row_stats (me_block_desc.x_stats) or the [C / 64, M, 2] partials a previous call returned (me_block_desc.x_parts);
+    want_stats: also return the partials of y, left by the fc2 epilogue, when the block can emit them (me_block_emits_stats) -- the
+    next block's x_stats.  No statistics pass and no combine launch sits between the blocks then."""
     lib = _capi.load()
     y = torch.empty_like(x2)
     saved = torch.empty(lib.me_block_saved_bytes(ctypes.byref(d)), dtype=torch.uint8, device=x2.device) if keep else None
@@ -231,12 +241,18 @@ def block_fwd(d, x2: torch.Tensor, keep: bool, x_stats: Optional[torch.Tensor] =
     y_stats = None
     if not keep:
         if x_stats is not None:
-            if x_stats.dtype != torch.float32 or x_stats.shape != (x2.shape[0], 2) or not x_stats.is_contiguous() or x_stats.device != x2.device:
-                raise MetaEncError("block_fwd: x_stats must be a contiguous [M, 2] float32 tensor on the tokens' device")
-            d.x_stats = ptr(x_stats)
+            M, C = x2.shape
+            if x_stats.dtype != torch.float32 or not x_stats.is_contiguous() or x_stats.device != x2.device or \
+                    tuple(x_stats.shape) not in ((M, 2), (C // 64, M, 2)):
+                raise MetaEncError("block_fwd: x_stats must be a contiguous float32 tensor on the tokens' device, [M, 2] pairs "
+                                   "(row_stats) or the [C / 64, M, 2] partials a previous block_fwd(want_stats=True) returned")
+            if x_stats.dim() == 3:
+                d.x_parts = ptr(x_stats)       # the fc2 partials themselves: this block's qkv GEMM forms the pairs (no combine launch)
+            else:
+                d.x_stats = ptr(x_stats)
         if want_stats and lib.me_block_emits_stats(ctypes.byref(d)):
-            y_stats = torch.empty((x2.shape[0], 2), dtype=torch.float32, device=x2.device)
-            d.y_stats = ptr(y_stats)
+            y_stats = torch.empty((x2.shape[1] // 64, x2.shape[0], 2), dtype=torch.float32, device=x2.device)
+            d.y_parts = ptr(y_stats)
     check(lib.me_block_fwd(ctypes.byref(d), ptr(x2), ptr(y), ptr(saved), ptr(ws), wsb, stream_ptr()), "me_block_fwd")
     return y, saved, y_stats
 
