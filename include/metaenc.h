@@ -65,9 +65,10 @@ int me_device_info(int dev, int* num_cus, int* lds_bytes, int* clock_mhz, char* 
 /* me_row_stats: per row of [rows, cols] the pair (rstd, -rstd * mean) -> out [rows][2] fp32: the statistics of the same
  * LayerNorm for a Linear that has the normalisation folded in (me_gemm_desc.row_affine).  One read of x, no write of x. */
 int me_row_stats(const void* x, int x_dtype, float* out, int64_t rows, int cols, float eps, void* stream);
-/* The same pairs from per-row PARTIAL statistics that a producing kernel left behind (me_gemm_desc.row_stats: [cols / 64][rows]
- * pairs (mean, M2) over 64-column groups): Chan's parallel combination -- mean = average of the group means, M2 = sum of the
- * group M2 + 64 * sum (group mean - mean)^2 -- then rstd = (M2 / cols + eps)^-1/2.  cols % 64 == 0. */
+/* The same pairs from per-row PARTIAL statistics that a producing kernel left behind (me_gemm_desc.row_stats: [cols / 256][rows]
+ * pairs (mean, M2) over 256-column groups): Chan's parallel combination -- mean = average of the group means, M2 = sum of the
+ * group M2 + 256 * sum (group mean - mean)^2 -- then rstd = (M2 / cols + eps)^-1/2.  cols % 256 == 0.  (A folded GEMM that takes
+ * the partials as me_gemm_desc.row_parts does this in its own epilogue; this call serves the shapes that cannot.) */
 size_t me_row_stats_partial_bytes(int64_t rows, int cols);
 int me_row_stats_combine(const float* partials, int64_t rows, int cols, float eps, float* out, void* stream);
 int me_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
@@ -141,16 +142,17 @@ typedef struct me_gemm_desc {
     const float* col_shift;
     /* optional, ME_GEMM_NT with a bf16 residual epilogue (the proj / fc2 launches of a block): the per-row statistics of the
      * OUTPUT rows on the side, so that the LayerNorm reading this residual stream next (norm2 behind proj, the next block's
-     * norm1 behind fc2) needs no pass of its own over it.  row_stats receives [N / 64][M] fp32 pairs (mean, M2 = sum of squared
-     * deviations from that mean) over 64-column groups -- me_row_stats_partial_bytes(M, N) bytes -- which
-     * me_row_stats_combine folds into the (rstd, -rstd * mean) pairs of me_row_stats.  Only when me_gemm_emits_row_stats(d)
-     * != 0 (whole 256 x 256 tiles on every CU, N % 64 == 0, plain residual epilogue); otherwise me_gemm rejects it. */
+     * norm1 behind fc2) needs no pass of its own over it.  row_stats receives [N / 256][M] fp32 pairs (mean, M2 = sum of squared
+     * deviations from that mean) over 256-column groups (one per output tile) -- me_row_stats_partial_bytes(M, N) bytes -- which
+     * the next GEMM takes as its row_parts, or me_row_stats_combine folds into the (rstd, -rstd * mean) pairs of me_row_stats.  Only
+     * when me_gemm_emits_row_stats(d) != 0 (whole 256 x 256 tiles on every CU, N % 256 == 0, plain residual epilogue); otherwise
+     * me_gemm rejects it. */
     float* row_stats;
     /* optional, ME_GEMM_NT, with col_shift and INSTEAD of row_affine: the folded LayerNorm's statistics handed over as the partials
      * themselves -- row_parts = the [row_nparts][M] (mean, M2) pairs a previous me_gemm left in ITS row_stats (row_nparts = that
-     * launch's N / 64 = this launch's K / 64); the kernel forms the (rstd, -rstd * mean) pairs of LayerNorm(K, row_eps) in its own
+     * launch's N / 256 = this launch's K / 256); the kernel forms the (rstd, -rstd * mean) pairs of LayerNorm(K, row_eps) in its own
      * epilogue, so no me_row_stats_combine launch sits between the two GEMMs.  Only when me_gemm_takes_row_parts(d) != 0 (the resident
-     * 256 x 256 kernel takes the problem; row_nparts even, 2 .. 16; plain bias / GELU epilogue); otherwise me_gemm rejects it. */
+     * 256 x 256 kernel takes the problem; K = 256 .. 1024; plain bias / GELU epilogue); otherwise me_gemm rejects it. */
     const float* row_parts;
     int32_t row_nparts;
     float row_eps;
@@ -283,7 +285,7 @@ typedef struct me_block_desc {
     const float* x_stats;
     float* y_stats;
     /* The same hand-over WITHOUT the combine launch (what me_encoder_fwd and metatransformer_amd.Block use): y_parts = where the fc2
-     * epilogue leaves the 64-column partials of y themselves ([C / 64][B*N] (mean, M2) pairs, me_row_stats_partial_bytes(B*N, C)
+     * epilogue leaves the 256-column partials of y themselves ([C / 256][B*N] (mean, M2) pairs, me_row_stats_partial_bytes(B*N, C)
      * bytes; written when me_block_emits_stats(d) != 0), x_parts = the previous block's y_parts on this block's input -- its qkv GEMM
      * forms the pairs in its own epilogue (me_gemm_desc.row_parts) where me_gemm_takes_row_parts allows, else one combine launch
      * runs first.  x_parts takes precedence over x_stats; y_stats may be asked for beside y_parts (one combine launch). */

@@ -151,7 +151,7 @@ bool wants_fold(const me_block_desc* d) {
 size_t stats_scratch(const Dims& s) { return 2 * align256(me_row_stats_partial_bytes(s.M, s.C)) + 2 * align256((size_t)s.M * 8); }
 // can the proj / fc2 launches of this block emit statistics?  (both have the same M, N = C; K differs -- ask for each)
 bool emits_stats(const me_block_desc* d, const Dims& s) {
-    if (!wants_fold(d) || d->gamma1 || d->gamma2 || s.C % 64) return false;
+    if (!wants_fold(d) || d->gamma1 || d->gamma2 || s.C % ME_STATS_GROUP) return false;
     static char dummy_mem[64] __attribute__((aligned(64)));
     me_gemm_desc g;
     for (int64_t K : {(int64_t)s.C, (int64_t)s.Hd}) {
@@ -166,14 +166,14 @@ bool emits_stats(const me_block_desc* d, const Dims& s) {
 
 // can the qkv / fc1 launches of this (folded) block take the partials directly (me_gemm_desc.row_parts: no combine launch)?
 bool takes_parts(const me_block_desc* d, const Dims& s) {
-    if (!wants_fold(d) || s.C % 128 || s.C > 1024) return false;
+    if (!wants_fold(d) || s.C % ME_STATS_GROUP || s.C > 4 * ME_STATS_GROUP) return false;
     static char dummy_mem[64] __attribute__((aligned(64)));
     me_gemm_desc g;
     for (int64_t N : {(int64_t)s.C3, (int64_t)s.Hd}) {
         gemm_desc(g, ME_GEMM_NT, d->dtype, s.M, N, s.C, dummy_mem, s.C, dummy_mem, s.C, dummy_mem, N, d->dtype);
         g.bias = reinterpret_cast<const float*>(dummy_mem);
         g.col_shift = reinterpret_cast<const float*>(dummy_mem);
-        g.row_parts = reinterpret_cast<const float*>(dummy_mem); g.row_nparts = (int32_t)(s.C / 64); g.row_eps = d->eps;
+        g.row_parts = reinterpret_cast<const float*>(dummy_mem); g.row_nparts = (int32_t)(s.C / ME_STATS_GROUP); g.row_eps = d->eps;
         if (N == s.Hd) g.act = ME_ACT_GELU;
         g.workspace = dummy_mem; g.workspace_bytes = (int64_t)1 << 40;
         if (!me_gemm_takes_row_parts(&g)) return false;
@@ -446,7 +446,7 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
         gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C3, s.C, x, s.C, d->qkv_wf, s.C, v.qkv, s.C3, dt);
         g.bias = d->qkv_c; g.col_shift = d->qkv_s;
         if (d->x_parts && parts) {
-            g.row_parts = d->x_parts; g.row_nparts = (int32_t)(s.C / 64); g.row_eps = d->eps;
+            g.row_parts = d->x_parts; g.row_nparts = (int32_t)(s.C / ME_STATS_GROUP); g.row_eps = d->eps;
         } else {
             const float* st1 = d->x_stats;
             if (d->x_parts) {
@@ -477,7 +477,7 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
         gemm_desc(g, ME_GEMM_NT, dt, s.M, s.Hd, s.C, v.x1, s.C, d->fc1_wf, s.C, v.a, s.Hd, dt);
         g.bias = d->fc1_c; g.col_shift = d->fc1_s;
         if (stats && parts) {
-            g.row_parts = partials; g.row_nparts = (int32_t)(s.C / 64); g.row_eps = d->eps;
+            g.row_parts = partials; g.row_nparts = (int32_t)(s.C / ME_STATS_GROUP); g.row_eps = d->eps;
         } else {
             if (stats) rc = me_row_stats_combine(partials, s.M, s.C, d->eps, v.mean2, stream);
             else rc = me_row_stats(v.x1, rdt, v.mean2, s.M, s.C, d->eps, stream);

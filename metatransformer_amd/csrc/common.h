@@ -32,6 +32,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+constexpr int ME_STATS_GROUP = 256;      // columns per partial (mean, M2) pair of me_gemm_desc.row_stats / row_parts: one output tile's width
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define ME_WAVE 64

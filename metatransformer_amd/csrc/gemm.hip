@@ -614,14 +614,14 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     p.out_group_stride = d->out_group_stride; p.out_row_offset = d->out_row_offset;
     p.split_k = 1; p.ksteps_per_split = 0;
     p.colsum_ws = nullptr;
-    ME_CHECK_ARG((d->row_affine == nullptr) == (d->col_shift == nullptr), "me_gemm: row_affine and col_shift go together");
+    ME_CHECK_ARG((d->row_affine == nullptr && d->row_parts == nullptr) == (d->col_shift == nullptr), "me_gemm: row_affine (or row_parts) and col_shift go together");
     ME_CHECK_ARG(!d->row_affine || d->op == ME_GEMM_NT, "me_gemm: row_affine (folded LayerNorm) is defined for ME_GEMM_NT");
     p.row_affine = d->row_affine; p.col_shift = d->col_shift;
     p.row_nparts = 0; p.row_eps = 0.0f;
     if (d->row_parts) {      // the same fold, its pairs formed in the kernel from a previous launch's row_stats partials
         ME_CHECK_ARG(!d->row_affine && d->col_shift && d->op == ME_GEMM_NT, "me_gemm: row_parts replaces row_affine (NT, with col_shift)");
-        ME_CHECK_ARG(d->row_nparts >= 2 && d->row_nparts <= 16 && d->row_nparts % 2 == 0 && (int64_t)d->row_nparts * 64 == d->K && d->row_eps >= 0.0f,
-                     "me_gemm: row_parts: row_nparts = K / 64, even, 2 .. 16 (see me_gemm_takes_row_parts)");
+        ME_CHECK_ARG(d->row_nparts >= 1 && d->row_nparts <= 4 && (int64_t)d->row_nparts * ME_STATS_GROUP == d->K && d->row_eps >= 0.0f,
+                     "me_gemm: row_parts: row_nparts = K / 256, 1 .. 4 (see me_gemm_takes_row_parts)");
         ME_CHECK_ARG((uintptr_t)d->row_parts % 8 == 0, "me_gemm: row_parts must be 8-byte aligned");
         p.row_affine = d->row_parts; p.row_nparts = d->row_nparts; p.row_eps = d->row_eps;
     }

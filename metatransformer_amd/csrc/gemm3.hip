@@ -239,26 +239,80 @@ __device__ __forceinline__ u32x4 g3r_lanes(const u32x4& v, int addr) {
     return o;
 }
 
+// ---- PRE 5: the folded LayerNorm's row pairs from the 256-column partials of the launch in front (see g3_epilogue_r).  Thread
+// t = 64 wave + lane of the workgroup owns rows 2 (t >> 2), + 1 of an item (m0 = its first row, rows = how many exist) and part
+// t & 3 (< row_nparts <= 4): ONE 16-byte load per thread -- 8 wave-level memory instructions per tile (a first version with 64 of them,
+// one 8-byte load per 64-column partial, cost the CU's memory path ~2 k clocks per tile in front of the stores).
+struct G3Parts { f32x4 v; };
+__device__ __forceinline__ G3Parts g3r_parts_load(const GemmParams& p, int64_t m0, int rows, int wave) {
+    G3Parts o;
+    const int lane = g3_lane_now();
+    const int t = wave * 64 + lane, rp = t >> 2, j = t & 3;
+    // [part][M] pairs seen from row m0: the last part ends `rows` rows in (rows past the item / the matrix: out of range -> zeros;
+    // an odd last row: the second pair of its 16 bytes is out of range -> zeros, never read back)
+    const __amdgpu_buffer_rsrc_t pars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.row_affine) + (rows > 0 ? m0 * 2 : 0), 0,
+                                                                           rows > 0 ? (int)((((int64_t)p.row_nparts - 1) * p.M + rows) * 8) : 0, 0x00020000);
+    const uint32_t off = (j < p.row_nparts && 2 * rp < rows) ? (uint32_t)(((int64_t)j * p.M + 2 * rp) * 8) : 0x80000000u;
+    o.v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pars, (int)off, 0, 0));
+    return o;
+}
+// ... folded into (rstd, -rstd * mean) of LayerNorm(256 row_nparts, row_eps) for both rows and written to LDS `lds_pairs`[row]: the
+// arithmetic of row_stats_combine_kernel (mean of the part means, M2 = sum M2_j + 256 sum (mean_j - mean)^2) with the sums over a
+// quad of lanes (two DPP swaps; the order (a + b) + (c + d) is the same in all four lanes: they hold the same bits)
+__device__ __forceinline__ void g3r_parts_fold(const GemmParams& p, const G3Parts& q, int wave, uint32_t lds_pairs) {
+    const int lane = g3_lane_now();
+    const int t = wave * 64 + lane, rp = t >> 2, j = t & 3;
+    auto quad = [](float x) {
+        x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xf, 0xf, true));      // quad_perm [1, 0, 3, 2]
+        x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x4E, 0xf, 0xf, true));      // quad_perm [2, 3, 0, 1]
+        return x;
+    };
+    const float w = j < p.row_nparts ? 1.0f : 0.0f;
+    const float inv_np = __builtin_amdgcn_rcpf((float)p.row_nparts);
+    const float inv_c = inv_np * (1.0f / 256.0f);
+    u32x4 out;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float mean = quad(q.v[2 * r]) * inv_np;                           // (parts past row_nparts / rows past the item are zeros)
+        const float m2 = quad(q.v[2 * r + 1]);
+        const float d = (q.v[2 * r] - mean) * w;
+        const float dev = quad(d * d);
+        const float rstd = __builtin_amdgcn_rsqf((m2 + 256.0f * dev) * inv_c + p.row_eps);
+        out[2 * r] = __float_as_uint(rstd);
+        out[2 * r + 1] = __float_as_uint(-rstd * mean);
+    }
+    // the four lanes of a row pair hold the same 16 bytes and write them to the same place: no exec-mask games
+    asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(lds_pairs + (uint32_t)rp * 16), "v"(out) : "memory");
+}
+
 // EPI: 0 bias, 1 GELU (PRE: 0 nothing saved, 1 pre-activation saved, 2 gelu'(pre-activation) saved), 2 + residual row
 // operand, 3 * gelu'(row operand), 6 * row operand.
 // PRE 3 (EPI 0 / 1): a LayerNorm folded into this Linear (GemmParams::row_affine / col_shift): the accumulators start at zero
 // and the epilogue applies v = rstd_m * acc + (-rstd_m mean_m) * s[n] + c[n] in the accumulator layout (one row per lane and
 // 16-row slab, four consecutive columns per register quad), ahead of the activation; nothing is saved.
 // PRE 5 (EPI 0 / 1): the same folded LayerNorm, its row pairs formed HERE from the 64-column partials (mean_i, M2_i) the residual
-// launch in front of this one left behind (PRE 4; GemmParams::row_affine = [row_nparts][M] pairs, row_nparts even, <= 16): thread t of
-// the workgroup takes row t >> 1 of the item and the even / odd parts (all loads up front, the two halves meet through one DPP
-// swap; the arithmetic of row_stats_combine_kernel: mean of the part means, M2 = sum M2_i + 64 sum (mean_i - mean)^2), the 256
-// pairs go through 2 KiB of LDS BESIDE the operand buffers (inline-asm ds operations: a compiler-visible LDS access would be
-// guarded with vmcnt(0) while the next tile's DMA is in flight) and one workgroup barrier -- both wave rows stand side by side
-// here anyway.  Replaces the row_stats_combine launch between the two GEMMs (24 per Base forward).
+// launch in front of this one left behind (PRE 4; GemmParams::row_affine = [row_nparts][M] pairs over 256 columns each, row_nparts <= 4) -- no
+// row_stats_combine launch between the two GEMMs (24 per Base forward).  Software-pipelined over the items of a workgroup so that
+// neither the memory latency nor the arithmetic sits in front of an epilogue: the epilogue of item i (a) reads item i's 256 pairs
+// from 2 KiB of LDS BESIDE the operand buffers (buffer i & 1), (b) issues the load of item i + 1's partials at its top -- thread t
+// of the workgroup takes rows 2 (t >> 2), + 1 of that item and part t & 3: one 16-byte load -- and (c) folds them BEHIND its last store, where the
+// CU's memory path is busy draining the stores and the first K-tile of item i + 1 would only wait for it (measured: K-tile 1 takes
+// 4.3 .. 5.1 k clocks against 2.4 k in steady state): the arithmetic of row_stats_combine_kernel (mean of the part means, M2 = sum
+// M2_j + 256 sum (mean_j - mean)^2; the parts of a row meet through two DPP swaps), pairs into buffer (i + 1) & 1.  A workgroup's
+// first item is folded in the prologue.  A first version that loaded, folded and exchanged the pairs at the TOP of each epilogue
+// (one workgroup barrier) cost 1 us per tile, and one 8-byte load per 64-column partial (64 wave-level loads per tile) 2 k clocks of
+// the CU's memory path in front of the stores -- each as much as the launches it removed (profiles/r06_row_parts_ab.txt).
+// All LDS traffic is inline asm: a compiler-visible LDS access would be guarded with vmcnt(0) while the next tile's DMA is in flight.
 // PRE 4 (EPI 2): the per-row statistics of the OUTPUT rows on the side (GemmParams::row_stats) -- the LayerNorm that reads this
 // residual stream next then needs no pass of its own over it (me_row_stats_combine folds the partials).  After the row re-deal
 // eight lanes hold one row's 64 columns of this wave: per half slab every lane forms (S, Q) = sum (v - P), sum (v - P)^2 of its
 // eight values against a pivot P = the row's first value in this wave column (shifted sums: no cancellation however far the row
 // mean is from zero; P reaches the eight lanes through one DPP move and two lane-row swaps), and the sixteen (half slab) pairs of
 // a wave are summed over the eight lanes as a REDUCE-SCATTER -- DPP row_ror:8, v_permlane16_swap, v_permlane32_swap, each step
-// halving the number of live values -- so that every lane ends up with two finished rows: (mean, M2) over n = 64 columns,
-// one 8-byte store each into [N / 64][M] (a 128-row item: four slabs, one row per lane).  The statistics are those of the values AS STORED (rounded to
+// halving the number of live values -- so that every lane ends up with two finished rows: (mean, M2) over n = 64 columns
+// (a 128-row item: four slabs, one row per lane).  Round 6: these per-wave-column pairs no longer go to memory -- the four wave columns
+// of a row meet in 8 KiB of LDS behind the last store and ONE pair per row over the tile's 256 columns is stored, [N / 256][M] (see
+// the block behind the slab loop).  The statistics are those of the values AS STORED (rounded to
 // bf16 and converted back: eight more operations per half slab) -- for a row whose mean dwarfs its spread the rounding IS the
 // spread, and the reference's LayerNorm sees the rounded stream too.
 // HALF: a 128 x 256 item (g3_make_src_half): accumulator slabs 0..3 only, this wave row's rows are m0 + 64 wr + ..; the
@@ -267,7 +321,7 @@ __device__ __forceinline__ u32x4 g3r_lanes(const u32x4& v, int addr) {
 template <int EPI, int PRE, bool HALF = false>
 __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int64_t m0, int tn, int lane, const G3Src& nxt, int nk,
                                               const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero, unsigned* ctr, int nx,
-                                              uint32_t lds_tick) {
+                                              uint32_t lds_tick, int64_t next_m0 = 0, int next_rows = 0, int par = 0) {
     constexpr bool SAVE = PRE == 1 || PRE == 2, LNF = PRE == 3 || PRE == 5, LNP = PRE == 5, STATS = PRE == 4;
     static_assert(!STATS || EPI == 2, "row statistics: the residual epilogue");
     constexpr int NMT = HALF ? 4 : 8, WROWS = HALF ? 64 : 128;      // 16-row slabs per wave, rows per wave row
@@ -325,14 +379,15 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
         o[4] = (bf16_t)b[0]; o[5] = (bf16_t)b[1]; o[6] = (bf16_t)b[2]; o[7] = (bf16_t)b[3];
         return __builtin_bit_cast(u32x4, o);
     };
-    // (STATS) destination of this wave column's partials: [part = 4 tn + wc][M] pairs; a part past the last column, or an item past
-    // the last row, gets a descriptor that admits nothing (the operation count stays what it is)
+    // (STATS) destination of this TILE's partials: [part = tn][M] pairs over its 256 columns; a part past the last whole column tile, or an
+    // item past the last row, gets a descriptor that admits nothing (the operation count stays what it is).  The four wave columns'
+    // 64-column pairs meet in 8 KiB of LDS beside the operand buffers ([row][wave column] pairs, behind the ticket word)
     float st_a[2][3], st_b[2][3];
     __amdgpu_buffer_rsrc_t srs = crs;
+    const uint32_t lds_stats = lds_tick + 64;
     if (STATS) {
-        const int64_t part = (int64_t)tn * 4 + wc;
-        const bool part_ok = item_ok && (part + 1) * 64 <= p.N;
-        srs = __builtin_amdgcn_make_buffer_rsrc(p.row_stats + (part_ok ? (part * p.M + m0) * 2 : 0), 0, part_ok ? (int)(rows * 8) : 0, 0x00020000);
+        const bool part_ok = item_ok && ((int64_t)tn + 1) * 256 <= p.N;
+        srs = __builtin_amdgcn_make_buffer_rsrc(p.row_stats + (part_ok ? ((int64_t)tn * p.M + m0) * 2 : 0), 0, part_ok ? (int)(rows * 8) : 0, 0x00020000);
     }
     constexpr int AHEAD = HALF ? G3_ROWOP_AHEAD_HALF : (EPI == 3 || STATS) ? G3_ROWOP_AHEAD_STATS : G3_ROWOP_AHEAD;      // row-operand slabs in flight ahead of their use (more spills: into the K-loop for gelu', onto the ticket register otherwise)
     u32x4 rowop[8][2];
@@ -343,19 +398,16 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     // folded LayerNorm: this tile's per-row pairs (rows wr*128 + 16 mt + r) and per-column s / c, all ahead of the DMA below
     f32x2 lnf_row[8];
     G3Bias lnf_s, lnf_c;
-    f32x2 lnp[8];                               // (LNP) this thread's share of the partials: parts hs, hs + 2, .. of row t >> 1
+    G3Parts lnp;                                // (LNP) this thread's share of the NEXT item's partials (folded behind the stores)
+    u32x2 lnq[8];                               // (LNP) this item's pairs on their way in from LDS
     if (LNF) {
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.col_shift), 0, (int)(p.N * 4), 0x00020000);
         if (LNP) {
-            const int t = s.wave * 64 + lane, lr = t >> 1, hs = t & 1, nh = p.row_nparts >> 1;
-            // [part][M] pairs seen from row m0: the last part ends `rows` rows in (rows past the item / the matrix: out of range -> zeros)
-            const __amdgpu_buffer_rsrc_t pars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.row_affine) + m0 * 2, 0,
-                                                                                   item_ok ? (int)((((int64_t)p.row_nparts - 1) * p.M + rows) * 8) : 0, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t off = (i < nh && lr < (int)rows) ? (uint32_t)((((int64_t)(2 * i + hs)) * p.M + lr) * 8) : 0x80000000u;
-                lnp[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(pars, (int)off, 0, 0));
-            }
+            const uint32_t pa = lds_tick + 64 + (uint32_t)par * 2048 + (uint32_t)(wr * WROWS + r) * 8;
+#define G3R_PAIR(i) if ((i) < NMT) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lnq[i]) : "v"(pa), "i"((i) * 128) : "memory");
+            G3R_PAIR(0) G3R_PAIR(1) G3R_PAIR(2) G3R_PAIR(3) G3R_PAIR(4) G3R_PAIR(5) G3R_PAIR(6) G3R_PAIR(7)
+#undef G3R_PAIR
+            lnp = g3r_parts_load(p, next_m0, next_rows, s.wave);
         } else {
             const __amdgpu_buffer_rsrc_t rars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.row_affine) + m0 * 2, 0, item_ok ? (int)(rows * 8) : 0, 0x00020000);
 #pragma unroll
@@ -372,37 +424,10 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     const G3Bias nb = g3r_bias(brs, ntn, s.wave, lane);
     __builtin_amdgcn_sched_barrier(0);
     if (LNP) {
-        const int t = s.wave * 64 + lane, lr = t >> 1, nh = p.row_nparts >> 1;
-        auto swap1 = [](float x) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xf, 0xf, true)); };      // quad_perm [1, 0, 3, 2]
-        float ms = 0.f, m2 = 0.f;
+        if (NMT == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lnq[0]), "+v"(lnq[1]), "+v"(lnq[2]), "+v"(lnq[3]), "+v"(lnq[4]), "+v"(lnq[5]), "+v"(lnq[6]), "+v"(lnq[7])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lnq[0]), "+v"(lnq[1]), "+v"(lnq[2]), "+v"(lnq[3])::"memory");
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { ms += lnp[i][0]; m2 += lnp[i][1]; }      // (parts past nh / rows past the item are zeros)
-        ms += swap1(ms);
-        m2 += swap1(m2);
-        const float mean = ms / (float)p.row_nparts;
-        float dev = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float w = i < nh ? 1.0f : 0.0f;                              // (wave-uniform)
-            const float d = (lnp[i][0] - mean) * w;
-            dev += d * d;
-        }
-        dev += swap1(dev);
-        const float rstd = rsqrtf((m2 + 64.0f * dev) / (64.0f * (float)p.row_nparts) + p.row_eps);
-        const u32x2 pair = {__float_as_uint(rstd), __float_as_uint(-rstd * mean)};
-        // both lanes of a row hold the same pair (the sums above commute) and write it to the same word: no exec-mask games
-        const uint32_t lds_pairs = lds_tick + 64;
-        asm volatile("ds_write_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(lds_pairs + (uint32_t)lr * 8), "v"(pair) : "memory");
-        __builtin_amdgcn_s_barrier();
-        const uint32_t pa = lds_pairs + (uint32_t)(wr * WROWS + r) * 8;
-        u32x2 q[8];
-#define G3R_PAIR(i) if ((i) < NMT) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[i]) : "v"(pa), "i"((i) * 128) : "memory");
-        G3R_PAIR(0) G3R_PAIR(1) G3R_PAIR(2) G3R_PAIR(3) G3R_PAIR(4) G3R_PAIR(5) G3R_PAIR(6) G3R_PAIR(7)
-#undef G3R_PAIR
-        if (NMT == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])::"memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3])::"memory");
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) lnf_row[mt] = __builtin_bit_cast(f32x2, q[mt]);
+        for (int mt = 0; mt < NMT; ++mt) lnf_row[mt] = __builtin_bit_cast(f32x2, lnq[mt]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -526,15 +551,41 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                     const float ds = S * (1.0f / 64.0f);
                     const u32x2 out = {__float_as_uint(P + ds), __float_as_uint(Q - S * ds)};
                     const int srow = wr * WROWS + 16 * (4 * (mt >> 2) + 2 * (int)b5 + (int)b4) + 8 * (int)b3 + (lane & 7);
-                    __builtin_amdgcn_raw_buffer_store_b64(out, srs, srow * 8, 0, 0);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(lds_stats + (uint32_t)(srow * 32 + wc * 8)), "v"(out) : "memory");
                 }
             }
         }
     }
+    if (STATS) {
+        // behind the last store: the four wave columns' (mean, M2) over 64 columns each -> ONE pair per row over the tile's 256 columns
+        // (Chan's combination for equal counts, pairwise; thread t of the workgroup: row t >> 1 of the item, wave columns 2 (t & 1) + {0, 1},
+        // the two halves of a row meet through one DPP swap), one 8-byte store per row -- a quarter of the partials, and of the
+        // statistics stores, of the per-wave-column form; what the consumer (PRE 5) or me_row_stats_combine folds is 3 pairs per row at
+        // C = 768 instead of 12.  Both wave rows stand side by side here (see gemm_g3r_kernel), so the barrier costs the skew of one epilogue.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int t = s.wave * 64 + lane, lr = t >> 1, h = t & 1;
+        u32x4 raw;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(lds_stats + (uint32_t)(lr * 32 + h * 16)) : "memory");
+        const float ma = __uint_as_float(raw[0]), qa = __uint_as_float(raw[1]), mb = __uint_as_float(raw[2]), qb = __uint_as_float(raw[3]);
+        const float d1 = mb - ma;
+        const float m1 = (ma + mb) * 0.5f, q1 = (qa + qb) + d1 * d1 * 32.0f;                 // n = 64 + 64
+        auto swap1 = [](float x) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xf, 0xf, true)); };      // quad_perm [1, 0, 3, 2]
+        const float mo = swap1(m1), qo = swap1(q1);
+        const float d2 = mo - m1;
+        const u32x2 tot = {__float_as_uint((m1 + mo) * 0.5f), __float_as_uint((q1 + qo) + d2 * d2 * 64.0f)};      // n = 128 + 128
+        __builtin_amdgcn_raw_buffer_store_b64(tot, srs, h == 0 ? lr * 8 : (int)0x80000000u, 0, 0);
+    }
+    if (LNP) {
+        // the next item's pairs, behind this item's last store (the other pair buffer: slower waves may still be reading this item's)
+        __builtin_amdgcn_sched_barrier(0);
+        g3r_parts_fold(p, lnp, s.wave, lds_tick + 64 + (uint32_t)(par ^ 1) * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (HALF) {
         // as many memory operations as a whole tile's epilogue issues behind the A-Y half-tile (stores: half of them went out
         // above; late row-operand loads: a whole tile issues 2 (8 - AHEAD) of them, this one none)
-        constexpr int PAD = (SAVE ? 16 : 8) + ((EPI == 2 || EPI == 6) ? 4 : EPI == 3 ? 8 : 0) + (STATS ? 1 : 0);      // (a whole tile stores two statistics pairs per lane, a 128-row item one)
+        constexpr int PAD = (SAVE ? 16 : 8) + ((EPI == 2 || EPI == 6) ? 4 : EPI == 3 ? 8 : 0) ;      // (the statistics store: one per lane for either item kind)
         const u32x4 z = {0u, 0u, 0u, 0u};
         const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000);
 #pragma unroll
@@ -623,6 +674,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const G3Bias b0 = g3r_bias(brs, tn, wave, lane);
         g3r_set_binit(s, b0, PRE == 3 || PRE == 5);
     }
+    if (PRE == 5) {      // the first item's LayerNorm pairs (every later item's are folded behind the epilogue in front of it)
+        const int64_t m00 = (int64_t)tm * G3_BM + (part >= 0 ? part * 128 : 0);
+        int64_t r0 = p.M - m00;
+        r0 = r0 < (part >= 0 ? 128 : 256) ? r0 : (part >= 0 ? 128 : 256);
+        const G3Parts q0 = g3r_parts_load(p, m00, r0 > 0 ? (int)r0 : 0, wave);
+        g3r_parts_fold(p, q0, wave, lds_tick + 64);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (dyn && wave == 0) g3r_publish(drawn0, ctr, nx, lds_tick);
     prime();
@@ -633,6 +691,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // second K-tile done, K-loop done, rows realigned, epilogue done (tools/gemm_dev, debug bit 8; dead code in the product build)
     unsigned long long* trace = kMeDev ? reinterpret_cast<unsigned long long*>(p.colsum_ws) : nullptr;
     int item = 0;
+    int item_par = 0;                    // (PRE 5) which LDS pair buffer holds the current item's LayerNorm pairs
 #define G3R_STAMP(i)                                                                                            \
     if (kMeDev && trace && (wave & 3) == 0 && item < 16) {                                                      \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                             \
@@ -698,8 +757,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             G3R_STAMP(3)
             if (wr == 0) __builtin_amdgcn_s_barrier();
             G3R_STAMP(4)
+            int64_t nm0 = 0;
+            int nrows = 0;
+            if (PRE == 5 && has_next) {
+                nm0 = (int64_t)ntm * G3_BM + (npart >= 0 ? npart * 128 : 0);
+                const int64_t left = p.M - nm0, cap = npart >= 0 ? 128 : 256;
+                nrows = (int)(left < cap ? (left > 0 ? left : 0) : cap);
+            }
             g3_epilogue_r<EPI, PRE, HALF>(p, s, (int64_t)tm * G3_BM + (HALF ? part * 128 : 0), tn, 0, nxt, nkt0 + 1, brs, ntn, PRE == 3 || PRE == 5,
-                                          has_next ? ctr : nullptr, nx, lds_tick);
+                                          has_next ? ctr : nullptr, nx, lds_tick, nm0, nrows, item_par);
         };
         if constexpr (HI) {
             if (part >= 0) run_item(std::true_type{});
@@ -711,6 +777,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (kMeDev) ++item;
         if (!has_next) break;
         if (wr == 1) __builtin_amdgcn_s_barrier();
+        item_par ^= 1;
         slot = nslot; tile = ntile; part = npart; kt0 = nkt0; kt1 = nkt1; tm = ntm; tn = ntn;
         cur = nxt;
     }
@@ -964,7 +1031,7 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
                                                //  sustained with four row-operand slabs in flight, 263 with two; train +0.4 ms with six -- off)
 #endif
     constexpr bool HI = EPI == 0 || (G3_HI_EPI2 && EPI == 2) || (G3_HI_EPI1 && EPI == 1) || (G3_HI_EPI6 && EPI == 6);      // which forms carry the 128-row items (see the kernel)
-    constexpr int LDS_BYTES = G3_LDS + 64 + (PRE == 5 ? 2048 : 0);      // operand buffers + the ticket word (+ PRE 5: 256 LayerNorm row pairs)
+    constexpr int LDS_BYTES = G3_LDS + 64 + (PRE == 5 ? 4096 : PRE == 4 ? 8192 : 0);      // operand buffers + the ticket word (+ PRE 5: two buffers of 256 LayerNorm row pairs; PRE 4: 256 rows x 4 wave columns of partial pairs)
     static OncePerDevice once;
     if (once.need())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3r_kernel<EPI, PRE, HI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -1106,7 +1173,7 @@ bool g3_emits_row_stats(const GemmParams& p) {
     const int G = g3_cus() & ~7;
     const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int64_t ldmax = std::max(p.ldc, p.ldres);
-    return G >= 8 && tiles >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && p.res_dtype == ME_BF16 && p.N % 64 == 0 &&
+    return G >= 8 && tiles >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && p.res_dtype == ME_BF16 && p.N % 256 == 0 &&
            256 * ldmax * 2 < (1ll << 31) && p.M * 8 < (1ll << 31);
 }
 
@@ -1118,7 +1185,7 @@ bool g3_emits_row_stats(const GemmParams& p) {
 bool g3_takes_row_parts(const GemmParams& p) {
     if (ME_NO_ROW_PARTS) return false;
     if (!g3_supported(p, ME_GEMM_NT) || gemm_dev().g3_persistent != 1 || !p.row_affine || !p.col_shift) return false;
-    if (p.row_nparts < 2 || p.row_nparts > 16 || (p.row_nparts & 1) || (int64_t)p.row_nparts * 64 != p.K) return false;
+    if (p.row_nparts < 1 || p.row_nparts > 4 || (int64_t)p.row_nparts * 256 != p.K) return false;
     if (p.flags || p.preact || p.aux || p.residual || p.colscale || p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return false;
     const int G = g3_cus() & ~7;
     const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);

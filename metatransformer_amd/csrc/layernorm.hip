@@ -160,10 +160,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_stats_generic_kernel(const void
     if (lane == 0) *reinterpret_cast<float2*>(out + row * 2) = float2{rstd, -rstd * mean};
 }
 
-// ---- the pairs of ln_stats_kernel from 64-column partials (mean_i, M2_i) a GEMM epilogue left behind ([nparts][rows] pairs,
-// me_gemm_desc.row_stats): one thread per row, the partials of consecutive rows are consecutive in memory.  Chan et al.'s
-// combination for equal group sizes; exact in the sense that no large numbers are subtracted anywhere (the group M2 are sums of
-// squared deviations already).
+// ---- the pairs of ln_stats_kernel from 256-column partials (mean_i, M2_i) a GEMM epilogue left behind ([nparts][rows] pairs,
+// me_gemm_desc.row_stats; round 6: one pair per row and 256-column tile, it was one per 64-column wave column): one thread per row,
+// the partials of consecutive rows are consecutive in memory.  Chan et al.'s combination for equal group sizes; exact in the sense
+// that no large numbers are subtracted anywhere (the group M2 are sums of squared deviations already).  The folded qkv / fc1 GEMMs
+// do the same arithmetic in their own epilogue where they can (me_gemm_desc.row_parts); this kernel serves the shapes they cannot.
 __global__ __launch_bounds__(256) void row_stats_combine_kernel(const float2* __restrict__ part, int nparts, int64_t rows, float inv_cols,
                                                                 float eps, float* __restrict__ out) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void row_stats_combine_kernel(const float2* __
         const float d = part[(int64_t)i * rows + row].x - mean;      // (second read: L2)
         dev += d * d;
     }
-    const float rstd = rsqrtf((m2 + 64.0f * dev) * inv_cols + eps);
+    const float rstd = rsqrtf((m2 + (float)ME_STATS_GROUP * dev) * inv_cols + eps);
     *reinterpret_cast<float2*>(out + row * 2) = float2{rstd, -rstd * mean};
 }
 
@@ -489,18 +490,18 @@ extern "C" int me_row_stats(const void* x, int x_dtype, float* out, int64_t rows
 }
 
 extern "C" size_t me_row_stats_partial_bytes(int64_t rows, int cols) {
-    return rows > 0 && cols > 0 ? (size_t)(cols / 64) * (size_t)rows * 2 * sizeof(float) : 0;
+    return rows > 0 && cols > 0 ? (size_t)(cols / ME_STATS_GROUP) * (size_t)rows * 2 * sizeof(float) : 0;
 }
 
 extern "C" int me_row_stats_combine(const float* partials, int64_t rows, int cols, float eps, float* out, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     ME_CHECK_ARG(partials && out, "me_row_stats_combine: null pointer");
-    ME_CHECK_ARG(rows >= 0 && cols > 0 && cols % 64 == 0, "me_row_stats_combine: cols must be a positive multiple of 64");
+    ME_CHECK_ARG(rows >= 0 && cols > 0 && cols % ME_STATS_GROUP == 0, "me_row_stats_combine: cols must be a positive multiple of 256");
     ME_CHECK_ARG((uintptr_t)partials % 8 == 0 && (uintptr_t)out % 8 == 0, "me_row_stats_combine: 8-byte aligned buffers");
     if (rows == 0) return ME_OK;
     ProfScope prof(ME_PROF_ROW_STATS, ME_F32, rows, cols, 1, stream);      // (K = 1: the combine pass; K = 0: me_row_stats over the tokens)
     hipLaunchKernelGGL(row_stats_combine_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream,
-                       reinterpret_cast<const float2*>(partials), cols / 64, rows, 1.0f / (float)cols, eps, out);
+                       reinterpret_cast<const float2*>(partials), cols / ME_STATS_GROUP, rows, 1.0f / (float)cols, eps, out);
     ME_CHECK_LAUNCH("me_row_stats_combine");
     return ME_OK;
 }

@@ -111,10 +111,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
     from the same kernel when the library can fuse it, else from me_colsum; the result is then (out, colsum).
     colsum_out: fp32 [M] buffer for it, accumulated with the same beta as out (only used when the kernel fuses it).
     flags: ME_GEMM_SAVE_GELU_GRAD (preact receives gelu'(pre-activation)) / ME_GEMM_AUX_IS_FACTOR (multiply by aux itself).
-    want_row_stats (NT + residual): also return the per-row partial statistics of the OUTPUT, [N / 64, M, 2] fp32 (mean, M2) over
-    64-column groups (me_gemm_desc.row_stats; fold with row_stats_combine) -- None when the kernel for this problem cannot emit
+    want_row_stats (NT + residual): also return the per-row partial statistics of the OUTPUT, [N / 256, M, 2] fp32 (mean, M2) over
+    256-column groups (me_gemm_desc.row_stats; fold with row_stats_combine) -- None when the kernel for this problem cannot emit
     them (me_gemm_emits_row_stats); the result is then (out, partials or None).
-    row_parts (NT, with col_shift, instead of row_affine): such partials of THIS launch's A operand, [K / 64, M, 2] -- the kernel forms the
+    row_parts (NT, with col_shift, instead of row_affine): such partials of THIS launch's A operand, [K / 256, M, 2] -- the kernel forms the
     folded LayerNorm(K, row_eps) pairs itself (me_gemm_desc.row_parts); raises where me_gemm_takes_row_parts says no (gemm_takes_row_parts)."""
     lib = _capi.load()
     _req(a, "a"); _req(b, "b")
@@ -149,10 +149,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
         d.row_affine, d.col_shift = ptr(_req(row_affine, "row_affine")), ptr(col_shift)
     if row_parts is not None:
         if row_affine is not None or col_shift is None or col_shift.numel() != N or row_parts.dtype != torch.float32 or \
-                tuple(row_parts.shape) != (K // 64, M, 2):
-            raise MetaEncError("gemm: row_parts must be [K / 64, M, 2] float32 partials (gemm(..., want_row_stats=True)), with col_shift [N], without row_affine")
+                K % 256 or tuple(row_parts.shape) != (K // 256, M, 2):
+            raise MetaEncError("gemm: row_parts must be [K / 256, M, 2] float32 partials (gemm(..., want_row_stats=True)), with col_shift [N], without row_affine")
         col_shift = _f32(col_shift).contiguous(); keep.append(col_shift)
-        d.row_parts, d.row_nparts, d.row_eps, d.col_shift = ptr(_req(row_parts, "row_parts")), K // 64, float(row_eps), ptr(col_shift)
+        d.row_parts, d.row_nparts, d.row_eps, d.col_shift = ptr(_req(row_parts, "row_parts")), K // 256, float(row_eps), ptr(col_shift)
     if bias is not None:
         bias = _f32(bias).contiguous(); keep.append(bias)
         d.bias = ptr(bias)
@@ -185,7 +185,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
         d.workspace, d.workspace_bytes = ptr(ws), ws_bytes
     partials = None
     if want_row_stats and lib.me_gemm_emits_row_stats(ctypes.byref(d)):
-        partials = torch.empty((N // 64, M, 2), dtype=torch.float32, device=a.device)
+        partials = torch.empty((N // 256, M, 2), dtype=torch.float32, device=a.device)
         d.row_stats = ptr(partials)
     check(lib.me_gemm(ctypes.byref(d), stream_ptr()), "me_gemm")
     if want_row_stats:
@@ -230,7 +230,7 @@ def block_desc(B, N, C, heads, hidden, eps, scale, cdt, rdt, w, wt, vec, x3: boo
 
 def block_fwd(d, x2: torch.Tensor, keep: bool, x_stats: Optional[torch.Tensor] = None, want_stats: bool = False):
     """-> (y, saved or None, y_stats or None).  x_stats: the LayerNorm statistics of x for this block's norm1 (folded inference): the
-    [M, 2] pairs of row_stats (me_block_desc.x_stats) or the [C / 64, M, 2] partials a previous call returned (me_block_desc.x_parts);
+    [M, 2] pairs of row_stats (me_block_desc.x_stats) or the [C / 256, M, 2] partials a previous call returned (me_block_desc.x_parts);
     want_stats: also return the partials of y, left by the fc2 epilogue, when the block can emit them (me_block_emits_stats) -- the
     next block's x_stats.  No statistics pass and no combine launch sits between the blocks then."""
     lib = _capi.load()
@@ -243,15 +243,15 @@ def block_fwd(d, x2: torch.Tensor, keep: bool, x_stats: Optional[torch.Tensor] =
         if x_stats is not None:
             M, C = x2.shape
             if x_stats.dtype != torch.float32 or not x_stats.is_contiguous() or x_stats.device != x2.device or \
-                    tuple(x_stats.shape) not in ((M, 2), (C // 64, M, 2)):
+                    tuple(x_stats.shape) not in ((M, 2), (C // 256, M, 2)):
                 raise MetaEncError("block_fwd: x_stats must be a contiguous float32 tensor on the tokens' device, [M, 2] pairs "
-                                   "(row_stats) or the [C / 64, M, 2] partials a previous block_fwd(want_stats=True) returned")
+                                   "(row_stats) or the [C / 256, M, 2] partials a previous block_fwd(want_stats=True) returned")
             if x_stats.dim() == 3:
                 d.x_parts = ptr(x_stats)       # the fc2 partials themselves: this block's qkv GEMM forms the pairs (no combine launch)
             else:
                 d.x_stats = ptr(x_stats)
         if want_stats and lib.me_block_emits_stats(ctypes.byref(d)):
-            y_stats = torch.empty((x2.shape[1] // 64, x2.shape[0], 2), dtype=torch.float32, device=x2.device)
+            y_stats = torch.empty((x2.shape[1] // 256, x2.shape[0], 2), dtype=torch.float32, device=x2.device)
             d.y_parts = ptr(y_stats)
     check(lib.me_block_fwd(ctypes.byref(d), ptr(x2), ptr(y), ptr(saved), ptr(ws), wsb, stream_ptr()), "me_block_fwd")
     return y, saved, y_stats
@@ -707,14 +707,14 @@ def ctypes_sizeof_ctl() -> int:
 
 
 def row_stats_combine(partials: torch.Tensor, eps: float) -> torch.Tensor:
-    """[C / 64, rows, 2] partial statistics (gemm(..., want_row_stats=True)) -> [rows, 2] pairs (rstd, -rstd * mean) of
+    """[C / 256, rows, 2] partial statistics (gemm(..., want_row_stats=True)) -> [rows, 2] pairs (rstd, -rstd * mean) of
     LayerNorm(C, eps): the same pairs as row_stats(x, eps) on the tensor the GEMM wrote (me_row_stats_combine)."""
     _req(partials, "partials")
     if partials.dtype != torch.float32 or partials.dim() != 3 or partials.shape[2] != 2:
-        raise MetaEncError("row_stats_combine: [C / 64, rows, 2] float32 partials required")
+        raise MetaEncError("row_stats_combine: [C / 256, rows, 2] float32 partials required")
     nparts, rows, _ = partials.shape
     out = torch.empty(rows, 2, dtype=torch.float32, device=partials.device)
-    check(_capi.load().me_row_stats_combine(ptr(partials), rows, nparts * 64, float(eps), ptr(out), stream_ptr()), "me_row_stats_combine")
+    check(_capi.load().me_row_stats_combine(ptr(partials), rows, nparts * 256, float(eps), ptr(out), stream_ptr()), "me_row_stats_combine")
     return out
 
 

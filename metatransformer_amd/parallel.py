@@ -476,7 +476,9 @@ class FusedAdamW:
         backward has written the unit's last gradient -- the HBM-bound AdamW pass (2.6 GB for Base) then runs under the rest of
         backward, which is matrix-bound -- followed by the zero-fill of that gradient slice (`flat.zero_grad()` of the next step
         becomes free) and, behind the last unit, by the refresh of the transposed weight copies the next backward needs.  `step()`
-        launches whatever is left and joins.  `grad_scale` must be given HERE (the launches happen before `step()` is called);
+        launches whatever is left and joins.  NOT for models that run a Block more than once per backward (an encoder shared by two
+        modalities, tied weights) or accumulate gradients over several backwards: the second gradient of a parameter raises
+        MetaEncError (its unit has been updated behind the first).  `grad_scale` must be given HERE (the launches happen before `step()` is called);
         after `step()` the gradients read as zero.  Same arithmetic, same bits as the one-pass form (tests).
         prefetch_transposes (one-pass form): rebuild the transposed weight copies the next BACKWARD needs on a side stream right behind
         the update, i.e. under the next forward, instead of at the head of that backward (one batched launch, ~0.15 ms for Base)."""
@@ -534,21 +536,31 @@ class FusedAdamW:
             for i in idx:
                 self._unit_of[i] = u
         self._left = [len(idx) for idx, _ in self._units]
-        self._seen = [False] * len(f.params)
+        self._seen = [0] * len(f.params)                # bit 0: autograd's post-accumulate hook, bit 1: FlatParams.grad_written
         self._launched = [False] * len(self._units)
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(f.params)]
-        f._listeners.append(self._fire)                 # gradients the fused Block backward wrote in place
+        f._listeners.append(lambda i: self._fire(i, 2))      # gradients the fused Block backward wrote in place
         f._zero_is_free = False
 
     def _make_hook(self, i):
         def hook(param):
-            self._fire(i)
+            self._fire(i, 1)
         return hook
 
-    def _fire(self, i: int) -> None:
-        if self._seen[i]:
+    def _fire(self, i: int, route: int = 1) -> None:
+        seen = self._seen[i]
+        if seen & route:
+            # The same route twice before step(): the parameter's Block ran more than once in this backward (one encoder shared by two
+            # modalities, tied weights) or a second backward was run.  The unit may already have been updated and its gradient slice
+            # zeroed behind the FIRST pass: the second pass would compute dX from updated weights and leave its weight
+            # gradients in the zeroed slice.  There is no way to know at the first announcement that another one follows -- refuse.
+            raise MetaEncError("FusedAdamW(overlap=True): a parameter received a second gradient before step() (a Block used more than once "
+                               "in one backward -- shared encoder, weight tying -- or gradient accumulation): the per-Block update has "
+                               "already been launched behind the first one, parameters and gradients are now inconsistent; use "
+                               "FusedAdamW(overlap=False) for such models")
+        self._seen[i] = seen | route
+        if seen:
             return                                      # (announced through both routes: counted once)
-        self._seen[i] = True
         u = self._unit_of[i]
         self._left[u] -= 1
         if self._left[u] == 0 and not self._launched[u]:
@@ -596,7 +608,7 @@ class FusedAdamW:
             from .encoder import _WeightCache
             _WeightCache.prefetch_transposed(f.flat_param.device)
         self._left = [len(idx) for idx, _ in self._units]
-        self._seen = [False] * len(f.params)
+        self._seen = [0] * len(f.params)
         self._launched = [False] * len(self._units)
         f._zero_is_free = True                          # every gradient slice was zeroed behind its update
 

@@ -964,7 +964,7 @@ def test_inference_with_folded_layernorm_matches_reference_golden(dev, name):
 
 @pytest.mark.parametrize("K,offset", [(768, 0.0), (3072, 0.0), (768, 40.0)])
 def test_residual_gemm_emits_row_statistics(dev, K, offset):
-    """me_gemm_desc.row_stats: the proj / fc2 launches leave per-row (mean, M2) partials of their OUTPUT over 64-column groups;
+    """me_gemm_desc.row_stats: the proj / fc2 launches leave per-row (mean, M2) partials of their OUTPUT over 256-column groups;
     me_row_stats_combine folds them into the pairs me_row_stats computes from the stored tensor.  `offset`: rows whose mean is
     hundreds of times their spread (the shifted sums must not cancel, and the statistics must be those of the bf16 values as
     stored).  The output itself is bit-identical to the same launch without statistics."""
@@ -977,11 +977,11 @@ def test_residual_gemm_emits_row_statistics(dev, K, offset):
     res = (torch.randn(M_rows, N, generator=g) * torch.rand(M_rows, 1, generator=g) + offset * torch.randn(M_rows, 1, generator=g)).bfloat16().to(dev)
     y0 = ops.gemm(a, w, bias=b, residual=res)
     y, part = ops.gemm(a, w, bias=b, residual=res, want_row_stats=True)
-    assert part is not None and part.shape == (N // 64, M_rows, 2)
+    assert part is not None and part.shape == (N // 256, M_rows, 2)
     assert torch.equal(y, y0)
     yd = y.double()
-    for i in range(N // 64):                       # every partial against the stored values of its 64 columns
-        blk = yd[:, 64 * i:64 * i + 64]
+    for i in range(N // 256):                      # every partial against the stored values of its 256 columns (one output tile)
+        blk = yd[:, 256 * i:256 * i + 256]
         mean, m2 = blk.mean(1), ((blk - blk.mean(1, keepdim=True)) ** 2).sum(1)
         assert float((part[i, :, 0].double() - mean).abs().max()) <= 2e-6 * float(blk.abs().max()), i
         assert float((part[i, :, 1].double() - m2).abs().max()) <= 2e-5 * float(m2.max()) + 1e-9, i

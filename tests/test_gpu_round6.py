@@ -36,8 +36,8 @@ def make_encoder(depth, dim, heads, dev, dtype=torch.float32, seed=3, eps=1e-5):
     (22016 + 37, 3072, 768, True, 0.0),       # fc1: GELU form
     (22016 + 37, 2304, 768, False, 40.0),     # rows whose mean is tens of times their spread
     (50432, 2304, 768, False, 3.0),           # config 2's qkv launch
-    (16384 + 128, 4096, 1024, True, 0.0),     # Large: 16 partials per row
-    (32768, 1152, 384, False, 0.0),           # 6 partials per row
+    (16384 + 128, 4096, 1024, True, 0.0),     # Large: 4 partials per row
+    (65536 + 1, 1536, 512, False, 0.0),       # 2 partials per row, an odd last row
 ])
 def test_folded_gemm_forms_pairs_from_partials(dev, M_rows, N_out, K, act, offset):
     """me_gemm(row_parts) == me_gemm(row_affine = me_row_stats_combine(partials)): the same folded Linear(LayerNorm(x)) [+ GELU], the
@@ -48,7 +48,7 @@ def test_folded_gemm_forms_pairs_from_partials(dev, M_rows, N_out, K, act, offse
     w0 = (torch.randn(K, K, generator=g) * K ** -0.5).bfloat16().to(dev)
     res = (torch.randn(M_rows, K, generator=g) * (0.5 + torch.rand(M_rows, 1, generator=g)) + offset * torch.randn(M_rows, 1, generator=g)).bfloat16().to(dev)
     x, part = ops.gemm(a0, w0, residual=res, want_row_stats=True)
-    assert part is not None and part.shape == (K // 64, M_rows, 2)
+    assert part is not None and part.shape == (K // 256, M_rows, 2)
     gamma, beta = 1.0 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
     w = torch.randn(N_out, K, generator=g) * K ** -0.5
     b = 0.1 * torch.randn(N_out, generator=g)
@@ -60,13 +60,15 @@ def test_folded_gemm_forms_pairs_from_partials(dev, M_rows, N_out, K, act, offse
     pairs = ops.row_stats_combine(part, eps)
     y_pairs = ops.gemm(x, wfd, row_affine=pairs, **kw)
     y_parts = ops.gemm(x, wfd, row_parts=part, row_eps=eps, **kw)
-    # the two routes differ only in the summation order of the twelve part means: a last-bit difference in rstd / mean moves an output
-    # across a bf16 rounding boundary now and then, never further
+    # the two routes differ only in the summation order of the part means and in rsq / rcp against rsqrtf / division: a last-bit difference
+    # in rstd / mean moves an output across a bf16 rounding boundary now and then, never further than that rounding step
     diff = (y_parts.float() - y_pairs.float()).abs()
     frac = float((diff > 0).float().mean())
     print(f"row_parts vs row_affine: {frac:.2e} of the outputs differ, max {float(diff.max()):.3g}")
-    assert frac < 2e-3
-    assert bool((diff <= 2.0 ** -7 * y_pairs.float().abs() + 1e-6).all())
+    assert frac < 5e-3
+    # (rows far off centre: the output is rstd (acc - mean s) + c, a last-bit step of a mean of ~|offset| x 3 moves EVERY output of the row
+    #  by ~1e-5 x s / std whatever its own size)
+    assert bool((diff <= 2.0 ** -6 * torch.maximum(y_pairs.float().abs(), y_parts.float().abs()) + 1e-5 + 2e-5 * offset).all())
     # ... and against fp64 LayerNorm -> Linear on a sample of rows (first / last tile, the ragged edge)
     rows = torch.cat([torch.arange(0, 300), torch.arange(M_rows // 2, M_rows // 2 + 300), torch.arange(M_rows - 300, M_rows)])
     xs = x[rows.to(dev)].double().cpu()
@@ -81,13 +83,13 @@ def test_folded_gemm_forms_pairs_from_partials(dev, M_rows, N_out, K, act, offse
 
 
 def test_row_parts_is_refused_where_the_resident_kernel_does_not_run(dev):
-    """small problems (fewer tiles than CUs), odd part counts: me_gemm_takes_row_parts says no and me_gemm rejects the descriptor
+    """small problems (fewer tiles than CUs), K not a multiple of 256 or above 1 024: me_gemm_takes_row_parts says no and me_gemm rejects the descriptor
     instead of reading partials as pairs"""
     lib = _capi.load()
-    for M_rows, N_out, K in ((4096, 2304, 768), (50432, 2304, 192), (50432, 2304, 1280)):
+    for M_rows, N_out, K in ((4096, 2304, 768), (50432, 2304, 384), (50432, 2304, 1280)):
         x = rnd(M_rows, K, seed=1).bfloat16().to(dev)
         w = rnd(N_out, K, seed=2).bfloat16().to(dev)
-        part = torch.zeros(K // 64, M_rows, 2, device=dev)
+        part = torch.zeros(max(K // 256, 1), M_rows, 2, device=dev)
         with pytest.raises(_capi.MetaEncError):
             ops.gemm(x, w, row_parts=part, row_eps=1e-6, col_shift=torch.zeros(N_out, device=dev))
         d = _capi.GemmDesc()
@@ -96,7 +98,7 @@ def test_row_parts_is_refused_where_the_resident_kernel_does_not_run(dev):
         out = torch.empty(M_rows, N_out, dtype=torch.bfloat16, device=dev)
         d.C, d.ldc, d.c_dtype, d.alpha = out.data_ptr(), N_out, _capi.ME_BF16, 1.0
         cs = torch.zeros(N_out, device=dev)
-        d.col_shift, d.row_parts, d.row_nparts, d.row_eps = cs.data_ptr(), part.data_ptr(), K // 64, 1e-6
+        d.col_shift, d.row_parts, d.row_nparts, d.row_eps = cs.data_ptr(), part.data_ptr(), max(K // 256, 1), 1e-6
         assert lib.me_gemm_takes_row_parts(ctypes.byref(d)) == 0
 
 
@@ -110,7 +112,7 @@ def test_folded_forward_runs_without_combine_launches(dev):
     with torch.no_grad():
         y = enc(x)
         tag = getattr(y, "_me_ln_stats", None)
-        assert tag is not None and tag[0].shape == (12, B * N, 2)
+        assert tag is not None and tag[0].shape == (3, B * N, 2)
         want = ops.row_stats(y.reshape(B * N, 768), 1e-6)
         got = ops.row_stats_combine(tag[0], 1e-6)
         assert rel_err(got[:, 0], want[:, 0]) < 2e-5

@@ -9,6 +9,7 @@ cp metatransformer_amd/libmetaenc.so /tmp/cur.so
 for rep in $(seq $REPS); do
   for arm in "$@"; do
     L=${arm%%=*}; P=${arm#*=}
+    [ "$P" = "metatransformer_amd/libmetaenc.so" ] && P=/tmp/cur.so      # (the in-tree library itself as an arm: its saved copy)
     cp $P metatransformer_amd/libmetaenc.so
     timeout 400 python bench.py $ARGS > /tmp/ab_$L.json 2> /tmp/ab_$L.err || { echo "$L: bench failed"; tail -3 /tmp/ab_$L.err; continue; }
     [ -n "$KEEP" ] && cp /tmp/ab_$L.json $KEEP/ab_${L}_$rep.json

@@ -9,6 +9,7 @@ cp metatransformer_amd/libmetaenc.so /tmp/cur.so
 for rep in $(seq $REPS); do
   for arm in "$@"; do
     L=${arm%%=*}; P=${arm#*=}
+    [ "$P" = "metatransformer_amd/libmetaenc.so" ] && P=/tmp/cur.so      # (the in-tree library itself as an arm: its saved copy)
     cp $P metatransformer_amd/libmetaenc.so
     timeout 400 python bench.py $ARGS > /tmp/abf_$L.json 2> /tmp/abf_$L.err || { echo "$L: bench failed"; tail -3 /tmp/abf_$L.err; continue; }
     [ -n "$KEEP" ] && cp /tmp/abf_$L.json $KEEP/abf_${L}_$rep.json

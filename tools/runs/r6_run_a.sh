@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r6a
 mkdir -p $O
 cd $R
-timeout 300 tools/_build/vmem_probe > $O/vmem_probe.txt 2>&1; echo "probe rc=$?"
-timeout 300 tools/_build/gemm_dev --iters 20 --check g3:50432:2304:768:0:8 g3:50432:768:768:2:8 g3:50432:3072:768:1:8 g3:50432:768:3072:2:8 > $O/seam_trace.txt 2>&1; echo "trace rc=$?"
+#timeout 300 tools/_build/vmem_probe > $O/vmem_probe.txt 2>&1; echo "probe rc=$?"
+#timeout 300 tools/_build/gemm_dev --iters 20 --check g3:50432:2304:768:0:8 g3:50432:768:768:2:8 g3:50432:3072:768:1:8 g3:50432:768:3072:2:8 > $O/seam_trace.txt 2>&1; echo "trace rc=$?"
 timeout 900 python -m pytest tests/test_gpu_round6.py -x -q -k "partials or refused or combine" > $O/tests_parts.txt 2>&1; echo "tests rc=$?"; tail -5 $O/tests_parts.txt
 timeout 600 python -m pytest tests/test_gpu_encoder.py -x -q -k "chains or folded or statistics" > $O/tests_fold.txt 2>&1; echo "tests2 rc=$?"; tail -3 $O/tests_fold.txt
 REPS=3 KEEP=$O bash tools/ab_fwd.sh parts=metatransformer_amd/libmetaenc.so combine=tools/_build_prod_noparts/libmetaenc.so > $O/ab_fwd.txt 2>&1
