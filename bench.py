@@ -61,7 +61,7 @@ def parse():
                          "and attention; roofline against the 157 TF f32-input MFMA peak")
     ap.add_argument("--fp32-mode", choices=["exact", "3xbf16"], default="exact",
                     help="with --dtype fp32: 3xbf16 = fp32-accurate arithmetic on the bf16 matrix pipe (ME_BF16X3: three bf16 products per "
-                         "Linear on hi / lo split operands, ~1e-5 relative; attention on the exact-fp32 kernels); roofline against 2500 / 3 TF")
+                         "Linear on hi / lo split operands, ~1e-5 relative; attention as three-product bf16 MFMA too -- me_attention_fwd_x3 / _bwd_x3 -- for head_dim 64, N > 64); roofline against 2500 / 3 TF")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-leg", action="store_true")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
@@ -352,8 +352,8 @@ def main():
         if with_wgrad and tn:
             f2 = sum(2.0 * m * n * k for m, n, k, _ in tn)
             ms2 = sum(t for *_, t in tn)
-            roof["wgrad_kernel"] = {"kernel": ("gemm_g3tn_kernel + fold on ME_BF16X3 planes: three launches per weight gradient, (hi,hi) + (lo,hi) + (hi,lo) accumulated by "
-                                               "beta = 1; `achieved` counts the bf16 flops as launched (3x the fp32 Linear's)" if x3 else
+            roof["wgrad_kernel"] = {"kernel": ("gemm_g3tn_x3_kernel + fold on ME_BF16X3 planes: ONE launch per weight gradient whose reduction runs over the three plane segments "
+                                               "(hi,hi) / (lo,hi) / (hi,lo), bias gradient on it (csrc/gemm3_x3.hip); `achieved` counts the bf16 flops as launched (3x the fp32 Linear's)" if x3 else
                                                "gemm_g128_kernel<float, TN> (exact-fp32 wgrad)" if f32 else
                                                "gemm_g3tn_kernel + splitk_reduce_kernel (wgrad dW = dY^T X with the bias-gradient column sums fused; 256x256x64 tiles, split-K folded in fixed order)"),
                                     "achieved": round(f2 / (ms2 * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
@@ -412,7 +412,7 @@ def main():
         "value": round(value, 2), "unit": "samples/s", "n_gpus": comm_info["world"] if comm_info else world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * step_s, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 as 3xbf16 (three bf16 MFMA products per Linear on hi / lo split operands, fp32 accumulate; attention, LayerNorm, GELU exact fp32)" if x3 else "f32" if f32 else ("bf16" if args.attn_dtype == "bf16" else "bf16 (attention forward in fp8 e4m3, fp32 softmax statistics)"),
+        "dtype": "f32 as 3xbf16 (three bf16 MFMA products per Linear AND per attention product on hi / lo split operands, fp32 accumulate; softmax, LayerNorm, GELU, residual stream fp32)" if x3 else "f32" if f32 else ("bf16" if args.attn_dtype == "bf16" else "bf16 (attention forward in fp8 e4m3, fp32 softmax statistics)"),
         "data": "synthetic",
         "config": {"workload": ("BASELINE config 2: " if is_metric else ("BASELINE config 4 (sequence-concat): " if args.workload == "mixed" else ""))
                                + f"Meta-Transformer-{model.capitalize()} {what}, tokens [{B},{N},{C}] {'fp32' if f32 else 'bf16'} per GPU, "

@@ -166,6 +166,13 @@ size_t me_gemm_workspace_bytes(const me_gemm_desc* d);
 int me_gemm_fuses_colsum(const me_gemm_desc* d);
 /* 1 if me_gemm(d) can serve d->row_stats (evaluated as if it were set) */
 int me_gemm_emits_row_stats(const me_gemm_desc* d);
+/* CUs that a communication library's kernels hold while gradient buckets are being reduced (RCCL: about one CU per channel).  Process-wide,
+ * 0 = none (the default); me_comm_init sets 16 for a communicator of more than one rank and me_comm_destroy clears it; returns the previous
+ * value.  It changes only how weight-gradient GEMMs (ME_GEMM_TN on the 256 x 256 family) are PLANNED: their split-K grid asks for exactly one
+ * workgroup per CU, so with any CU held the last workgroups run as a second round (+100 % per launch); with a reservation the reduction is
+ * cut into 256 - cus balanced static parts instead (cost ~cus / 256 of the launch).  Results are bit-reproducible per (shape, cus).  The
+ * workspace query covers either plan. */
+int me_gemm_reserve_cus(int cus);
 /* 1 if me_gemm(d) can serve d->row_parts (which must be set) */
 int me_gemm_takes_row_parts(const me_gemm_desc* d);
 int me_gemm(const me_gemm_desc* d, void* stream);
@@ -183,7 +190,8 @@ typedef struct me_gemm_profile_rec {
     float ms;          /* start of the (first) GEMM kernel to end of its last kernel (split-K fold included) */
     int32_t plan;      /* GEMM records: which kernel plan ran -- bits 0-3 the family (0 = exact-fp32 / generic 128 x 128 "g128", 2 = "g2b"
                         * 128 x 256 two workgroups per CU, 3 = "g2w" 256 x 256 K-step 32, 4 = "g3" 256 x 256 K-tile 64, resident when every
-                        * CU gets a tile), bit 4 = a split-K tail / whole-problem split ran with a fold, bits 8-15 = split-K parts; else 0 */
+                        * CU gets a tile), bit 4 = a split-K tail / whole-problem split ran with a fold, bit 5 = the balanced static partition of a weight
+                        * gradient (me_gemm_reserve_cus), bits 8-15 = split-K parts (bit 5: the most a tile gets); else 0 */
 } me_gemm_profile_rec;
 int me_gemm_profile_enable(int on);
 int me_gemm_profile_read(me_gemm_profile_rec* out, int max);

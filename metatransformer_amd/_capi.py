@@ -137,6 +137,7 @@ SIGNATURES = {
     "me_gemm_fuses_colsum": (c_int, [POINTER(GemmDesc)]),
     "me_gemm_emits_row_stats": (c_int, [POINTER(GemmDesc)]),
     "me_gemm_takes_row_parts": (c_int, [POINTER(GemmDesc)]),
+    "me_gemm_reserve_cus": (c_int, [c_int]),
     "me_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
     "me_gemm_profile_enable": (c_int, [c_int]),
     "me_gemm_profile_read": (c_int, [POINTER(GemmProfileRec), c_int]),

@@ -16,6 +16,8 @@
 //                                  interleaved into dwords so that LDS rows are again reduction-contiguous.
 #include "gemm_common.h"
 #include <string.h>
+#include <algorithm>
+#include <atomic>
 
 namespace {
 
@@ -242,8 +244,10 @@ __device__ __forceinline__ void fold_colsum(const GemmParams& p, const float* __
             const int64_t m = (int64_t)cb * 32 + (threadIdx.x & 31);
             const int jg = threadIdx.x >> 5;
             float s = 0.f;
+            // (balanced partition: the tn = 0 tile of this column's tile row left one partial row per part it was cut into)
+            const int np = p.sk_wgs ? sk_parts((int)(m >> 8) * p.tiles_n, p.sk_wgs, p.sk_upt, (int64_t)p.tiles_m * p.tiles_n * p.sk_upt) : n_part;
             if (m < p.M)
-                for (int j = jg; j < n_part; j += 8) s += cs_part[(int64_t)j * p.M + m];
+                for (int j = jg; j < np; j += 8) s += cs_part[(int64_t)j * p.M + m];
             red[jg][threadIdx.x & 31] = s;
             __syncthreads();
             if (threadIdx.x < 32 && m < p.M) {
@@ -317,7 +321,9 @@ __global__ __launch_bounds__(256) void splitk_fold_kernel(const GemmParams p, co
         if (RES == 1) r2 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.residual) + m * p.ldres + n);
         if (RES == 2) r4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + m * p.ldres + n);
         if (CST == 2) c4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + m * p.ldc + n);
-        f32x4 v = fold_slabs(slabs + m * p.N + n, S, sstride);
+        // (balanced partition: this tile's own slab count; a wave's 256 columns are one tile's)
+        const int St = p.sk_wgs ? sk_parts((int)(m >> 8) * p.tiles_n + (int)blockIdx.x, p.sk_wgs, p.sk_upt, (int64_t)p.tiles_m * p.tiles_n * p.sk_upt) : S;
+        f32x4 v = fold_slabs(slabs + m * p.N + n, St, sstride);
         v = v * p.alpha + bias4;
         if (ACT) v = gelu_for4(v, CST == 0 ? ME_BF16 : ME_F32);
         if (RES == 1) v += f32x4{__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u), __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
@@ -343,7 +349,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     if (q >= (int)(p.N / 4)) return;
     const int64_t n = (int64_t)q * 4;
     for (int64_t m = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); m < p.M; m += (int64_t)gridDim.y * 4) {
-        const f32x4 v = fold_slabs(slabs + m * p.N + n, S, sstride);
+        const int St = p.sk_wgs ? sk_parts((int)(m >> 8) * p.tiles_n + (int)blockIdx.x, p.sk_wgs, p.sk_upt, (int64_t)p.tiles_m * p.tiles_n * p.sk_upt) : S;
+        const f32x4 v = fold_slabs(slabs + m * p.N + n, St, sstride);
         if (LIN) epilogue_quad_lin(p, m, n, v);
         else epilogue_quad(p, m, n, v);
     }
@@ -404,7 +411,13 @@ struct GemmPlan {
     // NT tail split: the last tail_rows rows run as their own split-K problem (see plan_gemm)
     int64_t tail_rows;
     int tail_split, tail_ksteps;
+    // g3 wgrad next to a communication kernel (me_gemm_reserve_cus): the balanced static partition over sk_wgs workgroups of sk_upt
+    // K-tile pairs per tile (gemm3.hip, gemm_g3tn_sk_kernel); split_k then = the most slabs a tile gets
+    int sk_wgs = 0, sk_upt = 0;
 };
+
+// CUs a communication library's kernels hold while gradient buckets are reduced (me_gemm_reserve_cus; me_comm_init / _destroy set it)
+std::atomic<int> g_reserved_cus{0};
 
 #ifndef ME_SMALL_SPLIT_DEN
 #define ME_SMALL_SPLIT_DEN 2                     // whole-problem split-K when tiles <= slots / this.  Measured on the reference's shapes
@@ -414,7 +427,7 @@ struct GemmPlan {
 #ifndef ME_SMALL_SPLIT_LONGK
 #define ME_SMALL_SPLIT_LONGK 192
 #endif
-GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
+GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p, bool allow_sk = true) {
     GemmPlan pl{0, 0, 128, 0, 1, 0, 0, 0, 1, 0};
     const GemmDev dev = gemm_dev();
     const int ffam = dev.family, fbn = dev.bn;
@@ -463,16 +476,30 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p) {
         pl.bn = 256; pl.bm = 256; pl.kstep = 64;
         const int64_t tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
         const int nkt = (int)((d->K + 63) / 64);
-        int s = (int)(256 / tiles);
+        // workgroup slots: every CU, less the ones a communication kernel holds while this launch runs (me_gemm_reserve_cus) -- with
+        // exactly one item per CU, ANY held CU sends the launch's last workgroups into a second round (profiles/r05_contention.txt)
+        const int reserved = g_reserved_cus.load();
+        const int slots = 256 - (reserved > 0 ? (reserved < 128 ? reserved : 128) : 0);
+        int s = (int)(slots / tiles);
         if (s < 1) s = 1;
         int ktp = (nkt + s - 1) / s;
         ktp += ktp & 1;
         if (ktp < 2) ktp = 2;
         pl.ksteps_per_split = ktp;
         pl.split_k = (nkt + ktp - 1) / ktp;
-        pl.ws_bytes = (size_t)pl.split_k * (size_t)g3_tn_slab_stride(d->M, d->N) * sizeof(float);
-        if (d->colsum_a)                  // partial column sums of A: one [M] row per (split, N-tile)
-            pl.ws_bytes += (size_t)pl.split_k * (size_t)((d->N + 255) / 256) * (size_t)d->M * sizeof(float);
+        int slabs = pl.split_k;
+        const int upt = (nkt + 1) / 2;                                    // K-tile pairs per tile
+        if (reserved > 0 && tiles <= slots && tiles * upt >= 2 * (int64_t)slots && tiles * upt < (1ll << 30)) {
+            // the uniform split quantises badly on slots that are not a multiple of the tile count (36 tiles on 240 slots: 6 x 132 K-tiles
+            // instead of 7 x 114); the balanced partition carries slots / 256 of the load per workgroup whatever the count
+            int smax = 1;
+            for (int t = 0; t < (int)tiles; ++t) smax = std::max(smax, sk_parts(t, slots, upt, tiles * upt));
+            if (allow_sk) { pl.sk_wgs = slots; pl.sk_upt = upt; pl.split_k = smax; }
+            slabs = std::max(slabs, smax);                                // (the workspace query covers both forms)
+        }
+        pl.ws_bytes = (size_t)slabs * (size_t)g3_tn_slab_stride(d->M, d->N) * sizeof(float);
+        if (d->colsum_a)                  // partial column sums of A: one [M] row per (split, N-tile) / per part of the tn = 0 tiles
+            pl.ws_bytes += (size_t)slabs * (size_t)((d->N + 255) / 256) * (size_t)d->M * sizeof(float);
 #if G3_TN_FOLD
         pl.ws_bytes += 256 + (size_t)((d->M + 255) / 256) * sizeof(unsigned);      // tile-row counters of the in-kernel fold (behind the rest, 256-byte aligned)
 #endif
@@ -618,6 +645,7 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     ME_CHECK_ARG(!d->row_affine || d->op == ME_GEMM_NT, "me_gemm: row_affine (folded LayerNorm) is defined for ME_GEMM_NT");
     p.row_affine = d->row_affine; p.col_shift = d->col_shift;
     p.row_nparts = 0; p.row_eps = 0.0f;
+    p.sk_wgs = 0; p.sk_upt = 0;
     if (d->row_parts) {      // the same fold, its pairs formed in the kernel from a previous launch's row_stats partials
         ME_CHECK_ARG(!d->row_affine && d->col_shift && d->op == ME_GEMM_NT, "me_gemm: row_parts replaces row_affine (NT, with col_shift)");
         ME_CHECK_ARG(d->row_nparts >= 1 && d->row_nparts <= 4 && (int64_t)d->row_nparts * ME_STATS_GROUP == d->K && d->row_eps >= 0.0f,
@@ -669,6 +697,11 @@ extern "C" int me_gemm_emits_row_stats(const me_gemm_desc* d) {
     return g3_emits_row_stats(p) ? 1 : 0;
 }
 
+extern "C" int me_gemm_reserve_cus(int cus) {
+    const int c = cus < 0 ? 0 : (cus > 128 ? 128 : cus);
+    return g_reserved_cus.exchange(c);
+}
+
 extern "C" int me_gemm_takes_row_parts(const me_gemm_desc* d) {
     GemmParams p;
     if (!d || d->op != ME_GEMM_NT || d->ab_dtype != ME_BF16 || !d->row_parts || fill_params(d, p) != ME_OK) return 0;
@@ -695,12 +728,12 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out, TnLaunch
     GemmParams p;
     int rc = fill_params(d, p);
     if (rc) return rc;
-    GemmPlan pl = plan_gemm(d, p);
+    GemmPlan pl = plan_gemm(d, p, tn_launch == nullptr);      // (the custom wgrad launchers -- patch embed, three planes -- walk uniform splits)
     if (tn_launch && !(pl.family == 4 && d->op == ME_GEMM_TN && !G3_TN_FOLD)) return ME_ERR_UNSUPPORTED;
     {   // me_gemm_profile_rec.plan
         const bool have_ws = pl.ws_bytes && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes;
         const int parts = pl.split_k > 1 ? pl.split_k : (pl.tail_rows > 0 ? pl.tail_split : 1);
-        *plan_out = (pl.family & 15) | ((have_ws && parts > 1) ? 16 : 0) | ((have_ws ? parts : 1) << 8);
+        *plan_out = (pl.family & 15) | ((have_ws && parts > 1) ? 16 : 0) | (pl.sk_wgs ? 32 : 0) | ((have_ws ? parts : 1) << 8);
     }
     if (d->colsum_a)
         ME_CHECK_ARG(((pl.family == 2 && pl.split_k > 1) || pl.family == 4) && d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes,
@@ -738,7 +771,13 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out, TnLaunch
                 return launch_g3_tn_fold(pf, stream);
             }
 #endif
-            rc = tn_launch ? tn_launch(ps, stream, tn_ctx) : launch_g3_tn(ps, stream);
+            if (pl.sk_wgs) {
+                ps.sk_wgs = pl.sk_wgs; ps.sk_upt = pl.sk_upt;
+                rc = launch_g3_tn_sk(ps, stream);
+                p.sk_wgs = pl.sk_wgs; p.sk_upt = pl.sk_upt;      // (the fold sums each tile's own number of slabs)
+            } else {
+                rc = tn_launch ? tn_launch(ps, stream, tn_ctx) : launch_g3_tn(ps, stream);
+            }
             if (rc) return rc;
             p.split_k = 1;
             const int64_t quads = d->M * (d->N / 4);

@@ -975,6 +975,75 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 
+// ---- wgrad, balanced static partition ("stream-K" with a FIXED assignment): p.sk_wgs workgroups share the tile-major list of
+// (tile, K-tile pair) units evenly, so a workgroup's range may end one tile and begin the next (two segments, two slabs).  Why: the
+// (tile, split) grid above gives every workgroup one whole item and wants all 256 CUs at once; next to a communication kernel that holds R
+// CUs its last R workgroups run as a SECOND ROUND (+100 % per launch, +4 % per train step for any R = 8 .. 64: profiles/r05_contention.txt), and
+// a uniform split for 256 - R slots quantises badly (36 tiles on 240 slots: 6 parts of 132 K-tiles instead of 7 of 114 = +16 %).  Here any
+// number of workgroups carries the same load (36 x 394 pairs on 240: 59.1 pairs each = +7 % against 256), parts stay static -- a part is a
+// fixed K range and a fixed slab, the fold sums a tile's slabs in K order -- so the result is bit-reproducible per (shape, workgroups).
+// The bias gradient's column sums are taken by the tn = 0 tiles over their own K ranges ([part][M] rows; with ragged K ranges the N-tiles of a
+// tile row no longer stage the same rows at the same time, so they cannot share them round-robin as above).
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g3tn_sk_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);       // neighbours in the unit list share an XCD
+    const int tiles = p.tiles_m * p.tiles_n, W = p.sk_wgs, U = p.sk_upt;
+    const int64_t TU = (int64_t)tiles * U;
+    int64_t u0 = __builtin_amdgcn_readfirstlane((int)((int64_t)wgid * TU / W));
+    const int64_t u1 = __builtin_amdgcn_readfirstlane((int)((int64_t)(wgid + 1) * TU / W));
+
+    G3State s;
+    g3_init_lane_tn(s, p, smem, wave, lane);
+    const G3Src null = g3_null_src(p);
+    const bool do_cs = p.colsum_ws != nullptr;
+    while (u0 < u1) {
+        const int tile = __builtin_amdgcn_readfirstlane((int)(u0 / U));
+        const int64_t tu0 = (int64_t)tile * U;
+        const int64_t ue = u1 < tu0 + U ? u1 : tu0 + U;
+        const int kt0 = (int)(u0 - tu0) * 2, kt1 = (int)(ue - tu0) * 2;
+        const int part = wgid - sk_first(tile, W, U, TU);
+        const int tm = __builtin_amdgcn_readfirstlane(tile / p.tiles_n), tn = tile - tm * p.tiles_n;
+        const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
+        const G3Src src = g3_make_src_tn(p, tm, tn);
+        g3_zero(s);
+        g3_issue<0>(s, src, 0, kt0); g3_issue<1>(s, src, 0, kt0); g3_issue<2>(s, src, 0, kt0); g3_issue<3>(s, src, 0, kt0);
+        g3_issue<0>(s, src, 1, kt0 + 1); g3_issue<1>(s, src, 1, kt0 + 1); g3_issue<2>(s, src, 1, kt0 + 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        const bool cs = do_cs && tn == 0;
+        s.cs[0] = s.cs[1] = 0.f;
+        for (int kt = kt0; kt < kt1 - 2; kt += 2) {
+            g3_ktile<0, true>(s, src, kt + 1, src, kt + 2, cs);
+            g3_ktile<1, true>(s, src, kt + 2, src, kt + 3, cs);
+        }
+        g3_ktile<0, true>(s, src, kt1 - 1, null, 0, cs);
+        g3_ktile<1, true>(s, null, 0, null, 0, cs);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wr == 0) __builtin_amdgcn_s_barrier();          // (both wave rows are past their last fragment read: the next segment may refill the LDS)
+        if (cs) {
+            float c0 = s.cs[0], c1 = s.cs[1];
+            c0 += __shfl_xor(c0, 16, 64); c0 += __shfl_xor(c0, 32, 64);
+            c1 += __shfl_xor(c1, 16, 64); c1 += __shfl_xor(c1, 32, 64);
+            if (lane < 16) {
+                float* row = p.colsum_ws + (int64_t)part * p.M;
+                const int wcol = wave & 3;
+                const int64_t ma = m0 + wr * 128 + wcol * 16 + lane, mb = ma + 64;
+                if (ma < p.M) row[ma] = c0;
+                if (mb < p.M) row[mb] = c1;
+            }
+        }
+        g3_epilogue<5>(p, s, m0, n0, g3_lane_now(), reinterpret_cast<float*>(p.C) + (int64_t)part * p.slab_stride, 0);
+        u0 = ue;
+    }
+}
+
+
 // The work counters of the resident kernel: every stream gets its own set (launches on a stream are serialised, and the
 // kernel leaves its counters at zero), handed out on the host from a per-device pool (keyed by the STREAM's device) that is
 // allocated and zeroed once, at the first resident launch on the device; a set is zeroed again, on its own stream, when it is
@@ -1126,6 +1195,15 @@ int launch_g3_tn(const GemmParams& p, hipStream_t stream) {
     const int nwg = p.tiles_m * p.tiles_n * p.split_k;
     hipLaunchKernelGGL(gemm_g3tn_kernel<false>, dim3((unsigned)nwg), dim3(512), G3_LDS, stream, p);
     ME_CHECK_LAUNCH("me_gemm(g3 tn)");
+    return ME_OK;
+}
+
+int launch_g3_tn_sk(const GemmParams& p, hipStream_t stream) {
+    static OncePerDevice once;
+    if (once.need())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3tn_sk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+    hipLaunchKernelGGL(gemm_g3tn_sk_kernel, dim3((unsigned)p.sk_wgs), dim3(512), G3_LDS, stream, p);
+    ME_CHECK_LAUNCH("me_gemm(g3 tn, balanced partition)");
     return ME_OK;
 }
 

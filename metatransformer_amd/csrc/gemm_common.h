@@ -29,10 +29,19 @@ struct GemmParams {
                                             // resident kernel only (g3_takes_row_parts); the pairs are LayerNorm(K = 64 row_nparts, row_eps)'s
     const float* col_shift;                 // ... and s[n] = sum_k W'[n, k]
     float* tn_colsum_out;                   // g3 wgrad with the in-kernel fold: where the folded column sums of A go (follows C's beta), or null
+    int sk_wgs, sk_upt;                     // g3 wgrad, balanced static partition ("stream-K", gemm3.hip: gemm_g3tn_sk_kernel): sk_wgs > 0 workgroups share
+                                            // tiles x sk_upt units (K-tile pairs) evenly, crossing tile boundaries; a tile then has sk_parts(tile) slabs
     float* row_stats;                       // resident EPI 2 kernel only (me_gemm_desc.row_stats): per-row partial statistics of the OUTPUT,
                                             // [N / 64][M] pairs (mean, M2) over 64-column groups, or null
 };
 
+
+// ---- balanced static partition of a split-K weight gradient (GemmParams::sk_wgs): workgroup w owns units [w TU / W, (w + 1) TU / W) of the
+// tile-major list of (tile, K-tile pair) units (T tiles x U pairs each).  sk_owner(u) = the workgroup that holds unit u; a tile's slabs are
+// numbered in K order: part = owner - sk_owner(first unit of the tile), sk_parts of them.  Integer arithmetic only, the same on host and device.
+__host__ __device__ static inline int sk_owner(int64_t u, int W, int64_t TU) { return (int)(((u + 1) * W - 1) / TU); }
+__host__ __device__ static inline int sk_first(int tile, int W, int U, int64_t TU) { return sk_owner((int64_t)tile * U, W, TU); }
+__host__ __device__ static inline int sk_parts(int tile, int W, int U, int64_t TU) { return sk_owner((int64_t)(tile + 1) * U - 1, W, TU) - sk_first(tile, W, U, TU) + 1; }
 
 // One accumulator quad: 4 consecutive output columns n..n+3 of output row m (see include/metaenc.h for the order).
 __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, int64_t n, f32x4 v) {
@@ -211,6 +220,7 @@ bool g3_emits_row_stats(const GemmParams& p);          // will launch_g3 run the
 bool g3_takes_row_parts(const GemmParams& p);          // ... the resident folded-LayerNorm epilogue that consumes such partials directly (p.row_nparts)?
 size_t g3_workspace_bytes();
 int launch_g3_tn(const GemmParams& p, hipStream_t stream);      // p.split_k slabs into p.C, p.ksteps_per_split K-tiles of 64 each
+int launch_g3_tn_sk(const GemmParams& p, hipStream_t stream);   // the balanced static partition (p.sk_wgs workgroups; p.split_k = the most slabs a tile gets)
 // A/B arm, measured and NOT shipped (round 4): -DG3_TN_FOLD=1 = the split-K fold of the wgrad kernel INSIDE its launch.  Same-box
 // result: wgrad 211 us per launch against 176 us for kernel + separate fold launch (train step 32.8 vs 31.35 ms): the S partial
 // tiles of a tile are 64 MB per launch either way, and inside the launch their write-through, the wait for the tile row and the

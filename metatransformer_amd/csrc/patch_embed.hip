@@ -445,9 +445,21 @@ extern "C" int me_patch_embed_wgrad(const me_patch_embed_desc* d, const void* dy
     ME_CHECK_ARG(me_dtype_ok(d->x_dtype) && me_dtype_ok(d->w_dtype) && me_dtype_ok(dw_dtype), "me_patch_embed_wgrad: bad dtype");
     ME_CHECK_ARG(d->workspace && (size_t)d->workspace_bytes >= me_patch_embed_wgrad_workspace_bytes(d, dw_dtype, dbias != nullptr),
                  "me_patch_embed_wgrad: workspace of me_patch_embed_wgrad_workspace_bytes() required");
+    //  the column sums follow C's beta only for beta = 0 / 1 (me_colsum accumulates or overwrites)
+    ME_CHECK_ARG(beta == 0.0f || beta == 1.0f || !dbias, "me_patch_embed_wgrad: beta must be 0 or 1 when dbias is wanted");
     char* ws = reinterpret_cast<char*>(d->workspace);
     me_gemm_desc g = pe_wgrad_desc(d, s, dy, ld_dy, d->x, dw, dw_dtype, dbias, beta);
     const bool fused = pe_wgrad_fusable(d, s, g);
+    {   //  the workspace query plans with dense placeholder operands; a strided / misaligned dy can send THIS call down the
+        // two-pass route, whose gathered columns the query did not count -- size the real route and refuse instead of writing past the end
+        size_t need = (fused ? 0 : pe_cols_bytes(d, s)) + ((me_gemm_workspace_bytes(&g) + 255) & ~(size_t)255);
+        if (dbias) need += me_colsum_workspace(d->Cout);
+        if ((size_t)d->workspace_bytes < need) {
+            me_set_error("me_patch_embed_wgrad: workspace too small for this dy (strided / misaligned dy takes the two-pass route: %zu bytes needed, %lld given)",
+                         need, (long long)d->workspace_bytes);
+            return ME_ERR_WORKSPACE;
+        }
+    }
     if (!fused) {
         rc = me_patchify(d->x, d->x_dtype, ws, d->w_dtype, d->B, d->Cin, d->T, d->H, d->W, d->kt, d->kh, d->kw, d->st, d->sh, d->sw, stream_);
         if (rc) return rc;

@@ -576,14 +576,18 @@ class Block(nn.Module):
         self.attn_fp8 = False       # True: e4m3 attention forward (me_attention_fwd_fp8; bf16 compute, head_dim 64) -- config 5
         self.fold_norm = True       # (True: when it pays, see _desc; "always": whenever it is legal; False: never)  inference (no gradient wanted), bf16 compute on a bf16 token stream: norm1 / norm2 folded into
                                     # qkv / fc1 (me_row_stats + row_affine GEMM epilogue instead of me_layernorm_fwd + GEMM)
-        # fp32 compute: "exact" = the exact-fp32 MFMA (157 TF peak; parity mode, the default), "3xbf16" = fp32-accurate arithmetic on
-        # the bf16 matrix pipe (three bf16 products per Linear on hi / lo split operands, ~1e-5 relative; plain blocks -- no windowed /
-        # stochastic / layer-scale-gradient path -- with C and hidden multiples of 256; anything else runs exact).  Also selected by
-        # compute_dtype = "fp32_3xbf16".
-        self.fp32_mode = "exact"
+        # fp32 compute: "3xbf16" (the default since round 6: Block.default_fp32_mode) = fp32-accurate arithmetic on the bf16 matrix pipe --
+        # three bf16 products per Linear and per attention product on hi / lo split operands, ~1e-5 of the reference (bound 1e-4; the
+        # north star's fp32 bound is 1e-3), 2.3 .. 2.9x the exact path on every fp32 recipe of the reference (all of which run the plain
+        # Block: frozen encoder, no dropout -- SURVEY appendix B); "exact" = the exact-fp32 MFMA (157 TF peak; ~1e-6).  The three-product
+        # form covers plain blocks with C and hidden multiples of 256; windowed / stochastic / layer-scale-gradient paths and other
+        # widths run exact whatever the mode (uses_3xbf16 tells).  Also selected by compute_dtype = "fp32_3xbf16".
+        self.fp32_mode = Block.default_fp32_mode
         self._wcache = _WeightCache()
         self.chain_stats = True     # folded inference: LayerNorm statistics from the proj / fc2 epilogues, handed from block to block
         self._stats_in = self._stats_out = None      # (per-call hand-over between forward() and the autograd Function)
+
+    default_fp32_mode = "3xbf16"      # what a new Block's fp32_mode starts as; `Block.default_fp32_mode = "exact"` (or set_fp32_mode(model, "exact")) restores round 5's
 
     def uses_3xbf16(self, cdt, rdt) -> bool:
         """does the plain (one-call) path of this block run in the fp32-accurate three-product mode for these dtypes?"""
@@ -728,10 +732,10 @@ def build_encoder(depth: int = 12, dim: int = 768, num_heads: int = 12, mlp_rati
 
 def set_fp32_mode(model: nn.Module, mode: str) -> int:
     """Select the fp32 arithmetic of every Block inside `model` (any module tree: the reference's `nn.Sequential` encoder, or a task model
-    that owns one): "exact" -- the exact-fp32 MFMA, the parity default -- or "3xbf16" -- fp32-accurate (~5e-6 of the reference, bound 1e-4;
-    the north star's fp32 bound is 1e-3) on the bf16 matrix pipe: 2.3 .. 2.9x per step on the reference's fp32 recipes
-    (profiles/r05_refshapes.txt).  Returns the number of Blocks set.  One line at a call site that runs the encoder in fp32
-    (README.md:113-150): `metatransformer_amd.set_fp32_mode(encoder, "3xbf16")`."""
+    that owns one): "3xbf16" -- the default: fp32-accurate (~5e-6 of the reference, bound 1e-4; the north star's fp32 bound is 1e-3) on
+    the bf16 matrix pipe, 2.3 .. 2.9x per step on the reference's fp32 recipes (profiles/r05_refshapes.txt) -- or "exact" -- the
+    exact-fp32 MFMA (~1e-6): `metatransformer_amd.set_fp32_mode(encoder, "exact")` is the one line that restores it.  Returns the number
+    of Blocks set."""
     if mode not in ("exact", "3xbf16"):
         raise MetaEncError(f"fp32 mode must be 'exact' or '3xbf16' (got {mode!r})")
     n = 0
@@ -809,7 +813,12 @@ def encoder_forward_inference(encoder: nn.Sequential, x: torch.Tensor, graph: Op
         import weakref
         _graphs = weakref.WeakKeyDictionary()
     per_enc = _graphs.setdefault(encoder, {})
-    gkey = (B, N, C, x.dtype, x.device)
+    #  what the blocks RESOLVE to is part of the key: under torch.autocast the same encoder computes in another dtype, and a
+    # graph captured outside autocast must not be replayed inside it (or the reverse).  The static x / y buffers of a cached graph are
+    # shared by every caller with the same key: replay is serialised on the calling thread's current stream (copy in, replay, clone out
+    # are enqueued on it back to back); concurrent callers on DIFFERENT streams must pass graph=False or use their own encoder object.
+    cdts = tuple((str(b._compute_dtype(x)), b.uses_3xbf16(b._compute_dtype(x), x.dtype)) for b in blocks)
+    gkey = (B, N, C, x.dtype, x.device, cdts)
     wkey = _encoder_weight_key(blocks)
     g = per_enc.get(gkey)
     if g is None or g.wkey != wkey:

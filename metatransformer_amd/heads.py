@@ -260,10 +260,16 @@ def pack_encoder(encoder: nn.Sequential, device=None, warm: bool = True):
     if warm:
         for b in encoder:
             b._wcache.bind(b)
-            cdt = b.compute_dtype or torch.bfloat16
+            # the dtype the Block will compute in (compute_dtype may be the STRING "fp32_3xbf16", which is not a torch dtype)
+            cdt = torch.float32 if b.compute_dtype == "fp32_3xbf16" else (b.compute_dtype or torch.bfloat16)
+            x3 = b.uses_3xbf16(cdt, torch.float32)          # fp32-accurate mode: its compute copies are the three-plane split weights
             for name, w in (("qkv", b.attn.qkv.weight), ("proj", b.attn.proj.weight), ("fc1", b.mlp.fc1.weight), ("fc2", b.mlp.fc2.weight)):
-                b._wcache.fwd(name, w, cdt)
-                b._wcache.transposed(name, w, cdt)
+                if x3:
+                    b._wcache.split3(name, w, False)
+                    b._wcache.split3(name, w, True)
+                else:
+                    b._wcache.fwd(name, w, cdt)
+                    b._wcache.transposed(name, w, cdt)
     return flat
 
 

@@ -151,9 +151,9 @@ def test_set_fp32_mode_reaches_every_block_of_a_task_model():
     import torch
     enc = M.build_encoder(3, 256, 4)
     model = torch.nn.ModuleDict({"tokenizer": torch.nn.Linear(7, 256), "encoder": enc, "head": torch.nn.Linear(256, 10)})
-    assert all(b.fp32_mode == "exact" for b in enc)
-    assert M.set_fp32_mode(model, "3xbf16") == 3 and all(b.fp32_mode == "3xbf16" for b in enc)
+    assert all(b.fp32_mode == "3xbf16" for b in enc)              # the default since round 6 (Block.default_fp32_mode)
     assert M.set_fp32_mode(enc, "exact") == 3 and all(b.fp32_mode == "exact" for b in enc)
+    assert M.set_fp32_mode(model, "3xbf16") == 3 and all(b.fp32_mode == "3xbf16" for b in enc)
     with pytest.raises(M.MetaEncError):
         M.set_fp32_mode(model, "tf32")
 

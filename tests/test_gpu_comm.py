@@ -297,3 +297,57 @@ def test_gradients_bit_identical_while_a_communication_kernel_holds_cus():
         red.remove()
     for R in (16, 40):
         assert torch.equal(results[R][0], results[0][0]) and torch.equal(results[R][1], results[0][1]), R
+
+
+def test_gradients_reproducible_under_a_cu_reservation_and_a_hog():
+    """Round 6: with me_gemm_reserve_cus(16) (what me_comm_init sets for world > 1) the weight gradients are planned as 240 balanced static
+    parts (gemm_g3tn_sk_kernel).  Parts are a fixed K range and a fixed slab each, so the gradients are bit-identical run to run and with or
+    without a kernel holding CUs beside backward -- and equal the one-item-per-CU plan's up to fp32 summation order."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import contention
+    if not os.path.isfile(contention.HOG):
+        pytest.skip("tools/_build/libcuhog.so not built (python __graft_entry__.py builds it)")
+    import metatransformer_amd as M
+    from metatransformer_amd import _capi, parallel
+    dev = torch.device("cuda:0")
+    lib, capi = contention.load_hog(), _capi.load()
+
+    def grads(reserve, R):
+        prev = capi.me_gemm_reserve_cus(reserve)
+        try:
+            comm = contention.HogComm(lib, R, 20.0, dev)
+            torch.manual_seed(0)
+            enc = M.build_encoder(2, 768, 12).to(dev)
+            for p in enc.parameters():
+                if p.dim() == 2:
+                    torch.nn.init.normal_(p, std=0.02)
+            for blk in enc:
+                blk.compute_dtype = torch.bfloat16
+            enc.train()
+            fl = parallel.FlatParams(enc.named_parameters())
+            red = parallel.OverlappedGradReducer(fl, comm=comm, force=True, bucket_bytes=8 << 20)
+            g = torch.Generator().manual_seed(5)
+            x = torch.randn(256, 197, 768, generator=g).to(dev).bfloat16().requires_grad_(True)
+            gy = (torch.randn(256, 197, 768, generator=g) / 1000).to(dev).bfloat16()
+            out = []
+            for _ in range(2):
+                fl.zero_grad()
+                x.grad = None
+                enc(x).backward(gy)
+                red.finish()
+                torch.cuda.synchronize()
+                out.append((fl.flat_grad.clone(), x.grad.clone()))
+            red.remove()
+            return out
+        finally:
+            capi.me_gemm_reserve_cus(prev)
+
+    base = grads(0, 0)
+    quiet = grads(16, 0)
+    hogged = grads(16, 16)
+    assert torch.equal(quiet[0][0], quiet[1][0])                                  # run to run
+    for a, b in zip(quiet, hogged):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])                # with a kernel holding 16 CUs beside backward
+    assert torch.equal(base[0][1], quiet[0][1])                                   # dL/dx does not depend on the weight-gradient plan
+    err = float((quiet[0][0] - base[0][0]).abs().max() / base[0][0].abs().max())
+    assert 0.0 < err < 1e-5, err                                                  # same sums, another (fixed) order

@@ -205,3 +205,74 @@ def test_3xbf16_gemm_at_config2_rows(dev, M_rows, N_out, K):
     ref = ad.double() @ wd.double().t() + bias.to(dev).double()
     check_close(y, ref, TOL_3X, "3xbf16 NT at 50 432 rows")
     assert rel_err(y, ref) < 3e-5
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r5
+def test_overlapped_optimizer_refuses_a_block_used_twice(dev):
+    """FusedAdamW(overlap=True) updates a Block's parameters as soon as backward has written their gradients; a Block that runs twice in
+    one backward (shared encoder, tied weights) would get its second gradient after that update -- it must raise, not train on"""
+    from metatransformer_amd import parallel
+    enc = make_encoder(1, 256, 4, dev).train()
+    for b in enc:
+        b.compute_dtype = torch.bfloat16
+    flat = parallel.FlatParams(enc.named_parameters(), no_decay=parallel.no_decay_rule)
+    opt = parallel.FusedAdamW(flat, lr=1e-3, overlap=True)
+    x = rnd(4, 64, 256, seed=2).to(dev).bfloat16().requires_grad_(True)
+    flat.zero_grad()
+    y = enc(enc(x))                                   # the same Block twice
+    with pytest.raises(_capi.MetaEncError, match="second gradient"):
+        y.sum().backward()
+    del opt
+
+
+def test_pack_encoder_warms_the_three_product_copies(dev):
+    """compute_dtype = "fp32_3xbf16" is a string, not a torch dtype: pack_encoder(warm=True) must build the split three-plane weight
+    copies that mode reads (it used to hand the string to the bf16 cast)"""
+    from metatransformer_amd import heads
+    enc = make_encoder(2, 256, 4, dev)
+    for b in enc:
+        b.compute_dtype = "fp32_3xbf16"
+    flat = heads.pack_encoder(enc, warm=True)
+    assert flat.numel > 0
+    for b in enc:
+        assert all((n, t, dev) in b._wcache._x3 or (n, t, torch.device("cuda", 0)) in b._wcache._x3 for n in ("qkv", "proj", "fc1", "fc2") for t in (False, True))
+    x = rnd(2, 70, 256, seed=3).to(dev)
+    with torch.no_grad():
+        y = enc(x)
+    sd = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    check_close(y, bo.encoder_forward(x.cpu(), sd, 4), TOL_3X, "packed 3xbf16 encoder")
+
+
+# ------------------------------------------------------------------------------------------------ weight gradients as balanced static parts
+@pytest.mark.parametrize("Mo,No,K,reserve", [(2304, 768, 50432, 16), (768, 3072, 50432, 16), (3072, 768, 50432, 8), (768, 768, 50432, 32),
+                                             (768, 768, 33 * 197, 16), (1024, 4096, 65536, 16), (768, 2304, 50432, 64)])
+def test_wgrad_balanced_partition_vs_fp64(dev, Mo, No, K, reserve):
+    """me_gemm_reserve_cus(R): ME_GEMM_TN problems of the 256 x 256 family run as 256 - R balanced static parts (gemm_g3tn_sk_kernel: a
+    workgroup's K range may end one tile and begin the next; a tile's slabs are folded in K order).  dW and the fused bias gradient against
+    fp64 on the same bf16 operands, beta = 0 and 1, deterministic, and the plan is the one reported (me_gemm_profile_rec.plan bit 5)."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(Mo + No + reserve)
+    dy = torch.randn(K, Mo, generator=g).bfloat16().to(dev)
+    x = torch.randn(K, No, generator=g).bfloat16().to(dev)
+    ref = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    prev = lib.me_gemm_reserve_cus(reserve)
+    try:
+        lib.me_gemm_profile_enable(1)
+        dw, db = ops.gemm(dy, x, op=_capi.ME_GEMM_TN, out_dtype=torch.float32, want_colsum_a=True)
+        recs = (_capi.GemmProfileRec * 8)()
+        n = lib.me_gemm_profile_read(recs, 8)
+        lib.me_gemm_profile_enable(0)
+        assert n >= 1 and (recs[0].plan & 15) == 4 and (recs[0].plan & 32), hex(recs[0].plan)
+        dw2, db2 = ops.gemm(dy, x, op=_capi.ME_GEMM_TN, out_dtype=torch.float32, want_colsum_a=True)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+        acc, accb = dw.clone(), db.clone()
+        ops.gemm(dy, x, op=_capi.ME_GEMM_TN, out=acc, beta=1.0, want_colsum_a=True, colsum_out=accb)
+    finally:
+        lib.me_gemm_reserve_cus(prev)
+    check_close(dw, ref, 2e-5, "dW, balanced parts")
+    check_close(db, ref_b, 2e-5, "db, balanced parts")
+    check_close(acc, 2 * ref, 2e-5, "dW accumulated")
+    check_close(accb, 2 * ref_b, 2e-5, "db accumulated")
+    dw0, db0 = ops.gemm(dy, x, op=_capi.ME_GEMM_TN, out_dtype=torch.float32, want_colsum_a=True)      # the one-item-per-CU plan
+    assert rel_err(dw, dw0) < 1e-5 and rel_err(db, db0) < 1e-5

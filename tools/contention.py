@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--gbps", type=float, default=90.0)
     ap.add_argument("--out", default="")
+    ap.add_argument("--reserve", default="0", help="me_gemm_reserve_cus per run: a number, or 'R' = the CUs held (what me_comm_init does with 16)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = load_hog()
@@ -100,9 +101,12 @@ def main():
              f"(bucket bytes / {a.gbps:.0f} GB/s each, launched from the reducer's bucket hooks on its own stream; optimizer joins)",
              f"# device: {torch.cuda.get_device_name(0)};  {a.steps} steps per measurement, best of 3;  per-kernel columns: mean HIP-event "
              f"duration (us) inside that (overlapped) step",
+             f"# me_gemm_reserve_cus = {a.reserve} ('R': the CUs held; 0: round 5's one-item-per-CU weight-gradient grid)",
              f"{'R (CUs held)':>12} {'ms/step':>9} {'vs R=0':>8} {'held ms/step':>13} {'NT gemm':>9} {'wgrad':>9} {'attn bwd':>9} {'LN bwd':>8}"]
     base = None
     for R in [int(v) for v in a.cus.split(",")]:
+        res = R if a.reserve == "R" else int(a.reserve)
+        _capi.load().me_gemm_reserve_cus(res)       # (round 6: weight gradients planned as 256 - res balanced static parts)
         comm = HogComm(lib, R, a.gbps, dev)
         step, _ = build_step(dev, comm)
         for _ in range(3):
@@ -134,6 +138,7 @@ def main():
         print(lines[-1], flush=True)
         del step, comm
         torch.cuda.empty_cache()
+    _capi.load().me_gemm_reserve_cus(0)
     text = "\n".join(lines) + "\n"
     if a.out:
         with open(a.out, "w") as f:

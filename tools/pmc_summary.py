@@ -3,6 +3,18 @@ HBM traffic = 2 * FETCH_SIZE + WRITE_SIZE  (KB; on gfx950 FETCH_SIZE counts 64 B
 streams -- MI355X_MICROARCH.md "HBM" -- hence the factor 2; WRITE_SIZE is uncalibrated and taken as reported)."""
 import collections, csv, glob, hashlib, json, os, re, sys
 
+
+def _head():
+    """commit the profile was taken on: git where there is a checkout, else tools/_build/HEAD (written on the build box right before
+    the gpurun call -- the GPU box gets a snapshot without .git)"""
+    h = os.popen("git rev-parse --short HEAD 2>/dev/null").read().strip()
+    if not h:
+        try:
+            h = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "HEAD")).read().strip()
+        except OSError:
+            h = ""
+    return h or None
+
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     return re.sub(r"\(.*", "", name)
@@ -53,7 +65,7 @@ def main(mode):
         out[k] = e
     out["_meta"] = {"bench_steps_in_pass": 2, "note": "tools/pmc_bench.sh runs bench.py --steps 1 --warmup 1: launch counts cover 2 steps",
                     "kernel_src_sha16": kernel_src_sha16(), "kernel_src": KERNEL_SRC,
-                    "head": os.popen("git rev-parse --short HEAD 2>/dev/null").read().strip() or None}
+                    "head": _head()}
     json.dump(out, open(f"profiles/{ROUND}_pmc_{mode}.json", "w"), indent=1, sort_keys=True)
     for k, e in sorted(((k, e) for k, e in out.items() if k != "_meta"), key=lambda kv: -kv[1]["launches"] * kv[1]["avg_us_profiled"])[:12]:
         print(f"{k[:60]:60s}", {x: e[x] for x in e if x != "wave_cycles"})
