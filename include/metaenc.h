@@ -167,11 +167,12 @@ int me_gemm_fuses_colsum(const me_gemm_desc* d);
 /* 1 if me_gemm(d) can serve d->row_stats (evaluated as if it were set) */
 int me_gemm_emits_row_stats(const me_gemm_desc* d);
 /* CUs that a communication library's kernels hold while gradient buckets are being reduced (RCCL: about one CU per channel).  Process-wide,
- * 0 = none (the default); me_comm_init sets 16 for a communicator of more than one rank and me_comm_destroy clears it; returns the previous
- * value.  It changes only how weight-gradient GEMMs (ME_GEMM_TN on the 256 x 256 family) are PLANNED: their split-K grid asks for exactly one
- * workgroup per CU, so with any CU held the last workgroups run as a second round (+100 % per launch); with a reservation the reduction is
- * cut into 256 - cus balanced static parts instead (cost ~cus / 256 of the launch).  Results are bit-reproducible per (shape, cus).  The
- * workspace query covers either plan. */
+ * 0 = none (the default, and what me_comm_init leaves); returns the previous value.  It changes only how weight-gradient GEMMs (ME_GEMM_TN on the
+ * 256 x 256 family) are PLANNED: their split-K grid asks for exactly one workgroup per CU; with a reservation the reduction runs on 256 - cus
+ * workgroups instead -- whole split levels plus a leftover shared across tile boundaries, every part a fixed K range and slab, so results are
+ * bit-reproducible per (shape, cus); on a free GPU it times like the default grid.  OPT-IN: in the one-GPU rehearsal (a kernel holding 16 CUs
+ * beside backward) it did not remove the second-round penalty it was built for (profiles/r06_contention.txt) -- measure on the real node
+ * (bench.py --gpus N prints per-rank weight-gradient times) before turning it on.  The workspace query covers either plan. */
 int me_gemm_reserve_cus(int cus);
 /* 1 if me_gemm(d) can serve d->row_parts (which must be set) */
 int me_gemm_takes_row_parts(const me_gemm_desc* d);

@@ -123,15 +123,13 @@ extern "C" int me_comm_init(me_comm** out, const void* unique_id, int rank, int 
         return ME_ERR_HIP;
     }
     *out = c;
-    // weight-gradient GEMMs that run while this communicator reduces a bucket find ~one CU per RCCL channel taken: plan them for the rest
-    // (me_gemm_reserve_cus; 16 = RCCL's usual channel count on an 8-GPU xGMI node -- callers that know better call it themselves afterwards)
-    if (world > 1) (void)me_gemm_reserve_cus(16);
+    // (me_gemm_reserve_cus is NOT set here: in the one-GPU rehearsal a CU reservation made the weight gradients under a 16-CU hold slower,
+    //  not faster -- profiles/r06_contention.txt; it stays a caller's switch until an 8-GPU box says otherwise)
     return ME_OK;
 }
 
 extern "C" int me_comm_destroy(me_comm* c) {
     if (!c) return ME_OK;
-    if (c->world > 1) (void)me_gemm_reserve_cus(0);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl);
     if (c->ready) (void)hipEventDestroy(c->ready);

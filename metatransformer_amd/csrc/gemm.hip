@@ -245,7 +245,7 @@ __device__ __forceinline__ void fold_colsum(const GemmParams& p, const float* __
             const int jg = threadIdx.x >> 5;
             float s = 0.f;
             // (balanced partition: the tn = 0 tile of this column's tile row left one partial row per part it was cut into)
-            const int np = p.sk_wgs ? sk_parts((int)(m >> 8) * p.tiles_n, p.sk_wgs, p.sk_upt, (int64_t)p.tiles_m * p.tiles_n * p.sk_upt) : n_part;
+            const int np = p.sk_wgs ? p.sk_levels * p.tiles_n + (ME_SK_PARTS(p, (int)(m >> 8) * p.tiles_n) - p.sk_levels) : n_part;
             if (m < p.M)
                 for (int j = jg; j < np; j += 8) s += cs_part[(int64_t)j * p.M + m];
             red[jg][threadIdx.x & 31] = s;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void splitk_fold_kernel(const GemmParams p, co
         if (RES == 2) r4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.residual) + m * p.ldres + n);
         if (CST == 2) c4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + m * p.ldc + n);
         // (balanced partition: this tile's own slab count; a wave's 256 columns are one tile's)
-        const int St = p.sk_wgs ? sk_parts((int)(m >> 8) * p.tiles_n + (int)blockIdx.x, p.sk_wgs, p.sk_upt, (int64_t)p.tiles_m * p.tiles_n * p.sk_upt) : S;
+        const int St = p.sk_wgs ? ME_SK_PARTS(p, (int)(m >> 8) * p.tiles_n + (int)blockIdx.x) : S;
         f32x4 v = fold_slabs(slabs + m * p.N + n, St, sstride);
         v = v * p.alpha + bias4;
         if (ACT) v = gelu_for4(v, CST == 0 ? ME_BF16 : ME_F32);
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     if (q >= (int)(p.N / 4)) return;
     const int64_t n = (int64_t)q * 4;
     for (int64_t m = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); m < p.M; m += (int64_t)gridDim.y * 4) {
-        const int St = p.sk_wgs ? sk_parts((int)(m >> 8) * p.tiles_n + (int)blockIdx.x, p.sk_wgs, p.sk_upt, (int64_t)p.tiles_m * p.tiles_n * p.sk_upt) : S;
+        const int St = p.sk_wgs ? ME_SK_PARTS(p, (int)(m >> 8) * p.tiles_n + (int)blockIdx.x) : S;
         const f32x4 v = fold_slabs(slabs + m * p.N + n, St, sstride);
         if (LIN) epilogue_quad_lin(p, m, n, v);
         else epilogue_quad(p, m, n, v);
@@ -413,7 +413,7 @@ struct GemmPlan {
     int tail_split, tail_ksteps;
     // g3 wgrad next to a communication kernel (me_gemm_reserve_cus): the balanced static partition over sk_wgs workgroups of sk_upt
     // K-tile pairs per tile (gemm3.hip, gemm_g3tn_sk_kernel); split_k then = the most slabs a tile gets
-    int sk_wgs = 0, sk_upt = 0;
+    int sk_wgs = 0, sk_upt = 0, sk_levels = 0, sk_l1 = 0;
 };
 
 // CUs a communication library's kernels hold while gradient buckets are reduced (me_gemm_reserve_cus; me_comm_init / _destroy set it)
@@ -489,12 +489,16 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p, bool allow_sk = t
         pl.split_k = (nkt + ktp - 1) / ktp;
         int slabs = pl.split_k;
         const int upt = (nkt + 1) / 2;                                    // K-tile pairs per tile
-        if (reserved > 0 && tiles <= slots && tiles * upt >= 2 * (int64_t)slots && tiles * upt < (1ll << 30)) {
-            // the uniform split quantises badly on slots that are not a multiple of the tile count (36 tiles on 240 slots: 6 x 132 K-tiles
-            // instead of 7 x 114); the balanced partition carries slots / 256 of the load per workgroup whatever the count
-            int smax = 1;
-            for (int t = 0; t < (int)tiles; ++t) smax = std::max(smax, sk_parts(t, slots, upt, tiles * upt));
-            if (allow_sk) { pl.sk_wgs = slots; pl.sk_upt = upt; pl.split_k = smax; }
+        const int S = (int)(slots / tiles), E = (int)(slots - S * tiles);
+        if (reserved > 0 && S >= 1 && E > 0 && tiles * upt >= 2 * (int64_t)slots && tiles * upt < (1ll << 30)) {
+            // slots that are not a multiple of the tile count: the uniform split would leave E = slots - S tiles of them idle (36 tiles on 240
+            // slots: 6 parts of 132 K-tiles instead of 7 of 114 = +16 %).  Instead: S whole split levels of L1 pairs + the leftover of every
+            // tile shared by the E extra workgroups (gemm3.hip, gemm_g3tn_sk_kernel): every workgroup carries ~tiles x pairs / slots
+            const int L1 = (int)(tiles * upt / slots);
+            const int Ul = upt - S * L1;
+            int smax = S;
+            for (int t = 0; t < (int)tiles; ++t) smax = std::max(smax, S + sk_left_parts(t, E, Ul, tiles * (int64_t)Ul));
+            if (allow_sk && L1 >= 1) { pl.sk_wgs = slots; pl.sk_upt = upt; pl.sk_levels = S; pl.sk_l1 = L1; pl.split_k = smax; }
             slabs = std::max(slabs, smax);                                // (the workspace query covers both forms)
         }
         pl.ws_bytes = (size_t)slabs * (size_t)g3_tn_slab_stride(d->M, d->N) * sizeof(float);
@@ -645,7 +649,7 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     ME_CHECK_ARG(!d->row_affine || d->op == ME_GEMM_NT, "me_gemm: row_affine (folded LayerNorm) is defined for ME_GEMM_NT");
     p.row_affine = d->row_affine; p.col_shift = d->col_shift;
     p.row_nparts = 0; p.row_eps = 0.0f;
-    p.sk_wgs = 0; p.sk_upt = 0;
+    p.sk_wgs = 0; p.sk_upt = 0; p.sk_levels = 0; p.sk_l1 = 0;
     if (d->row_parts) {      // the same fold, its pairs formed in the kernel from a previous launch's row_stats partials
         ME_CHECK_ARG(!d->row_affine && d->col_shift && d->op == ME_GEMM_NT, "me_gemm: row_parts replaces row_affine (NT, with col_shift)");
         ME_CHECK_ARG(d->row_nparts >= 1 && d->row_nparts <= 4 && (int64_t)d->row_nparts * ME_STATS_GROUP == d->K && d->row_eps >= 0.0f,
@@ -772,9 +776,9 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out, TnLaunch
             }
 #endif
             if (pl.sk_wgs) {
-                ps.sk_wgs = pl.sk_wgs; ps.sk_upt = pl.sk_upt;
+                ps.sk_wgs = pl.sk_wgs; ps.sk_upt = pl.sk_upt; ps.sk_levels = pl.sk_levels; ps.sk_l1 = pl.sk_l1;
                 rc = launch_g3_tn_sk(ps, stream);
-                p.sk_wgs = pl.sk_wgs; p.sk_upt = pl.sk_upt;      // (the fold sums each tile's own number of slabs)
+                p.sk_wgs = pl.sk_wgs; p.sk_upt = pl.sk_upt; p.sk_levels = pl.sk_levels; p.sk_l1 = pl.sk_l1;      // (the fold sums each tile's own number of slabs)
             } else {
                 rc = tn_launch ? tn_launch(ps, stream, tn_ctx) : launch_g3_tn(ps, stream);
             }

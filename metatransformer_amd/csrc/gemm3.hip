@@ -975,15 +975,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 
-// ---- wgrad, balanced static partition ("stream-K" with a FIXED assignment): p.sk_wgs workgroups share the tile-major list of
-// (tile, K-tile pair) units evenly, so a workgroup's range may end one tile and begin the next (two segments, two slabs).  Why: the
-// (tile, split) grid above gives every workgroup one whole item and wants all 256 CUs at once; next to a communication kernel that holds R
-// CUs its last R workgroups run as a SECOND ROUND (+100 % per launch, +4 % per train step for any R = 8 .. 64: profiles/r05_contention.txt), and
-// a uniform split for 256 - R slots quantises badly (36 tiles on 240 slots: 6 parts of 132 K-tiles instead of 7 of 114 = +16 %).  Here any
-// number of workgroups carries the same load (36 x 394 pairs on 240: 59.1 pairs each = +7 % against 256), parts stay static -- a part is a
-// fixed K range and a fixed slab, the fold sums a tile's slabs in K order -- so the result is bit-reproducible per (shape, workgroups).
-// The bias gradient's column sums are taken by the tn = 0 tiles over their own K ranges ([part][M] rows; with ragged K ranges the N-tiles of a
-// tile row no longer stage the same rows at the same time, so they cannot share them round-robin as above).
+// ---- wgrad on a workgroup count that is NOT a multiple of the tile count (a communication kernel holds R CUs: me_gemm_reserve_cus).  The
+// (tile, split) grid above gives every workgroup one whole item and wants all 256 CUs at once; with ANY CU held its last workgroups run as a
+// SECOND ROUND (+100 % per launch, +3.5 % per train step for R = 8 .. 32: profiles/r05_contention.txt), and a uniform split for 256 - R slots
+// quantises badly (36 tiles on 240 slots: 6 parts of 132 K-tiles instead of 7 of 114 = +16 %).  Here p.sk_wgs workgroups carry the same load:
+//   * workgroups [0, S T): S = p.sk_levels whole split levels of L1 = p.sk_l1 K-tile pairs per tile, split-major exactly as above -- the
+//     workgroups an XCD runs together read the SAME rows of dY and X (a first version that cut the whole tile-major unit list evenly lost
+//     that sharing: every workgroup streamed private rows, ~5x the operand traffic, +22 % on the weight gradients: profiles/r06_contention.txt);
+//   * the E = sk_wgs - S T workgroups left over share the LEFTOVER U - S L1 pairs of every tile as one tile-major list, evenly, across tile
+//     boundaries: such a workgroup may end one tile and begin the next (a segment and a slab each).
+// Parts stay static -- a part is a fixed K range and a fixed slab, the fold sums a tile's slabs in K order (levels, then leftover parts) -- so
+// the result is bit-reproducible per (shape, workgroups).  Bias gradient: the levels share the column sums round-robin over the N-tiles as
+// above ([level x tiles_n + tn][M] partial rows); a leftover segment of a tn = 0 tile takes its own K range ([S tiles_n + leftover part][M]).
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g3tn_sk_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -991,23 +994,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wr = wave >> 2;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);       // neighbours in the unit list share an XCD
-    const int tiles = p.tiles_m * p.tiles_n, W = p.sk_wgs, U = p.sk_upt;
-    const int64_t TU = (int64_t)tiles * U;
-    int64_t u0 = __builtin_amdgcn_readfirstlane((int)((int64_t)wgid * TU / W));
-    const int64_t u1 = __builtin_amdgcn_readfirstlane((int)((int64_t)(wgid + 1) * TU / W));
-
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);       // neighbours in the id list share an XCD
+    const int T = p.tiles_m * p.tiles_n, S = p.sk_levels, L1 = p.sk_l1, E = p.sk_wgs - S * T, Ul = p.sk_upt - S * L1;
+    const int64_t TUl = (int64_t)T * Ul;
+    const bool regular = wgid < S * T;
+    // leftover workgroups: units [u0, u1) of the tile-major leftover list; a regular workgroup is one segment (u0 = 0, u1 = 1: one pass)
+    int64_t u0 = 0, u1 = 1;
+    if (!regular) {
+        const int e = wgid - S * T;
+        u0 = __builtin_amdgcn_readfirstlane((int)((int64_t)e * TUl / E));
+        u1 = __builtin_amdgcn_readfirstlane((int)((int64_t)(e + 1) * TUl / E));
+    }
     G3State s;
     g3_init_lane_tn(s, p, smem, wave, lane);
     const G3Src null = g3_null_src(p);
     const bool do_cs = p.colsum_ws != nullptr;
     while (u0 < u1) {
-        const int tile = __builtin_amdgcn_readfirstlane((int)(u0 / U));
-        const int64_t tu0 = (int64_t)tile * U;
-        const int64_t ue = u1 < tu0 + U ? u1 : tu0 + U;
-        const int kt0 = (int)(u0 - tu0) * 2, kt1 = (int)(ue - tu0) * 2;
-        const int part = wgid - sk_first(tile, W, U, TU);
+        int tile, kt0, kt1, part, cs_row;
+        int64_t ue;
+        if (regular) {
+            const int level = __builtin_amdgcn_readfirstlane(wgid / T);
+            tile = wgid - level * T;
+            kt0 = level * L1 * 2; kt1 = kt0 + L1 * 2;
+            part = level;
+            ue = u1;
+        } else {
+            tile = __builtin_amdgcn_readfirstlane((int)(u0 / Ul));
+            const int64_t tu0 = (int64_t)tile * Ul;
+            ue = u1 < tu0 + Ul ? u1 : tu0 + Ul;
+            kt0 = (S * L1 + (int)(u0 - tu0)) * 2; kt1 = (S * L1 + (int)(ue - tu0)) * 2;
+            part = S + (wgid - S * T) - sk_first(tile, E, Ul, TUl);
+        }
         const int tm = __builtin_amdgcn_readfirstlane(tile / p.tiles_n), tn = tile - tm * p.tiles_n;
+        cs_row = regular ? part * p.tiles_n + tn : S * p.tiles_n + (part - S);
         const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
         const G3Src src = g3_make_src_tn(p, tm, tn);
         g3_zero(s);
@@ -1016,22 +1035,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();
-        const bool cs = do_cs && tn == 0;
+        // column sums: a level's N-tiles stage the same dY rows and share them pair by pair, round-robin; a leftover segment stands alone
+        const bool cs_any = do_cs && (regular || tn == 0);
         s.cs[0] = s.cs[1] = 0.f;
+        int cs_turn = regular ? tn : 0;
+        auto my_turn = [&]() {
+            if (!cs_any) return false;
+            if (!regular) return true;
+            const bool mine = cs_turn == 0;
+            cs_turn = mine ? p.tiles_n - 1 : cs_turn - 1;
+            return mine;
+        };
         for (int kt = kt0; kt < kt1 - 2; kt += 2) {
-            g3_ktile<0, true>(s, src, kt + 1, src, kt + 2, cs);
-            g3_ktile<1, true>(s, src, kt + 2, src, kt + 3, cs);
+            const bool c = my_turn();
+            g3_ktile<0, true>(s, src, kt + 1, src, kt + 2, c);
+            g3_ktile<1, true>(s, src, kt + 2, src, kt + 3, c);
         }
-        g3_ktile<0, true>(s, src, kt1 - 1, null, 0, cs);
-        g3_ktile<1, true>(s, null, 0, null, 0, cs);
+        {
+            const bool c = my_turn();
+            g3_ktile<0, true>(s, src, kt1 - 1, null, 0, c);
+            g3_ktile<1, true>(s, null, 0, null, 0, c);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (wr == 0) __builtin_amdgcn_s_barrier();          // (both wave rows are past their last fragment read: the next segment may refill the LDS)
-        if (cs) {
+        if (cs_any) {
             float c0 = s.cs[0], c1 = s.cs[1];
             c0 += __shfl_xor(c0, 16, 64); c0 += __shfl_xor(c0, 32, 64);
             c1 += __shfl_xor(c1, 16, 64); c1 += __shfl_xor(c1, 32, 64);
             if (lane < 16) {
-                float* row = p.colsum_ws + (int64_t)part * p.M;
+                float* row = p.colsum_ws + (int64_t)cs_row * p.M;
                 const int wcol = wave & 3;
                 const int64_t ma = m0 + wr * 128 + wcol * 16 + lane, mb = ma + 64;
                 if (ma < p.M) row[ma] = c0;

@@ -29,19 +29,27 @@ struct GemmParams {
                                             // resident kernel only (g3_takes_row_parts); the pairs are LayerNorm(K = 64 row_nparts, row_eps)'s
     const float* col_shift;                 // ... and s[n] = sum_k W'[n, k]
     float* tn_colsum_out;                   // g3 wgrad with the in-kernel fold: where the folded column sums of A go (follows C's beta), or null
-    int sk_wgs, sk_upt;                     // g3 wgrad, balanced static partition ("stream-K", gemm3.hip: gemm_g3tn_sk_kernel): sk_wgs > 0 workgroups share
-                                            // tiles x sk_upt units (K-tile pairs) evenly, crossing tile boundaries; a tile then has sk_parts(tile) slabs
+    int sk_wgs, sk_upt, sk_levels, sk_l1;   // g3 wgrad on sk_wgs > 0 workgroups that are NOT a multiple of the tile count (gemm3.hip: gemm_g3tn_sk_kernel): sk_levels
+                                            // whole split levels of sk_l1 K-tile pairs per tile (one workgroup each, split-major as the uniform grid) + the rest of every
+                                            // tile's sk_upt pairs shared evenly, across tile boundaries, by the sk_wgs - sk_levels x tiles workgroups left over
     float* row_stats;                       // resident EPI 2 kernel only (me_gemm_desc.row_stats): per-row partial statistics of the OUTPUT,
                                             // [N / 64][M] pairs (mean, M2) over 64-column groups, or null
 };
 
 
-// ---- balanced static partition of a split-K weight gradient (GemmParams::sk_wgs): workgroup w owns units [w TU / W, (w + 1) TU / W) of the
-// tile-major list of (tile, K-tile pair) units (T tiles x U pairs each).  sk_owner(u) = the workgroup that holds unit u; a tile's slabs are
-// numbered in K order: part = owner - sk_owner(first unit of the tile), sk_parts of them.  Integer arithmetic only, the same on host and device.
-__host__ __device__ static inline int sk_owner(int64_t u, int W, int64_t TU) { return (int)(((u + 1) * W - 1) / TU); }
-__host__ __device__ static inline int sk_first(int tile, int W, int U, int64_t TU) { return sk_owner((int64_t)tile * U, W, TU); }
-__host__ __device__ static inline int sk_parts(int tile, int W, int U, int64_t TU) { return sk_owner((int64_t)(tile + 1) * U - 1, W, TU) - sk_first(tile, W, U, TU) + 1; }
+// ---- a split-K weight gradient on W workgroups, W not a multiple of the T tiles (GemmParams::sk_*): S = W / T whole split levels of L1 pairs
+// per tile, then the LEFTOVER Ul = U - S L1 pairs of every tile as a tile-major list of T Ul units that the E = W - S T extra workgroups share
+// evenly: extra workgroup e owns units [e T Ul / E, (e + 1) T Ul / E) -- it may end one tile's leftover and begin the next.  sk_owner(u) = the
+// extra workgroup that holds leftover unit u; a tile's leftover slabs are numbered in K order behind its S level slabs.  Integer arithmetic
+// only, the same on host and device.
+__host__ __device__ static inline int sk_owner(int64_t u, int E, int64_t TUl) { return (int)(((u + 1) * E - 1) / TUl); }
+__host__ __device__ static inline int sk_first(int tile, int E, int Ul, int64_t TUl) { return sk_owner((int64_t)tile * Ul, E, TUl); }
+__host__ __device__ static inline int sk_left_parts(int tile, int E, int Ul, int64_t TUl) {
+    return Ul > 0 ? sk_owner((int64_t)(tile + 1) * Ul - 1, E, TUl) - sk_first(tile, E, Ul, TUl) + 1 : 0;
+}
+// slabs of tile `tile` under GemmParams p (p.sk_wgs > 0)
+#define ME_SK_PARTS(p, tile) ((p).sk_levels + sk_left_parts((tile), (p).sk_wgs - (p).sk_levels * (p).tiles_m * (p).tiles_n, (p).sk_upt - (p).sk_levels * (p).sk_l1, \
+                                                            (int64_t)(p).tiles_m * (p).tiles_n * ((p).sk_upt - (p).sk_levels * (p).sk_l1)))
 
 // One accumulator quad: 4 consecutive output columns n..n+3 of output row m (see include/metaenc.h for the order).
 __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, int64_t n, f32x4 v) {

@@ -247,8 +247,8 @@ def test_pack_encoder_warms_the_three_product_copies(dev):
 @pytest.mark.parametrize("Mo,No,K,reserve", [(2304, 768, 50432, 16), (768, 3072, 50432, 16), (3072, 768, 50432, 8), (768, 768, 50432, 32),
                                              (768, 768, 33 * 197, 16), (1024, 4096, 65536, 16), (768, 2304, 50432, 64)])
 def test_wgrad_balanced_partition_vs_fp64(dev, Mo, No, K, reserve):
-    """me_gemm_reserve_cus(R): ME_GEMM_TN problems of the 256 x 256 family run as 256 - R balanced static parts (gemm_g3tn_sk_kernel: a
-    workgroup's K range may end one tile and begin the next; a tile's slabs are folded in K order).  dW and the fused bias gradient against
+    """me_gemm_reserve_cus(R): ME_GEMM_TN problems of the 256 x 256 family run on 256 - R workgroups as whole split levels + a shared leftover
+    (gemm_g3tn_sk_kernel: a leftover workgroup's K range may end one tile and begin the next; a tile's slabs are folded in K order).  dW and the fused bias gradient against
     fp64 on the same bf16 operands, beta = 0 and 1, deterministic, and the plan is the one reported (me_gemm_profile_rec.plan bit 5)."""
     lib = _capi.load()
     g = torch.Generator().manual_seed(Mo + No + reserve)
@@ -263,7 +263,9 @@ def test_wgrad_balanced_partition_vs_fp64(dev, Mo, No, K, reserve):
         recs = (_capi.GemmProfileRec * 8)()
         n = lib.me_gemm_profile_read(recs, 8)
         lib.me_gemm_profile_enable(0)
-        assert n >= 1 and (recs[0].plan & 15) == 4 and (recs[0].plan & 32), hex(recs[0].plan)
+        T, slots, upt = ((Mo + 255) // 256) * ((No + 255) // 256), 256 - reserve, ((K + 63) // 64 + 1) // 2
+        want_sk = slots % T != 0 and T * upt >= 2 * slots        # (else the uniform split fills the slots / the reduction is too short to cut)
+        assert n >= 1 and (recs[0].plan & 15) == 4 and bool(recs[0].plan & 32) == want_sk, hex(recs[0].plan)
         dw2, db2 = ops.gemm(dy, x, op=_capi.ME_GEMM_TN, out_dtype=torch.float32, want_colsum_a=True)
         assert torch.equal(dw, dw2) and torch.equal(db, db2)
         acc, accb = dw.clone(), db.clone()
