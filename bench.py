@@ -278,7 +278,7 @@ def main():
         cannot run inside the process: tools/pmc_bench.sh collects FETCH_SIZE / WRITE_SIZE in separate passes and
         tools/pmc_summary.py folds them, traffic = 2 * FETCH_SIZE + WRITE_SIZE).  None when the file is not there."""
         pm, src = None, None
-        for rnd in ("r05", "r04", "r03"):            # the newest committed set
+        for rnd in ("r06", "r05", "r04", "r03"):            # the newest committed set
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{rnd}_pmc_{mode}.json")
             try:
                 with open(path) as f:

@@ -19,7 +19,7 @@ def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     return re.sub(r"\(.*", "", name)
 
-ROUND = os.environ.get("ROUND", "r05")
+ROUND = os.environ.get("ROUND", "r06")
 # the sources that define the roofline kernel (gemm_g3r_kernel): bench.py prints `traffic: null` when the running tree's differ from
 # the ones these counters were collected on (a committed constant silently going stale)
 KERNEL_SRC = ["gemm3.hip", "gemm3_core.h", "gemm_common.h", "gemm.hip", "common.h"]

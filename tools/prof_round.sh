@@ -3,7 +3,8 @@
 # the bench lines of the other BASELINE configurations.  Everything lands under gpurun_out/; tools/prof_summary.py and
 # tools/pmc_summary.py fold it into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/prof_r05
+RND=${ROUND:-r06}
+O=$R/gpurun_out/prof_$RND
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fwd-leg > $O/train.json 2> $O/train.err
