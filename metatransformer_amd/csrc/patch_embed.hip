@@ -290,7 +290,10 @@ int pe_shape(const me_patch_embed_desc* d, PeShape& s) {
 bool pe_fusable(const me_patch_embed_desc* d, const PeShape& s) {
     if (d->x_dtype != ME_BF16 || d->w_dtype != ME_BF16) return false;
     if (d->kh * d->kw != 256 || !(d->kw == 8 || d->kw == 16 || d->kw == 32 || d->kw == 64)) return false;
-    if (d->W % 8 || d->sw % 8 || ((int64_t)d->H * d->W) % 8 || (uintptr_t)d->x % 16) return false;
+    // patch rows are read as 16-byte chunks by LDS-DMA; the SOURCE only has to be dword-aligned (round 6: the spectrogram tokenizer's stride 10 --
+    // Data2Seq/Acoustic.py:5-23, ast_models.py:86 -- puts a patch row at byte 20 tx: 4-byte aligned; chunks that straddle a 128-byte line cost a
+    // second request, nothing else)
+    if (d->W % 2 || d->sw % 2 || ((int64_t)d->H * d->W) % 2 || (uintptr_t)d->x % 16) return false;
     const int64_t x_bytes = (int64_t)d->B * d->Cin * d->T * d->H * d->W * 2;
     if (x_bytes >= (1ll << 31) || s.M >= (1ll << 31)) return false;
     if (d->Cout % 8 || 256 * s.K * 2 >= (1ll << 31)) return false;

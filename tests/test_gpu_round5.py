@@ -484,6 +484,9 @@ PE_CASES = [
     ((4, 1, 64, 128), (1, 8, 32, 1, 8, 32), 256, False, 2),            # kh x kw = 8 x 32: two patch rows per K-tile, one plane
     ((2, 2, 48, 64), (1, 32, 8, 1, 16, 8), 264, False, 0),             # 32 x 8 patches overlapping vertically (stride 16), Cout % 256 != 0
     ((1, 3, 16, 16), (1, 16, 16, 1, 16, 16), 768, False, 0),           # a single token
+    ((2, 1, 128, 100), (1, 16, 16, 1, 10, 10), 768, True, 0),          # round 6: the spectrogram tokenizer (Data2Seq/Acoustic.py, ast_models.py:86): stride 10,
+                                                                       # overlapping patches whose rows start at byte 20 tx (dword-, not 16-byte-aligned)
+    ((3, 1, 128, 256), (1, 16, 16, 1, 10, 10), 768, False, 1),         # 12 x 25 tokens per clip
 ]
 
 
@@ -536,7 +539,7 @@ def test_patch_embed_gathers_inside_the_gemm(dev, case):
     check_close(dw2.float(), dw_ref, TOL_BF16_OP, "wgrad, bf16 out")
 
 
-@pytest.mark.parametrize("case", PE_CASES[1:6], ids=lambda c: "x".join(map(str, c[0][1:])) + "_k" + "x".join(map(str, c[1][:3])))
+@pytest.mark.parametrize("case", PE_CASES[1:6] + PE_CASES[7:9], ids=lambda c: "x".join(map(str, c[0][1:])) + "_k" + "x".join(map(str, c[1][:3])))
 def test_patch_embed_wgrad_gathers_inside_the_kernel(dev, case):
     """the same geometries with enough samples for the split-K wgrad kernel (>= 4 096 tokens, a ragged count): patches gathered in its B
     stager, patch origins recomputed per K-tile by multiplication; dW and the bias gradient per element against fp64"""
@@ -590,8 +593,8 @@ def test_patch_embed_config2_batch_and_every_token(dev):
 
 
 def test_patch_embed_two_pass_cases_share_the_entry_point(dev):
-    """fp32 pixels with fp32 weights (exact arithmetic) and the spectrogram's stride-10 patches are not fusable: same entry points,
-    me_patchify + me_gemm inside"""
+    """fp32 pixels with fp32 weights (exact arithmetic) are not fusable: same entry points, me_patchify + me_gemm inside.  (The spectrogram's
+    stride-10 patches were the other two-pass case until round 6; in bf16 they now run fused, in fp32 they stay here.)"""
     geom = (1, 16, 16, 1, 10, 10)
     x = rnd(2, 1, 128, 100, seed=31)
     cols = to.patchify_2d(x, 16, 16, 10, 10)
@@ -599,7 +602,7 @@ def test_patch_embed_two_pass_cases_share_the_entry_point(dev):
     for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, TOL_BF16_OP)):
         xq = x.to(dt)
         w = (0.05 * rnd(256, K, seed=32)).to(dt)
-        assert not ops.patch_embed_fused(xq.to(dev), geom, dt, 256)
+        assert ops.patch_embed_fused(xq.to(dev), geom, dt, 256) == (dt == torch.bfloat16)
         y, tps = ops.patch_embed(xq.to(dev), w.to(dev), None, None, geom, 0, torch.float32)
         ref = to.patchify_2d(xq.float(), 16, 16, 10, 10).double() @ w.double().t()
         check_close(y.reshape(B, tokens, 256), ref, tol, f"two-pass {dt}")
