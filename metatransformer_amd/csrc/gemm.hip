@@ -661,7 +661,7 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
                  "me_gemm: row_stats goes with ME_GEMM_NT and a residual operand (8-byte aligned)");
     p.row_stats = d->row_stats;
     p.tn_colsum_out = nullptr;
-    p.g3_full_tiles = 0; p.g3_split = 0; p.g3_ktp = 0; p.g3_slabs = nullptr; p.slab_stride = 0; p.g3_tickets = nullptr; p.g3_half = 0;
+    p.g3_full_tiles = 0; p.g3_split = 0; p.g3_ktp = 0; p.g3_slabs = nullptr; p.slab_stride = 0; p.g3_tickets = nullptr; p.g3_half = 0; p.g3_colgroups = 1;
     if (d->colsum_a) ME_CHECK_ARG(d->op == ME_GEMM_TN, "me_gemm: colsum_a is defined for ME_GEMM_TN only");
     p.debug = gemm_dev().debug;
     p.tiles_m = (int)((d->M + BM - 1) / BM);

@@ -620,14 +620,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int bid = blockIdx.x, xcd = bid & 7, c = bid >> 3, G8 = gridDim.x >> 3;
     const int tiles = p.tiles_m * p.tiles_n, F = p.g3_full_tiles;
     const int nwork = F + (tiles - F) * 2;                             // (F == tiles unless p.g3_half)
-    const int nf = (F >> 3) + (xcd < (F & 7) ? 1 : 0);                 // whole tiles / all items of this XCD
-    const int nx = (nwork >> 3) + (xcd < (nwork & 7) ? 1 : 0);
+    int nf = (F >> 3) + (xcd < (F & 7) ? 1 : 0);                       // whole tiles / all items of this XCD
+    int nx = (nwork >> 3) + (xcd < (nwork & 7) ? 1 : 0);
     const int base_f = xcd * (F >> 3) + (xcd < (F & 7) ? xcd : (F & 7));
     const int base_all = xcd * (nwork >> 3) + (xcd < (nwork & 7) ? xcd : (nwork & 7));
     const int nkt = (int)(p.K / G3_BK);
+    // Column groups (p.g3_colgroups = Gc > 1, round 6): a weight matrix whose column panels do not fit the XCD's 4 MiB L2 together (fc1:
+    // 12 panels x 393 KB = 4.7 MB) is re-read from the Infinity Cache by every round of 32 concurrent tiles -- +343 MB per fc1 launch, at
+    // ~64 pJ per byte (profiles/r06_pmc_fwd.json, r06_energy_probe.txt).  The XCDs then split the COLUMN tiles too: XCD x walks the
+    // sub-grid (row group x / Gc of 8 / Gc, column group x % Gc of Gc) row-major, so its tiles_n / Gc weight panels stay resident; every
+    // token panel is read by Gc XCDs instead of one (+ (Gc - 1) x the A bytes, the smaller side of the trade).  Whole tiles only.
+    const int Gc = p.g3_colgroups;
+    int cg_c0 = 0, cg_cn = p.tiles_n, cg_r0 = 0;
+    if (Gc > 1) {
+        const int Rg = 8 / Gc, rg = xcd / Gc;
+        cg_cn = p.tiles_n / Gc;
+        cg_c0 = (xcd % Gc) * cg_cn;
+        cg_r0 = rg * p.tiles_m / Rg;
+        nf = nx = ((rg + 1) * p.tiles_m / Rg - cg_r0) * cg_cn;
+    }
     auto decode = [&](int slot, int& tile, int& part, int& kt0, int& kt1) {
         part = -1; kt0 = 0; kt1 = nkt;
-        if (slot < nf) {
+        if (Gc > 1) {
+            const int jr = __builtin_amdgcn_readfirstlane(slot / cg_cn);
+            tile = (cg_r0 + jr) * p.tiles_n + cg_c0 + (slot - jr * cg_cn);
+        } else if (slot < nf) {
             tile = base_f + slot;
         } else {
             // a tile of the last, mostly empty round: two 128-row items (part = which half), the whole reduction each
@@ -1142,7 +1159,28 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
     // each -- same kernel, same epilogue, no slabs (g3_phase<.., HALF>): the last round then costs a little over half a round.
     const int tiles = q.tiles_m * q.tiles_n, rem = tiles % G;
     q.g3_full_tiles = tiles; q.g3_split = 1; q.g3_half = 0;
-    if (HI && tiles >= G && rem > 0 && 2 * rem <= G && q.K >= 4 * G3_BK && gemm_dev().tail_split != 3) {
+    // column groups (see the kernel): the fewest groups that make an XCD's share of the weight panels fit its L2 next to the token panels in
+    // flight (<= 2.5 MB), when the column tiles divide evenly and every XCD still gets a round of tiles
+#ifndef G3_COLGROUPS
+#define G3_COLGROUPS 0                         // (A/B arm, OFF: measured +0.8 % on the forward and +0.2 % on the train step, profiles/r06_colgroups_ab.txt --
+                                               //  the weight re-reads it removes are Infinity-Cache hits, the token re-reads it adds are not all)
+#endif
+    q.g3_colgroups = 1;
+    if (G3_COLGROUPS && G == 256 && q.tiles_n >= 4) {
+        const int64_t panel = 256 * q.K * 2;
+        for (int gc = 1; gc <= 4; gc *= 2) {
+            if (q.tiles_n % gc) break;
+            if ((q.tiles_n / gc) * panel <= (5ll << 19)) {
+                // worth it when the weight re-reads it removes (one pass over B per round of 32 tiles and XCD) outweigh the token re-reads it adds
+                const int64_t b_reread = q.N * q.K * 2 * ((int64_t)tiles / 32), a_extra = (int64_t)(gc - 1) * q.M * q.K * 2;
+                if (gc > 1 && (int64_t)(q.tiles_m / (8 / gc)) * (q.tiles_n / gc) >= 64 && b_reread > 2 * a_extra) q.g3_colgroups = gc;
+                break;
+            }
+        }
+    }
+    if (q.g3_colgroups > 1) {
+        // (whole tiles only: the 128-row items' bookkeeping assumes the row-major tile list)
+    } else if (HI && tiles >= G && rem > 0 && 2 * rem <= G && q.K >= 4 * G3_BK && gemm_dev().tail_split != 3) {
         q.g3_full_tiles = tiles - rem;
         q.g3_half = 1;
     }

@@ -22,6 +22,7 @@ struct GemmParams {
     int g3_full_tiles, g3_split, g3_ktp;
     float* g3_slabs;
     int g3_half;                            // resident kernel: tiles [g3_full_tiles, tiles) run as two 128-row items each (real epilogue, no slabs)
+    int g3_colgroups;                       // resident kernel: the XCDs split the column tiles into this many groups (1 = every XCD walks whole tile rows)
     unsigned* g3_tickets;                   // resident g3 kernel: per-XCD work counters (16 words apart), null = static schedule
     int64_t slab_stride;                    // g3 wgrad: floats between the split-K slabs in C (>= M * N, padded: see g3_tn_slab_stride)
     const float* row_affine;                // folded LayerNorm (me_gemm_desc.row_affine): [M][2] = (rstd, -rstd * mean), or null
