@@ -223,15 +223,65 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, steps, warmup):
+    class _Power:
+        """socket power over a timed region: hwmon power1_average, sampled every 10 ms from a host thread (rank 0; best effort: absent on
+        boxes that do not expose it).  Why it is in the line: config 2 runs AT the socket's power cap, so joules per step is what sets
+        the step time (profiles/r06_power.txt)."""
+
+        def __init__(self):
+            import glob
+            self.files = (glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")
+                          or glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")) if rank == 0 else []
+            self.w, self.stop, self.th = [], False, None
+
+        def _run(self):
+            while not self.stop:
+                best = 0.0
+                for f in self.files:
+                    try:
+                        best = max(best, float(open(f).read().strip()) * 1e-6)
+                    except (OSError, ValueError):
+                        pass
+                if best > 0:
+                    self.w.append(best)
+                time.sleep(0.01)
+
+        def start(self):
+            if self.files:
+                import threading
+                self.w, self.stop = [], False
+                self.th = threading.Thread(target=self._run, daemon=True)
+                self.th.start()
+
+        def finish(self, seconds, steps):
+            if self.th is None:
+                return None
+            self.stop = True
+            self.th.join()
+            self.th = None
+            if len(self.w) < 3:
+                return None
+            mean = sum(self.w) / len(self.w)
+            return {"mean_W": round(mean, 1), "max_W": round(max(self.w), 1), "samples": len(self.w),
+                    "J_per_step": round(mean * seconds / steps, 2),
+                    "source": "hwmon power1_average of the busiest visible socket, 10 ms samples over the timed steps (n_gpus = 1: this GPU)"}
+
+    power_meter = _Power()
+    power_info = {}
+
+    def timed(fn, steps, warmup, power_key=None):
         for _ in range(warmup):
             fn()
         sync()
+        if power_key:
+            power_meter.start()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         sync()
         el = time.perf_counter() - t0
+        if power_key:
+            power_info[power_key] = power_meter.finish(el, steps)
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -256,7 +306,7 @@ def main():
     # overlapped ones (profiles/r04_train_serial_summary.txt / r04_train_summary.txt).
     overlap = bool(train and not args.no_wgrad_overlap and os.environ.get("ME_WGRAD_OVERLAP", "1") != "0")
     ops.block_bwd_overlap(overlap)
-    elapsed = timed(step, args.steps, args.warmup)
+    elapsed = timed(step, args.steps, args.warmup, power_key="step")
     psteps = max(1, min(args.steps, 5))
     serial_el = None
     if train:
@@ -268,7 +318,7 @@ def main():
     fwd = None
     if train and not args.no_fwd_leg:
         enc.eval()
-        fwd_el = timed(fwd_step, args.steps, min(args.warmup, 2))
+        fwd_el = timed(fwd_step, args.steps, min(args.warmup, 2), power_key="fwd")
         fwd_prof = profiled(fwd_step, psteps)
         enc.train()
         fwd = (fwd_el, fwd_prof)
@@ -430,6 +480,9 @@ def main():
         "roofline": gemm_roofline(prof, serial_el or step_s, psteps, train),
         "other_kernels": other_kernels(prof, serial_el or step_s, psteps),
     }
+    if power_info.get("step"):
+        # (measured, not modelled: the step runs at the socket's power cap -- T = J / P)
+        out["power"] = dict(power_info["step"], pJ_per_model_flop=round(power_info["step"]["J_per_step"] / (B * model_flops) * 1e12, 3))      # (this GPU's joules over this GPU's samples)
     if train:
         out["schedule"] = {"wgrad_side_stream": overlap,
                            "serial_ms_per_step": round(1e3 * serial_el, 3) if serial_el else None,
@@ -446,6 +499,8 @@ def main():
                       "mfma_frac": round(fv * fwd_flops / 1e12 / ((PEAK_X3_TFLOPS if x3 else PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS) * world), 4),
                       "roofline": gemm_roofline(fwd_prof, fs, psteps, False),
                       "other_kernels": other_kernels(fwd_prof, fs, psteps)}
+        if power_info.get("fwd"):
+            out["fwd"]["power"] = power_info["fwd"]
     if not args.no_cpu_baseline and world == 1:
         # the CPU leg runs in its own process (fresh OpenMP pool, hard timeout) so it can never stall the bench
         cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--depth", str(L), "--dim", str(C), "--heads", str(H),

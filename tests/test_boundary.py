@@ -66,8 +66,8 @@ def test_struct_layouts_match_c(cname, pyname):
 
 def test_patch_embed_fuses_the_reference_geometries(lib):
     """host-side decision only (no kernel runs): the image and tubelet embeds of the reference gather inside the GEMM's operand stager
-    when pixels and weight are bf16; the spectrogram's stride-10 patches, fp32 arithmetic and odd patch shapes take the two-pass route and
-    ask for a workspace"""
+    when pixels and weight are bf16 -- since round 6 the spectrogram's stride-10 patches too (patch rows only have to be dword-aligned);
+    fp32 arithmetic, odd patch shapes and odd image widths take the two-pass route and ask for a workspace"""
     def desc(shape, geom, xdt=_capi.ME_BF16, wdt=_capi.ME_BF16, cout=768):
         d = _capi.PatchEmbedDesc()
         d.x, d.x_dtype = 4096, xdt                                  # (an aligned address; never dereferenced by these two queries)
@@ -79,9 +79,10 @@ def test_patch_embed_fuses_the_reference_geometries(lib):
     image = desc((256, 3, 1, 224, 224), (1, 16, 16, 1, 16, 16))                      # Data2Seq/Image.py:19-28
     video = desc((8, 3, 16, 224, 224), (2, 16, 16, 2, 16, 16))                       # Video/models/modeling_finetune.py:283-297
     audio = desc((12, 1, 1, 128, 1024), (1, 16, 16, 1, 10, 10))                      # Audio/src/models/ast_models.py:86
-    for d, want in ((image, 1), (video, 1), (audio, 0), (desc((2, 3, 1, 224, 224), (1, 16, 16, 1, 16, 16), xdt=_capi.ME_F32), 0),
+    for d, want in ((image, 1), (video, 1), (audio, 1), (desc((2, 3, 1, 224, 224), (1, 16, 16, 1, 16, 16), xdt=_capi.ME_F32), 0),
                     (desc((2, 3, 1, 224, 224), (1, 16, 16, 1, 16, 16), xdt=_capi.ME_F32, wdt=_capi.ME_F32), 0),
-                    (desc((2, 3, 1, 224, 224), (1, 14, 14, 1, 14, 14)), 0), (desc((2, 3, 1, 220, 220), (1, 16, 16, 1, 16, 16)), 0),
+                    (desc((2, 3, 1, 224, 224), (1, 14, 14, 1, 14, 14)), 0), (desc((2, 3, 1, 220, 220), (1, 16, 16, 1, 16, 16)), 1),
+                    (desc((2, 3, 1, 224, 221), (1, 16, 16, 1, 16, 16)), 0), (desc((2, 1, 1, 128, 100), (1, 16, 16, 1, 10, 9)), 0),
                     (desc((2, 3, 1, 224, 224), (1, 16, 16, 1, 16, 16), cout=772), 0)):
         assert lib.me_patch_embed_fused(ctypes.byref(d)) == want
         assert (lib.me_patch_embed_workspace_bytes(ctypes.byref(d)) == 0) == bool(want)

@@ -487,6 +487,7 @@ PE_CASES = [
     ((2, 1, 128, 100), (1, 16, 16, 1, 10, 10), 768, True, 0),          # round 6: the spectrogram tokenizer (Data2Seq/Acoustic.py, ast_models.py:86): stride 10,
                                                                        # overlapping patches whose rows start at byte 20 tx (dword-, not 16-byte-aligned)
     ((3, 1, 128, 256), (1, 16, 16, 1, 10, 10), 768, False, 1),         # 12 x 25 tokens per clip
+    ((2, 3, 224, 220), (1, 16, 16, 1, 16, 16), 768, False, 0),         # an image width that is not a multiple of 8: patch rows 8-byte aligned only
 ]
 
 
@@ -539,7 +540,7 @@ def test_patch_embed_gathers_inside_the_gemm(dev, case):
     check_close(dw2.float(), dw_ref, TOL_BF16_OP, "wgrad, bf16 out")
 
 
-@pytest.mark.parametrize("case", PE_CASES[1:6] + PE_CASES[7:9], ids=lambda c: "x".join(map(str, c[0][1:])) + "_k" + "x".join(map(str, c[1][:3])))
+@pytest.mark.parametrize("case", PE_CASES[1:6] + PE_CASES[7:10], ids=lambda c: "x".join(map(str, c[0][1:])) + "_k" + "x".join(map(str, c[1][:3])))
 def test_patch_embed_wgrad_gathers_inside_the_kernel(dev, case):
     """the same geometries with enough samples for the split-K wgrad kernel (>= 4 096 tokens, a ragged count): patches gathered in its B
     stager, patch origins recomputed per K-tile by multiplication; dW and the bias gradient per element against fp64"""
