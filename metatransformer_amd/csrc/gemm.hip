@@ -245,9 +245,18 @@ __device__ __forceinline__ void fold_colsum(const GemmParams& p, const float* __
             const int jg = threadIdx.x >> 5;
             float s = 0.f;
             // (balanced partition: the tn = 0 tile of this column's tile row left one partial row per part it was cut into)
-            const int np = p.sk_wgs ? p.sk_levels * p.tiles_n + (ME_SK_PARTS(p, (int)(m >> 8) * p.tiles_n) - p.sk_levels) : n_part;
-            if (m < p.M)
-                for (int j = jg; j < np; j += 8) s += cs_part[(int64_t)j * p.M + m];
+            if (m < p.M) {
+                if (p.sk_wgs) {
+                    // levels: every (level, N-tile) row; leftover: row S tiles_n + j tiles_n + tn exists for the j-th leftover part of tile (tm, tn)
+                    const int lv = p.sk_levels * p.tiles_n, t0 = (int)(m >> 8) * p.tiles_n;
+                    for (int j = jg; j < n_part; j += 8) {
+                        const bool ok = j < lv || (j - lv) / p.tiles_n < ME_SK_PARTS(p, t0 + (j - lv) % p.tiles_n) - p.sk_levels;
+                        if (ok) s += cs_part[(int64_t)j * p.M + m];
+                    }
+                } else {
+                    for (int j = jg; j < n_part; j += 8) s += cs_part[(int64_t)j * p.M + m];
+                }
+            }
             red[jg][threadIdx.x & 31] = s;
             __syncthreads();
             if (threadIdx.x < 32 && m < p.M) {
@@ -494,7 +503,14 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p, bool allow_sk = t
             // slots that are not a multiple of the tile count: the uniform split would leave E = slots - S tiles of them idle (36 tiles on 240
             // slots: 6 parts of 132 K-tiles instead of 7 of 114 = +16 %).  Instead: S whole split levels of L1 pairs + the leftover of every
             // tile shared by the E extra workgroups (gemm3.hip, gemm_g3tn_sk_kernel): every workgroup carries ~tiles x pairs / slots
-            const int L1 = (int)(tiles * upt / slots);
+            // pairs per level part: the integer next to tiles x pairs / slots that leaves the extra workgroups no more than a level part carries
+            // (rounding DOWN pushes S x the remainder into the leftover: 9 tiles x 394 pairs on 240 slots -> 14 per part but 45 per extra
+            // workgroup, a 3x tail -- the first version's +24 % on a free GPU, profiles/r06_contention.txt)
+            int L1 = (int)(tiles * upt / slots);
+            {
+                auto tail = [&](int l1) { return S * l1 > upt ? (int64_t)1 << 40 : std::max<int64_t>(l1, (tiles * (int64_t)(upt - S * l1) + E - 1) / E); };
+                if (tail(L1 + 1) < tail(L1)) L1 += 1;
+            }
             const int Ul = upt - S * L1;
             int smax = S;
             for (int t = 0; t < (int)tiles; ++t) smax = std::max(smax, S + sk_left_parts(t, E, Ul, tiles * (int64_t)Ul));

@@ -1002,8 +1002,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   * the E = sk_wgs - S T workgroups left over share the LEFTOVER U - S L1 pairs of every tile as one tile-major list, evenly, across tile
 //     boundaries: such a workgroup may end one tile and begin the next (a segment and a slab each).
 // Parts stay static -- a part is a fixed K range and a fixed slab, the fold sums a tile's slabs in K order (levels, then leftover parts) -- so
-// the result is bit-reproducible per (shape, workgroups).  Bias gradient: the levels share the column sums round-robin over the N-tiles as
-// above ([level x tiles_n + tn][M] partial rows); a leftover segment of a tn = 0 tile takes its own K range ([S tiles_n + leftover part][M]).
+// the result is bit-reproducible per (shape, workgroups).  Bias gradient: the N-tiles of a tile row share the column sums round-robin pair by
+// pair ([level x tiles_n + tn][M] partial rows for the levels, [S tiles_n + leftover part x tiles_n + tn][M] for the leftover segments).
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g3tn_sk_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             part = S + (wgid - S * T) - sk_first(tile, E, Ul, TUl);
         }
         const int tm = __builtin_amdgcn_readfirstlane(tile / p.tiles_n), tn = tile - tm * p.tiles_n;
-        cs_row = regular ? part * p.tiles_n + tn : S * p.tiles_n + (part - S);
+        cs_row = regular ? part * p.tiles_n + tn : S * p.tiles_n + (part - S) * p.tiles_n + tn;
         const int64_t m0 = (int64_t)tm * G3_BM, n0 = (int64_t)tn * G3_BN;
         const G3Src src = g3_make_src_tn(p, tm, tn);
         g3_zero(s);
@@ -1052,13 +1052,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();
-        // column sums: a level's N-tiles stage the same dY rows and share them pair by pair, round-robin; a leftover segment stands alone
-        const bool cs_any = do_cs && (regular || tn == 0);
+        // column sums: the N-tiles of a tile row stage the same dY rows and share them pair by pair, round-robin -- inside a level all N-tiles walk
+        // the same K range; in the leftover the segments of different N-tiles are ragged, so the turn is tied to the ABSOLUTE pair index (pair k
+        // belongs to N-tile k % tiles_n: whichever of that tile's segments covers it takes it).  (A first version let the tn = 0 segments sum
+        // every pair: those workgroups became the launch's tail, +33 % -- profiles/r06_contention.txt.)
+        const bool cs_any = do_cs;
         s.cs[0] = s.cs[1] = 0.f;
-        int cs_turn = regular ? tn : 0;
+        int cs_turn = regular ? tn : (tn + p.tiles_n - ((kt0 >> 1) % p.tiles_n)) % p.tiles_n;
         auto my_turn = [&]() {
             if (!cs_any) return false;
-            if (!regular) return true;
             const bool mine = cs_turn == 0;
             cs_turn = mine ? p.tiles_n - 1 : cs_turn - 1;
             return mine;
