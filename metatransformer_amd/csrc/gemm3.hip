@@ -46,6 +46,11 @@
 #ifndef G3_TRAIN_GELU_POLY
 #define G3_TRAIN_GELU_POLY 0                   // (A/B arm: the two bf16-mode polynomials instead of the shared-exponential erf pair where gelu AND gelu' are stored)
 #endif
+#ifndef G3_COLGROUPS
+#define G3_COLGROUPS 0                         // (A/B arm, OFF: a column-grouped tile walk of the resident kernel -- measured +0.8 % on the forward and +0.2 % on the
+                                               //  train step, profiles/r06_colgroups_ab.txt: the weight re-reads it removes are Infinity-Cache hits, the token re-reads
+                                               //  it adds are not all.  Compiled out when 0: its scalars would live across the item loop)
+#endif
 #ifndef G3_ROWOP_AHEAD
 #define G3_ROWOP_AHEAD 4                       // row-operand slabs in flight ahead of their use in a whole tile's epilogue (6 until round 4: proj 84.6 -> 80.6 us,
                                                // fc2 205.7 -> 201.7 us sustained, gpurun_out r4s / profiles/r04_rowop_ahead.txt: fewer spills at the seam)
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ~64 pJ per byte (profiles/r06_pmc_fwd.json, r06_energy_probe.txt).  The XCDs then split the COLUMN tiles too: XCD x walks the
     // sub-grid (row group x / Gc of 8 / Gc, column group x % Gc of Gc) row-major, so its tiles_n / Gc weight panels stay resident; every
     // token panel is read by Gc XCDs instead of one (+ (Gc - 1) x the A bytes, the smaller side of the trade).  Whole tiles only.
-    const int Gc = p.g3_colgroups;
+    const int Gc = G3_COLGROUPS ? p.g3_colgroups : 1;
     int cg_c0 = 0, cg_cn = p.tiles_n, cg_r0 = 0;
     if (Gc > 1) {
         const int Rg = 8 / Gc, rg = xcd / Gc;
@@ -658,6 +663,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         tn = tile - tm * p.tiles_n;
         return part >= 0 ? g3_make_src_half(p, tm, tn, part, wr) : g3_make_src(p, tm, tn);
     };
+    const bool dyn = p.g3_tickets != nullptr;
+    unsigned* const ctr = dyn ? p.g3_tickets + xcd * 16 : nullptr;
+    const uint32_t lds_tick = (uint32_t)(uintptr_t)smem + G3_LDS;
     int slot = c;
     if (slot >= nx) return;
     if (kMeDev && (p.debug >> 4)) {              // dev: stagger the CUs of an XCD (their output bursts spread out)
@@ -676,9 +684,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < SEAM; ++i) __builtin_amdgcn_raw_buffer_store_b128(z, null.a, 0, 0, 0);
     };
 
-    const bool dyn = p.g3_tickets != nullptr;
-    unsigned* const ctr = dyn ? p.g3_tickets + xcd * 16 : nullptr;
-    const uint32_t lds_tick = (uint32_t)(uintptr_t)smem + G3_LDS;
     unsigned drawn0 = 0;
     if (dyn && wave == 0) drawn0 = g3r_draw(ctr);          // item 1 (item 0 is this workgroup's own slot)
 
@@ -1163,10 +1168,6 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
     q.g3_full_tiles = tiles; q.g3_split = 1; q.g3_half = 0;
     // column groups (see the kernel): the fewest groups that make an XCD's share of the weight panels fit its L2 next to the token panels in
     // flight (<= 2.5 MB), when the column tiles divide evenly and every XCD still gets a round of tiles
-#ifndef G3_COLGROUPS
-#define G3_COLGROUPS 0                         // (A/B arm, OFF: measured +0.8 % on the forward and +0.2 % on the train step, profiles/r06_colgroups_ab.txt --
-                                               //  the weight re-reads it removes are Infinity-Cache hits, the token re-reads it adds are not all)
-#endif
     q.g3_colgroups = 1;
     if (G3_COLGROUPS && G == 256 && q.tiles_n >= 4) {
         const int64_t panel = 256 * q.K * 2;

@@ -278,3 +278,4 @@ def test_wgrad_balanced_partition_vs_fp64(dev, Mo, No, K, reserve):
     check_close(accb, 2 * ref_b, 2e-5, "db accumulated")
     dw0, db0 = ops.gemm(dy, x, op=_capi.ME_GEMM_TN, out_dtype=torch.float32, want_colsum_a=True)      # the one-item-per-CU plan
     assert rel_err(dw, dw0) < 1e-5 and rel_err(db, db0) < 1e-5
+
