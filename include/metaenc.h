@@ -47,7 +47,11 @@ enum { ME_F32 = 0, ME_BF16 = 1,
                       * third of the bf16 rate instead of the 1/16 of the exact-fp32 MFMA.  Written by me_split3, by me_layernorm_fwd
                       * (y_dtype) and by me_gemm (c_dtype, left-operand order: the next Linear's A operand); read by me_gemm as plain
                       * ME_BF16 operands with K = 3 * cols.  me_block_desc.dtype = ME_BF16X3 selects this arithmetic for a whole Block
-                      * (fp32 tokens in and out).  Reference arithmetic it stands in for: the fp32 default of README.md:113-150. */ };
+                      * (fp32 tokens in and out).  Reference arithmetic it stands in for: the fp32 default of README.md:113-150. */,
+       ME_BF16X2 = 4 /* the same WITHOUT the repeated plane: [ hi | lo ] in one row of 2 * cols bf16 values -- me_gemm output only (c_dtype,
+                      * ldc >= 2 N).  As the A operand of the next GEMM it needs me_gemm_desc.a_wrap_k = 2 * cols (the kernel re-reads the hi
+                      * plane for the third K segment); as an operand of a plane weight gradient only hi and lo are read anyway.  Two thirds of
+                      * the ME_BF16X3 bytes for the two [tokens, hidden] tensors of an ME_BF16X3 Block's MLP (round 6). */ };
 
 enum { ME_OK = 0, ME_ERR_ARG = -1, ME_ERR_UNSUPPORTED = -2, ME_ERR_HIP = -3, ME_ERR_WORKSPACE = -4 };
 
@@ -156,6 +160,10 @@ typedef struct me_gemm_desc {
     const float* row_parts;
     int32_t row_nparts;
     float row_eps;
+    /* optional, ME_GEMM_NT with ME_BF16 operands: the A operand's reduction index WRAPS -- column k >= a_wrap_k of A is read at k - a_wrap_k.  For an
+     * A held as ME_BF16X2 planes [hi | lo] (lda >= 2 * cols) against ME_BF16X3 weights [hi | hi | lo]: K = 3 * cols, a_wrap_k = 2 * cols.  A
+     * multiple of 128; only on the one-tile 256 x 256 family (me_gemm rejects it where the planner picks another: at least 128 tiles). 0 = off. */
+    int64_t a_wrap_k;
 } me_gemm_desc;
 
 /* Scratch the kernel selected for this problem can use (0 = none).  wgrad-shaped problems (tiny output, very long
@@ -174,6 +182,8 @@ int me_gemm_emits_row_stats(const me_gemm_desc* d);
  * beside backward) it did not remove the second-round penalty it was built for (profiles/r06_contention.txt) -- measure on the real node
  * (bench.py --gpus N prints per-rank weight-gradient times) before turning it on.  The workspace query covers either plan. */
 int me_gemm_reserve_cus(int cus);
+/* 1 if me_gemm(d) can serve d->a_wrap_k (which must be set) */
+int me_gemm_takes_a_wrap(const me_gemm_desc* d);
 /* 1 if me_gemm(d) can serve d->row_parts (which must be set) */
 int me_gemm_takes_row_parts(const me_gemm_desc* d);
 int me_gemm(const me_gemm_desc* d, void* stream);
@@ -270,7 +280,8 @@ int me_attention_bwd_x3(const float* qkv, int64_t ld_qkv, const float* out, int6
 typedef struct me_block_desc {
     int32_t dtype;        /* compute dtype: ME_BF16 (bf16 MFMA), ME_F32 (exact fp32 MFMA) or ME_BF16X3 (fp32-accurate on the bf16 MFMA:
                            * res_dtype must be ME_F32, every weight pointer is the ME_BF16X3 right-operand form of the fp32 matrix --
-                           * [out, 3 * in], and [in, 3 * out] for the *_wt copies; attention runs as three-product bf16 MFMA too
+                           * [out, 3 * in], and [in, 3 * out] for the *_wt copies; the stash and scratch layouts are the library's own (the two [tokens,
+                           * hidden] tensors of the MLP are ME_BF16X2 where the GEMMs that read them can wrap their A operand); attention runs as three-product bf16 MFMA too
                            * (me_attention_fwd_x3 / _bwd_x3, ~1e-5) for head_dim 64 and N > 64, on the exact-fp32 kernels otherwise) */
     int32_t res_dtype;    /* dtype of x, y, dx, dy */
     int32_t B, N, C, heads, hidden;

@@ -189,6 +189,23 @@ bool takes_parts(const me_block_desc* d, const Dims& s) {
 // themselves (LayerNorm, the fc1 epilogue) or one split pass follows them (attention output, incoming gradients); LayerNorm,
 // softmax, GELU (erf form), residual stream and every accumulator stay fp32; attention runs on the exact-fp32 kernels.
 // Weight gradients: dW = dY^T X as three TN launches on the planes (hi,hi) + (lo,hi) + (hi,lo), accumulated by beta = 1.
+// The two [tokens, hidden] tensors of the MLP -- gelu(fc1) going forward, dL/dh going back -- as ME_BF16X2 planes [hi | lo] instead of
+// ME_BF16X3's [hi | lo | hi] (round 6): a third fewer bytes written by the two launches that are bound by their output (EPI 9 / 10), and
+// saved for backward.  Needs the NT GEMMs that READ them as their A operand to wrap A's reduction index (me_gemm_desc.a_wrap_k): the
+// one-tile 256 x 256 family -- i.e. from ~128 tiles on; below that the three-plane form stays.
+bool x3_two_planes(const Dims& s) {
+    static char dummy_mem[64] __attribute__((aligned(64)));
+    me_gemm_desc g;
+    for (int res = 0; res < 2; ++res) {      // fc2 forward (fp32 residual epilogue) and the fc1 dgrad (plain fp32 output)
+        gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, s.C, 3 * s.Hd, dummy_mem, 2 * s.Hd, dummy_mem, 3 * s.Hd, dummy_mem, s.C, ME_F32);
+        g.a_wrap_k = 2 * s.Hd;
+        if (res) { g.bias = reinterpret_cast<const float*>(dummy_mem); g.residual = dummy_mem; g.ldres = s.C; g.res_dtype = ME_F32; }
+        g.workspace = dummy_mem; g.workspace_bytes = (int64_t)1 << 40;
+        if (!me_gemm_takes_a_wrap(&g)) return false;
+    }
+    return true;
+}
+
 struct SavedX3 {
     char *xn1, *qkv, *o, *o3, *x1, *xn2, *hpre, *a;      // xn1 / o3 / xn2 [M, 3C] bf16, a [M, 3 Hd] bf16; qkv / o / x1 / hpre (= gelu') fp32
     float *mean1, *rstd1, *mean2, *rstd2, *lse;
@@ -206,7 +223,7 @@ SavedX3 carve_saved_x3(const me_block_desc* d, const Dims& s, void* base) {
     v.x1 = take(s.M * s.C * 4);
     v.xn2 = take(s.M * s.C * 6);
     v.hpre = take(s.M * s.Hd * 4);
-    v.a = take(s.M * s.Hd * 6);
+    v.a = take(s.M * s.Hd * (x3_two_planes(s) ? 4 : 6));
     v.mean1 = reinterpret_cast<float*>(take(s.M * 4));
     v.rstd1 = reinterpret_cast<float*>(take(s.M * 4));
     v.mean2 = reinterpret_cast<float*>(take(s.M * 4));
@@ -240,7 +257,7 @@ size_t gemm_scratch_x3(const Dims& s, bool backward) {
     return align256(w);
 }
 size_t bwd_scratch_x3(const me_block_desc* d, const Dims& s) {
-    // dy3, dh3, dxn (fp32), dx1 (fp32), dx1_3, dout (fp32), dqkv (fp32), dqkv3, delta, LayerNorm partials
+    // dy3, dh3 (two or three planes), dxn (fp32), dx1 (fp32), dx1_3, dout (fp32), dqkv (fp32), dqkv3, delta, LayerNorm partials
     return align256(s.M * s.C * 6) * 2 + align256(s.M * s.Hd * 6) + align256(s.M * s.C * 4) * 3 + align256(s.M * s.C3 * 4) +
            align256(s.M * s.C3 * 6) + align256((size_t)d->B * d->heads * d->N * 4) + align256(me_layernorm_bwd_workspace(s.C));
 }
@@ -274,11 +291,14 @@ int block_fwd_x3(const me_block_desc* d, const Dims& s, const void* x, void* y, 
     g.bias = d->proj_b; g.colscale = d->gamma1; g.residual = x; g.ldres = C; g.res_dtype = ME_F32;
     if ((rc = run(g))) return rc;
     if ((rc = me_layernorm_fwd(v.x1, ME_F32, d->ln2_g, d->ln2_b, v.xn2, ME_BF16X3, keep ? v.mean2 : nullptr, keep ? v.rstd2 : nullptr, s.M, s.C, d->eps, stream))) return rc;
-    gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, Hd, 3 * C, v.xn2, 3 * C, d->fc1_w, 3 * C, v.a, 3 * Hd, ME_BF16X3);
+    const bool two = x3_two_planes(s);
+    const int64_t lda_a = two ? 2 * Hd : 3 * Hd;
+    gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, Hd, 3 * C, v.xn2, 3 * C, d->fc1_w, 3 * C, v.a, lda_a, two ? ME_BF16X2 : ME_BF16X3);
     g.bias = d->fc1_b; g.act = ME_ACT_GELU;
     if (keep) { g.preact = v.hpre; g.ldpre = Hd; g.preact_dtype = ME_F32; g.flags = ME_GEMM_SAVE_GELU_GRAD; }
     if ((rc = run(g))) return rc;
-    gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, C, 3 * Hd, v.a, 3 * Hd, d->fc2_w, 3 * Hd, y, C, ME_F32);
+    gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, C, 3 * Hd, v.a, lda_a, d->fc2_w, 3 * Hd, y, C, ME_F32);
+    if (two) g.a_wrap_k = 2 * Hd;
     g.bias = d->fc2_b; g.colscale = d->gamma2; g.residual = v.x1; g.ldres = C; g.res_dtype = ME_F32;
     return run(g);
 }
@@ -308,8 +328,10 @@ int block_bwd_x3(const me_block_desc* d, const Dims& s, const void* x, const voi
     me_gemm_desc g;
     int rc;
     // dX-side GEMM: C[M, N] = A3[M, 3K] W3t[N, 3K]^T
-    auto nt = [&](const void* A3, int64_t K, const void* Wt3, void* Cout, int64_t N, int cdt, const void* factor) -> int {
-        gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, N, 3 * K, A3, 3 * K, Wt3, 3 * K, Cout, cdt == ME_BF16X3 ? 3 * N : N, cdt);
+    // (a2: the A operand is ME_BF16X2 planes [hi | lo] -- lda = 2 K, the reduction index wraps; cdt ME_BF16X2 / ME_BF16X3: the output planes)
+    auto nt = [&](const void* A3, int64_t K, const void* Wt3, void* Cout, int64_t N, int cdt, const void* factor, bool a2 = false) -> int {
+        gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, N, 3 * K, A3, a2 ? 2 * K : 3 * K, Wt3, 3 * K, Cout, cdt == ME_BF16X3 ? 3 * N : cdt == ME_BF16X2 ? 2 * N : N, cdt);
+        if (a2) g.a_wrap_k = 2 * K;
         if (factor) { g.aux = factor; g.ldaux = N; g.aux_dtype = ME_F32; g.flags = ME_GEMM_AUX_IS_FACTOR; }
         g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
         return me_gemm(&g, stream);
@@ -318,14 +340,17 @@ int block_bwd_x3(const me_block_desc* d, const Dims& s, const void* x, const voi
     // The bias gradient db = colsum(dOut) rides on the first two launches where the kernel can fuse it (me_gemm_desc.colsum_a: the column
     // sums of the A operand from the fragments the kernel stages anyway, accumulated with C's beta): term 0 leaves colsum(hi), term 1
     // adds colsum(lo) -- 2^-17 relative, as the planes themselves; otherwise two plane passes of me_colsum.
-    auto wgrad = [&](const uint16_t* dOut3, int64_t n_out, const void* In3_, int64_t n_in, void* dW, float* dB) -> int {
+    // (ld_out / ld_in: row lengths of the plane matrices -- 3 n for ME_BF16X3 rows, 2 n for ME_BF16X2 ones; only the hi and lo planes are read)
+    auto wgrad = [&](const uint16_t* dOut3, int64_t n_out, const void* In3_, int64_t n_in, void* dW, float* dB, int64_t ld_out = 0, int64_t ld_in = 0) -> int {
         const uint16_t* In3 = reinterpret_cast<const uint16_t*>(In3_);
+        if (!ld_out) ld_out = 3 * n_out;
+        if (!ld_in) ld_in = 3 * n_in;
         const int64_t pa[3] = {0, n_out, 0}, pb[3] = {0, 0, n_in};
         bool db_done = dB == nullptr;
         if (dW) {
             // one launch + one fold: the three products as three segments of the wgrad kernel's reduction (gemm3_x3.hip); the bias gradient
             // rides on it.  Not for problems the planner keeps off the g3 wgrad family (few tokens): the three me_gemm calls below.
-            gemm_desc(g, ME_GEMM_TN, ME_BF16, n_out, n_in, s.M, dOut3, 3 * n_out, In3, 3 * n_in, dW, n_in, gr->w_dtype);
+            gemm_desc(g, ME_GEMM_TN, ME_BF16, n_out, n_in, s.M, dOut3, ld_out, In3, ld_in, dW, n_in, gr->w_dtype);
             g.beta = gr->accumulate ? 1.0f : 0.0f;
             g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
             g.colsum_a = dB;
@@ -333,7 +358,7 @@ int block_bwd_x3(const me_block_desc* d, const Dims& s, const void* x, const voi
             if (r1 == ME_OK) return ME_OK;
             if (r1 != ME_ERR_UNSUPPORTED) return r1;
             for (int t = 0; t < 3; ++t) {
-                gemm_desc(g, ME_GEMM_TN, ME_BF16, n_out, n_in, s.M, dOut3 + pa[t], 3 * n_out, In3 + pb[t], 3 * n_in, dW, n_in, gr->w_dtype);
+                gemm_desc(g, ME_GEMM_TN, ME_BF16, n_out, n_in, s.M, dOut3 + pa[t], ld_out, In3 + pb[t], ld_in, dW, n_in, gr->w_dtype);
                 g.beta = (t == 0 && !gr->accumulate) ? 0.0f : 1.0f;
                 g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
                 if (dB && t < 2 && (t == 1 ? db_done : me_gemm_fuses_colsum(&g))) {      // (both or neither: term 1 adds onto term 0's sums)
@@ -345,17 +370,19 @@ int block_bwd_x3(const me_block_desc* d, const Dims& s, const void* x, const voi
             }
         }
         if (!db_done) {
-            const int r = me_colsum(dOut3, ME_BF16, 3 * n_out, s.M, n_out, dB, gr->accumulate, aws, stream);
-            return r ? r : me_colsum(dOut3 + n_out, ME_BF16, 3 * n_out, s.M, n_out, dB, 1, aws, stream);
+            const int r = me_colsum(dOut3, ME_BF16, ld_out, s.M, n_out, dB, gr->accumulate, aws, stream);
+            return r ? r : me_colsum(dOut3 + n_out, ME_BF16, ld_out, s.M, n_out, dB, 1, aws, stream);
         }
         return ME_OK;
     };
     // ---- MLP branch
     if ((rc = me_split3(reinterpret_cast<const float*>(dy), C, dy3, s.M, C, 0, stream))) return rc;
-    if ((rc = wgrad(dy3, C, v.a, Hd, gr->fc2_w, gr->fc2_b))) return rc;
-    if ((rc = nt(dy3, C, d->fc2_wt, dh3, Hd, ME_BF16X3, v.hpre))) return rc;                  // dA * gelu'(h), three planes
-    if ((rc = wgrad(dh3, Hd, v.xn2, C, gr->fc1_w, gr->fc1_b))) return rc;
-    if ((rc = nt(dh3, Hd, d->fc1_wt, dxn, C, ME_F32, nullptr))) return rc;
+    const bool two = x3_two_planes(s);                    // (the layout of v.a is the forward's: same rule, same answer)
+    const int64_t ldh = two ? 2 * Hd : 3 * Hd;
+    if ((rc = wgrad(dy3, C, v.a, Hd, gr->fc2_w, gr->fc2_b, 0, ldh))) return rc;
+    if ((rc = nt(dy3, C, d->fc2_wt, dh3, Hd, two ? ME_BF16X2 : ME_BF16X3, v.hpre))) return rc;      // dA * gelu'(h) as planes
+    if ((rc = wgrad(dh3, Hd, v.xn2, C, gr->fc1_w, gr->fc1_b, ldh, 0))) return rc;
+    if ((rc = nt(dh3, Hd, d->fc1_wt, dxn, C, ME_F32, nullptr, two))) return rc;
     rc = me_ln_bwd_deferred(dxn, ME_F32, v.x1, ME_F32, v.mean2, v.rstd2, d->ln2_g, dy, ME_F32, dx1, ME_F32, gr->ln2_g, gr->ln2_b, gr->accumulate,
                             s.M, s.C, ln2_ws, stream, &folds[0]);
     if (rc) return rc;

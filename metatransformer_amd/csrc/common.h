@@ -83,7 +83,8 @@ struct ProfScope {
 static inline size_t me_dtype_size(int dt) { return dt == ME_F32 ? 4 : 2; }
 static inline bool me_dtype_ok(int dt) { return dt == ME_F32 || dt == ME_BF16; }                    // compute dtypes
 static inline bool me_storage_dtype_ok(int dt) { return me_dtype_ok(dt) || dt == ME_F16; }          // me_cast only
-static inline bool me_out_dtype_ok(int dt) { return me_dtype_ok(dt) || dt == ME_BF16X3; }           // me_gemm C / me_layernorm_fwd y
+static inline bool me_out_dtype_ok(int dt) { return me_dtype_ok(dt) || dt == ME_BF16X3; }           // me_layernorm_fwd y (and me_gemm C, which also takes ME_BF16X2)
+static inline bool me_is_planes(int dt) { return dt == ME_BF16X3 || dt == ME_BF16X2; }             // fp32 values stored as bf16 hi / lo planes
 
 // ---- LayerNorm backward with the dgamma / dbeta fold deferred (layernorm.hip; me_block_bwd folds both LayerNorms of a block in one launch)
 constexpr int LN_FOLD_SETS = 4;
@@ -142,6 +143,17 @@ __device__ __forceinline__ void store4_split3(uint16_t* row, int64_t cols, int64
     *reinterpret_cast<bf16x4*>(row + c) = h;
     *reinterpret_cast<bf16x4*>(row + cols + c) = right_operand ? h : l;
     *reinterpret_cast<bf16x4*>(row + 2 * cols + c) = right_operand ? l : h;
+}
+// ME_BF16X2: [hi | lo] only
+__device__ __forceinline__ void store4_split2(uint16_t* row, int64_t cols, int64_t c, f32x4 v) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (bf16_t)v[e];
+        l[e] = (bf16_t)(v[e] - (float)h[e]);
+    }
+    *reinterpret_cast<bf16x4*>(row + c) = h;
+    *reinterpret_cast<bf16x4*>(row + cols + c) = l;
 }
 
 __device__ __forceinline__ float load1_as_f32(const void* base, int dt, int64_t idx) {

@@ -376,7 +376,7 @@ static void launch_splitk_reduce(const GemmParams& p, unsigned /*nb*/, hipStream
 #define ME_FOLD(BIAS, RES, CST, ACT, CS) \
     do { hipLaunchKernelGGL((splitk_fold_kernel<BIAS, RES, CST, ACT, CS>), grid, dim3(256), 0, stream, p, slabs, S, cs_part, n_part, colsum_out, sstride); return; } while (0)
     const bool simple = !p.preact && !p.aux && !p.row_affine && !p.colscale && !p.flags && p.res_row_mod == 0 && p.out_group_rows == 0 &&
-                        p.c_dtype != ME_BF16X3;
+                        !me_is_planes(p.c_dtype);
     const int res = !p.residual ? 0 : (p.res_dtype == ME_BF16 ? 1 : 2);
     if (simple) {
         const bool bias = p.bias != nullptr, gelu = p.act == ME_ACT_GELU;
@@ -624,10 +624,13 @@ GemmPlan plan_gemm(const me_gemm_desc* d, const GemmParams& p, bool allow_sk = t
 int fill_params(const me_gemm_desc* d, GemmParams& p) {
     ME_CHECK_ARG(d != nullptr, "me_gemm: null descriptor");
     ME_CHECK_ARG(d->op == ME_GEMM_NT || d->op == ME_GEMM_TN, "me_gemm: bad op %d", d->op);
-    ME_CHECK_ARG(me_dtype_ok(d->ab_dtype) && me_out_dtype_ok(d->c_dtype), "me_gemm: bad dtype");
-    if (d->c_dtype == ME_BF16X3)      // fp32 result written as three bf16 planes: the A operand of the next fp32-accurate Linear
-        ME_CHECK_ARG(d->op == ME_GEMM_NT && d->beta == 0.0f && d->ldc >= 3 * d->N && d->out_group_rows == 0 && !d->colsum_a,
-                     "me_gemm: ME_BF16X3 output: NT, beta = 0, ldc >= 3 N, plain rows");
+    ME_CHECK_ARG(me_dtype_ok(d->ab_dtype) && (me_out_dtype_ok(d->c_dtype) || d->c_dtype == ME_BF16X2), "me_gemm: bad dtype");
+    if (me_is_planes(d->c_dtype))     // fp32 result written as bf16 planes: the A operand of the next fp32-accurate Linear
+        ME_CHECK_ARG(d->op == ME_GEMM_NT && d->beta == 0.0f && d->ldc >= (d->c_dtype == ME_BF16X3 ? 3 : 2) * d->N && d->out_group_rows == 0 && !d->colsum_a,
+                     "me_gemm: ME_BF16X3 / ME_BF16X2 output: NT, beta = 0, ldc >= 3 N / 2 N, plain rows");
+    ME_CHECK_ARG(d->a_wrap_k == 0 || (d->op == ME_GEMM_NT && d->ab_dtype == ME_BF16 && d->a_wrap_k > 0 && d->a_wrap_k % 128 == 0 && d->a_wrap_k < d->K &&
+                                      d->K - d->a_wrap_k <= d->a_wrap_k && d->lda >= d->a_wrap_k),
+                 "me_gemm: a_wrap_k: NT, bf16, a multiple of 128 with K / 2 <= a_wrap_k < K, lda >= a_wrap_k");
     ME_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "me_gemm: empty problem M=%lld N=%lld K=%lld",
                  (long long)d->M, (long long)d->N, (long long)d->K);
     ME_CHECK_ARG(d->A && d->B && d->C, "me_gemm: null operand");
@@ -666,6 +669,7 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     p.row_affine = d->row_affine; p.col_shift = d->col_shift;
     p.row_nparts = 0; p.row_eps = 0.0f;
     p.sk_wgs = 0; p.sk_upt = 0; p.sk_levels = 0; p.sk_l1 = 0;
+    p.a_wrap_kt = (int)(d->a_wrap_k / 64);
     if (d->row_parts) {      // the same fold, its pairs formed in the kernel from a previous launch's row_stats partials
         ME_CHECK_ARG(!d->row_affine && d->col_shift && d->op == ME_GEMM_NT, "me_gemm: row_parts replaces row_affine (NT, with col_shift)");
         ME_CHECK_ARG(d->row_nparts >= 1 && d->row_nparts <= 4 && (int64_t)d->row_nparts * ME_STATS_GROUP == d->K && d->row_eps >= 0.0f,
@@ -717,6 +721,14 @@ extern "C" int me_gemm_emits_row_stats(const me_gemm_desc* d) {
     return g3_emits_row_stats(p) ? 1 : 0;
 }
 
+extern "C" int me_gemm_takes_a_wrap(const me_gemm_desc* d) {
+    GemmParams p;
+    if (!d || d->op != ME_GEMM_NT || d->ab_dtype != ME_BF16 || !d->a_wrap_k || fill_params(d, p) != ME_OK) return 0;
+    const GemmPlan pl = plan_gemm(d, p);
+    const int e = pick_epi_ex(p);
+    return (pl.family == 4 && (e == 0 || e == 4 || e == 8)) ? 1 : 0;
+}
+
 extern "C" int me_gemm_reserve_cus(int cus) {
     const int c = cus < 0 ? 0 : (cus > 128 ? 128 : cus);
     return g_reserved_cus.exchange(c);
@@ -760,6 +772,9 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out, TnLaunch
                      "me_gemm: colsum_a needs the split-K wgrad kernel and its workspace (see me_gemm_fuses_colsum)");
     if (d->row_stats)
         ME_CHECK_ARG(pl.family == 4 && d->op == ME_GEMM_NT && pl.tail_rows == 0, "me_gemm: row_stats is not available for this problem (see me_gemm_emits_row_stats)");
+    if (d->a_wrap_k)
+        ME_CHECK_ARG(pl.family == 4 && d->op == ME_GEMM_NT && (pick_epi_ex(p) == 0 || pick_epi_ex(p) == 4 || pick_epi_ex(p) == 8),
+                     "me_gemm: a_wrap_k is not available for this problem (see me_gemm_takes_a_wrap)");
     if (d->row_parts)
         ME_CHECK_ARG(pl.family == 4 && d->op == ME_GEMM_NT && pl.tail_rows == 0 && g3_takes_row_parts(p),
                      "me_gemm: row_parts is not available for this problem (see me_gemm_takes_row_parts)");

@@ -58,7 +58,7 @@
 namespace {
 
 // ---- one tile per workgroup
-template <int EPI>
+template <int EPI, bool WRAP = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g3_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -103,8 +103,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         kt0 = part * p.g3_ktp;
         kt1 = kt0 + p.g3_ktp < nkt ? kt0 + p.g3_ktp : nkt;
     }
-    g3_issue<0>(s, src, 0, kt0); g3_issue<1>(s, src, 0, kt0); g3_issue<2>(s, src, 0, kt0); g3_issue<3>(s, src, 0, kt0);
-    g3_issue<0>(s, src, 1, kt0 + 1); g3_issue<1>(s, src, 1, kt0 + 1); g3_issue<2>(s, src, 1, kt0 + 1);
+    s.wrap_kt = WRAP ? p.a_wrap_kt : 0;
+    g3_issue<0, WRAP>(s, src, 0, kt0); g3_issue<1, WRAP>(s, src, 0, kt0); g3_issue<2, WRAP>(s, src, 0, kt0); g3_issue<3, WRAP>(s, src, 0, kt0);
+    g3_issue<0, WRAP>(s, src, 1, kt0 + 1); g3_issue<1, WRAP>(s, src, 1, kt0 + 1); g3_issue<2, WRAP>(s, src, 1, kt0 + 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -112,11 +113,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // past the end of the K-range the source is a null descriptor (see g3_phase)
     const G3Src null = g3_null_src(p);
     for (int kt = kt0; kt < kt1 - 2; kt += 2) {
-        g3_ktile<0>(s, src, kt + 1, src, kt + 2);
-        g3_ktile<1>(s, src, kt + 2, src, kt + 3);
+        g3_ktile<0, false, 0, false, 0, WRAP>(s, src, kt + 1, src, kt + 2);
+        g3_ktile<1, false, 0, false, 0, WRAP>(s, src, kt + 2, src, kt + 3);
     }
-    g3_ktile<0>(s, src, kt1 - 1, null, 0);
-    g3_ktile<1>(s, null, 0, null, 0);
+    g3_ktile<0, false, 0, false, 0, WRAP>(s, src, kt1 - 1, null, 0);
+    g3_ktile<1, false, 0, false, 0, WRAP>(s, null, 0, null, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wr == 0) __builtin_amdgcn_s_barrier();
     if (kMeDev && (p.debug & 1)) {               // dev: K-loop only
@@ -1220,6 +1221,20 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
     const int nwg = q.g3_full_tiles + (tiles - q.g3_full_tiles) * q.g3_split;
     // the resident form (one workgroup per CU, operand stream running through the epilogues) whenever every CU gets work
     // and the output / row operands are bf16 with tile-local 32-bit offsets
+    if (p.a_wrap_kt) {
+        // A held as two planes [hi | lo], three reduction segments (me_gemm_desc.a_wrap_k): the one-tile kernel's WRAP instantiations only
+        if constexpr (EPI == 0 || EPI == 4 || EPI == 8) {
+            static OncePerDevice once_w;
+            if (once_w.need())
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_g3_kernel<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+            hipLaunchKernelGGL((gemm_g3_kernel<EPI, true>), dim3((unsigned)nwg), dim3(512), G3_LDS, stream, q);
+            ME_CHECK_LAUNCH("me_gemm(g3, wrapped A)");
+            return ME_OK;
+        } else {
+            me_set_error("me_gemm: a_wrap_k is served for plain / fp32-residual epilogues only (see me_gemm_takes_a_wrap)");
+            return ME_ERR_UNSUPPORTED;
+        }
+    }
     if (gemm_dev().g3_persistent == 1) {
         int repi = EPI <= 3 ? EPI : -1, pre = (EPI == 1 && p.preact) ? 1 : 0;
         const bool plain = p.beta == 0.0f && p.out_group_rows == 0 && p.res_row_mod == 0 && !p.colscale && !p.residual;

@@ -89,6 +89,7 @@ struct G3State {
     uint32_t ra[2][2], rb[2][2];// NT: fragment read LDS addresses [buffer][k-sub]: buffer + wave / lane part inside a half-tile
     uint32_t ta[4], tb[2];      // TN: transposing-read byte offsets per m-tile / n-tile of a quadrant (wave + lane part)
     int kstep_a, kstep_b;       // source bytes per K-tile: NT 128 (along the row); TN 64 rows = 128 * ld
+    int wrap_kt;                // (WRAP instantiations: GemmParams::a_wrap_kt) K-tiles of A from this one on re-read A from K-tile 0
     f32x4 binit[4];             // resident NT kernel: what the accumulators of n-tile 0..3 START at (the columns' bias, or zero) --
                                 // the C operand of the first MFMAs behind an epilogue (g3_phase<.., SEAM>); dead in between
     float cs[2];                // TN: running column sums of A (the bias gradient) for m-tiles wc and 4 + wc of this wave row
@@ -143,9 +144,13 @@ __device__ __forceinline__ G3Src g3_null_src(const GemmParams& p) {
 }
 
 // half-tile type J of K-tile kt (of the source's own numbering) into buffer buf
-template <int J> __device__ __forceinline__ void g3_issue(const G3State& s, const G3Src& src, int buf, int kt) {
+// WRAP (one-tile NT kernel only; me_gemm_desc.a_wrap_k): the A operand is an fp32 matrix held as TWO bf16 planes [hi | lo] while the reduction
+// walks three segments (hi, lo, hi) against weights [hi | hi | lo] -- from K-tile s.wrap_kt on, A's offset starts over at K-tile 0 (a scalar
+// select per issue; the third plane of the ME_BF16X3 layout is not stored at all)
+template <int J, bool WRAP = false> __device__ __forceinline__ void g3_issue(const G3State& s, const G3Src& src, int buf, int kt) {
     char* dst = s.smem + buf * G3_BUF + J * G3_HALF + s.wave * 2048;
     const __amdgpu_buffer_rsrc_t r = (J & 1) ? src.a : src.b;
+    if (WRAP && (J & 1)) kt = kt >= s.wrap_kt ? kt - s.wrap_kt : kt;
     const int koff = kt * ((J & 1) ? s.kstep_a : s.kstep_b);
     constexpr int pol = (J & 1) ? G3_POL_A : G3_POL_B;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void3*)dst, 16, (int)s.src[J][0], koff, 0, pol);
@@ -220,7 +225,7 @@ __device__ __forceinline__ float g3_frag_sum(bf16x8 f) {
 // Seams: the K-tile ahead of an item's first and second one were issued by the previous item's last K-tiles / epilogue in either
 // item's pattern (a whole tile's tail issues A-Y too: out of range for a 128-row item, see g3_make_src_half); the first two K-tiles of an
 // item wait with SLACK = the epilogue's operation count more (they sit between those half-tiles and the K-tile's own in the queue).
-template <int BUF, int P, bool TN = false, int SEAM = 0, bool HALF = false, int SLACK = SEAM>
+template <int BUF, int P, bool TN = false, int SEAM = 0, bool HALF = false, int SLACK = SEAM, bool WRAP = false>
 __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1, bool cs_on = false) {
     if (HALF) {
         static_assert(!HALF || (!TN && P < 2), "128-row items: NT, phases 0 and 1");
@@ -284,10 +289,10 @@ __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, co
 #undef G3_RD_A
 #undef G3_RD_B
     __builtin_amdgcn_sched_barrier(0);
-    if (P == 0 && SEAM == 0) g3_issue<3>(s, s0, BUF ^ 1, k0);
-    if (P == 1) g3_issue<0>(s, s1, BUF, k1);
-    if (P == 2) g3_issue<1>(s, s1, BUF, k1);
-    if (P == 3) g3_issue<2>(s, s1, BUF, k1);
+    if (P == 0 && SEAM == 0) g3_issue<3, WRAP>(s, s0, BUF ^ 1, k0);
+    if (P == 1) g3_issue<0, WRAP>(s, s1, BUF, k1);
+    if (P == 2) g3_issue<1, WRAP>(s, s1, BUF, k1);
+    if (P == 3) g3_issue<2, WRAP>(s, s1, BUF, k1);
     __builtin_amdgcn_sched_barrier(0);
     // (the B-X reads are issued first: NT 4 of 12, TN 8 of 24 DS operations -- retire exactly those before the barrier)
     if (P == 0) { if (TN) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); }
@@ -314,13 +319,13 @@ __device__ __forceinline__ void g3_phase(G3State& s, const G3Src& s0, int k0, co
     __builtin_amdgcn_s_barrier();
 }
 
-template <int BUF, bool TN = false, int SEAM = 0, bool HALF = false, int SLACK = SEAM>
+template <int BUF, bool TN = false, int SEAM = 0, bool HALF = false, int SLACK = SEAM, bool WRAP = false>
 __device__ __forceinline__ void g3_ktile(G3State& s, const G3Src& s0, int k0, const G3Src& s1, int k1, bool cs_on = false) {
-    g3_phase<BUF, 0, TN, SEAM, HALF, SLACK>(s, s0, k0, s1, k1, cs_on);
-    g3_phase<BUF, 1, TN, SEAM, HALF, SLACK>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 0, TN, SEAM, HALF, SLACK, WRAP>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 1, TN, SEAM, HALF, SLACK, WRAP>(s, s0, k0, s1, k1, cs_on);
     if (HALF) return;
-    g3_phase<BUF, 2, TN, SEAM, false, SLACK>(s, s0, k0, s1, k1, cs_on);
-    g3_phase<BUF, 3, TN, SEAM, false, SLACK>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 2, TN, SEAM, false, SLACK, WRAP>(s, s0, k0, s1, k1, cs_on);
+    g3_phase<BUF, 3, TN, SEAM, false, SLACK, WRAP>(s, s0, k0, s1, k1, cs_on);
 }
 
 __device__ __forceinline__ void g3_init_lane(G3State& s, const GemmParams& p, char* smem, int wave, int lane) {
@@ -546,7 +551,7 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
                     uint16_t* row = Cp + m * p.ldc + n[q];
                     *reinterpret_cast<bf16x8*>(row) = hi;
                     *reinterpret_cast<bf16x8*>(row + p.N) = lo;
-                    *reinterpret_cast<bf16x8*>(row + 2 * p.N) = hi;
+                    if (p.c_dtype == ME_BF16X3) *reinterpret_cast<bf16x8*>(row + 2 * p.N) = hi;      // (ME_BF16X2: [hi | lo] only -- a third fewer bytes)
                 }
             }
         }

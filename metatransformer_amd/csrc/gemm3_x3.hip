@@ -108,7 +108,8 @@ int launch_g3tn_x3(const GemmParams& p, hipStream_t stream, const void*) {
 // fold.  d: an ME_GEMM_TN descriptor over the PLANE matrices -- A = dOut3 (lda = 3 M), B = In3 (ldb = 3 N), K = tokens, colsum_a = dbias.
 // ME_ERR_UNSUPPORTED when the planner does not give the problem to the g3 wgrad family (the caller then runs the three products).
 int gemm_tn_x3_planes(const me_gemm_desc* d, hipStream_t stream) {
-    if (!d || d->op != ME_GEMM_TN || d->ab_dtype != ME_BF16 || d->lda < 3 * d->M || d->ldb < 3 * d->N) return ME_ERR_UNSUPPORTED;
+    // (only the hi and lo planes of either operand are read -- offsets 0 and M / N -- so ME_BF16X2 rows, ld >= 2 M / 2 N, serve as well as ME_BF16X3 ones)
+    if (!d || d->op != ME_GEMM_TN || d->ab_dtype != ME_BF16 || d->lda < 2 * d->M || d->ldb < 2 * d->N) return ME_ERR_UNSUPPORTED;
     // (the lo planes end 2 M / 2 N columns further right than the planner's bounds check assumes)
     if (d->K * d->lda * 2 >= (1ll << 31) || d->K * d->ldb * 2 >= (1ll << 31)) return ME_ERR_UNSUPPORTED;
     return gemm_tn_with_launcher(d, stream, launch_g3tn_x3, nullptr);

@@ -33,6 +33,7 @@ struct GemmParams {
     int sk_wgs, sk_upt, sk_levels, sk_l1;   // g3 wgrad on sk_wgs > 0 workgroups that are NOT a multiple of the tile count (gemm3.hip: gemm_g3tn_sk_kernel): sk_levels
                                             // whole split levels of sk_l1 K-tile pairs per tile (one workgroup each, split-major as the uniform grid) + the rest of every
                                             // tile's sk_upt pairs shared evenly, across tile boundaries, by the sk_wgs - sk_levels x tiles workgroups left over
+    int a_wrap_kt;                          // one-tile g3 NT kernel: A's K-tile index wraps back to 0 from this K-tile on (me_gemm_desc.a_wrap_k / 64; 0 = off)
     float* row_stats;                       // resident EPI 2 kernel only (me_gemm_desc.row_stats): per-row partial statistics of the OUTPUT,
                                             // [N / 64][M] pairs (mean, M2) over 64-column groups, or null
 };
@@ -75,6 +76,10 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, in
         store4_split3(reinterpret_cast<uint16_t*>(p.C) + orow * p.ldc, p.N, n, v);
         return;
     }
+    if (p.c_dtype == ME_BF16X2) {                      // ... as two planes [hi | lo]
+        store4_split2(reinterpret_cast<uint16_t*>(p.C) + orow * p.ldc, p.N, n, v);
+        return;
+    }
     if (p.beta != 0.0f) v += p.beta * load4_as_f32(p.C, p.c_dtype, orow * p.ldc + n);
     store4_from_f32(p.C, p.c_dtype, orow * p.ldc + n, v);
 }
@@ -97,6 +102,10 @@ __device__ __forceinline__ void epilogue_quad_lin(const GemmParams& p, int64_t m
                              : m;
     if (p.c_dtype == ME_BF16X3) {
         store4_split3(reinterpret_cast<uint16_t*>(p.C) + orow * p.ldc, p.N, n, v);
+        return;
+    }
+    if (p.c_dtype == ME_BF16X2) {
+        store4_split2(reinterpret_cast<uint16_t*>(p.C) + orow * p.ldc, p.N, n, v);
         return;
     }
     if (p.beta != 0.0f) v += p.beta * load4_as_f32(p.C, p.c_dtype, orow * p.ldc + n);
@@ -171,6 +180,12 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
         store4_split3(row, p.N, n + 4, v1);
         return;
     }
+    if (p.c_dtype == ME_BF16X2) {
+        uint16_t* row = reinterpret_cast<uint16_t*>(p.C) + orow * p.ldc;
+        store4_split2(row, p.N, n, v0);
+        store4_split2(row, p.N, n + 4, v1);
+        return;
+    }
     if (p.beta != 0.0f) {
         f32x4 c0, c1;
         load8_as_f32(p.C, p.c_dtype, orow * p.ldc + n, c0, c1);
@@ -184,7 +199,7 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
 //   3 ... * gelu'(bf16 aux row operand)   4 generic (anything include/metaenc.h allows)   5 raw fp32 split-K slab
 static inline int pick_epi(const GemmParams& p) {
     if (p.split_k > 1) return 5;
-    if (p.c_dtype == ME_BF16X3) return 4;   // (three-plane stores live in the generic epilogue only)
+    if (me_is_planes(p.c_dtype)) return 4;  // (plane stores live in the generic epilogue only)
     if (p.flags || p.row_affine) return 4;  // (the resident g3 kernel has its own forms of these: launch_g3)
     if (p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return 4;
     const int nrow = (p.residual ? 1 : 0) + (p.aux ? 1 : 0);
@@ -204,7 +219,7 @@ static inline int pick_epi_ex(const GemmParams& p) {
     const int e = pick_epi(p);
     // three-plane (ME_BF16X3) outputs of the MLP of an ME_BF16X3 Block: straight-line forms in the one-tile g3 kernel (9: bias + erf GELU,
     // optionally saving gelu' as an fp32 pre-activation; 10: x fp32 row operand); the other families take the generic epilogue for them
-    if (p.c_dtype == ME_BF16X3 && p.split_k <= 1 && !p.row_affine && !p.colscale && !p.residual && p.beta == 0.0f && p.out_group_rows == 0 &&
+    if (me_is_planes(p.c_dtype) && p.split_k <= 1 && !p.row_affine && !p.colscale && !p.residual && p.beta == 0.0f && p.out_group_rows == 0 &&
         p.res_row_mod == 0 && p.ldc % 8 == 0 && p.N % 8 == 0) {
         if (p.act == ME_ACT_GELU && !p.aux && (!p.preact ? p.flags == 0 : (p.flags == ME_GEMM_SAVE_GELU_GRAD && p.preact_dtype == ME_F32 && p.ldpre % 4 == 0)))
             return 9;
@@ -214,7 +229,7 @@ static inline int pick_epi_ex(const GemmParams& p) {
     if (e == 4 && p.c_dtype == ME_F32 && p.residual && p.res_dtype == ME_F32 && !p.aux && !p.preact && p.act == ME_ACT_NONE && !p.flags &&
         !p.row_affine && p.beta == 0.0f && p.out_group_rows == 0 && p.res_row_mod == 0 && p.split_k <= 1 && p.ldres % 4 == 0)
         return 8;
-    if (e != 4 || p.c_dtype == ME_BF16X3 || p.row_affine || p.colscale || p.residual || p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return e;
+    if (e != 4 || me_is_planes(p.c_dtype) || p.row_affine || p.colscale || p.residual || p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return e;
     if (p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_BF16 && !p.preact) return 6;
     if (p.flags == ME_GEMM_SAVE_GELU_GRAD && p.act == ME_ACT_GELU && p.preact && !p.aux) return 7;
     return e;

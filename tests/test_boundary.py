@@ -91,6 +91,46 @@ def test_patch_embed_fuses_the_reference_geometries(lib):
     assert b"kernel larger than input" in lib.me_last_error()
 
 
+def test_gemm_planning_queries_of_round_6(lib):
+    """host-side decisions only (no kernel runs): me_gemm_takes_row_parts (LayerNorm partials consumed by the folded GEMM), me_gemm_takes_a_wrap
+    (A as two planes with a wrapped reduction), and the workspace query under me_gemm_reserve_cus (weight gradients on fewer workgroups: the query
+    must cover either plan)"""
+    def desc(M_, N_, K_, op=_capi.ME_GEMM_NT, cdt=_capi.ME_BF16, lda=None, ldb=None):
+        d = _capi.GemmDesc()
+        d.op, d.ab_dtype, d.M, d.N, d.K = op, _capi.ME_BF16, M_, N_, K_
+        d.A, d.lda = 4096, lda or (K_ if op == _capi.ME_GEMM_NT else M_)
+        d.B, d.ldb = 8192, ldb or (K_ if op == _capi.ME_GEMM_NT else N_)
+        d.C, d.ldc, d.c_dtype, d.alpha = 16384, N_, cdt, 1.0
+        return d
+    # row_parts: K = 256 .. 1024 in steps of 256, every CU a 256 x 256 tile, bf16 output, plain bias / GELU epilogue
+    for M_, N_, K_, want in ((50432, 2304, 768, 1), (50432, 3072, 768, 1), (65536, 4096, 1024, 1), (4096, 2304, 768, 0), (50432, 2304, 384, 0),
+                             (50432, 2304, 1280, 0)):
+        d = desc(M_, N_, K_)
+        d.col_shift, d.row_parts, d.row_nparts, d.row_eps = 32768, 65536, max(K_ // 256, 1), 1e-6
+        assert lib.me_gemm_takes_row_parts(ctypes.byref(d)) == want, (M_, N_, K_)
+    d = desc(50432, 2304, 768, cdt=_capi.ME_F32)
+    d.col_shift, d.row_parts, d.row_nparts, d.row_eps = 32768, 65536, 3, 1e-6
+    assert lib.me_gemm_takes_row_parts(ctypes.byref(d)) == 0              # (the resident kernel writes bf16)
+    # a_wrap_k: the one-tile 256 x 256 family, plain or fp32-residual epilogue
+    for M_, N_, Kc, want in ((50432, 768, 3072, 1), (8192, 1024, 4096, 1), (512, 768, 3072, 0)):
+        d = desc(M_, N_, 3 * Kc, cdt=_capi.ME_F32, lda=2 * Kc)
+        d.a_wrap_k = 2 * Kc
+        assert lib.me_gemm_takes_a_wrap(ctypes.byref(d)) == want, (M_, N_, Kc)
+    d = desc(50432, 768, 9216, cdt=_capi.ME_F32, lda=6144)
+    d.a_wrap_k = 6144 + 64                                                 # not a multiple of 128
+    assert lib.me_gemm_takes_a_wrap(ctypes.byref(d)) == 0
+    # weight gradients: the workspace query with a reservation covers the default plan too (more slabs per tile, never fewer bytes)
+    for Mo, No in ((2304, 768), (768, 3072), (768, 768)):
+        d = desc(Mo, No, 50432, op=_capi.ME_GEMM_TN, cdt=_capi.ME_F32)
+        w0 = lib.me_gemm_workspace_bytes(ctypes.byref(d))
+        prev = lib.me_gemm_reserve_cus(16)
+        try:
+            w16 = lib.me_gemm_workspace_bytes(ctypes.byref(d))
+        finally:
+            assert lib.me_gemm_reserve_cus(prev) == 16
+        assert w0 > 0 and w16 >= w0, (Mo, No, w0, w16)
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "metatransformer_amd")
     for dp, _, files in os.walk(pkg):

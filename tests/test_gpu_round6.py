@@ -279,3 +279,64 @@ def test_wgrad_balanced_partition_vs_fp64(dev, Mo, No, K, reserve):
     dw0, db0 = ops.gemm(dy, x, op=_capi.ME_GEMM_TN, out_dtype=torch.float32, want_colsum_a=True)      # the one-item-per-CU plan
     assert rel_err(dw, dw0) < 1e-5 and rel_err(db, db0) < 1e-5
 
+
+
+# ------------------------------------------------------------------------------------------------ ME_BF16X2: two planes + a wrapped A operand
+@pytest.mark.parametrize("M_rows,N_out,Kc,res", [(50432, 768, 3072, True), (50432, 768, 3072, False), (8192 + 77, 1024, 4096, True), (33000, 768, 768, False)])
+def test_gemm_reads_two_plane_operand_with_wrapped_reduction(dev, M_rows, N_out, Kc, res):
+    """me_gemm_desc.a_wrap_k: A = [hi | lo] planes of an fp32 matrix (lda = 2 Kc), weights ME_BF16X3 [hi | hi | lo], K = 3 Kc -- the kernel re-reads
+    the hi plane for the third segment.  Equals the three-plane form bit for bit (same products in the same order) and fp64 at 1e-4."""
+    lib = _capi.load()
+    a, w, bias = rnd(M_rows, Kc, seed=21).to(dev), (0.05 * rnd(N_out, Kc, seed=22)).to(dev), (0.1 * rnd(N_out, seed=23)).to(dev)
+    r = rnd(M_rows, N_out, seed=24).to(dev) if res else None
+    a3, w3 = ops.split3(a), ops.split3(w, right_operand=True)
+    a2 = a3[:, :2 * Kc].contiguous()                                  # [hi | lo]
+    y3 = ops.gemm(a3, w3, bias=bias, residual=r, out_dtype=torch.float32)
+    d = _capi.GemmDesc()
+    d.op, d.ab_dtype, d.M, d.N, d.K = _capi.ME_GEMM_NT, _capi.ME_BF16, M_rows, N_out, 3 * Kc
+    d.A, d.lda, d.B, d.ldb = a2.data_ptr(), 2 * Kc, w3.data_ptr(), 3 * Kc
+    y2 = torch.empty(M_rows, N_out, dtype=torch.float32, device=dev)
+    d.C, d.ldc, d.c_dtype, d.alpha = y2.data_ptr(), N_out, _capi.ME_F32, 1.0
+    d.bias, d.a_wrap_k = bias.data_ptr(), 2 * Kc
+    if res:
+        d.residual, d.ldres, d.res_dtype = r.data_ptr(), N_out, _capi.ME_F32
+    assert lib.me_gemm_takes_a_wrap(ctypes.byref(d)) == 1
+    wsb = lib.me_gemm_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
+    _capi.check(lib.me_gemm(ctypes.byref(d), _capi.stream_ptr()), "me_gemm")
+    assert torch.equal(y2, y3)
+    ref = a.double() @ w.double().t() + bias.double() + (r.double() if res else 0)
+    check_close(y2, ref, TOL_3X, "two-plane A, wrapped reduction")
+    # small problems (another kernel family) say no instead of mis-reading the operand
+    d.M = 512
+    assert lib.me_gemm_takes_a_wrap(ctypes.byref(d)) == 0 and lib.me_gemm(ctypes.byref(d), _capi.stream_ptr()) != 0
+
+
+def test_gemm_writes_two_plane_output(dev):
+    """c_dtype ME_BF16X2: the MLP epilogues of an ME_BF16X3 Block write [hi | lo] only (fc1: bias + erf GELU with gelu' saved; fc2 dgrad: x the saved
+    factor) -- the same hi / lo values as the three-plane form"""
+    lib = _capi.load()
+    M_rows, N_out, Kc = 50432 // 4, 3072, 768
+    a, w, bias = rnd(M_rows, Kc, seed=31).to(dev), (0.05 * rnd(N_out, Kc, seed=32)).to(dev), (0.1 * rnd(N_out, seed=33)).to(dev)
+    a3, w3 = ops.split3(a), ops.split3(w, right_operand=True)
+    outs = {}
+    for cdt, planes in ((_capi.ME_BF16X3, 3), (_capi.ME_BF16X2, 2)):
+        out = torch.zeros(M_rows, planes * N_out, dtype=torch.bfloat16, device=dev)
+        pre = torch.zeros(M_rows, N_out, dtype=torch.float32, device=dev)
+        d = _capi.GemmDesc()
+        d.op, d.ab_dtype, d.M, d.N, d.K = _capi.ME_GEMM_NT, _capi.ME_BF16, M_rows, N_out, 3 * Kc
+        d.A, d.lda, d.B, d.ldb = a3.data_ptr(), 3 * Kc, w3.data_ptr(), 3 * Kc
+        d.C, d.ldc, d.c_dtype, d.alpha = out.data_ptr(), planes * N_out, cdt, 1.0
+        d.bias, d.act = bias.data_ptr(), _capi.ME_ACT_GELU
+        d.preact, d.ldpre, d.preact_dtype, d.flags = pre.data_ptr(), N_out, _capi.ME_F32, _capi.ME_GEMM_SAVE_GELU_GRAD
+        wsb = lib.me_gemm_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
+        _capi.check(lib.me_gemm(ctypes.byref(d), _capi.stream_ptr()), "me_gemm")
+        outs[planes] = (out, pre)
+    o3, p3 = outs[3]
+    o2, p2 = outs[2]
+    assert torch.equal(o2, o3[:, :2 * N_out]) and torch.equal(p2, p3)
+    ref = bo.gelu_erf(a.double() @ w.double().t() + bias.double())
+    check_close(o2[:, :N_out].float() + o2[:, N_out:].float(), ref, TOL_3X, "two-plane GELU output")
