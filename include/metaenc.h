@@ -51,7 +51,12 @@ enum { ME_F32 = 0, ME_BF16 = 1,
        ME_BF16X2 = 4 /* the same WITHOUT the repeated plane: [ hi | lo ] in one row of 2 * cols bf16 values -- me_gemm output only (c_dtype,
                       * ldc >= 2 N).  As the A operand of the next GEMM it needs me_gemm_desc.a_wrap_k = 2 * cols (the kernel re-reads the hi
                       * plane for the third K segment); as an operand of a plane weight gradient only hi and lo are read anyway.  Two thirds of
-                      * the ME_BF16X3 bytes for the two [tokens, hidden] tensors of an ME_BF16X3 Block's MLP (round 6). */ };
+                      * the ME_BF16X3 bytes for the two [tokens, hidden] tensors of an ME_BF16X3 Block's MLP (round 6). */,
+       ME_GG8 = 5 /* gelu'(h) in EIGHT BITS: one byte q per element, gelu' = -0.13 + q * (1.26 / 255)  (gelu' lies in [-0.129, 1.129]; step
+                   * 0.0049, |error| <= 0.0025).  Only as me_gemm_desc.preact_dtype with ME_GEMM_SAVE_GELU_GRAD (the fc1 forward of a training
+                   * Block writes it) and as aux_dtype with ME_GEMM_AUX_IS_FACTOR (the fc2 dgrad multiplies by it); ldpre / ldaux in BYTES =
+                   * elements, multiples of 8.  Served by the resident kernel only: ask me_gemm_takes_gg8.  Half the HBM bytes of the bf16
+                   * factor -- at config 2 a train step is bound by energy and an HBM byte costs what 300 bf16 flops cost. */ };
 
 enum { ME_OK = 0, ME_ERR_ARG = -1, ME_ERR_UNSUPPORTED = -2, ME_ERR_HIP = -3, ME_ERR_WORKSPACE = -4 };
 
@@ -182,6 +187,8 @@ int me_gemm_emits_row_stats(const me_gemm_desc* d);
  * beside backward) it did not remove the second-round penalty it was built for (profiles/r06_contention.txt) -- measure on the real node
  * (bench.py --gpus N prints per-rank weight-gradient times) before turning it on.  The workspace query covers either plan. */
 int me_gemm_reserve_cus(int cus);
+/* 1 if me_gemm(d) can serve d's ME_GG8 preact / aux (which must be set) */
+int me_gemm_takes_gg8(const me_gemm_desc* d);
 /* 1 if me_gemm(d) can serve d->a_wrap_k (which must be set) */
 int me_gemm_takes_a_wrap(const me_gemm_desc* d);
 /* 1 if me_gemm(d) can serve d->row_parts (which must be set) */

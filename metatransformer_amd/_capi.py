@@ -20,9 +20,9 @@ LIB_PATH = os.path.join(_HERE, "libmetaenc.so")
 ME_F32, ME_BF16, ME_F16 = 0, 1, 2      # ME_F16: storage dtype of me_cast / me_transpose_cast only
 ME_BF16X3 = 3                          # an fp32 matrix as three bf16 planes [hi | lo | hi] / [hi | hi | lo] (include/metaenc.h)
 ME_BF16X2 = 4                          # ... as two planes [hi | lo] (me_gemm output; as an A operand with GemmDesc.a_wrap_k)
+ME_GG8 = 5                             # gelu'(h) in eight bits (preact of a SAVE_GELU_GRAD GEMM / aux of an AUX_IS_FACTOR GEMM)
 ME_GEMM_NT, ME_GEMM_TN = 0, 1
 ME_ACT_NONE, ME_ACT_GELU = 0, 1
-ME_GEMM_SAVE_GELU_GRAD, ME_GEMM_AUX_IS_FACTOR = 1, 2
 ME_GEMM_SAVE_GELU_GRAD, ME_GEMM_AUX_IS_FACTOR = 1, 2
 ME_PROF_LN_FWD, ME_PROF_LN_BWD, ME_PROF_ATTN_FWD, ME_PROF_ATTN_BWD, ME_PROF_ROW_STATS = 16, 17, 18, 19, 20      # me_gemm_profile_rec.op codes
 ME_COMM_ID_BYTES = 128
@@ -141,6 +141,7 @@ SIGNATURES = {
     "me_gemm_takes_row_parts": (c_int, [POINTER(GemmDesc)]),
     "me_gemm_reserve_cus": (c_int, [c_int]),
     "me_gemm_takes_a_wrap": (c_int, [POINTER(GemmDesc)]),
+    "me_gemm_takes_gg8": (c_int, [POINTER(GemmDesc)]),
     "me_gemm": (c_int, [POINTER(GemmDesc), c_void_p]),
     "me_gemm_profile_enable": (c_int, [c_int]),
     "me_gemm_profile_read": (c_int, [POINTER(GemmProfileRec), c_int]),

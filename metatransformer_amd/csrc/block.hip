@@ -181,6 +181,29 @@ bool takes_parts(const me_block_desc* d, const Dims& s) {
     return true;
 }
 
+// does a training bf16 Block keep gelu'(h) in eight bits (ME_GG8)?  When BOTH launches that touch it -- the fc1 forward that saves it, the fc2
+// dgrad that multiplies by it -- run on the resident kernel.  Same rule going forward and back (the stash slot keeps its bf16 size).
+// OFF by default (-DME_BLOCK_GG8=1 turns it on): same-box A/B at config 2, profiles/r06_gelu_grad_8bit_ab.txt -- the step does not get
+// faster for the 620 MB less it moves per layer (fc1 forward 289 -> 296 us with the extra pack arithmetic, fc2 dgrad 244.6 -> 243.9 us),
+// so the bf16 factor's precision stays.  me_gemm serves ME_GG8 either way.
+#ifndef ME_BLOCK_GG8
+#define ME_BLOCK_GG8 0
+#endif
+bool gelu_grad_gg8(const me_block_desc* d, const Dims& s) {
+    if (!ME_BLOCK_GG8 || d->dtype != ME_BF16 || s.Hd % 8) return false;
+    static char dummy_mem[64] __attribute__((aligned(64)));
+    me_gemm_desc g;
+    gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, s.Hd, s.C, dummy_mem, s.C, dummy_mem, s.C, dummy_mem, s.Hd, ME_BF16);
+    g.bias = reinterpret_cast<const float*>(dummy_mem); g.act = ME_ACT_GELU;
+    g.preact = dummy_mem; g.ldpre = s.Hd; g.preact_dtype = ME_GG8; g.flags = ME_GEMM_SAVE_GELU_GRAD;
+    g.workspace = dummy_mem; g.workspace_bytes = (int64_t)1 << 40;
+    if (!me_gemm_takes_gg8(&g)) return false;
+    gemm_desc(g, ME_GEMM_NT, ME_BF16, s.M, s.Hd, s.C, dummy_mem, s.C, dummy_mem, s.C, dummy_mem, s.Hd, ME_BF16);
+    g.aux = dummy_mem; g.ldaux = s.Hd; g.aux_dtype = ME_GG8; g.flags = ME_GEMM_AUX_IS_FACTOR;
+    g.workspace = dummy_mem; g.workspace_bytes = (int64_t)1 << 40;
+    return me_gemm_takes_gg8(&g) != 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // ME_BF16X3 blocks: the reference's DEFAULT arithmetic (fp32 tokens, fp32 weights: README.md:113-150) at matrix-pipe speed.  Every
 // Linear runs as ONE bf16 NT GEMM over three-plane operands (include/metaenc.h, ME_BF16X3: A = [hi | lo | hi], W = [hi | hi | lo],
@@ -519,7 +542,7 @@ extern "C" int me_block_fwd(const me_block_desc* d, const void* x, void* y, void
     }
     g.act = ME_ACT_GELU;
     // (saved for backward: gelu'(h), not h -- the fc2 dgrad epilogue then multiplies by a stored factor)
-    if (keep) { g.preact = v.hpre; g.ldpre = s.Hd; g.preact_dtype = dt; g.flags = ME_GEMM_SAVE_GELU_GRAD; }
+    if (keep) { g.preact = v.hpre; g.ldpre = s.Hd; g.preact_dtype = gelu_grad_gg8(d, s) ? ME_GG8 : dt; g.flags = ME_GEMM_SAVE_GELU_GRAD; }
     g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
     if ((rc = me_gemm(&g, stream))) return rc;
     gemm_desc(g, ME_GEMM_NT, dt, s.M, s.C, s.Hd, v.a, s.Hd, d->fc2_w, s.Hd, y, s.C, rdt);
@@ -591,9 +614,10 @@ extern "C" int me_block_bwd(const me_block_desc* d, const void* x, const void* d
         return rc_in;
     };
 
+    const int gdt = gelu_grad_gg8(d, s) ? ME_GG8 : dt;        // (how the forward stored gelu': same rule, same answer)
     auto nt = [&](const void* A, int64_t K, const void* Wt, void* C, int64_t N, const void* aux) -> int {
         gemm_desc(g, ME_GEMM_NT, dt, s.M, N, K, A, K, Wt, K, C, N, dt);
-        if (aux) { g.aux = aux; g.ldaux = N; g.aux_dtype = dt; g.flags = ME_GEMM_AUX_IS_FACTOR; }
+        if (aux) { g.aux = aux; g.ldaux = N; g.aux_dtype = gdt; g.flags = ME_GEMM_AUX_IS_FACTOR; }
         g.workspace = gws; g.workspace_bytes = (int64_t)gsz;
         return me_gemm(&g, stream);
     };

@@ -32,6 +32,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+// ME_GG8 (include/metaenc.h): gelu'(h) in eight bits, g = ME_GG8_LO + ME_GG8_STEP * q
+constexpr float ME_GG8_LO = -0.13f, ME_GG8_STEP = 1.26f / 255.0f;
 constexpr int ME_STATS_GROUP = 256;      // columns per partial (mean, M2) pair of me_gemm_desc.row_stats / row_parts: one output tile's width
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
@@ -80,7 +82,7 @@ struct ProfScope {
     ~ProfScope();
 };
 
-static inline size_t me_dtype_size(int dt) { return dt == ME_F32 ? 4 : 2; }
+static inline size_t me_dtype_size(int dt) { return dt == ME_F32 ? 4 : dt == ME_GG8 ? 1 : 2; }
 static inline bool me_dtype_ok(int dt) { return dt == ME_F32 || dt == ME_BF16; }                    // compute dtypes
 static inline bool me_storage_dtype_ok(int dt) { return me_dtype_ok(dt) || dt == ME_F16; }          // me_cast only
 static inline bool me_out_dtype_ok(int dt) { return me_dtype_ok(dt) || dt == ME_BF16X3; }           // me_layernorm_fwd y (and me_gemm C, which also takes ME_BF16X2)

@@ -649,8 +649,11 @@ int fill_params(const me_gemm_desc* d, GemmParams& p) {
     ME_CHECK_ARG((d->flags & ~(ME_GEMM_SAVE_GELU_GRAD | ME_GEMM_AUX_IS_FACTOR)) == 0, "me_gemm: unknown flags");
     ME_CHECK_ARG(!(d->flags & ME_GEMM_SAVE_GELU_GRAD) || (d->act == ME_ACT_GELU && d->preact), "me_gemm: ME_GEMM_SAVE_GELU_GRAD needs act = GELU and preact");
     ME_CHECK_ARG(!(d->flags & ME_GEMM_AUX_IS_FACTOR) || d->aux, "me_gemm: ME_GEMM_AUX_IS_FACTOR needs aux");
-    if (d->preact) ME_CHECK_ARG(me_dtype_ok(d->preact_dtype) && d->ldpre % 4 == 0, "me_gemm: bad preact");
-    if (d->aux) ME_CHECK_ARG(me_dtype_ok(d->aux_dtype) && d->ldaux % 4 == 0, "me_gemm: bad aux");
+    // (ME_GG8: the saved gelu' in eight bits -- only as the flagged factor, 8-byte rows; see me_gemm_takes_gg8)
+    if (d->preact) ME_CHECK_ARG((me_dtype_ok(d->preact_dtype) && d->ldpre % 4 == 0) ||
+                                (d->preact_dtype == ME_GG8 && d->flags == ME_GEMM_SAVE_GELU_GRAD && d->ldpre % 8 == 0 && (uintptr_t)d->preact % 8 == 0), "me_gemm: bad preact");
+    if (d->aux) ME_CHECK_ARG((me_dtype_ok(d->aux_dtype) && d->ldaux % 4 == 0) ||
+                             (d->aux_dtype == ME_GG8 && d->flags == ME_GEMM_AUX_IS_FACTOR && d->ldaux % 8 == 0 && (uintptr_t)d->aux % 8 == 0), "me_gemm: bad aux");
     if (d->residual) ME_CHECK_ARG(me_dtype_ok(d->res_dtype) && d->ldres % 4 == 0, "me_gemm: bad residual");
     p.A = d->A; p.B = d->B; p.C = d->C;
     p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
@@ -742,6 +745,15 @@ extern "C" int me_gemm_takes_row_parts(const me_gemm_desc* d) {
     return g3_takes_row_parts(p) ? 1 : 0;
 }
 
+extern "C" int me_gemm_takes_gg8(const me_gemm_desc* d) {
+    GemmParams p;
+    if (!d || d->op != ME_GEMM_NT || d->ab_dtype != ME_BF16 || fill_params(d, p) != ME_OK) return 0;
+    if (!((d->preact && d->preact_dtype == ME_GG8) || (d->aux && d->aux_dtype == ME_GG8))) return 0;
+    const GemmPlan pl = plan_gemm(d, p);
+    if (pl.family != 4 || pl.tail_rows > 0) return 0;
+    return g3_takes_gg8(p) ? 1 : 0;
+}
+
 namespace {
 // tn_launch: a replacement for launch_g3_tn (patch_embed.hip: the wgrad kernel that gathers its B operand from the image); with it,
 // a problem the planner does not give to the g3 wgrad family is refused (ME_ERR_UNSUPPORTED) instead of run
@@ -778,6 +790,9 @@ int gemm_impl(const me_gemm_desc* d, hipStream_t stream, int* plan_out, TnLaunch
     if (d->row_parts)
         ME_CHECK_ARG(pl.family == 4 && d->op == ME_GEMM_NT && pl.tail_rows == 0 && g3_takes_row_parts(p),
                      "me_gemm: row_parts is not available for this problem (see me_gemm_takes_row_parts)");
+    if ((d->preact && d->preact_dtype == ME_GG8) || (d->aux && d->aux_dtype == ME_GG8))
+        ME_CHECK_ARG(pl.family == 4 && d->op == ME_GEMM_NT && pl.tail_rows == 0 && g3_takes_gg8(p),
+                     "me_gemm: ME_GG8 is not available for this problem (see me_gemm_takes_gg8)");
     if (pl.family >= 1) {
         if (pl.family == 4 && d->op == ME_GEMM_TN) {
             ME_CHECK_ARG(d->workspace && (size_t)d->workspace_bytes >= pl.ws_bytes,

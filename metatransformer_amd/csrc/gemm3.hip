@@ -328,7 +328,14 @@ template <int EPI, int PRE, bool HALF = false>
 __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, int64_t m0, int tn, int lane, const G3Src& nxt, int nk,
                                               const __amdgpu_buffer_rsrc_t brs, int ntn, bool next_zero, unsigned* ctr, int nx,
                                               uint32_t lds_tick, int64_t next_m0 = 0, int next_rows = 0, int par = 0) {
-    constexpr bool SAVE = PRE == 1 || PRE == 2, LNF = PRE == 3 || PRE == 5, LNP = PRE == 5, STATS = PRE == 4;
+    // PRE 6 (EPI 1 / EPI 6): gelu'(h) travels as EIGHT BITS (ME_GG8: q = rint((g + 0.13) x 255 / 1.26), g in [-0.129, 1.129]) -- EPI 1 saves it,
+    // EPI 6 multiplies by it.  Half the bytes of the bf16 factor (310 MB less written and 310 MB less read per layer at config 2: at ~120 pJ
+    // per HBM byte the largest single item a train step can shed, profiles/r06_energy_probe.txt); the same number of memory operations,
+    // each half as wide (8 bytes per lane, 8 consecutive lanes = the wave's 64-byte row segment), so every counted wait stays what it is.
+    // Step 0.0049: |error| <= 0.0025 absolute, about what bf16 leaves at g ~ 1 and more than bf16 leaves near 0.
+    constexpr bool G8 = PRE == 6, G8S = G8 && EPI == 1, G8L = G8 && EPI == 6;
+    static_assert(!G8 || EPI == 1 || EPI == 6, "8-bit gelu': the fc1 forward that saves it, the fc2 dgrad that reads it");
+    constexpr bool SAVE = PRE == 1 || PRE == 2 || G8S, LNF = PRE == 3 || PRE == 5, LNP = PRE == 5, STATS = PRE == 4;
     static_assert(!STATS || EPI == 2, "row statistics: the residual epilogue");
     constexpr int NMT = HALF ? 4 : 8, WROWS = HALF ? 64 : 128;      // 16-row slabs per wave, rows per wave row
     // (claimed schedule: wave 0 draws the ticket for the item after next FIRST, ahead of every store of this epilogue)
@@ -344,17 +351,17 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     rows = rows < 1 ? 1 : rows;                 // (an item past the last row: every access below is then out of range)
     cols = cols < G3_BN ? cols : G3_BN;
     const bool item_ok = p.M > m0;
-    auto tile_rsrc = [&](const void* base, int64_t ld) {
+    auto tile_rsrc = [&](const void* base, int64_t ld, int esz = 2) {
         if (!item_ok) return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0, 0x00020000);
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (m0 * ld + n0) * 2, 0,
-                                                 (int)(((rows - 1) * ld + cols) * 2), 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (m0 * ld + n0) * esz, 0,
+                                                 (int)(((rows - 1) * ld + cols) * esz), 0x00020000);
     };
     // dev (debug bit 4): the stores go nowhere (zero-record descriptor), everything else unchanged
     // (debug bit 2 with bit 4: only the first workgroup of every XCD keeps its stores)
     const bool drop = kMeDev && (p.debug & 4) && !((p.debug & 2) && (blockIdx.x >> 3) == 0);
     const __amdgpu_buffer_rsrc_t crs = drop ? __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000) : tile_rsrc(p.C, p.ldc);
-    const __amdgpu_buffer_rsrc_t prs = SAVE ? tile_rsrc(p.preact, p.ldpre) : crs;
-    const __amdgpu_buffer_rsrc_t rrs = EPI == 2 ? tile_rsrc(p.residual, p.ldres) : (EPI == 3 || EPI == 6) ? tile_rsrc(p.aux, p.ldaux) : crs;
+    const __amdgpu_buffer_rsrc_t prs = SAVE ? tile_rsrc(p.preact, p.ldpre, G8S ? 1 : 2) : crs;
+    const __amdgpu_buffer_rsrc_t rrs = EPI == 2 ? tile_rsrc(p.residual, p.ldres) : (EPI == 3 || EPI == 6) ? tile_rsrc(p.aux, p.ldaux, G8L ? 1 : 2) : crs;
     const int rop_ld = (int)(EPI == 2 ? p.ldres : p.ldaux);
     // memory side: lane t = row t >> 3 of an 8-row half slab, 16-byte chunk t & 7 of the wave's 128-byte row segment.  A
     // chunk past the column edge gets an offset no descriptor admits; rows past the row edge fall behind the descriptor's end.
@@ -362,16 +369,46 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     const bool ok = (colb >> 1) + 8 <= (int)cols;
     const int row = wr * WROWS + (lane >> 3);
     const uint32_t coff = ok ? (uint32_t)(row * (int)p.ldc * 2 + colb) : 0x80000000u;
-    const uint32_t poff = ok && SAVE ? (uint32_t)(row * (int)p.ldpre * 2 + colb) : 0x80000000u;
-    const uint32_t roff = ok ? (uint32_t)(row * rop_ld * 2 + colb) : 0x80000000u;
-    const int cstep = (int)p.ldc * 16, pstep = (int)p.ldpre * 16, rstep = rop_ld * 16;       // 8 rows, bytes
+    const uint32_t poff = ok && SAVE ? (G8S ? (uint32_t)(row * (int)p.ldpre + (colb >> 1)) : (uint32_t)(row * (int)p.ldpre * 2 + colb)) : 0x80000000u;
+    const uint32_t roff = ok ? (G8L ? (uint32_t)(row * rop_ld + (colb >> 1)) : (uint32_t)(row * rop_ld * 2 + colb)) : 0x80000000u;
+    const int cstep = (int)p.ldc * 16, pstep = (int)p.ldpre * (G8S ? 8 : 16), rstep = rop_ld * (G8L ? 8 : 16);       // 8 rows, bytes
     // register side (after g3r_rows8): lane (r, g) = row r & 7, chunk 4 (r >> 3) + 2 (g & 1) + (g >> 1).  to_mem: the lane
     // that holds memory lane t's chunk; to_reg: the memory lane that holds this lane's chunk (x 4: bpermute byte addresses)
     const int to_mem = 4 * ((lane >> 3) + 8 * ((lane >> 2) & 1) + 16 * (((lane >> 1) & 1) | ((lane & 1) << 1)));
     const int to_reg = 4 * (8 * (r & 7) + 4 * (r >> 3) + 2 * (g & 1) + (g >> 1));
     auto fetch = [&](const int mt, u32x4 (&raw)[2]) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) raw[h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(roff + (2 * mt + h) * rstep), 0, G3_POL_R);
+        for (int h = 0; h < 2; ++h) {
+            if (G8L) {
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rrs, (int)(roff + (2 * mt + h) * rstep), 0, G3_POL_R);
+                raw[h] = u32x4{t[0], t[1], 0u, 0u};
+            } else {
+                raw[h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(roff + (2 * mt + h) * rstep), 0, G3_POL_R);
+            }
+        }
+    };
+    // 8-bit gelu' (ME_GG8): eight bytes <-> eight factors
+    auto unpack8 = [](const u32x4& rw, f32x4& a, f32x4& b) {
+        const f32x4 qa = {(float)(rw[0] & 0xffu), (float)((rw[0] >> 8) & 0xffu), (float)((rw[0] >> 16) & 0xffu), (float)(rw[0] >> 24)};
+        const f32x4 qb = {(float)(rw[1] & 0xffu), (float)((rw[1] >> 8) & 0xffu), (float)((rw[1] >> 16) & 0xffu), (float)(rw[1] >> 24)};
+        a = qa * ME_GG8_STEP + ME_GG8_LO;
+        b = qb * ME_GG8_STEP + ME_GG8_LO;
+    };
+    auto pack8 = [](const f32x4& a, const f32x4& b) {
+        // v_cvt_pk_u8_f32 rounds to nearest even and saturates to 0 .. 255 (NaN -> 0): tools/cvt_pk_u8_probe.hip -- one fma and one pack per factor
+        unsigned w0 = 0u, w1 = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            w0 = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(a[e], 1.0f / ME_GG8_STEP, -ME_GG8_LO / ME_GG8_STEP), e, w0);
+            w1 = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(b[e], 1.0f / ME_GG8_STEP, -ME_GG8_LO / ME_GG8_STEP), e, w1);
+        }
+        return u32x4{w0, w1, 0u, 0u};
+    };
+    auto lanes2 = [](const u32x4& v, int addr) {        // g3r_lanes on the two live words
+        u32x4 o = {0u, 0u, 0u, 0u};
+        o[0] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v[0]);
+        o[1] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v[1]);
+        return o;
     };
     auto unpack = [](const u32x4& rw, f32x4& a, f32x4& b) {
         a[0] = __uint_as_float(rw[0] << 16); a[1] = __uint_as_float(rw[0] & 0xffff0000u);
@@ -440,8 +477,13 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
     for (int mt = 0; mt < NMT; ++mt) {
         f32x4 ro[2][2];
         if (EPI == 2 || EPI == 3 || EPI == 6) {
-            unpack(g3r_lanes(rowop[mt][0], to_reg), ro[0][0], ro[0][1]);
-            unpack(g3r_lanes(rowop[mt][1], to_reg), ro[1][0], ro[1][1]);
+            if (G8L) {
+                unpack8(lanes2(rowop[mt][0], to_reg), ro[0][0], ro[0][1]);
+                unpack8(lanes2(rowop[mt][1], to_reg), ro[1][0], ro[1][1]);
+            } else {
+                unpack(g3r_lanes(rowop[mt][0], to_reg), ro[0][0], ro[0][1]);
+                unpack(g3r_lanes(rowop[mt][1], to_reg), ro[1][0], ro[1][1]);
+            }
             if (mt + AHEAD < NMT) fetch(mt + AHEAD, rowop[mt + AHEAD]);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -479,7 +521,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
         for (int h = 0; h < 2; ++h) {           // half A: rows 0..7 of the slab, half B: rows 8..15
             f32x4 v0 = v[h][0], v1 = v[h][1];
             if (EPI == 1) {
-                if (PRE == 2) {
+                if (PRE == 2 || G8S) {
                     // gelu and gelu' from the same Phi / Gaussian parts: the backward GEMM multiplies by the saved factor.  (The
                     // erf form stays here: with BOTH outputs wanted it shares one exponential between them, and the two
                     // polynomial chains of the bf16-mode forms measured no faster -- 344 against 339 us per fc1 launch.)
@@ -494,7 +536,12 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
                     phi_parts4(v0, ph0, ga0);
                     phi_parts4(v1, ph1, ga1);
                     const f32x4 d0 = ph0 + v0 * ga0 * 0.3989422804014327f, d1 = ph1 + v1 * ga1 * 0.3989422804014327f;
-                    __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(d0, d1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, G3_POL_P);
+                    if (G8S) {
+                        const u32x4 q8 = lanes2(pack8(d0, d1), to_mem);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{q8[0], q8[1]}, prs, (int)(poff + (2 * mt + h) * pstep), 0, G3_POL_P);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(g3r_lanes(pack(d0, d1), to_mem), prs, (int)(poff + (2 * mt + h) * pstep), 0, G3_POL_P);
+                    }
                     v0 *= ph0;
                     v1 *= ph1;
 #endif
@@ -610,7 +657,7 @@ __device__ __forceinline__ void g3_epilogue_r(const GemmParams& p, G3State& s, i
 
 // memory operations one g3_epilogue_r issues per wave behind the next tile's A-Y half-tile: >= the stores (+ the later
 // row-operand loads); an under-count only makes the wait stricter
-template <int EPI, int PRE> constexpr int g3r_seam() { return (PRE == 1 || PRE == 2) ? 32 : EPI >= 2 ? 20 : 16; }
+template <int EPI, int PRE> constexpr int g3r_seam() { return (PRE == 1 || PRE == 2 || (PRE == 6 && EPI == 1)) ? 32 : EPI >= 2 ? 20 : 16; }
 
 // HI: this instantiation also carries the 128-row item form (run_item<HALF>): a second K-loop and epilogue in the kernel.  Only the
 // bias-only forms are built with it (launch3r): around the row-operand epilogues the extra scalar state pushed 16-27 VGPRs of
@@ -1200,10 +1247,10 @@ template <int EPI, int PRE> int launch3r(const GemmParams& q0, int G, hipStream_
 int launch3r_any(int epi, int pre, const GemmParams& q, int G, hipStream_t stream) {
     switch (epi) {
         case 0: return pre == 5 ? launch3r<0, 5>(q, G, stream) : pre == 3 ? launch3r<0, 3>(q, G, stream) : launch3r<0, 0>(q, G, stream);
-        case 1: return pre == 5 ? launch3r<1, 5>(q, G, stream) : pre == 3 ? launch3r<1, 3>(q, G, stream) : pre == 2 ? launch3r<1, 2>(q, G, stream) : pre ? launch3r<1, 1>(q, G, stream) : launch3r<1, 0>(q, G, stream);
+        case 1: return pre == 6 ? launch3r<1, 6>(q, G, stream) : pre == 5 ? launch3r<1, 5>(q, G, stream) : pre == 3 ? launch3r<1, 3>(q, G, stream) : pre == 2 ? launch3r<1, 2>(q, G, stream) : pre ? launch3r<1, 1>(q, G, stream) : launch3r<1, 0>(q, G, stream);
         case 2: return pre == 4 ? launch3r<2, 4>(q, G, stream) : launch3r<2, 0>(q, G, stream);
         case 3: return launch3r<3, 0>(q, G, stream);
-        default: return launch3r<6, 0>(q, G, stream);
+        default: return pre == 6 ? launch3r<6, 6>(q, G, stream) : launch3r<6, 0>(q, G, stream);
     }
 }
 
@@ -1245,14 +1292,16 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
         if (EPI == 4 && p.flags && !p.row_affine) {
             // the two halves of the "save gelu'" pair (pick_epi sends flagged descriptors to the generic epilogue)
             if (plain && p.flags == ME_GEMM_SAVE_GELU_GRAD && p.act == ME_ACT_GELU && p.preact && !p.aux) { repi = 1; pre = 2; }
-            if (plain && p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_BF16 && !p.preact) repi = 6;
+            if (plain && p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && (p.aux_dtype == ME_BF16 || p.aux_dtype == ME_GG8) && !p.preact) repi = 6;
         }
         if (EPI == 6) repi = 6;                                   // (pick_epi_ex has checked the same conditions)
         if (EPI == 7) { repi = 1; pre = 2; }
+        if (repi == 1 && pre == 2 && p.preact_dtype == ME_GG8) pre = 6;       // gelu' in eight bits, both halves of the pair
+        if (repi == 6 && p.aux_dtype == ME_GG8) pre = 6;
         if (EPI == 2 && p.row_stats) pre = 4;
         const int G = g3_cus() & ~7;
         const int64_t ldmax = std::max(std::max(p.ldc, p.preact ? p.ldpre : 0), std::max(p.residual ? p.ldres : 0, p.aux ? p.ldaux : 0));
-        if (repi >= 0 && !p.colscale && G >= 8 && nwg >= G && q.g3_split <= 1 && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!(pre == 1 || pre == 2) || p.preact_dtype == ME_BF16) &&
+        if (repi >= 0 && !p.colscale && G >= 8 && nwg >= G && q.g3_split <= 1 && p.alpha == 1.0f && p.c_dtype == ME_BF16 && (!(pre == 1 || pre == 2) || p.preact_dtype == ME_BF16) && (pre != 6 || !p.preact || p.ldpre % 8 == 0) &&
             256 * ldmax * 2 < (1ll << 31))
             return launch3r_any(repi, pre, q, G, stream);
     }
@@ -1262,6 +1311,10 @@ template <int EPI> int launch3e(const GemmParams& p, void* ws, hipStream_t strea
     }
     if (p.row_nparts) {
         me_set_error("me_gemm: row_parts needs the resident kernel's folded-LayerNorm epilogue (see me_gemm_takes_row_parts)");
+        return ME_ERR_UNSUPPORTED;
+    }
+    if ((p.preact && p.preact_dtype == ME_GG8) || (p.aux && p.aux_dtype == ME_GG8)) {
+        me_set_error("me_gemm: ME_GG8 needs the resident kernel (see me_gemm_takes_gg8)");
         return ME_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL((gemm_g3_kernel<EPI>), dim3((unsigned)nwg), dim3(512), G3_LDS, stream, q);
@@ -1356,6 +1409,22 @@ bool g3_takes_row_parts(const GemmParams& p) {
     const int G = g3_cus() & ~7;
     const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     return G >= 8 && tiles >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && 256 * p.ldc * 2 < (1ll << 31) && p.M * 8 * 16 < (1ll << 31);
+}
+
+// ME_GG8 (gelu' in eight bits): the two flagged descriptors of the training MLP, when launch3e sends them to the resident kernel
+bool g3_takes_gg8(const GemmParams& p) {
+#ifdef ME_NO_GG8
+    return false;                               // (A/B arm)
+#endif
+    if (!g3_supported(p, ME_GEMM_NT) || gemm_dev().g3_persistent != 1) return false;
+    if (p.row_affine || p.residual || p.colscale || p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0 || p.a_wrap_kt) return false;
+    const bool save = p.flags == ME_GEMM_SAVE_GELU_GRAD && p.act == ME_ACT_GELU && p.preact && p.preact_dtype == ME_GG8 && !p.aux;
+    const bool load = p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_GG8 && !p.preact;
+    if (!save && !load) return false;
+    const int G = g3_cus() & ~7;
+    const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int64_t ldmax = std::max(p.ldc, save ? p.ldpre : p.ldaux);
+    return G >= 8 && tiles >= G && p.alpha == 1.0f && p.c_dtype == ME_BF16 && 256 * ldmax * 2 < (1ll << 31);
 }
 
 // scratch of the persistent stream-K form (dev build): one fp32 partial tile per workgroup + the hand-over flags (+ 1

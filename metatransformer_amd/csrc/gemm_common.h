@@ -230,7 +230,7 @@ static inline int pick_epi_ex(const GemmParams& p) {
         !p.row_affine && p.beta == 0.0f && p.out_group_rows == 0 && p.res_row_mod == 0 && p.split_k <= 1 && p.ldres % 4 == 0)
         return 8;
     if (e != 4 || me_is_planes(p.c_dtype) || p.row_affine || p.colscale || p.residual || p.beta != 0.0f || p.out_group_rows != 0 || p.res_row_mod != 0) return e;
-    if (p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && p.aux_dtype == ME_BF16 && !p.preact) return 6;
+    if (p.flags == ME_GEMM_AUX_IS_FACTOR && p.act == ME_ACT_NONE && p.aux && (p.aux_dtype == ME_BF16 || p.aux_dtype == ME_GG8) && !p.preact) return 6;
     if (p.flags == ME_GEMM_SAVE_GELU_GRAD && p.act == ME_ACT_GELU && p.preact && !p.aux) return 7;
     return e;
 }
@@ -242,6 +242,7 @@ int launch_g3(const GemmParams& p, int epi, void* ws, hipStream_t stream);      
 bool g3_supported(const GemmParams& p, int op);
 bool g3_emits_row_stats(const GemmParams& p);          // will launch_g3 run the resident residual kernel that can emit p.row_stats?
 bool g3_takes_row_parts(const GemmParams& p);          // ... the resident folded-LayerNorm epilogue that consumes such partials directly (p.row_nparts)?
+bool g3_takes_gg8(const GemmParams& p);         // ME_GG8 preact / aux: the resident kernel's PRE 6 forms only
 size_t g3_workspace_bytes();
 int launch_g3_tn(const GemmParams& p, hipStream_t stream);      // p.split_k slabs into p.C, p.ksteps_per_split K-tiles of 64 each
 int launch_g3_tn_sk(const GemmParams& p, hipStream_t stream);   // the balanced static partition (p.sk_wgs workgroups; p.split_k = the most slabs a tile gets)

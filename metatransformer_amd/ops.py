@@ -161,10 +161,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
         d.colscale = ptr(colscale)
     if preact is not None:
         _req(preact, "preact")
-        d.preact, d.ldpre, d.preact_dtype = ptr(preact), preact.stride(-2), dtype_code(preact.dtype)
+        # (uint8 = ME_GG8: gelu' in eight bits, -0.13 + q * 1.26 / 255 -- with ME_GEMM_SAVE_GELU_GRAD, where gemm_takes_gg8 says yes)
+        d.preact, d.ldpre, d.preact_dtype = ptr(preact), preact.stride(-2), _capi.ME_GG8 if preact.dtype == torch.uint8 else dtype_code(preact.dtype)
     if aux is not None:
         _req(aux, "aux")
-        d.aux, d.ldaux, d.aux_dtype = ptr(aux), aux.stride(-2), dtype_code(aux.dtype)
+        d.aux, d.ldaux, d.aux_dtype = ptr(aux), aux.stride(-2), _capi.ME_GG8 if aux.dtype == torch.uint8 else dtype_code(aux.dtype)
     if residual is not None:
         _req(residual, "residual")
         d.residual, d.ldres, d.res_dtype = ptr(residual), residual.stride(-2), dtype_code(residual.dtype)
@@ -195,6 +196,31 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, op: int = _capi.ME_GEMM_NT, out: O
             cs = colsum(a2, out=colsum_out, accumulate=beta != 0.0)
         return out, cs
     return out
+
+
+GG8_LO, GG8_STEP = -0.13, 1.26 / 255.0      # ME_GG8 (include/metaenc.h)
+
+
+def gemm_takes_gg8(M: int, N: int, K: int) -> bool:
+    """Do the two flagged GEMMs of a bf16 training MLP -- [M, K] x [N, K]^T with gelu' saved / multiplied -- take it in eight bits
+    (me_gemm_takes_gg8: both on the resident kernel)?  Needs a GPU (the answer depends on its CU count)."""
+    lib = _capi.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dummy = torch.empty(64, dtype=torch.uint8, device=dev)
+    for save in (True, False):
+        d = GemmDesc()
+        d.op, d.ab_dtype, d.c_dtype = _capi.ME_GEMM_NT, _capi.ME_BF16, _capi.ME_BF16
+        d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, K, K, N
+        d.A = d.B = d.C = ptr(dummy)
+        d.alpha = 1.0
+        if save:
+            d.act, d.flags, d.preact, d.ldpre, d.preact_dtype = _capi.ME_ACT_GELU, _capi.ME_GEMM_SAVE_GELU_GRAD, ptr(dummy), N, _capi.ME_GG8
+        else:
+            d.flags, d.aux, d.ldaux, d.aux_dtype = _capi.ME_GEMM_AUX_IS_FACTOR, ptr(dummy), N, _capi.ME_GG8
+        d.workspace, d.workspace_bytes = ptr(dummy), 1 << 40
+        if not lib.me_gemm_takes_gg8(ctypes.byref(d)):
+            return False
+    return True
 
 
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:

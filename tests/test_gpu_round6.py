@@ -340,3 +340,59 @@ def test_gemm_writes_two_plane_output(dev):
     assert torch.equal(o2, o3[:, :2 * N_out]) and torch.equal(p2, p3)
     ref = bo.gelu_erf(a.double() @ w.double().t() + bias.double())
     check_close(o2[:, :N_out].float() + o2[:, N_out:].float(), ref, TOL_3X, "two-plane GELU output")
+
+
+# ----------------------------------------------------------------------------- gelu' in eight bits (ME_GG8)
+
+@pytest.mark.parametrize("M_rows,N_out,Kc", [(50432 // 2, 3072, 768), (16384 + 40, 4096, 1024)])
+def test_gelu_grad_in_eight_bits(dev, M_rows, N_out, Kc):
+    """ME_GG8: the fc1 forward of a bf16 training Block saves gelu'(h) as one byte (-0.13 + q * 1.26 / 255), the fc2 dgrad multiplies by it.
+    Saved bytes = the quantised fp32 gelu' of the SAME accumulators the bf16 form rounds to bf16 (so: within one step of the bf16 form's bytes,
+    within half a step + the GEMM's own error of the float64 gelu'); the GELU output is bit-identical to the bf16-factor launch; the dgrad
+    equals (A W^T) * decode(q) like the bf16-factor launch equals (A W^T) * factor; a ragged last row tile is covered (second case)."""
+    if not ops.gemm_takes_gg8(M_rows, N_out, Kc):
+        pytest.skip("the resident kernel does not take this shape here")
+    a, w, bias = rnd(M_rows, Kc, seed=41).bfloat16(), (0.05 * rnd(N_out, Kc, seed=42)).bfloat16(), 0.1 * rnd(N_out, seed=43)
+    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
+    q = torch.full((M_rows, N_out), 7, dtype=torch.uint8, device=dev)
+    y8 = ops.gemm(ad, wd, bias=bd, act=_capi.ME_ACT_GELU, preact=q, flags=_capi.ME_GEMM_SAVE_GELU_GRAD)
+    sav = torch.empty(M_rows, N_out, dtype=torch.bfloat16, device=dev)
+    y16 = ops.gemm(ad, wd, bias=bd, act=_capi.ME_ACT_GELU, preact=sav, flags=_capi.ME_GEMM_SAVE_GELU_GRAD)
+    assert torch.equal(y8, y16)
+    dec = ops.GG8_LO + ops.GG8_STEP * q.float()
+    # against the bf16 form (same accumulators): half a step + bf16's own rounding of a value <= 1.13
+    assert float((dec - sav.float()).abs().max()) <= 0.5 * ops.GG8_STEP + 2.0 ** -8 + 1e-6
+    # against float64 on a row sample
+    rows = torch.randperm(M_rows, generator=torch.Generator().manual_seed(5))[:2048]
+    h = (a[rows].double() @ w.double().t() + bias.double()).requires_grad_(True)
+    bo.gelu_erf(h).sum().backward()
+    err = (dec[rows.to(dev)].cpu().double() - h.grad).abs()
+    assert float(err.max()) <= 0.5 * ops.GG8_STEP + 6e-3 and float(err.mean()) <= 0.3 * ops.GG8_STEP + 2e-4, (float(err.max()), float(err.mean()))
+    # the dgrad half: x decode(q), against the bf16-factor launch fed the decoded factor rounded to bf16 (differs by that rounding only)
+    g, wt = rnd(M_rows, Kc, seed=44).bfloat16().to(dev), (0.05 * rnd(N_out, Kc, seed=45)).bfloat16().to(dev)
+    d8 = ops.gemm(g, wt, aux=q, flags=_capi.ME_GEMM_AUX_IS_FACTOR)
+    lin = g[rows.to(dev)].double().cpu() @ wt.double().cpu().t()
+    check_close(d8[rows.to(dev)].float(), lin * dec[rows.to(dev)].double().cpu(), 8e-3, "dgrad x eight-bit factor")
+    for _ in range(2):
+        assert torch.equal(ops.gemm(g, wt, aux=q, flags=_capi.ME_GEMM_AUX_IS_FACTOR), d8)
+    # every code point decodes where the header says (a factor tensor holding all 256 codes)
+    allq = (torch.arange(M_rows * N_out, device=dev) % 256).to(torch.uint8).reshape(M_rows, N_out)
+    dall = ops.gemm(g, wt, aux=allq, flags=_capi.ME_GEMM_AUX_IS_FACTOR)
+    check_close(dall[rows.to(dev)].float(), lin * (ops.GG8_LO + ops.GG8_STEP * allq[rows.to(dev)].double().cpu()), 8e-3, "all 256 codes")
+
+
+def test_eight_bit_factor_is_refused_off_the_resident_kernel(dev):
+    """small problems (another kernel family) and unflagged uses say no instead of mis-reading bytes"""
+    a, w = rnd(512, 768, seed=1).bfloat16().to(dev), rnd(3072, 768, seed=2).bfloat16().to(dev)
+    q = torch.zeros(512, 3072, dtype=torch.uint8, device=dev)
+    assert not ops.gemm_takes_gg8(512, 3072, 768)
+    with pytest.raises(_capi.MetaEncError):
+        ops.gemm(a, w, aux=q, flags=_capi.ME_GEMM_AUX_IS_FACTOR)
+    with pytest.raises(_capi.MetaEncError):
+        ops.gemm(a, w, act=_capi.ME_ACT_GELU, preact=q, flags=_capi.ME_GEMM_SAVE_GELU_GRAD)
+    a2, w2 = rnd(50432 // 2, 768, seed=1).bfloat16().to(dev), w
+    q2 = torch.zeros(50432 // 2, 3072, dtype=torch.uint8, device=dev)
+    with pytest.raises(_capi.MetaEncError):
+        ops.gemm(a2, w2, aux=q2)                    # eight bits only as the flagged factor
+    with pytest.raises(_capi.MetaEncError):
+        ops.gemm(a2, w2, preact=q2, act=_capi.ME_ACT_GELU)
