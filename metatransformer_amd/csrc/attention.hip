@@ -1963,63 +1963,71 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
 #ifndef ME_ST_BWD_MINN
 #define ME_ST_BWD_MINN 513
 #endif
+#ifndef ME_ST_BWD_ROWS
+#define ME_ST_BWD_ROWS 32                      // keys per compute wave of the streaming dK / dV kernel: 16 (16 waves) or 32 (8 waves)  -- A/B arm
+#endif
 constexpr int ST_BWD_MINN = ME_ST_BWD_MINN;
 
-// loader waves of the streaming backward kernels: array 0 / 1 of a chunk from (a0, ld0) / (a1, ld1); FL: 128 floats of f0 / f1 per chunk
-template <int HD, bool FL>
-__device__ __forceinline__ void st16_bwd_loader(char* smem, char* fring, int wave, int lane, int QB, int total, int NCH, int vid, int G,
+// loader waves of the streaming backward kernels: array 0 / 1 of a chunk from (a0, ld0) / (a1, ld1); FL: 128 floats of f0 / f1 per chunk.
+// NW waves per workgroup, the last NL of them load (the others past the compute waves keep the barrier count): NL = 4 (two waves per array),
+// 2 (one per array) or 1 (one wave fills both arrays -- the 8-wave kernels with seven compute waves).
+template <int HD, bool FL, int NW>
+__device__ __forceinline__ void st16_bwd_loader(char* smem, char* fring, int wave, int lane, int NL, int total, int NCH, int vid, int G,
                                                 int nblk, int H, int N, int hd, const bf16_t* a0, int64_t ld0, int64_t hoff0,
                                                 const bf16_t* a1, int64_t ld1, int64_t hoff1, const float* f0, const float* f1) {
     typedef RCfg<HD> R;
     constexpr int arr_bytes = ST_KC * R::RB;
     constexpr int slot_bytes = 2 * arr_bytes;
     constexpr int NPC = ST_KC / R::RPI;
-    const int NL = QB <= 12 * 16 ? 4 : 2;
-    if (wave < 16 - NL) {                             // spare waves: the barrier count only
+    static_assert(2 * NPC + 4 <= 63, "vmcnt range");
+    if (wave < NW - NL) {                             // spare waves: the barrier count only
         for (int k = 0; k < total; ++k) __builtin_amdgcn_s_barrier();
         return;
     }
-    const int lw = wave - (16 - NL);
-    const int which = lw & 1;
-    const int part = lw >> 1, nparts = NL >> 1;
-    const bf16_t* const arr = which ? a1 : a0;
-    const int64_t ldw = which ? ld1 : ld0, hoff = which ? hoff1 : hoff0;
-    const float* const farr = which ? f1 : f0;
+    const int lw = wave - (NW - NL);
+    const int which0 = NL == 1 ? 0 : (lw & 1), nwhich = NL == 1 ? 2 : 1;
+    const int part = lw >> 1, nparts = NL == 4 ? 2 : 1;
     const int rg = (lane * 16) / R::RB, pos = ((lane * 16) % R::RB) / 16;
     const int csrc = pos ^ r16_swz<R::CPR>(rg);
-    const int dma_voff = (csrc * 8 < hd) ? rg * (int)ldw * 2 + csrc * 16 : 0x7f000000;
-    const int dma_gstep = R::RPI * (int)ldw * 2;
-    const int rec_bytes = (int)(((int64_t)(N - 1) * ldw + hd) * 2);
     auto fill = [&](int j) {
         if (j >= total) return;
         const int it = vid + (j / NCH) * G, c = j % NCH;
         const int bh = it / nblk;
-        const bf16_t* base = arr + (int64_t)(bh / H) * N * ldw + (bh % H) * hd + hoff;
-        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, rec_bytes, 0x00020000);
-        char* dst = smem + (j % ST_RING) * slot_bytes + which * arr_bytes;
-        const int voff = dma_voff + c * NPC * dma_gstep;
-        if (nparts == 1) {
-#pragma unroll
-            for (int i = 0; i < NPC; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(dst + i * 1024), 16, voff + i * dma_gstep, 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NPC / 2; ++i) {
-                const int p = 2 * i + part;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(dst + p * 1024), 16, voff + p * dma_gstep, 0, 0, 0);
-            }
-        }
-        if (FL) {
-            // 128 floats of this loader's statistics array: two dword pieces of 64 (one each when two loaders share the array)
-            const __amdgpu_buffer_rsrc_t rf =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(farr + (int64_t)bh * N), 0, N * 4, 0x00020000);
-            char* fdst = fring + ((j % ST_RING) * 2 + which) * (ST_KC * 4);
-            const int fvoff = (c * ST_KC + lane) * 4;
+        for (int w = 0; w < nwhich; ++w) {
+            const int which = which0 + w;
+            const bf16_t* const arr = which ? a1 : a0;
+            const int64_t ldw = which ? ld1 : ld0, hoff = which ? hoff1 : hoff0;
+            const int dma_voff = (csrc * 8 < hd) ? rg * (int)ldw * 2 + csrc * 16 : 0x7f000000;
+            const int dma_gstep = R::RPI * (int)ldw * 2;
+            const int rec_bytes = (int)(((int64_t)(N - 1) * ldw + hd) * 2);
+            const bf16_t* base = arr + (int64_t)(bh / H) * N * ldw + (bh % H) * hd + hoff;
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, rec_bytes, 0x00020000);
+            char* dst = smem + (j % ST_RING) * slot_bytes + which * arr_bytes;
+            const int voff = dma_voff + c * NPC * dma_gstep;
             if (nparts == 1) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_dma_t*)fdst, 4, fvoff, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_dma_t*)(fdst + 256), 4, fvoff + 256, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NPC; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(dst + i * 1024), 16, voff + i * dma_gstep, 0, 0, 0);
             } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_dma_t*)(fdst + 256 * part), 4, fvoff + 256 * part, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NPC / 2; ++i) {
+                    const int p = 2 * i + part;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_dma_t*)(dst + p * 1024), 16, voff + p * dma_gstep, 0, 0, 0);
+                }
+            }
+            if (FL) {
+                // 128 floats of this array's statistics: two dword pieces of 64 (one each when two loaders share the array)
+                const float* const farr = which ? f1 : f0;
+                const __amdgpu_buffer_rsrc_t rf =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(farr + (int64_t)bh * N), 0, N * 4, 0x00020000);
+                char* fdst = fring + ((j % ST_RING) * 2 + which) * (ST_KC * 4);
+                const int fvoff = (c * ST_KC + lane) * 4;
+                if (nparts == 1) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_dma_t*)fdst, 4, fvoff, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_dma_t*)(fdst + 256), 4, fvoff + 256, 0, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (lds_dma_t*)(fdst + 256 * part), 4, fvoff + 256 * part, 0, 0, 0);
+                }
             }
         }
     };
@@ -2028,7 +2036,8 @@ __device__ __forceinline__ void st16_bwd_loader(char* smem, char* fring, int wav
     for (int k = 0; k < total; ++k) {
         // chunk k has landed once at most chunk k + 1's pieces (of this loader) are outstanding (in-order retirement)
         if (k + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (nparts == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC + (FL ? 2 : 0)) : "memory");
+        else if (NL == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC + (FL ? 4 : 0)) : "memory");
+        else if (NL == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC + (FL ? 2 : 0)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC / 2 + (FL ? 1 : 0)) : "memory");
         __builtin_amdgcn_s_barrier();                 // chunk k ready; everybody is done with chunk k - 1
         fill(k + 2);                                  // ... whose slot takes chunk k + 2
@@ -2059,7 +2068,7 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_dq_stream16_kernel(const
     const int vid = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int my_items = vid < items ? (items - vid + G - 1) / G : 0;
     if (16 * wave >= QB) {
-        st16_bwd_loader<HD, false>(smem, nullptr, wave, lane, QB, my_items * NCH, NCH, vid, G, nqb, H, N, hd, qkv, ld, Cdim, qkv, ld,
+        st16_bwd_loader<HD, false, 16>(smem, nullptr, wave, lane, QB <= 12 * 16 ? 4 : 2, my_items * NCH, NCH, vid, G, nqb, H, N, hd, qkv, ld, Cdim, qkv, ld,
                                    2 * Cdim, nullptr, nullptr);
         return;
     }
@@ -2199,7 +2208,7 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_dkdv_stream16_kernel(con
     const int my_items = vid < items ? (items - vid + G - 1) / G : 0;
     char* const fring = smem + ST_RING * slot_bytes;
     if (16 * wave >= KB) {
-        st16_bwd_loader<HD, true>(smem, fring, wave, lane, KB, my_items * NCH, NCH, vid, G, nkb, H, N, hd, qkv, ld, 0, dout, lddo, 0, lse,
+        st16_bwd_loader<HD, true, 16>(smem, fring, wave, lane, KB <= 12 * 16 ? 4 : 2, my_items * NCH, NCH, vid, G, nkb, H, N, hd, qkv, ld, 0, dout, lddo, 0, lse,
                                   delta);
         return;
     }
@@ -2315,6 +2324,218 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_dkdv_stream16_kernel(con
         bf16_t* grow0 = dqkv + ((int64_t)b * N + k0) * lddq + head * hd;
         r16_store_rows<HD>(scr, dk, scale, grow0 + Cdim, lddq, N - k0, hd, lane);
         r16_store_rows<HD>(scr, dv, 1.0f, grow0 + 2 * Cdim, lddq, N - k0, hd, lane);
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// The dK / dV kernel with 32 KEYS PER WAVE (round 6): 8 waves of up to 256 registers instead of 16 of 128 -- seven compute waves own 2 x 16
+// keys each (224 keys per workgroup, as before), the eighth loads both arrays.  Every fragment a wave reads from the streamed {Q, dO} chunk
+// (row form for S / dP, transposed form for the two gradient products) now feeds TWO 16-key tiles: half the LDS bytes per MFMA -- the
+// 16-row kernel reads 16 KB per 20 MFMAs and keeps the LDS array busy 45 % of the time with the matrix pipe at 35 %
+// (profiles/r04_attn_pmc_stream.txt) -- and twice the independent MFMA chains per wave, against half the waves issuing softmax arithmetic.
+// Same box, profiles/r06_attn_bwd_stream32.txt: N = 1568 (config 5) 852 -> 763 us, 592 (config 4) 443 -> 411 us.  Taken when the key
+// blocks fill seven waves (192 < keys per block <= 224); six compute waves on four SIMDs run as slowly as eight (N = 520: +12 %).
+// The dQ kernel in the same form (8 waves: 575 vs 562 us at N = 1568; 12 waves of 137 registers, 320-query blocks: 547 vs 538 us) does
+// not gain -- 12 MFMAs per 12 KB there, and it is not the LDS that paces it -- and stays on 16-row waves.
+constexpr int ST32_THREADS = 512;
+#ifndef ME_ST32_PIPE
+#define ME_ST32_PIPE 2                          // (A/B arms: 1 = the same source order without the scheduling barriers)
+#endif
+
+template <int HD>
+__global__ __launch_bounds__(ST32_THREADS) void attn_bwd_dkdv_stream32_kernel(const bf16_t* __restrict__ qkv, int64_t ld,
+                                                                              const bf16_t* __restrict__ dout, int64_t lddo,
+                                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                              bf16_t* __restrict__ dqkv, int64_t lddq, int N, int H, int hd,
+                                                                              float scale, int KB, int nkb, int items) {
+    typedef Cfg<bf16_t, HD> C;
+    typedef RCfg<HD> R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int arr_bytes = ST_KC * R::RB;
+    constexpr int slot_bytes = 2 * arr_bytes;
+    constexpr int NKS = HD / 32, NDT = HD / 16;
+    constexpr int SCR = 16 * C::RROW;
+    constexpr int FRING = ST_RING * 2 * ST_KC * 4;    // {lse, delta} of a chunk, per ring slot
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int Cdim = H * hd;
+    const int G = (int)gridDim.x;
+    const int NCH = (N + ST_KC - 1) / ST_KC;
+    const int vid = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int my_items = vid < items ? (items - vid + G - 1) / G : 0;
+    char* const fring = smem + ST_RING * slot_bytes;
+    const int ncw = KB >> 5;
+    if (wave >= ncw) {
+        st16_bwd_loader<HD, true, 8>(smem, fring, wave, lane, 8 - ncw >= 4 ? 4 : 8 - ncw >= 2 ? 2 : 1, my_items * NCH, NCH, vid, G, nkb, H, N, hd, qkv,
+                                     ld, 0, dout, lddo, 0, lse, delta);
+        return;
+    }
+    char* scr = fring + FRING + wave * SCR;
+    const float sl = scale * LOG2E;
+    int koff[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) koff[ks] = l15 * R::RB + 16 * ((4 * ks + g) ^ r16_swz<R::CPR>(l15));
+    int troff[NDT];
+    {
+        const int rr = 4 * g + (l15 >> 2);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+            troff[dt] = rr * R::RB + 16 * ((2 * dt + ((l15 & 3) >> 1)) ^ r16_swz<R::CPR>(rr)) + 8 * (l15 & 1);
+    }
+    auto rowread = [&](const char* arr, int t, bf16x8 (&dst)[NKS]) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) dst[ks] = *reinterpret_cast<const bf16x8*>(arr + 16 * t * R::RB + koff[ks]);
+    };
+    auto trread = [&](const char* arr, int kk, int dt) {
+        union { bf16x4 q4[2]; bf16x8 v; } a;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            a.q4[r] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)((uint32_t)(uintptr_t)arr + (32 * kk + 16 * r) * R::RB + troff[dt]));
+        return a.v;
+    };
+    const f32x4 zero4f = {0.f, 0.f, 0.f, 0.f};
+    // the wave's own K / V rows (two 16-key tiles): the next item's are fetched under this item's last chunk
+    u32x4 kn[2][NKS], vn[2][NKS];
+    auto own_issue = [&](int it) {
+        const int bh = it / nkb, kb = it % nkb;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int k = kb * KB + 32 * wave + 16 * r + l15;
+            const bf16_t* kptr = qkv + ((int64_t)(bh / H) * N + (k < N ? k : N - 1)) * ld + (bh % H) * hd + Cdim;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int d = 32 * ks + 8 * g, dc = d < hd ? d : 0;
+                kn[r][ks] = *reinterpret_cast<const u32x4*>(kptr + dc);
+                vn[r][ks] = *reinterpret_cast<const u32x4*>(kptr + Cdim + dc);
+            }
+        }
+    };
+    if (my_items > 0) own_issue(vid);
+    int j = 0;
+    for (int ii = 0; ii < my_items; ++ii) {
+        const int it = vid + ii * G;
+        const int bh = it / nkb, kb = it % nkb;
+        const int b = bh / H, head = bh % H;
+        const int k0 = kb * KB + 32 * wave;
+        bf16x8 kf[2][NKS], vf[2][NKS];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bool ok = 32 * ks + 8 * g < hd;
+                const u32x4 kv = ok ? kn[r][ks] : zero4(), vv = ok ? vn[r][ks] : zero4();
+                kf[r][ks] = *reinterpret_cast<const bf16x8*>(&kv);
+                vf[r][ks] = *reinterpret_cast<const bf16x8*>(&vv);
+            }
+        f32x4 dk[2][NDT], dv[2][NDT];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) { dk[r][dt] = zero4f; dv[r][dt] = zero4f; }
+        // one chunk = four 32-query steps, software-pipelined in program order: the S / dP products of step qq + 1 are issued BEFORE the
+        // softmax arithmetic of step qq (which then runs under them), the gradient products of step qq behind it
+        auto chunk = [&](int c) {
+            const char* Qb = smem + (j % ST_RING) * slot_bytes;
+            const char* Db = Qb + arr_bytes;
+            const float* lsb = reinterpret_cast<const float*>(fring + (j % ST_RING) * 2 * (ST_KC * 4));
+            const float* deb = lsb + ST_KC;
+            auto sdp = [&](int qq, f32x4 (&s)[2][2], f32x4 (&dp)[2][2]) {      // [query tile of the pair][key tile]
+                {
+                    bf16x8 qa[2][NKS];
+                    rowread(Qb, 2 * qq, qa[0]); rowread(Qb, 2 * qq + 1, qa[1]);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) s[tt][r] = mma16(qa[tt][0], kf[r][0], zero4f);
+#pragma unroll
+                    for (int ks = 1; ks < NKS; ++ks)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) s[tt][r] = mma16(qa[tt][ks], kf[r][ks], s[tt][r]);
+                }
+                {
+                    bf16x8 da[2][NKS];
+                    rowread(Db, 2 * qq, da[0]); rowread(Db, 2 * qq + 1, da[1]);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) dp[tt][r] = mma16(da[tt][0], vf[r][0], zero4f);
+#pragma unroll
+                    for (int ks = 1; ks < NKS; ++ks)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) dp[tt][r] = mma16(da[tt][ks], vf[r][ks], dp[tt][r]);
+                }
+            };
+            f32x4 s[2][2], dp[2][2];
+            sdp(0, s, dp);
+#pragma unroll
+            for (int qq = 0; qq < ST_KC / 32; ++qq) {
+                // stage order held by scheduling barriers (the compiler otherwise sinks the next step's products behind this step's and
+                // waits on every transposed read pair in turn): next S / dP -> this step's transposed dO fragments + statistics ->
+                // softmax arithmetic (under both) -> transposed Q fragments -> dV products (under which those land) -> dK products
+                f32x4 s2[2][2], dp2[2][2];
+                if (qq + 1 < ST_KC / 32) sdp(qq + 1, s2, dp2);
+                if (ME_ST32_PIPE == 2) __builtin_amdgcn_sched_barrier(0);
+                bf16x8 td[NDT], tq[NDT];
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) td[dt] = trread(Db, qq, dt);
+                f32x4 L[2], D[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    L[tt] = *reinterpret_cast<const f32x4*>(lsb + 16 * (2 * qq + tt) + 4 * g);
+                    D[tt] = *reinterpret_cast<const f32x4*>(deb + 16 * (2 * qq + tt) + 4 * g);
+                }
+                if (ME_ST32_PIPE == 2) __builtin_amdgcn_sched_barrier(0);
+                bf16x8 pb[2], dsb[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float pe = r16_p(s[tt][r][e] * sl - L[tt][e] * LOG2E);
+                            pb[r][4 * tt + e] = (bf16_t)pe;
+                            dsb[r][4 * tt + e] = (bf16_t)(pe * (dp[tt][r][e] - D[tt][e]));      // dS / scale (scale applied to dK once)
+                        }
+                if (ME_ST32_PIPE == 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) tq[dt] = trread(Qb, qq, dt);      // (lands under the dV products)
+                if (ME_ST32_PIPE == 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) dv[r][dt] = mma16(td[dt], pb[r], dv[r][dt]);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) dk[r][dt] = mma16(tq[dt], dsb[r], dk[r][dt]);
+                if (ME_ST32_PIPE == 2) __builtin_amdgcn_sched_barrier(0);
+                if (qq + 1 < ST_KC / 32) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) { s[tt][r] = s2[tt][r]; dp[tt][r] = dp2[tt][r]; }
+                }
+            }
+        };
+        for (int c = 0; c + 1 < NCH; ++c, ++j) {
+            __syncthreads();
+            chunk(c);
+        }
+        __syncthreads();
+        own_issue(ii + 1 < my_items ? it + G : it);
+        chunk(NCH - 1);
+        ++j;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            bf16_t* grow0 = dqkv + ((int64_t)b * N + k0 + 16 * r) * lddq + head * hd;
+            r16_store_rows<HD>(scr, dk[r], scale, grow0 + Cdim, lddq, N - k0 - 16 * r, hd, lane);
+            r16_store_rows<HD>(scr, dv[r], 1.0f, grow0 + 2 * Cdim, lddq, N - k0 - 16 * r, hd, lane);
+        }
     }
 }
 
@@ -2895,12 +3116,15 @@ template <int HD>
 int launch_bwd_stream16(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
                         float* delta, void* dqkv, int64_t lddq, int B, int N, int H, int hd, float scale, hipStream_t stream) {
     typedef RCfg<HD> R;
-    constexpr size_t smem1 = (size_t)ST_RING * 2 * ST_KC * R::RB + (R16_THREADS / 64) * 16 * Cfg<bf16_t, HD>::RROW;
-    constexpr size_t smem2 = smem1 + (size_t)ST_RING * 2 * ST_KC * sizeof(float);
+    constexpr size_t ring = (size_t)ST_RING * 2 * ST_KC * R::RB, fl = (size_t)ST_RING * 2 * ST_KC * sizeof(float);
+    constexpr size_t smem1 = ring + (R16_THREADS / 64) * 16 * Cfg<bf16_t, HD>::RROW;
+    constexpr size_t smem2 = smem1 + fl;
+    constexpr size_t smem3 = ring + (ST32_THREADS / 64) * 16 * Cfg<bf16_t, HD>::RROW + fl;
     static OncePerDevice once;
     if (once.need()) {
         set_smem(attn_bwd_dq_stream16_kernel<HD>, smem1);
         set_smem(attn_bwd_dkdv_stream16_kernel<HD>, smem2);
+        set_smem(attn_bwd_dkdv_stream32_kernel<HD>, smem3);
     }
     // row blocks of (at most) 14 x 16 rows, evened out over the sequence (queries in the first kernel, keys in the second)
     const int nrb = (N + 223) / 224;
@@ -2913,6 +3137,15 @@ int launch_bwd_stream16(const void* qkv, int64_t ld, const void* out, int64_t ld
                        reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta, reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd, scale,
                        RBk, nrb, (int)items);
     ME_CHECK_LAUNCH("me_attention_bwd(dq stream16)");
+    // dK / dV: 32-key waves when the key blocks fill seven of them (see attn_bwd_dkdv_stream32_kernel)
+    const int KB32 = (RBk + 31) / 32 * 32;
+    if (ME_ST_BWD_ROWS == 32 && KB32 == 224) {
+        hipLaunchKernelGGL((attn_bwd_dkdv_stream32_kernel<HD>), dim3(grid), dim3(ST32_THREADS), smem3, stream,
+                           reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta,
+                           reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd, scale, KB32, nrb, (int)items);
+        ME_CHECK_LAUNCH("me_attention_bwd(dkdv stream32)");
+        return ME_OK;
+    }
     hipLaunchKernelGGL((attn_bwd_dkdv_stream16_kernel<HD>), dim3(grid), dim3(R16_THREADS), smem2, stream,
                        reinterpret_cast<const bf16_t*>(qkv), ld, reinterpret_cast<const bf16_t*>(dout), lddo, lse, delta,
                        reinterpret_cast<bf16_t*>(dqkv), lddq, N, H, hd, scale, RBk, nrb, (int)items);
