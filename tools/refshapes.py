@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--only", default="")
-    ap.add_argument("--dtypes", default="fp32,bf16")
+    ap.add_argument("--dtypes", default="fp32,fp32x3,bf16")
     a = ap.parse_args()
     res = {"_meta": {"mode": "frozen encoder (requires_grad=False on every Block parameter): forward + dL/dx; `fwd` = forward alone under no_grad",
                      "peaks_TFLOPs": {"fp32": 157.3, "fp32x3": 833.3, "bf16": 2500.0}, "device": torch.cuda.get_device_name(0)}}
