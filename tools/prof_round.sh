@@ -13,6 +13,11 @@ ME_WGRAD_OVERLAP=0 timeout 500 rocprofv3 --kernel-trace --stats --output-format 
 echo "train (serial order: ME_WGRAD_OVERLAP=0) rc=$?"
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fwd -o t -- python $R/bench.py --steps 5 --warmup 2 --mode fwd --no-cpu-baseline > $O/fwd.json 2> $O/fwd.err
 echo "fwd rc=$?"
+# configs 5 and 3 (Large, 1568 / 512 tokens): kernel traces of the train step
+for wl in large1568 large512; do
+  timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${wl}_train -o t -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-fwd-leg > $O/${wl}_train_under_rocprof.json 2> $O/${wl}_train.err
+  echo "$wl train rc=$?"
+done
 find $O -name "*agent*" -delete
 ME_WGRAD_OVERLAP=0 MODE=train bash $R/tools/pmc_bench.sh
 MODE=fwd bash $R/tools/pmc_bench.sh
