@@ -912,6 +912,30 @@ template <int HD> struct RCfg {
 // Waves 14 and 15 are the loaders (paced LDS-DMA of the next item's K and V into the other ring half), other waves >= ceil(N / 16)
 // only keep the barrier.
 constexpr int R16_THREADS = 1024;
+// exp2(s * sl - m) of four scores in place, summed into a pair of partial sums: on PAIRS (round 6: v_pk_fma_f32 for the argument, v_pk_add_f32
+// for the sum -- 2 instead of 3 VALU instructions per score)
+#ifndef ME_R16_PK
+#define ME_R16_PK 1                             // (A/B arm: 0 = element by element)
+#endif
+__device__ __forceinline__ void r16_exp4(f32x4& s, float sl, float m, f32x2& ps) {
+#if ME_R16_PK
+    const f32x2 slv = {sl, sl}, mv = {m, m};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 arg = f32x2{s[2 * h], s[2 * h + 1]} * slv - mv;
+        const f32x2 pe = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+        s[2 * h] = pe[0]; s[2 * h + 1] = pe[1];
+        ps += pe;
+    }
+#else
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(s[e] * sl - m);
+        s[e] = pe;
+        ps[0] += pe;
+    }
+#endif
+}
 #ifndef ME_R16_SLEEP
 #define ME_R16_SLEEP 1      // loader pacing: s_sleep units (64 clocks) behind every DMA piece
 #endif
@@ -1107,15 +1131,10 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_ring16_kernel(const bf16
         mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         m2 = mt * sl;
-        float ps = 0.f;
+        f32x2 psv = {0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pe = __builtin_amdgcn_exp2f(s[t][e] * sl - m2);
-                s[t][e] = pe;
-                ps += pe;
-            }
+        for (int t = 0; t < NT; ++t) r16_exp4(s[t], sl, m2, psv);
+        float ps = psv[0] + psv[1];
         ps += __shfl_xor(ps, 16, 64);
         l_tot = ps + __shfl_xor(ps, 32, 64);
         TRACE_STAMP(it, 4);
@@ -1597,15 +1616,10 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float m_new = fmaxf(m_run, mt * sl);     // every chunk holds a valid key: finite from the first chunk on
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            float ps = 0.f;
+            f32x2 psv = {0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < NTC; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pe = __builtin_amdgcn_exp2f(s[t][e] * sl - m_new);
-                    s[t][e] = pe;
-                    ps += pe;
-                }
+            for (int t = 0; t < NTC; ++t) r16_exp4(s[t], sl, m_new, psv);
+            const float ps = psv[0] + psv[1];
             l_run = l_run * alpha + ps;
             m_run = m_new;
 #pragma unroll
@@ -1652,6 +1666,29 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf
 
 // a softmax probability from its log2-domain argument: v_exp_f32 with the clamp output modifier (hipcc folds the med3 into it)
 __device__ __forceinline__ float r16_p(float arg) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(arg), 0.f, 1.f); }
+
+// four probabilities and their dS / scale of the backward kernels:  pe = exp2(s * sl - l2),  ds = pe * (dp - d).  On PAIRS (round 6): v_pk_fma_f32
+// for the argument, v_pk_mul_f32 + v_pk_fma_f32 for ds = pe * dp - pe * d (the compiler does not select a packed subtract for pe * (dp - d)):
+// 3.5 VALU instructions per score instead of 5, in kernels where this arithmetic is the longer side of its overlap with the MFMAs
+__device__ __forceinline__ void r16_pds4(const f32x4& s, const f32x4& dp, float sl, const f32x4& l2, const f32x4& d, f32x4& pe, f32x4& ds) {
+#if ME_R16_PK
+    const f32x2 slv = {sl, sl};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 arg = f32x2{s[2 * h], s[2 * h + 1]} * slv - f32x2{l2[2 * h], l2[2 * h + 1]};
+        const f32x2 p = {r16_p(arg[0]), r16_p(arg[1])};
+        const f32x2 x = p * f32x2{dp[2 * h], dp[2 * h + 1]} - p * f32x2{d[2 * h], d[2 * h + 1]};
+        pe[2 * h] = p[0]; pe[2 * h + 1] = p[1];
+        ds[2 * h] = x[0]; ds[2 * h + 1] = x[1];
+    }
+#else
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        pe[e] = r16_p(s[e] * sl - l2[e]);
+        ds[e] = pe[e] * (dp[e] - d[e]);
+    }
+#endif
+}
 
 // -----------------------------------------------------------------------------------------------------
 // Backward in the ring form (SM_MINN < N <= RS_MAXN), 16 waves, 16 rows per wave (see attn_fwd_ring16_kernel for why).
@@ -1868,12 +1905,12 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
             // keys >= N: their K rows are zeros, so whatever dS holds there adds nothing to dQ -- no mask
             bf16x8 dsb;
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+            for (int tt = 0; tt < 2; ++tt) {
+                f32x4 pe, ds;
+                r16_pds4(s[tt], dp[tt], sl, f32x4{lse2, lse2, lse2, lse2}, f32x4{del, del, del, del}, pe, ds);      // dS^T / scale (scale applied to dQ once)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pe = r16_p(s[tt][e] * sl - lse2);
-                    dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - del));      // dS^T / scale (scale applied to dQ once)
-                }
+                for (int e = 0; e < 4; ++e) dsb[4 * tt + e] = (bf16_t)ds[e];
+            }
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) dq[dt] = mma16(kt[dt], dsb, kk == 0 ? zero4f : dq[dt]);
         }
@@ -1926,12 +1963,10 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
             for (int tt = 0; tt < 2; ++tt) {
                 const f32x4 L = *reinterpret_cast<const f32x4*>(lse_s + 16 * (2 * qq + tt) + 4 * g);
                 const f32x4 D = *reinterpret_cast<const f32x4*>(del_s + 16 * (2 * qq + tt) + 4 * g);
+                f32x4 pe, ds;
+                r16_pds4(s[tt], dp[tt], sl, L, D, pe, ds);      // dS / scale (scale applied to dK once)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pe = r16_p(s[tt][e] * sl - L[e]);
-                    pb[4 * tt + e] = (bf16_t)pe;
-                    dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - D[e]));      // dS / scale (scale applied to dK once)
-                }
+                for (int e = 0; e < 4; ++e) { pb[4 * tt + e] = (bf16_t)pe[e]; dsb[4 * tt + e] = (bf16_t)ds[e]; }
             }
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) dv[dt] = mma16(trread(QDr + arr_bytes, qq, dt), pb, qq == 0 ? zero4f : dv[dt]);
@@ -2162,12 +2197,12 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_dq_stream16_kernel(const
                 for (int dt = 0; dt < NDT; ++dt) kt[dt] = trread(Kb, kk, dt);
                 bf16x8 dsb;
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
+                for (int tt = 0; tt < 2; ++tt) {
+                    f32x4 pe, ds;
+                    r16_pds4(s[tt], dp[tt], sl, f32x4{lse2, lse2, lse2, lse2}, f32x4{del, del, del, del}, pe, ds);      // dS^T / scale (scale applied to dQ once)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float pe = r16_p(s[tt][e] * sl - lse2);
-                        dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - del));      // dS^T / scale (scale applied to dQ once)
-                    }
+                    for (int e = 0; e < 4; ++e) dsb[4 * tt + e] = (bf16_t)ds[e];
+                }
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) dq[dt] = mma16(kt[dt], dsb, dq[dt]);
             }
@@ -2300,12 +2335,10 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_dkdv_stream16_kernel(con
                 for (int tt = 0; tt < 2; ++tt) {
                     const f32x4 L = *reinterpret_cast<const f32x4*>(lsb + 16 * (2 * qq + tt) + 4 * g);
                     const f32x4 D = *reinterpret_cast<const f32x4*>(deb + 16 * (2 * qq + tt) + 4 * g);
+                    f32x4 pe, ds;
+                    r16_pds4(s[tt], dp[tt], sl, L * LOG2E, D, pe, ds);      // dS / scale (scale applied to dK once)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float pe = r16_p(s[tt][e] * sl - L[e] * LOG2E);
-                        pb[4 * tt + e] = (bf16_t)pe;
-                        dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - D[e]));      // dS / scale (scale applied to dK once)
-                    }
+                    for (int e = 0; e < 4; ++e) { pb[4 * tt + e] = (bf16_t)pe[e]; dsb[4 * tt + e] = (bf16_t)ds[e]; }
                 }
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) dv[dt] = mma16(trread(Db, qq, dt), pb, dv[dt]);
@@ -2492,15 +2525,16 @@ __global__ __launch_bounds__(ST32_THREADS) void attn_bwd_dkdv_stream32_kernel(co
                 if (ME_ST32_PIPE == 2) __builtin_amdgcn_sched_barrier(0);
                 bf16x8 pb[2], dsb[2];
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
+                for (int tt = 0; tt < 2; ++tt) {
+                    const f32x4 L2 = L[tt] * LOG2E;
 #pragma unroll
-                    for (int r = 0; r < 2; ++r)
+                    for (int r = 0; r < 2; ++r) {
+                        f32x4 pe, ds;
+                        r16_pds4(s[tt][r], dp[tt][r], sl, L2, D[tt], pe, ds);      // dS / scale (scale applied to dK once)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float pe = r16_p(s[tt][r][e] * sl - L[tt][e] * LOG2E);
-                            pb[r][4 * tt + e] = (bf16_t)pe;
-                            dsb[r][4 * tt + e] = (bf16_t)(pe * (dp[tt][r][e] - D[tt][e]));      // dS / scale (scale applied to dK once)
-                        }
+                        for (int e = 0; e < 4; ++e) { pb[r][4 * tt + e] = (bf16_t)pe[e]; dsb[r][4 * tt + e] = (bf16_t)ds[e]; }
+                    }
+                }
                 if (ME_ST32_PIPE == 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) tq[dt] = trread(Qb, qq, dt);      // (lands under the dV products)

@@ -343,7 +343,10 @@ RING_SHAPES = [(40, 197, 12, 64), (30, 100, 12, 48), (2, 209, 3, 64), (3, 224, 2
                (9, 640, 4, 64), (300, 66, 2, 32),
                # streaming backward (N >= 560, 32 < hd <= 64): several items per workgroup, the shortest sequence it takes, four
                # loader waves (176-row blocks), a ragged last block and chunk, head_dim below the template width
-               (12, 592, 12, 64), (2, 560, 2, 64), (2, 673, 3, 64), (1, 3136, 2, 64), (3, 577, 2, 40)]
+               (12, 592, 12, 64), (2, 560, 2, 64), (2, 673, 3, 64), (1, 3136, 2, 64), (3, 577, 2, 40),
+               # the 32-key dK / dV kernel (key blocks that fill seven waves: 192 < keys per block <= 224): full last block, a last block
+               # whose second key tiles lie past N, a last block of ONE key, more items than CUs with a short head_dim
+               (2, 896, 2, 64), (1, 870, 3, 64), (1, 1345, 1, 64), (24, 600, 12, 48)]
 
 
 @pytest.mark.parametrize("B,N,H,hd", RING_SHAPES)
