@@ -912,30 +912,6 @@ template <int HD> struct RCfg {
 // Waves 14 and 15 are the loaders (paced LDS-DMA of the next item's K and V into the other ring half), other waves >= ceil(N / 16)
 // only keep the barrier.
 constexpr int R16_THREADS = 1024;
-// exp2(s * sl - m) of four scores in place, summed into a pair of partial sums: on PAIRS (round 6: v_pk_fma_f32 for the argument, v_pk_add_f32
-// for the sum -- 2 instead of 3 VALU instructions per score)
-#ifndef ME_R16_PK
-#define ME_R16_PK 1                             // (A/B arm: 0 = element by element)
-#endif
-__device__ __forceinline__ void r16_exp4(f32x4& s, float sl, float m, f32x2& ps) {
-#if ME_R16_PK
-    const f32x2 slv = {sl, sl}, mv = {m, m};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const f32x2 arg = f32x2{s[2 * h], s[2 * h + 1]} * slv - mv;
-        const f32x2 pe = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-        s[2 * h] = pe[0]; s[2 * h + 1] = pe[1];
-        ps += pe;
-    }
-#else
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float pe = __builtin_amdgcn_exp2f(s[e] * sl - m);
-        s[e] = pe;
-        ps[0] += pe;
-    }
-#endif
-}
 #ifndef ME_R16_SLEEP
 #define ME_R16_SLEEP 1      // loader pacing: s_sleep units (64 clocks) behind every DMA piece
 #endif
@@ -1131,10 +1107,15 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_ring16_kernel(const bf16
         mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         m2 = mt * sl;
-        f32x2 psv = {0.f, 0.f};
+        float ps = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) r16_exp4(s[t], sl, m2, psv);
-        float ps = psv[0] + psv[1];
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(s[t][e] * sl - m2);
+                s[t][e] = pe;
+                ps += pe;
+            }
         ps += __shfl_xor(ps, 16, 64);
         l_tot = ps + __shfl_xor(ps, 32, 64);
         TRACE_STAMP(it, 4);
@@ -1616,10 +1597,15 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float m_new = fmaxf(m_run, mt * sl);     // every chunk holds a valid key: finite from the first chunk on
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            f32x2 psv = {0.f, 0.f};
+            float ps = 0.f;
 #pragma unroll
-            for (int t = 0; t < NTC; ++t) r16_exp4(s[t], sl, m_new, psv);
-            const float ps = psv[0] + psv[1];
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(s[t][e] * sl - m_new);
+                    s[t][e] = pe;
+                    ps += pe;
+                }
             l_run = l_run * alpha + ps;
             m_run = m_new;
 #pragma unroll
@@ -1667,9 +1653,14 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf
 // a softmax probability from its log2-domain argument: v_exp_f32 with the clamp output modifier (hipcc folds the med3 into it)
 __device__ __forceinline__ float r16_p(float arg) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(arg), 0.f, 1.f); }
 
-// four probabilities and their dS / scale of the backward kernels:  pe = exp2(s * sl - l2),  ds = pe * (dp - d).  On PAIRS (round 6): v_pk_fma_f32
-// for the argument, v_pk_mul_f32 + v_pk_fma_f32 for ds = pe * dp - pe * d (the compiler does not select a packed subtract for pe * (dp - d)):
-// 3.5 VALU instructions per score instead of 5, in kernels where this arithmetic is the longer side of its overlap with the MFMAs
+// four probabilities and their dS / scale of the backward kernels:  pe = exp2(s * sl - l2),  ds = pe * (dp - d).  ME_R16_PK = 1 (A/B arm, OFF): the
+// same on PAIRS -- v_pk_fma_f32 for the argument, v_pk_mul_f32 + v_pk_fma_f32 for dS, 3.5 instead of 5 VALU instructions per score (and, tried with
+// it, v_pk_fma_f32 / v_pk_add_f32 in the forward kernels' exp2 + row sum: 2 instead of 3) -- measured SLOWER everywhere (same box,
+// profiles/r06_attn_bwd_stream32.txt: N = 197 forward 68.7 -> 74.7 us, backward 212.9 -> 222.7; N = 1568 forward 477 -> 504, backward
+// 1 218 -> 1 247): the packed fp32 operations do not issue at the rate of two scalar ones here, and assembling the pairs costs moves.
+#ifndef ME_R16_PK
+#define ME_R16_PK 0
+#endif
 __device__ __forceinline__ void r16_pds4(const f32x4& s, const f32x4& dp, float sl, const f32x4& l2, const f32x4& d, f32x4& pe, f32x4& ds) {
 #if ME_R16_PK
     const f32x2 slv = {sl, sl};
