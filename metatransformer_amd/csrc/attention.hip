@@ -1986,6 +1986,7 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
 // 0 -> P = 1 meets a zero dO row and dS = 0), every P goes through r16_p() and stays finite, and rows a wave owns past N are
 // never stored.  Replaces the 8-wave / 32-row chunk kernels (same box, profiles/r04_attn_bwd_stream16_vs_chunk.txt: N = 1568 1 442 vs
 // 1 520 us, 1000: 657 vs 711, 592: 409 vs 477, 520: 634 vs 797; 3136: 2 672 vs 2 640).
+// Round 6: where a key block fills seven 32-key waves the second phase runs as attn_bwd_dkdv_stream32_kernel (further down; -15 % on that phase).
 #ifndef ME_ST_BWD_MINN
 #define ME_ST_BWD_MINN 513
 #endif
