@@ -1653,9 +1653,9 @@ __global__ __launch_bounds__(R16_THREADS) void attn_fwd_stream16_kernel(const bf
 // a softmax probability from its log2-domain argument: v_exp_f32 with the clamp output modifier (hipcc folds the med3 into it)
 __device__ __forceinline__ float r16_p(float arg) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(arg), 0.f, 1.f); }
 
-// four probabilities and their dS / scale of the backward kernels:  pe = exp2(s * sl - l2),  ds = pe * (dp - d).  ME_R16_PK = 1 (A/B arm, OFF): the
+// four probabilities and their dS / scale (the 32-key dK / dV kernel):  pe = exp2(s * sl - l2),  ds = pe * (dp - d).  ME_R16_PK = 1 (A/B arm, OFF): the
 // same on PAIRS -- v_pk_fma_f32 for the argument, v_pk_mul_f32 + v_pk_fma_f32 for dS, 3.5 instead of 5 VALU instructions per score (and, tried with
-// it, v_pk_fma_f32 / v_pk_add_f32 in the forward kernels' exp2 + row sum: 2 instead of 3) -- measured SLOWER everywhere (same box,
+// it, the same form in every other backward kernel and v_pk_fma_f32 / v_pk_add_f32 in the forward kernels' exp2 + row sum) -- measured SLOWER everywhere (same box,
 // profiles/r06_attn_bwd_stream32.txt: N = 197 forward 68.7 -> 74.7 us, backward 212.9 -> 222.7; N = 1568 forward 477 -> 504, backward
 // 1 218 -> 1 247): the packed fp32 operations do not issue at the rate of two scalar ones here, and assembling the pairs costs moves.
 #ifndef ME_R16_PK
@@ -1896,12 +1896,12 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
             // keys >= N: their K rows are zeros, so whatever dS holds there adds nothing to dQ -- no mask
             bf16x8 dsb;
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                f32x4 pe, ds;
-                r16_pds4(s[tt], dp[tt], sl, f32x4{lse2, lse2, lse2, lse2}, f32x4{del, del, del, del}, pe, ds);      // dS^T / scale (scale applied to dQ once)
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dsb[4 * tt + e] = (bf16_t)ds[e];
-            }
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = r16_p(s[tt][e] * sl - lse2);
+                    dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - del));      // dS^T / scale (scale applied to dQ once)
+                }
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) dq[dt] = mma16(kt[dt], dsb, kk == 0 ? zero4f : dq[dt]);
         }
@@ -1954,10 +1954,12 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_ring16_kernel(const bf16
             for (int tt = 0; tt < 2; ++tt) {
                 const f32x4 L = *reinterpret_cast<const f32x4*>(lse_s + 16 * (2 * qq + tt) + 4 * g);
                 const f32x4 D = *reinterpret_cast<const f32x4*>(del_s + 16 * (2 * qq + tt) + 4 * g);
-                f32x4 pe, ds;
-                r16_pds4(s[tt], dp[tt], sl, L, D, pe, ds);      // dS / scale (scale applied to dK once)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { pb[4 * tt + e] = (bf16_t)pe[e]; dsb[4 * tt + e] = (bf16_t)ds[e]; }
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = r16_p(s[tt][e] * sl - L[e]);
+                    pb[4 * tt + e] = (bf16_t)pe;
+                    dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - D[e]));      // dS / scale (scale applied to dK once)
+                }
             }
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) dv[dt] = mma16(trread(QDr + arr_bytes, qq, dt), pb, qq == 0 ? zero4f : dv[dt]);
@@ -2189,12 +2191,12 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_dq_stream16_kernel(const
                 for (int dt = 0; dt < NDT; ++dt) kt[dt] = trread(Kb, kk, dt);
                 bf16x8 dsb;
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    f32x4 pe, ds;
-                    r16_pds4(s[tt], dp[tt], sl, f32x4{lse2, lse2, lse2, lse2}, f32x4{del, del, del, del}, pe, ds);      // dS^T / scale (scale applied to dQ once)
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dsb[4 * tt + e] = (bf16_t)ds[e];
-                }
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = r16_p(s[tt][e] * sl - lse2);
+                        dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - del));      // dS^T / scale (scale applied to dQ once)
+                    }
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) dq[dt] = mma16(kt[dt], dsb, dq[dt]);
             }
@@ -2327,10 +2329,12 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_dkdv_stream16_kernel(con
                 for (int tt = 0; tt < 2; ++tt) {
                     const f32x4 L = *reinterpret_cast<const f32x4*>(lsb + 16 * (2 * qq + tt) + 4 * g);
                     const f32x4 D = *reinterpret_cast<const f32x4*>(deb + 16 * (2 * qq + tt) + 4 * g);
-                    f32x4 pe, ds;
-                    r16_pds4(s[tt], dp[tt], sl, L * LOG2E, D, pe, ds);      // dS / scale (scale applied to dK once)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { pb[4 * tt + e] = (bf16_t)pe[e]; dsb[4 * tt + e] = (bf16_t)ds[e]; }
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = r16_p(s[tt][e] * sl - L[e] * LOG2E);
+                        pb[4 * tt + e] = (bf16_t)pe;
+                        dsb[4 * tt + e] = (bf16_t)(pe * (dp[tt][e] - D[e]));      // dS / scale (scale applied to dK once)
+                    }
                 }
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) dv[dt] = mma16(trread(Db, qq, dt), pb, dv[dt]);
