@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const float* __restric
         // S^T tiles: rows = keys 16 T + 4 g + r, column = query q of tile u; a K fragment read serves both query tiles.  The fragment
         // reads run ONE STEP AHEAD of the MFMAs that use them (sched_barrier pins the order): left to itself hipcc emits read -> wait ->
         // six MFMAs per step, i.e. one exposed LDS latency per 96 matrix-pipe clocks.
+        const int nvalid = q0 < N ? N - c * X3_KC : 0;          // valid keys of this chunk (0: this wave owns no query -- last row block)
         f32x4 s[X3_QT][4];
 #pragma unroll
         for (int u = 0; u < X3_QT; ++u)
@@ -221,24 +222,28 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const float* __restric
                     nl = *reinterpret_cast<const bf16x8*>(kbase_l + off);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (16 * T < nvalid) {                          // (round 6: key tiles wholly past N -- masked to P = 0 below -- skip their products)
 #pragma unroll
-                for (int u = 0; u < X3_QT; ++u) {
-                    s[u][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, qh[u][ks], s[u][T], 0, 0, 0);
-                    s[u][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, qh[u][ks], s[u][T], 0, 0, 0);
-                    s[u][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, ql[u][ks], s[u][T], 0, 0, 0);
+                    for (int u = 0; u < X3_QT; ++u) {
+                        s[u][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, qh[u][ks], s[u][T], 0, 0, 0);
+                        s[u][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, qh[u][ks], s[u][T], 0, 0, 0);
+                        s[u][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, ql[u][ks], s[u][T], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 fh = nh; fl = nl;
             }
         }
         bf16x8 ph[X3_QT][2], pl[X3_QT][2];                      // P^T B-operand fragments of the two 32-key blocks
+        if (nvalid > 0)                                         // (a wave without a query of its own has nothing to normalise)
 #pragma unroll
         for (int u = 0; u < X3_QT; ++u) {
             // mask keys past N, scale into log2 units, chunk maximum of query q (in-lane over 16, then over the four lane groups)
             float mx = -INFINITY;
             if (c * X3_KC + X3_KC > N) {                        // (wave-uniform: only a ragged LAST chunk has keys to mask)
 #pragma unroll
-                for (int T = 0; T < 4; ++T)
+                for (int T = 0; T < 4; ++T) {
+                    if (16 * T >= nvalid) continue;             // (a tile wholly past N: no arithmetic at all, P = 0 below)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = c * X3_KC + 16 * T + 4 * g + r;
@@ -246,6 +251,7 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const float* __restric
                         s[u][T][r] = v;
                         mx = fmaxf(mx, v);
                     }
+                }
             } else {
 #pragma unroll
                 for (int T = 0; T < 4; ++T) {
@@ -259,7 +265,12 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const float* __restric
             const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
             float sum = 0.f;
 #pragma unroll
-            for (int T = 0; T < 4; ++T)
+            for (int T = 0; T < 4; ++T) {
+                if (16 * T >= nvalid) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ph[u][T >> 1][4 * (T & 1) + r] = (bf16_t)0.0f; pl[u][T >> 1][4 * (T & 1) + r] = (bf16_t)0.0f; }
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = __builtin_amdgcn_exp2f(s[u][T][r] - m_new);
@@ -269,6 +280,7 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const float* __restric
                     ph[u][T >> 1][4 * (T & 1) + r] = hh;
                     pl[u][T >> 1][4 * (T & 1) + r] = ll;
                 }
+            }
             sum = x3_sum4(sum);
             l_run[u] = l_run[u] * alpha + sum;
             m_run[u] = m_new;
@@ -292,11 +304,13 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const float* __restric
                     nl = *reinterpret_cast<const bf16x8*>(vbase_l + off);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (32 * blk < nvalid) {                        // (a 32-key block wholly past N holds P = 0)
 #pragma unroll
-                for (int u = 0; u < X3_QT; ++u) {
-                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, ph[u][blk], acc[u][t], 0, 0, 0);
-                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, ph[u][blk], acc[u][t], 0, 0, 0);
-                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, pl[u][blk], acc[u][t], 0, 0, 0);
+                    for (int u = 0; u < X3_QT; ++u) {
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, ph[u][blk], acc[u][t], 0, 0, 0);
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, ph[u][blk], acc[u][t], 0, 0, 0);
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, pl[u][blk], acc[u][t], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 fh = nh; fl = nl;
@@ -482,6 +496,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_kernel(const float* __rest
     const float* base = qkv + (int64_t)b * N * ld_qkv + h * X3_HD;
     const int q0 = qb * X3_QB + wave * 16 * X3_QT;
     const int ldq = (int)ld_qkv;
+    const bool own = q0 < N;                                    // (wave-uniform) this wave owns at least one query
 
     // owned: Q and dO fragments (B operands), lse and delta of this lane's query
     bf16x8 qh[X3_QT][2], ql[X3_QT][2], doh[X3_QT][2], dol[X3_QT][2];
@@ -532,8 +547,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_kernel(const float* __rest
         __syncthreads();
         if (c + 1 < nchunk) gload(c + 1);
         bf16x8 dsh[X3_QT][2], dsl[X3_QT][2];                    // dS^T as B operand of the two 32-key blocks
+        // round 6: 16-key tiles that lie wholly past N (the ragged last chunk: 3 of its 4 tiles at N = 197, all but one key at 257) and waves
+        // whose own rows do (the last row block) skip their products -- wave-uniform branches; their dS stays zero
+        const int nvalid = own ? N - c * X3_KC : 0;             // valid keys of this chunk for this wave (0: nothing to do)
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
+            if (16 * T >= nvalid) {
+#pragma unroll
+                for (int u = 0; u < X3_QT; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { dsh[u][T >> 1][4 * (T & 1) + r] = (bf16_t)0.0f; dsl[u][T >> 1][4 * (T & 1) + r] = (bf16_t)0.0f; }
+                continue;
+            }
             f32x4 s[X3_QT], dp[X3_QT];
 #pragma unroll
             for (int u = 0; u < X3_QT; ++u) { s[u] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[u] = s[u]; }
@@ -562,13 +587,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_x3_kernel(const float* __rest
         }
         // dQ^T[hd][q] += K^T[hd][keys] dS^T[keys][q]
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int blk = 0; blk < 2; ++blk) {
+            if (32 * blk >= nvalid) continue;
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
+            for (int t = 0; t < 4; ++t) {
                 const bf16x8 kh = x3_frag(Kth, L, t, blk), kl = x3_frag(Ktl, L, t, blk);
 #pragma unroll
                 for (int u = 0; u < X3_QT; ++u) dq[u][t] = x3_mma3(kh, kl, dsh[u][blk], dsl[u][blk], dq[u][t]);
             }
+        }
     }
     __syncthreads();
     x3_store_rows(lds + wave * (16 * X3_QT * 272), dq, scale, lane, dqkv ? dqkv + (int64_t)b * N * ld_dqkv + h * X3_HD : nullptr, ld_dqkv, q0, N,
@@ -601,6 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* drow = delta + ((int64_t)b * H + h) * N;
     const int k0 = kb * X3_QB + wave * 16 * X3_QT;                      // this wave's first key (tile u: k0 + 16 u + n)
     const int ldq = (int)ld_qkv, ldd = (int)ld_do;
+    const bool own = k0 < N;                                            // (wave-uniform) this wave owns at least one key
 
     bf16x8 kh[X3_QT][2], kl[X3_QT][2], vh[X3_QT][2], vl[X3_QT][2];      // owned K, V fragments (B operands)
 #pragma unroll
@@ -641,12 +669,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         else if (tid < 128) Dl[tid - 64] = sreg;
         __syncthreads();
         if (c + 1 < nchunk) gload(c + 1);
+        // (round 6: query tiles wholly past N and waves without a key of their own skip their products, as in the dQ kernel)
+        const int nvalid = own ? N - c * X3_KC : 0;                     // valid queries of this chunk for this wave
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
+            if (32 * blk >= nvalid) continue;
             bf16x8 ph[X3_QT], pl[X3_QT], dsh[X3_QT], dsl[X3_QT];        // P and dS of this 32-query block as B operands
 #pragma unroll
             for (int Tl = 0; Tl < 2; ++Tl) {
                 const int T = 2 * blk + Tl;
+                if (16 * T >= nvalid) {
+#pragma unroll
+                    for (int u = 0; u < X3_QT; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            ph[u][4 * Tl + r] = (bf16_t)0.0f; pl[u][4 * Tl + r] = (bf16_t)0.0f;
+                            dsh[u][4 * Tl + r] = (bf16_t)0.0f; dsl[u][4 * Tl + r] = (bf16_t)0.0f;
+                        }
+                    continue;
+                }
                 f32x4 s[X3_QT], dp[X3_QT];
 #pragma unroll
                 for (int u = 0; u < X3_QT; ++u) { s[u] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[u] = s[u]; }

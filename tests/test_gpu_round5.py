@@ -309,7 +309,9 @@ def test_bf16_stream_layer_by_layer_vs_oracle(dev, route):
     assert worst < TOL_BF16_STREAM1
 
 
-X3_ATTN_SHAPES = [(2, 197, 12, 64), (1, 64, 2, 64), (3, 37, 2, 64), (1, 1, 1, 64), (1, 257, 2, 64), (1, 513, 1, 64), (2, 1568, 2, 64), (64, 65, 3, 64)]
+X3_ATTN_SHAPES = [(2, 197, 12, 64), (1, 64, 2, 64), (3, 37, 2, 64), (1, 1, 1, 64), (1, 257, 2, 64), (1, 513, 1, 64), (2, 1568, 2, 64), (64, 65, 3, 64),
+                  # (round 6: tiles past N are skipped) every count of valid 16-row tiles in the last 64-row chunk, row blocks whose last waves own nothing
+                  (2, 80, 2, 64), (2, 96, 3, 64), (1, 112, 2, 64), (2, 129, 2, 64), (1, 161, 2, 64), (1, 225, 2, 64), (3, 300, 2, 64)]
 
 
 @pytest.mark.parametrize("B,N,H,hd", X3_ATTN_SHAPES)

@@ -2,7 +2,11 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from metatransformer_amd import ops
+from metatransformer_amd import _capi, ops
+if "--lib" in sys.argv:          # an A/B arm of the library (python -m metatransformer_amd.build --variant NAME ...)
+    i = sys.argv.index("--lib")
+    _capi.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 B, N, H = [int(v) for v in sys.argv[1:4]] if len(sys.argv) >= 4 else (256, 197, 12)
 hd = 64
 dev = torch.device("cuda:0")
