@@ -217,6 +217,13 @@ __device__ __forceinline__ f32x4 gelu_erf_grad4(f32x4 x) {
     phi_parts4(x, phi, g);
     return phi + x * g * 0.3989422804014327f;
 }
+// both at once (ONE Phi / Gaussian: two separate calls on either side of a branch are not merged by the compiler)
+__device__ __forceinline__ void gelu_erf_pair4(f32x4 x, f32x4& y, f32x4& dy) {
+    f32x4 phi, g;
+    phi_parts4(x, phi, g);
+    y = x * phi;
+    dy = phi + x * g * 0.3989422804014327f;
+}
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf4(f32x4{x, x, x, x})[0]; }
 __device__ __forceinline__ float gelu_erf_grad(float x) { return gelu_erf_grad4(f32x4{x, x, x, x})[0]; }
 

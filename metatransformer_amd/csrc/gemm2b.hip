@@ -328,9 +328,10 @@ __global__ __launch_bounds__((BM == 64 ? 256 : BM * 2)) __attribute__((amdgpu_wa
                 v1 = gelu_for4(v1, p.c_dtype);
             }
             if (EPI == 7) {                               // the saved tensor is gelu'(h); the erf pair, as everywhere this flag is served
-                if (ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, gelu_erf_grad4(v0), gelu_erf_grad4(v1));
-                v0 = gelu_erf4(v0);
-                v1 = gelu_erf4(v1);
+                f32x4 d0, d1;
+                gelu_erf_pair4(v0, v0, d0);
+                gelu_erf_pair4(v1, v1, d1);
+                if (ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, d0, d1);
             }
             f32x4 ra, rb;
             if (ROWOP) unpack(cur.raw[i], ra, rb);

@@ -520,13 +520,16 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
                 v0 = v0 * alpha4 + bias[q][0];
                 v1 = v1 * alpha4 + bias[q][1];
                 if (EPI == 9) {
+                    // Phi and the Gaussian ONCE for GELU and its derivative (round 6: as two calls behind / in front of the branch the
+                    // compiler formed them twice -- 256 v_exp_f32 + 256 v_rcp_f32 per thread and tile instead of 128 + 128)
+                    f32x4 d0, d1;
+                    gelu_erf_pair4(v0, v0, d0);
+                    gelu_erf_pair4(v1, v1, d1);
                     if (p.preact && ok) {
                         float* pp = reinterpret_cast<float*>(p.preact) + m * p.ldpre + n[q];
-                        *reinterpret_cast<f32x4*>(pp) = gelu_erf_grad4(v0);
-                        *reinterpret_cast<f32x4*>(pp + 4) = gelu_erf_grad4(v1);
+                        *reinterpret_cast<f32x4*>(pp) = d0;
+                        *reinterpret_cast<f32x4*>(pp + 4) = d1;
                     }
-                    v0 = gelu_erf4(v0);
-                    v1 = gelu_erf4(v1);
                 } else if (EPI == 10) {
                     v0 *= fa[mt & 1][q][0];
                     v1 *= fa[mt & 1][q][1];
@@ -604,9 +607,10 @@ __device__ __forceinline__ void g3_epilogue(const GemmParams& p, G3State& s, int
                 v1 = gelu_for4(v1, p.c_dtype);
             }
             if (EPI == 7) {                               // saved: gelu'(h) (ME_GEMM_SAVE_GELU_GRAD), the erf pair as the resident kernel
-                if (ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n[q], gelu_erf_grad4(v0), gelu_erf_grad4(v1));
-                v0 = gelu_erf4(v0);
-                v1 = gelu_erf4(v1);
+                f32x4 d0, d1;
+                gelu_erf_pair4(v0, v0, d0);
+                gelu_erf_pair4(v1, v1, d1);
+                if (ok) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n[q], d0, d1);
             }
             const f32x4 qa = ro[q][0], qb = ro[q][1];
             if (EPI == 3) {

@@ -58,8 +58,14 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int64_t m, in
     v *= p.alpha;
     if (p.row_affine) v = v * p.row_affine[2 * m] + *reinterpret_cast<const f32x4*>(p.col_shift + n) * p.row_affine[2 * m + 1];
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-    if (p.preact) store4_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, (p.flags & ME_GEMM_SAVE_GELU_GRAD) ? gelu_erf_grad4(v) : v);
-    if (p.act == ME_ACT_GELU) v = (p.flags & ME_GEMM_SAVE_GELU_GRAD) ? gelu_erf4(v) : gelu_for4(v, p.c_dtype);
+    if (p.flags & ME_GEMM_SAVE_GELU_GRAD) {        // (act = GELU and preact set: fill_params) -- GELU and its derivative from one Phi / Gaussian
+        f32x4 dv;
+        gelu_erf_pair4(v, v, dv);
+        store4_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, dv);
+    } else {
+        if (p.preact) store4_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v);
+        if (p.act == ME_ACT_GELU) v = gelu_for4(v, p.c_dtype);
+    }
     if (p.aux) {
         const f32x4 a = load4_as_f32(p.aux, p.aux_dtype, m * p.ldaux + n);
         v *= (p.flags & ME_GEMM_AUX_IS_FACTOR) ? a : gelu_grad_for4(a, p.c_dtype);
@@ -147,13 +153,14 @@ __device__ __forceinline__ void epilogue_oct(const GemmParams& p, int64_t m, int
         v0 += *reinterpret_cast<const f32x4*>(p.bias + n);
         v1 += *reinterpret_cast<const f32x4*>(p.bias + n + 4);
     }
-    if (p.preact) {
-        if (p.flags & ME_GEMM_SAVE_GELU_GRAD) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, gelu_erf_grad4(v0), gelu_erf_grad4(v1));
-        else store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
-    }
-    if (p.act == ME_ACT_GELU) {
-        if (p.flags & ME_GEMM_SAVE_GELU_GRAD) { v0 = gelu_erf4(v0); v1 = gelu_erf4(v1); }      // (the pair: erf form, as the resident kernel)
-        else { v0 = gelu_for4(v0, p.c_dtype); v1 = gelu_for4(v1, p.c_dtype); }
+    if (p.flags & ME_GEMM_SAVE_GELU_GRAD) {        // (act = GELU and preact set: fill_params) -- the pair from one Phi / Gaussian: erf form, as the resident kernel
+        f32x4 d0, d1;
+        gelu_erf_pair4(v0, v0, d0);
+        gelu_erf_pair4(v1, v1, d1);
+        store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, d0, d1);
+    } else {
+        if (p.preact) store8_from_f32(p.preact, p.preact_dtype, m * p.ldpre + n, v0, v1);
+        if (p.act == ME_ACT_GELU) { v0 = gelu_for4(v0, p.c_dtype); v1 = gelu_for4(v1, p.c_dtype); }
     }
     if (p.aux) {
         f32x4 a0, a1;
