@@ -25,6 +25,7 @@ Compute dtype: bf16 when the parameters are bf16 or when called under ``torch.au
 from __future__ import annotations
 
 from typing import Optional
+import warnings
 
 import torch
 import torch.nn as nn
@@ -270,6 +271,22 @@ class _WeightCache:
         return mine
 
 
+_exact_notes = set()
+
+
+def _note_exact_fp32(blk, cdt, rdt, reason: str) -> None:
+    """fp32_mode = "3xbf16" (the default) covers the plain one-call Block with widths that are multiples of 256; every other fp32 Block runs
+    the exact-fp32 kernels -- correct, ~2.5x slower.  Say so ONCE per reason instead of silently (missing #6)."""
+    if cdt != torch.float32 or rdt != torch.float32 or reason in _exact_notes:
+        return
+    if not (blk.fp32_mode == "3xbf16" or blk.compute_dtype == "fp32_3xbf16"):
+        return
+    _exact_notes.add(reason)
+    warnings.warn(f"metatransformer_amd: an fp32 Block runs on the exact-fp32 kernels although fp32_mode = '3xbf16': {reason} "
+                  "(the three-product mode covers plain blocks -- no window, no stochastic path, no layer-scale gradient -- with dim and hidden "
+                  "multiples of 256)", stacklevel=3)
+
+
 class _BlockFn(torch.autograd.Function):
     """forward + backward of one Block on the HIP kernels.  Restates Block.forward (attention.py:55-58)."""
 
@@ -294,6 +311,8 @@ class _BlockFn(torch.autograd.Function):
         if stoch is None and win is None and blk.c_side and not fp8 and not (need_grad and g1 is not None):
             # plain path: the whole block is ONE library call (me_block_fwd), the launch sequence lives on the C side
             x3 = blk.uses_3xbf16(cdt, rdt)
+            if not x3:
+                _note_exact_fp32(blk, cdt, rdt, "dim / hidden not multiples of 256")
             d, keep = _BlockFn._desc(blk, cache, cdt, rdt, B, N, C, H, (n1w, n1b, n2w, n2b, qkvw, qkvb, projw, projb,
                                                                         fc1w, fc1b, fc2w, fc2b, g1, g2), False,
                                      fold=not need_grad and blk.fold_norm, x3=x3)
@@ -310,6 +329,8 @@ class _BlockFn(torch.autograd.Function):
                 ctx.blk, ctx.cdt, ctx.dims, ctx.in_dtype, ctx.fast, ctx.x3 = blk, cdt, (B, N, C, H, hd), in_dtype, True, x3
             return ops.cast(y, in_dtype).reshape(B, N, C)
 
+        _note_exact_fp32(blk, cdt, rdt, "windowed attention" if win is not None else "stochastic path (drop-path / dropout)" if stoch is not None
+                         else "layer-scale gradient" if (need_grad and g1 is not None) else "op-by-op composition (c_side = False)")
         xn1, mean1, rstd1 = ops.layernorm_fwd(x2, n1w, n1b, blk.eps, cdt, save_stats=need_grad)
         qkv = ops.gemm(xn1, cache.fwd("qkv", qkvw, cdt), bias=qkvb)
         p_attn = stoch[3] if stoch is not None else 0.0      # training-mode attn_drop (attention.py:33)

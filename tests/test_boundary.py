@@ -252,3 +252,24 @@ def test_attention_backward_isa_keeps_its_ticket_register():
         assert vgpr <= 128 and body.count("scratch_") <= allowed, (m.group(1), vgpr, body.count("scratch_"))
         seen += 1
     assert seen >= 10, seen      # ring16 forward / backward for every sub-tile count and both head widths, three streaming kernels
+
+
+def test_fp32_block_that_cannot_run_three_products_says_so_once():
+    """fp32_mode = "3xbf16" (default) covers the plain Block; the others run exact fp32 -- with ONE warning per reason, not silently"""
+    import warnings
+    import torch
+    from metatransformer_amd import encoder
+
+    class _B:
+        fp32_mode, compute_dtype = "3xbf16", None
+
+    encoder._exact_notes.discard("windowed attention")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        encoder._note_exact_fp32(_B(), torch.float32, torch.float32, "windowed attention")
+        encoder._note_exact_fp32(_B(), torch.float32, torch.float32, "windowed attention")        # once
+        encoder._note_exact_fp32(_B(), torch.bfloat16, torch.bfloat16, "windowed attention")      # not an fp32 block
+        b = _B(); b.fp32_mode = "exact"
+        encoder._exact_notes.discard("layer-scale gradient")
+        encoder._note_exact_fp32(b, torch.float32, torch.float32, "layer-scale gradient")         # asked for exact: nothing to say
+    assert len(w) == 1 and "exact-fp32 kernels" in str(w[0].message) and "windowed attention" in str(w[0].message)
