@@ -374,6 +374,36 @@ def test_attention_persistent_kernels_fwd_bwd(dev, B, N, H, hd):
     assert torch.equal(dqkv, ops.attention_bwd(qkv.to(dev), out, do.to(dev), lse, B, N, H, hd, scale))
 
 
+@pytest.mark.parametrize("B,N,H,hd", [(32, 1568, 16, 64), (64, 592, 12, 64), (128, 512, 16, 64)])
+def test_attention_full_batch_of_configs_3_4_5(dev, B, N, H, hd):
+    """the attention launches of BASELINE configs 5 / 4 / 3 at the batch bench.py runs them at (the CPU-oracle tests above cut the batch):
+    forward, lse and every gradient against float64 attention computed on the GPU one batch item at a time, per item -- the streaming
+    kernels then walk 14 / 9 items per workgroup (config 5: 3 584 key blocks on 256 CUs, the 32-key dK / dV kernel)"""
+    dt = torch.bfloat16
+    C = H * hd
+    g = torch.Generator().manual_seed(B + N)
+    qkv = torch.randn(B * N, 3 * C, generator=g).to(dt).to(dev)
+    do = torch.randn(B * N, C, generator=g).to(dt).to(dev)
+    scale = hd ** -0.5
+    out, lse = ops.attention_fwd(qkv, B, N, H, hd, scale, True)
+    dqkv = ops.attention_bwd(qkv, out, do, lse, B, N, H, hd, scale)
+    worst_o = worst_g = worst_l = 0.0
+    for b in range(B):
+        x = qkv[b * N:(b + 1) * N].double().requires_grad_(True)
+        q, k, v = (x[:, i * C:(i + 1) * C].reshape(N, H, hd).transpose(0, 1) for i in range(3))
+        sc = (q @ k.transpose(1, 2)) * scale
+        ref_lse = torch.logsumexp(sc, dim=-1)                       # [H, N]
+        ref = (torch.softmax(sc, dim=-1) @ v).transpose(0, 1).reshape(N, C)
+        ref.backward(do[b * N:(b + 1) * N].double())
+        so, sg = float(ref.detach().abs().max()), float(x.grad.abs().max())
+        worst_o = max(worst_o, float((out[b * N:(b + 1) * N].double() - ref.detach()).abs().max()) / so)
+        worst_g = max(worst_g, float((dqkv[b * N:(b + 1) * N].double() - x.grad).abs().max()) / sg)
+        worst_l = max(worst_l, float((lse[b].double() - ref_lse.detach()).abs().max()))
+    # per item max-abs error relative to the item's own scale: bf16 operands and probabilities (2^-9), fp32 accumulation
+    assert worst_o < 2e-2 and worst_g < 3e-2 and worst_l < 2e-2, (worst_o, worst_g, worst_l)
+    assert torch.equal(dqkv, ops.attention_bwd(qkv, out, do, lse, B, N, H, hd, scale))
+
+
 @pytest.mark.parametrize("B,N,H,hd", [(4, 130, 8, 32), (2, 40, 32, 24), (1, 300, 2, 64)])
 @pytest.mark.parametrize("dt", DTYPES)
 def test_attention_dropout(dev, B, N, H, hd, dt):
