@@ -872,6 +872,51 @@ def test_large_config3_backward_vs_oracle(dev):
             check_close(p.grad, dp_ref[k], tg, f"config 3 d{k} {dt}")
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("L,C,Hh,B,N", [(2, 1024, 16, 32, 1568), (2, 1024, 16, 128, 512), (2, 768, 12, 64, 592)], ids=["config5", "config3", "config4"])
+def test_configs_3_4_5_full_batch_backward_vs_oracle(dev, L, C, Hh, B, N):
+    """BASELINE config 5 (and 3, 4) at the batch bench.py runs it at -- tokens [32, 1568, 1024], Large width, 16 heads ([128, 512, 1024];
+    [64, 592, 768] Base: the sequence-concat reading of config 4) -- through a 2-block slice in bf16
+    (bf16 token stream, the bench's configuration): y, dL/dx of every sample and all 24 parameter gradients against the CPU oracle in fp32
+    on the same bf16-rounded inputs (batch in chunks of 4 samples, parameter gradients summed: the loss is a sum over samples).  This is the
+    size at which the resident GEMMs run K = 1024 / 4096, the weight gradients reduce over 50 176 rows and the streaming attention kernels
+    walk 14 items per workgroup (the 32-key dK / dV kernel)."""
+    from metatransformer_amd import parallel
+    sd = bo.make_encoder_state_dict(L, C, seed=91)
+    g = torch.Generator().manual_seed(92)
+    x = torch.randn(B, N, C, generator=g)
+    go = torch.randn(B, N, C, generator=g) / (B * N) ** 0.5
+    enc = M.build_encoder(L, C, Hh)
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(dev).train()
+    for blk in enc:
+        blk.compute_dtype = torch.bfloat16
+    flat = parallel.FlatParams(enc.named_parameters(), no_decay=parallel.no_decay_rule)
+    xd = x.to(dev).bfloat16().requires_grad_(True)
+    flat.zero_grad()
+    y = enc(xd)
+    y.backward(go.to(dev).bfloat16())
+    torch.cuda.synchronize()
+    xr, gor = x.bfloat16().float(), go.bfloat16().float()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    dx_ref, y_ref = torch.empty_like(xr), torch.empty_like(xr)
+    torch.set_num_threads(max(1, min(64, len(os.sched_getaffinity(0)))))
+    ch = max(1, 8192 // N)                              # ~8 k tokens per oracle chunk
+    for i in range(0, B, ch):
+        xs = xr[i:i + ch].clone().requires_grad_(True)
+        ys = bo.encoder_forward(xs, params, Hh)
+        (ys * gor[i:i + ch]).sum().backward()
+        dx_ref[i:i + ch] = xs.grad
+        y_ref[i:i + ch] = ys.detach()
+    check_close(y.float(), y_ref, TOL_BF16_STREAM1, f"[{B},{N},{C}] y (2 bf16 layers, bf16 stream)")
+    check_close(xd.grad.float(), dx_ref, TOL_BF16_GRAD, f"[{B},{N},{C}] dx")
+    worst = {}
+    for k, p in enc.named_parameters():
+        worst[k.split(".", 1)[1]] = max(worst.get(k.split(".", 1)[1], 0.0), rel_err(p.grad, params[k].grad))
+        check_close(p.grad, params[k].grad, TOL_BF16_GRAD, f"[{B},{N},{C}] d{k}")
+    print(f"[{B},{N},{C}] full-batch gradient errors (worst over the 2 layers):", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
 def test_block_with_fp8_attention_config5_shape(dev):
     """BASELINE config 5's block (Large: 1024-d, 16 heads) on video-length sequences with attn_fp8: forward against the fp32
     oracle, backward (bf16 kernels on the saved bf16 qkv with the fp8 forward's LSE) against the oracle's gradients."""
