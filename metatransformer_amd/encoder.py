@@ -655,6 +655,10 @@ class Block(nn.Module):
         cdt = self._compute_dtype(x)
         if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise MetaEncError(f"unsupported token dtype {x.dtype}")
+        if x.shape[0] == 0 or x.shape[1] == 0:
+            # an empty batch (the last, ragged step of a data loader with drop_last = False on another rank) or no tokens: the reference's Block
+            # returns the empty tensor; so does this one, without a launch (the parameters receive no gradient from it)
+            return x.clone()
         x = x.contiguous()
         a, m = self.attn, self.mlp
         g1 = self.gamma1 if self.layer_scale else None

@@ -396,3 +396,16 @@ def test_eight_bit_factor_is_refused_off_the_resident_kernel(dev):
         ops.gemm(a2, w2, aux=q2)                    # eight bits only as the flagged factor
     with pytest.raises(_capi.MetaEncError):
         ops.gemm(a2, w2, preact=q2, act=_capi.ME_ACT_GELU)
+
+
+def test_block_takes_an_empty_batch(dev):
+    """an empty batch (or no tokens) goes through a Block and the encoder like through the reference's: an empty tensor comes back, backward runs"""
+    enc = make_encoder(2, 768, 12, dev, torch.bfloat16).train()
+    for shape in ((0, 197, 768), (3, 0, 768)):
+        x = torch.zeros(*shape, dtype=torch.bfloat16, device=dev, requires_grad=True)
+        y = enc(x)
+        assert tuple(y.shape) == shape and y.dtype == x.dtype
+        y.sum().backward()
+        assert x.grad is not None and tuple(x.grad.shape) == shape
+    with torch.no_grad():
+        assert tuple(enc.eval()(torch.zeros(0, 50, 768, dtype=torch.float32, device=dev)).shape) == (0, 50, 768)
