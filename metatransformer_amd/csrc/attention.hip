@@ -2364,7 +2364,8 @@ __global__ __launch_bounds__(R16_THREADS) void attn_bwd_dkdv_stream16_kernel(con
 // (profiles/r04_attn_pmc_stream.txt) -- and twice the independent MFMA chains per wave, against half the waves issuing softmax arithmetic.
 // Same box, profiles/r06_attn_bwd_stream32.txt: N = 1568 (config 5) 852 -> 763 us, 592 (config 4) 443 -> 411 us.  Taken when the key
 // blocks fill seven waves (192 < keys per block <= 224); six compute waves on four SIMDs run as slowly as eight (N = 520: +12 %).
-// The dQ kernel in the same form (8 waves: 575 vs 562 us at N = 1568; 12 waves of 137 registers, 320-query blocks: 547 vs 538 us) does
+// The dQ kernel in the same form (8 waves: 575 vs 562 us at N = 1568; 12 waves of 137 registers, 320-query blocks: 547 vs 538 us; 12 waves with
+// the steps staged like here: 573 vs 567 us) does
 // not gain -- 12 MFMAs per 12 KB there, and it is not the LDS that paces it -- and stays on 16-row waves.
 constexpr int ST32_THREADS = 512;
 #ifndef ME_ST32_PIPE
